@@ -1,0 +1,264 @@
+/*
+ * qavit.h -- C-ABI of libqavit_hip.so: the MI355X (gfx950) kernels behind the QA-ViT / HQA-ViT
+ * nn.Module surface.
+ *
+ * The reference (cujoramirez/QA-ViT) has no FFI: its "operator interface" for this path is the set of
+ * torch.nn.functional / nn.Module calls made inside the model classes.  Each entry point below names the
+ * reference call sites it replaces (file:line in /root/reference).  INTEGRATION.md shows the ctypes
+ * binding a maintainer adds on the reference side.
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; every buffer is owned by the caller (PyTorch's caching allocator);
+ *     the library never allocates device memory and keeps no pointer past the call;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no internal synchronisation, so all
+ *     entry points are hipGraph-capturable; the library is stateless and re-entrant;
+ *   - return 0 on success, a negative QAVIT_E* code on invalid arguments or launch failure;
+ *     qavit_last_error() returns a thread-local message for the last failure;
+ *   - `dtype` selects the storage type of activations / packed weights: QAVIT_F32 or QAVIT_BF16;
+ *     arithmetic and accumulation are fp32, 1-D parameters (bias, LayerNorm, gates) and all gradients
+ *     of parameters are fp32;
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef QAVIT_H
+#define QAVIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QAVIT_F32 0
+#define QAVIT_BF16 1
+
+#define QAVIT_OK 0
+#define QAVIT_EINVAL (-1)   /* bad shape / dtype / alignment */
+#define QAVIT_ELAUNCH (-2)  /* hipGetLastError() after launch */
+
+int qavit_version(void);
+const char* qavit_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * C[M,N] = epilogue( prologue(A)[M,K] . B[N,K]^T + bias )          (MFMA; A rows resident in LDS)
+ * Replaces nn.Linear / F.linear call sites of the block, e.g. HQAViT_CIFAR100.py:448 (qkv), :464 (proj),
+ * :1074-1077 (LayerNorm + compress), :652-656 (BottleneckMLP fc1+GELU+dropout, fc2+dropout), :704-712
+ * (CCF-FFN fc1/fc2), and their autograd input-gradients (dX = dZ . W with B := W^T packed).
+ *
+ * a_mode 0: A as stored.
+ * a_mode 1: A := LayerNorm_K(A) * ln_gamma + ln_beta (nn.LayerNorm fused as prologue; writes ln_mean/ln_rstd).
+ * a_mode 2: A := A * droppath(a_dp) * dropout(a_drop) * gelu'(a_Z)   -- the backward of a layer's epilogue
+ *           applied to its incoming gradient; the transformed tile is also written to a_out (dZ).
+ * epilogue: v = acc + bias; Z := v (if Z); v = gelu(v) (act==1); v *= dropout; v *= scale; v *= droppath; v += R.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_gemm_args {
+  int dtype;
+  int M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias;
+  /* A prologue */
+  int a_mode;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  float* ln_mean; float* ln_rstd;
+  const void* a_Z; int64_t a_ldz; int a_act;
+  float a_drop_p; int a_drop_site;
+  float a_dp_p; int a_dp_site; int a_dp_rows;
+  float a_scale;
+  void* a_out; int64_t a_ldo;
+  /* epilogue */
+  void* Z; int64_t ldz;
+  int act;
+  float drop_p; int drop_site;
+  float scale;
+  float dp_p; int dp_site; int dp_rows;
+  const void* R; int64_t ldr;
+  const int64_t* rng; /* device int64[2]: seed, step */
+} qavit_gemm_args;
+
+int qavit_gemm_nt(const qavit_gemm_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * C[N,K] += A[M,N]^T . B[M,K]   (fp32 atomics, split over M);   colsum[N] += sum_m A[m,n]
+ * The weight / bias gradient of every nn.Linear above (autograd of F.linear).  B may be LayerNorm-ed on
+ * load with saved statistics (the fused-prologue layers).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_gemm_tn_args {
+  int dtype;
+  int M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  float* C; int64_t ldc;
+  float* colsum;
+  const float* ln_gamma; const float* ln_beta; const float* ln_mean; const float* ln_rstd;
+  int splits;
+} qavit_gemm_tn_args;
+
+int qavit_gemm_tn(const qavit_gemm_tn_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * nn.LayerNorm over the last dim C (HQAViT_CIFAR100.py:1072 norm1, :1083 norm2, :1273 norm, :1029 ...).
+ * fwd: y = LN(x)*gamma+beta (+ add[row % add_rows] if add != NULL: the pos_embed add of :1250);
+ *      mean/rstd [rows] saved for backward.
+ * bwd: dx = LN'(dy); dgamma/dbeta += (fp32 atomics); dadd[row % add_rows] += dy when dadd != NULL.
+ * ------------------------------------------------------------------------------------------------- */
+int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
+                        float eps, int rows, int C, float* mean, float* rstd,
+                        const float* add, int add_rows, void* stream);
+int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
+                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                        int rows, int C, float* dadd, int add_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Attention core of the four branches: O = softmax(Q K_full^T / sqrt(D)) V_full per (group g, head h), with
+ *   mode 0 (SWA / MSDA):  K_full = [ E_k[:L]^T . k_tok[g] (KC rows) ; shared_k (S rows) ]   (Linformer + bank)
+ *   mode 1 (CGA / cross): K_full = [ k_tok[g] (L rows, may be 0) ; shared_k (S rows) ]
+ * HQAViT_CIFAR100.py:452-461 (SWA), :514-525 (MSDA), :332-352 (LinformerCompression; zero padding to
+ * seq_len is skipped algebraically: only the first L rows of E contribute), :584-587 (CGA, D=4),
+ * :616-621 (cross), :355-397 (efficient_attention, default scale 1/sqrt(D), no mask).
+ * One wavefront per (g,h); MFMA tiles read their operands from LDS.
+ *   q      : element (g,i,h,d) at q[(g*Nq+i)*ldq + h*D + d]          (activation dtype)
+ *   k_tok  : element (g,l,h,d) at k_tok[(g*L+l)*ldk + h*D + d]; v_tok likewise
+ *   E_k/E_v: fp32 [*, KC] row-major (mode 0), first L rows used
+ *   sh_k/sh_v: fp32 [S, H*D] shared rows (the bank, or a Linear of the bank)
+ *   o      : element (g,i,h,d) at o[(g*Nq+i)*ldo + h*D + d]
+ *   nan_flag (optional): set to 1 if any q/k/v input or output element is NaN (the reference then returns
+ *   zeros for the WHOLE tensor: call qavit_nan_guard afterwards).
+ * bwd: writes dq / dk_tok / dv_tok, and per-wave partial sums of dE_k, dE_v [L,KC] and dsh_k, dsh_v
+ *   [S,D] (head slice) into `ws`; qavit_attn_bwd_reduce folds them into the fp32 gradient buffers (+=).
+ *   qavit_attn_ws_floats() gives the workspace size.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_attn_args {
+  int dtype; int mode;
+  int G, Nq, L, H, D, KC, S;
+  const void* q; int64_t ldq;
+  const void* k_tok; int64_t ldk;
+  const void* v_tok; int64_t ldv;
+  const float* E_k; const float* E_v;
+  const float* sh_k; const float* sh_v;
+  void* o; int64_t ldo;
+  int* nan_flag;
+  /* backward */
+  const void* d_o; int64_t lddo;
+  void* dq; int64_t lddq;
+  void* dk_tok; int64_t lddk;
+  void* dv_tok; int64_t lddv;
+  float* ws; int64_t ws_floats;
+  float* dE_k; float* dE_v; float* dsh_k; float* dsh_v;
+} qavit_attn_args;
+
+int qavit_attn_fwd(const qavit_attn_args* a, void* stream);
+int qavit_attn_bwd(const qavit_attn_args* a, void* stream);      /* includes the partial-sum reduction */
+int64_t qavit_attn_ws_floats(const qavit_attn_args* a);
+/* zero `n` elements of x if *flag != 0, then clear the flag (efficient_attention's NaN -> zeros rule) */
+int qavit_nan_guard(int dtype, void* x, int64_t n, int* flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * TokenLearner mixing (HQAViT_CIFAR100.py:996-1000): p = softmax over the N axis of scores[B,N,M];
+ * xc[B,M,C] = p^T x.  bwd: dx (direct path) and dscores.
+ * ------------------------------------------------------------------------------------------------- */
+int qavit_tokmix_fwd(int dtype, const void* scores, const void* x, void* p, void* xc,
+                     int B, int N, int M, int C, void* stream);
+int qavit_tokmix_bwd(int dtype, const void* p, const void* x, const void* dxc, void* dx, void* dscores,
+                     int B, int N, int M, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * TokenUpMix (HQAViT_CIFAR100.py:1026-1029): up[b,n,c] = sum_m W[n,m] xc[b,m,c] + bias[n]; y = LN_C(up).
+ * bwd: dxc, dW[N,M], dbias[N], dgamma, dbeta (fp32 atomics).
+ * ------------------------------------------------------------------------------------------------- */
+int qavit_upmix_fwd(int dtype, const void* xc, const float* W, const float* bias, const float* gamma,
+                    const float* beta, float eps, void* y, float* mean, float* rstd,
+                    int B, int N, int M, int C, void* stream);
+int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const float* W, const float* bias,
+                    const float* gamma, const float* mean, const float* rstd, void* dxc, float* dW,
+                    float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * MSDA landmark tokens (HQAViT_CIFAR100.py:499-501): dilated gathers x[:, ::d, ::d] concatenated, then
+ * AvgPool1d(stride, stride) over the token axis.  idx[NP*stride] are source-token indices (host-built,
+ * device-resident): pooled[b,j,:] = mean_s x[b, idx[j*stride+s], :].
+ * ------------------------------------------------------------------------------------------------- */
+int qavit_gather_pool_fwd(int dtype, const void* x, const int32_t* idx, void* y, int B, int N, int NP,
+                          int stride, int C, void* stream);
+int qavit_gather_pool_bwd(int dtype, const void* dy, const int32_t* idx, void* dx, int B, int N, int NP,
+                          int stride, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CCF-FFN middle (HQAViT_CIFAR100.py:706-708, :670-675): h2 = LN2( scale * dwconv3x3( LN1(h) ) (+bias) )
+ * on [B, Hs*Ws, C] channel-last tokens.  flags bit0: LN1/LN2 present (v1 has none), bit1: conv bias,
+ * bit2: per-channel scale.  bwd accumulates all parameter grads with fp32 atomics.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_ccf_args {
+  int dtype; int flags;
+  int B, Hs, Ws, C;
+  const void* h; void* out;
+  const float* g1; const float* b1; const float* g2; const float* b2; float eps;
+  const float* w;      /* [C,1,3,3] */
+  const float* cbias;  /* [C] or NULL */
+  const float* cscale; /* [C] or NULL */
+  float* mean1; float* rstd1; float* mean2; float* rstd2;  /* [B*Hs*Ws] saved stats */
+  /* backward */
+  const void* d_out; void* d_h;
+  float* dg1; float* db1; float* dg2; float* db2; float* dw; float* dcbias; float* dcscale;
+} qavit_ccf_args;
+
+int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream);
+int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * GlobalTokenBank.write (HQAViT_CIFAR100.py:296-321; QAViT.py:205-224), train mode only, no gradient.
+ * stats: acc[S,C] = sum_b  softmax_tokens( tn Wg^T + bg )^T tn,  tn = LN_write(LN_branch(tokens))
+ *        (per-wave partials in `ws`, then one reduction; under data parallelism `acc` is what gets
+ *        all-reduced before apply -- SURVEY.md section 8e exception 1)
+ * apply: U = acc / B_total; upd_v = clamp(U); upd_k = clamp(U Wc^T + bc)  (exact: softmax columns sum to 1);
+ *        bank += rate*upd; clamp; update_count += 1; acc := 0.   mode 0 = HQA rule (rate by count, clamps
+ *        0.05/0.5), mode 1 = QAViT.py rule (rate 0.01, clamps 0.1/1.0, no counter).
+ * ------------------------------------------------------------------------------------------------- */
+int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const float* b_branch,
+                     const float* g_write, const float* b_write, const float* Wg, const float* bg,
+                     float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps, void* stream);
+int64_t qavit_bank_ws_floats(int B, int N, int C, int S);
+int qavit_bank_apply(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
+                     int64_t* update_count, int S, int C, float inv_batch, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * small helpers
+ * ------------------------------------------------------------------------------------------------- */
+/* 4x4/stride-p patch gather for the patch-embed conv as a GEMM (HQAViT_CIFAR100.py:1133,1137):
+ * cols[b*NP + py*Wp + px, c*p*p + dy*p + dx] = img[b,c,py*p+dy,px*p+dx] (img fp32 NCHW) */
+int qavit_patchify(int dtype, const float* img, void* cols, int B, int Cin, int H, int W, int p, void* stream);
+/* y[b,:] = mean_n x[b,n,:] (HQAViT_CIFAR100.py:1274) and its backward */
+int qavit_token_mean_fwd(int dtype, const void* x, void* y, int B, int N, int C, void* stream);
+int qavit_token_mean_bwd(int dtype, const void* dy, void* dx, int B, int N, int C, void* stream);
+/* HybridFusion (HQAViT_CIFAR100.py:637-640): y[:, i*Cb:(i+1)*Cb] = x[:, i*Cb:(i+1)*Cb] * softmax(fw)[i];
+ * bwd: dx and dfw[nb] += (through the softmax) */
+int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, void* y, int rows, int nb, int Cb, void* stream);
+int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, const float* fw, void* dx, float* dfw,
+                          int rows, int nb, int Cb, void* stream);
+/* y = x + droppath( gamma[0] * u )  (CCF-FFN gamma + residual, HQAViT_CIFAR100.py:712,1083); gamma may be NULL (=1) */
+int qavit_scale_add_fwd(int dtype, const void* x, const void* u, const float* gamma, void* y, int rows, int C,
+                        float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
+int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, const float* gamma, void* du, float* dgamma,
+                        int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
+/* y = dropout(x) (pos_drop, HQAViT_CIFAR100.py:1251); bwd is the same call on dy */
+int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream);
+/* packed weights: dst = cast(src) and dstT = cast(src)^T for 2-D [rows, cols] fp32 params; descriptor table on device */
+typedef struct qavit_pack_desc { const float* src; void* dst; void* dstT; int rows; int cols; } qavit_pack_desc;
+int qavit_pack_weights(int dtype, const qavit_pack_desc* descs_dev, int n_desc, int max_elems, void* stream);
+/* rng[1] += 1 */
+int qavit_rng_advance(int64_t* rng, void* stream);
+/* fused AdamW over a flat fp32 buffer with a per-element group mask (skip[i] != 0: parameter never receives a
+ * gradient -> untouched, as torch.optim.AdamW skips grad-is-None tensors, HQAViT_CIFAR100.py:1566-1571) and
+ * global-norm clipping folded in: g *= min(1, max_norm / (*gnorm + 1e-6)) (clip_grad_norm_, :1432).
+ * lr and step come from device scalars so a captured graph replays with a moving schedule. */
+int qavit_adamw(float* p, const float* g, float* m, float* v, const uint8_t* skip, int64_t n,
+                const float* lr_dev, float beta1, float beta2, float eps, float wd,
+                const float* step_dev, const float* gnorm_dev, float max_norm, void* stream);
+/* out[0] = sqrt(sum g^2) over a flat buffer (two-pass, deterministic order within a block) */
+int qavit_l2norm(const float* g, int64_t n, float* partial, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QAVIT_H */

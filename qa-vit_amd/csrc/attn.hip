@@ -1,0 +1,395 @@
+// Attention core of the four QA-ViT branches (see include/qavit.h, qavit_attn_args).
+// One wavefront per (group g, head h) problem; all operands of the problem live in that wave's LDS slice
+// as fp32 and feed 16x16 MFMA tiles (mma_lds.cuh).  Key-side matrices (Linformer-compressed keys + bank
+// rows) are built once per problem and reused by every 16-row query tile.
+#include "common.cuh"
+#include "mma_lds.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+
+namespace qv {
+
+struct AttnDims {
+  int NK, NKo, NKp;   // total keys, own/compressed keys, padded row stride of the score tile
+};
+__host__ __device__ inline AttnDims attn_dims(const qavit_attn_args& a) {
+  AttnDims d;
+  d.NKo = (a.mode == 0) ? a.KC : a.L;
+  d.NK = d.NKo + a.S;
+  d.NKp = d.NK + 4;
+  return d;
+}
+
+// LDS layout (floats), shared by fwd and bwd
+struct AttnLds {
+  int q, s, kf, vf, kt, vt, ek, ev;            // fwd
+  int d_o, dp, dkf, dvf, acc_ek, acc_ev, acc_shk, acc_shv;   // bwd only
+  int total;
+};
+__host__ __device__ inline AttnLds attn_lds(const qavit_attn_args& a, bool bwd) {
+  const AttnDims d = attn_dims(a);
+  AttnLds L; int o = 0;
+  L.q = o; o += 16 * a.D;
+  L.s = o; o += 16 * d.NKp;
+  L.kf = o; o += d.NK * a.D;
+  L.vf = o; o += d.NK * a.D;
+  L.kt = L.vt = L.ek = L.ev = 0;
+  if (a.mode == 0) {
+    L.kt = o; o += a.L * a.D;
+    L.vt = o; o += a.L * a.D;
+    L.ek = o; o += a.L * a.KC;
+    L.ev = o; o += a.L * a.KC;
+  }
+  L.d_o = L.dp = L.dkf = L.dvf = L.acc_ek = L.acc_ev = L.acc_shk = L.acc_shv = 0;
+  if (bwd) {
+    L.d_o = o; o += 16 * a.D;
+    L.dp = o; o += 16 * d.NKp;
+    L.dkf = o; o += d.NK * a.D;
+    L.dvf = o; o += d.NK * a.D;
+    if (a.mode == 0) { L.acc_ek = o; o += a.L * a.KC; L.acc_ev = o; o += a.L * a.KC; }
+    L.acc_shk = o; o += a.S * a.D;
+    L.acc_shv = o; o += a.S * a.D;
+  }
+  L.total = (o + 3) / 4 * 4;
+  return L;
+}
+
+// floats of workspace one wave writes: [dE_k (L*KC) | dE_v | dsh_k (S*D) | dsh_v]
+__host__ __device__ inline int64_t attn_ws_per_wave(const qavit_attn_args& a) {
+  return (a.mode == 0 ? 2 * (int64_t)a.L * a.KC : 0) + 2 * (int64_t)a.S * a.D;
+}
+
+static inline int attn_grid(const qavit_attn_args& a, bool bwd) {
+  const int64_t problems = (int64_t)a.G * a.H;
+  int64_t cap = bwd ? 1024 : 4096;          // bwd: bounded so the partial-sum workspace stays small
+  int64_t g = problems < cap ? problems : cap;
+  g = g / a.H * a.H;                          // a multiple of H: the head of a wave is fixed
+  if (g < a.H) g = a.H;
+  return (int)g;
+}
+
+// ---- shared staging: builds Kf / Vf (and keeps kt/vt/ek/ev for bwd) for problem (g,h) ----
+template <typename T, bool BF>
+__device__ __forceinline__ bool stage_keys(const qavit_attn_args& a, const AttnDims& d, const AttnLds& L, float* sm, int g, int h) {
+  const int lane = threadIdx.x;
+  const int D = a.D;
+  bool bad = false;
+  // shared rows
+  for (int i = lane; i < a.S * D; i += 64) {
+    const int s = i / D, dd = i - s * D;
+    const float k = a.sh_k[(size_t)s * a.H * D + h * D + dd];
+    const float v = a.sh_v[(size_t)s * a.H * D + h * D + dd];
+    bad |= (k != k) | (v != v);
+    sm[L.kf + (d.NKo + s) * D + dd] = k;
+    sm[L.vf + (d.NKo + s) * D + dd] = v;
+  }
+  const T* kt = reinterpret_cast<const T*>(a.k_tok);
+  const T* vt = reinterpret_cast<const T*>(a.v_tok);
+  if (a.mode == 0) {
+    for (int i = lane; i < a.L * D; i += 64) {
+      const int l = i / D, dd = i - l * D;
+      const float k = to_f<T>(kt[((size_t)g * a.L + l) * a.ldk + h * D + dd]);
+      const float v = to_f<T>(vt[((size_t)g * a.L + l) * a.ldv + h * D + dd]);
+      bad |= (k != k) | (v != v);
+      sm[L.kt + i] = k;
+      sm[L.vt + i] = v;
+    }
+    for (int i = lane; i < a.L * a.KC; i += 64) { sm[L.ek + i] = a.E_k[i]; sm[L.ev + i] = a.E_v[i]; }
+    __syncthreads();
+    // Kf[j][d] = sum_l E_k[l][j] * kt[l][d]
+    for (int jt = 0; jt * 16 < a.KC; ++jt)
+      for (int dt = 0; dt * 16 < D; ++dt) {
+        f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+        ak = mma_tile<BF>(sm + L.ek + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.kt + dt * 16, D, 1, D - dt * 16, a.L, ak);
+        av = mma_tile<BF>(sm + L.ev + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.vt + dt * 16, D, 1, D - dt * 16, a.L, av);
+        tile_to_f32<false>(sm + L.kf + jt * 16 * D + dt * 16, D, 1, a.KC - jt * 16, D - dt * 16, ak);
+        tile_to_f32<false>(sm + L.vf + jt * 16 * D + dt * 16, D, 1, a.KC - jt * 16, D - dt * 16, av);
+      }
+  } else {
+    for (int i = lane; i < a.L * D; i += 64) {
+      const int l = i / D, dd = i - l * D;
+      const float k = to_f<T>(kt[((size_t)g * a.L + l) * a.ldk + h * D + dd]);
+      const float v = to_f<T>(vt[((size_t)g * a.L + l) * a.ldv + h * D + dd]);
+      bad |= (k != k) | (v != v);
+      sm[L.kf + i] = k;
+      sm[L.vf + i] = v;
+    }
+  }
+  __syncthreads();
+  return bad;
+}
+
+// scores of a 16-row query tile -> probabilities in sm[L.s] (row stride NKp)
+template <bool BF>
+__device__ __forceinline__ void scores_softmax(const qavit_attn_args& a, const AttnDims& d, const AttnLds& L, float* sm, int rows, float scale) {
+  const int D = a.D;
+  for (int nt = 0; nt * 16 < d.NK; ++nt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = mma_tile<BF>(sm + L.q, D, 1, rows, sm + L.kf + nt * 16 * D, 1, D, d.NK - nt * 16, D, acc);
+    tile_to_f32<false>(sm + L.s + nt * 16, d.NKp, 1, rows, d.NK - nt * 16, acc, scale);
+  }
+  __syncthreads();
+  {  // 4 lanes per row
+    const int lane = threadIdx.x, row = lane >> 2, part = lane & 3;
+    float* srow = sm + L.s + row * d.NKp;
+    float mx = -INFINITY;
+    if (row < rows) for (int j = part; j < d.NK; j += 4) mx = fmaxf(mx, srow[j]);
+    mx = group_max<4>(mx);
+    float sum = 0.f;
+    if (row < rows) for (int j = part; j < d.NK; j += 4) { const float e = __expf(srow[j] - mx); srow[j] = e; sum += e; }
+    sum = group_sum<4>(sum);
+    const float inv = 1.f / sum;
+    if (row < rows) for (int j = part; j < d.NK; j += 4) srow[j] *= inv;
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ bool load_rows16(const T* src, int64_t ld, int rows, int D, float* dst) {
+  bool bad = false;
+  for (int i = threadIdx.x; i < 16 * D; i += 64) {
+    const int r = i / D, dd = i - r * D;
+    const float v = (r < rows) ? to_f<T>(src[(size_t)r * ld + dd]) : 0.f;
+    bad |= (v != v);
+    dst[i] = v;
+  }
+  return bad;
+}
+
+template <typename T, bool BF>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(qavit_attn_args a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const AttnDims d = attn_dims(a);
+  const AttnLds L = attn_lds(a, false);
+  const int D = a.D;
+  const float scale = rsqrtf((float)D);
+  bool bad = false;
+  const T* q = reinterpret_cast<const T*>(a.q);
+  T* o = reinterpret_cast<T*>(a.o);
+  for (int pid = blockIdx.x; pid < a.G * a.H; pid += gridDim.x) {
+    const int g = pid / a.H, h = pid - g * a.H;
+    __syncthreads();
+    bad |= stage_keys<T, BF>(a, d, L, sm, g, h);
+    for (int q0 = 0; q0 < a.Nq; q0 += 16) {
+      const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
+      __syncthreads();
+      bad |= load_rows16<T>(q + ((size_t)g * a.Nq + q0) * a.ldq + h * D, a.ldq, rows, D, sm + L.q);
+      __syncthreads();
+      scores_softmax<BF>(a, d, L, sm, rows, scale);
+      for (int dt = 0; dt * 16 < D; ++dt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_tile<BF>(sm + L.s, d.NKp, 1, rows, sm + L.vf + dt * 16, D, 1, D - dt * 16, d.NK, acc);
+        bad |= (acc[0] != acc[0]) | (acc[1] != acc[1]) | (acc[2] != acc[2]) | (acc[3] != acc[3]);
+        tile_to_global<T>(o + ((size_t)g * a.Nq + q0) * a.ldo + h * D + dt * 16, a.ldo, rows, D - dt * 16, acc);
+      }
+    }
+  }
+  if (a.nan_flag && __any(bad) && threadIdx.x == 0) atomicOr(a.nan_flag, 1);
+}
+
+template <typename T, bool BF>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const AttnDims d = attn_dims(a);
+  const AttnLds L = attn_lds(a, true);
+  const int D = a.D;
+  const float scale = rsqrtf((float)D);
+  const int lane = threadIdx.x;
+  const T* q = reinterpret_cast<const T*>(a.q);
+  const T* dO = reinterpret_cast<const T*>(a.d_o);
+  T* dq = reinterpret_cast<T*>(a.dq);
+  T* dkt = reinterpret_cast<T*>(a.dk_tok);
+  T* dvt = reinterpret_cast<T*>(a.dv_tok);
+  const int n_acc = (a.mode == 0 ? 2 * a.L * a.KC : 0) + 2 * a.S * D;
+  const int acc0 = (a.mode == 0) ? L.acc_ek : L.acc_shk;        // accumulators are contiguous in LDS
+  for (int i = lane; i < n_acc; i += 64) sm[acc0 + i] = 0.f;
+
+  for (int pid = blockIdx.x; pid < a.G * a.H; pid += gridDim.x) {
+    const int g = pid / a.H, h = pid - g * a.H;
+    __syncthreads();
+    stage_keys<T, BF>(a, d, L, sm, g, h);
+    for (int i = lane; i < 2 * d.NK * D; i += 64) sm[L.dkf + i] = 0.f;     // dkf and dvf are adjacent
+    for (int q0 = 0; q0 < a.Nq; q0 += 16) {
+      const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
+      __syncthreads();
+      load_rows16<T>(q + ((size_t)g * a.Nq + q0) * a.ldq + h * D, a.ldq, rows, D, sm + L.q);
+      load_rows16<T>(dO + ((size_t)g * a.Nq + q0) * a.lddo + h * D, a.lddo, rows, D, sm + L.d_o);
+      __syncthreads();
+      scores_softmax<BF>(a, d, L, sm, rows, scale);                          // P in sm[L.s]
+      // dP = dO . Vf^T ;  dVf += P^T . dO
+      for (int nt = 0; nt * 16 < d.NK; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_tile<BF>(sm + L.d_o, D, 1, rows, sm + L.vf + nt * 16 * D, 1, D, d.NK - nt * 16, D, acc);
+        tile_to_f32<false>(sm + L.dp + nt * 16, d.NKp, 1, rows, d.NK - nt * 16, acc);
+        for (int dt = 0; dt * 16 < D; ++dt) {
+          f32x4 av = {0.f, 0.f, 0.f, 0.f};
+          av = mma_tile<BF>(sm + L.s + nt * 16, 1, d.NKp, d.NK - nt * 16, sm + L.d_o + dt * 16, D, 1, D - dt * 16, rows, av);
+          tile_to_f32<true>(sm + L.dvf + nt * 16 * D + dt * 16, D, 1, d.NK - nt * 16, D - dt * 16, av);
+        }
+      }
+      __syncthreads();
+      {  // dS = P * (dP - sum_j P*dP) * scale   (in place in dp)
+        const int row = lane >> 2, part = lane & 3;
+        float* prow = sm + L.s + row * d.NKp;
+        float* drow = sm + L.dp + row * d.NKp;
+        float dot = 0.f;
+        if (row < rows) for (int j = part; j < d.NK; j += 4) dot += prow[j] * drow[j];
+        dot = group_sum<4>(dot);
+        if (row < rows) for (int j = part; j < d.NK; j += 4) drow[j] = prow[j] * (drow[j] - dot) * scale;
+      }
+      __syncthreads();
+      // dQ = dS . Kf ;  dKf += dS^T . Q
+      for (int dt = 0; dt * 16 < D; ++dt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_tile<BF>(sm + L.dp, d.NKp, 1, rows, sm + L.kf + dt * 16, D, 1, D - dt * 16, d.NK, acc);
+        tile_to_global<T>(dq + ((size_t)g * a.Nq + q0) * a.lddq + h * D + dt * 16, a.lddq, rows, D - dt * 16, acc);
+        for (int nt = 0; nt * 16 < d.NK; ++nt) {
+          f32x4 ak = {0.f, 0.f, 0.f, 0.f};
+          ak = mma_tile<BF>(sm + L.dp + nt * 16, 1, d.NKp, d.NK - nt * 16, sm + L.q + dt * 16, D, 1, D - dt * 16, rows, ak);
+          tile_to_f32<true>(sm + L.dkf + nt * 16 * D + dt * 16, D, 1, d.NK - nt * 16, D - dt * 16, ak);
+        }
+      }
+    }
+    __syncthreads();
+    // shared-row gradients (this wave's head slice)
+    for (int i = lane; i < a.S * D; i += 64) {
+      sm[L.acc_shk + i] += sm[L.dkf + d.NKo * D + i];
+      sm[L.acc_shv + i] += sm[L.dvf + d.NKo * D + i];
+    }
+    if (a.mode == 0) {
+      // dk_tok[l][d] = sum_j E_k[l][j] dKf[j][d] ;  dE_k[l][j] += sum_d kt[l][d] dKf[j][d]
+      for (int lt = 0; lt * 16 < a.L; ++lt) {
+        for (int dt = 0; dt * 16 < D; ++dt) {
+          f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+          ak = mma_tile<BF>(sm + L.ek + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dkf + dt * 16, D, 1, D - dt * 16, a.KC, ak);
+          av = mma_tile<BF>(sm + L.ev + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dvf + dt * 16, D, 1, D - dt * 16, a.KC, av);
+          tile_to_global<T>(dkt + ((size_t)g * a.L + lt * 16) * a.lddk + h * D + dt * 16, a.lddk, a.L - lt * 16, D - dt * 16, ak);
+          tile_to_global<T>(dvt + ((size_t)g * a.L + lt * 16) * a.lddv + h * D + dt * 16, a.lddv, a.L - lt * 16, D - dt * 16, av);
+        }
+        for (int jt = 0; jt * 16 < a.KC; ++jt) {
+          f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+          ak = mma_tile<BF>(sm + L.kt + lt * 16 * D, D, 1, a.L - lt * 16, sm + L.dkf + jt * 16 * D, 1, D, a.KC - jt * 16, D, ak);
+          av = mma_tile<BF>(sm + L.vt + lt * 16 * D, D, 1, a.L - lt * 16, sm + L.dvf + jt * 16 * D, 1, D, a.KC - jt * 16, D, av);
+          tile_to_f32<true>(sm + L.acc_ek + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, ak);
+          tile_to_f32<true>(sm + L.acc_ev + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, av);
+        }
+      }
+    } else {
+      for (int i = lane; i < a.L * D; i += 64) {
+        const int l = i / D, dd = i - l * D;
+        dkt[((size_t)g * a.L + l) * a.lddk + h * D + dd] = from_f<T>(sm[L.dkf + i]);
+        dvt[((size_t)g * a.L + l) * a.lddv + h * D + dd] = from_f<T>(sm[L.dvf + i]);
+      }
+    }
+  }
+  __syncthreads();
+  float* ws = a.ws + (size_t)blockIdx.x * attn_ws_per_wave(a);
+  for (int i = lane; i < n_acc; i += 64) ws[i] = sm[acc0 + i];
+}
+
+// fold the per-wave partials into the gradient buffers: one thread per output element
+__global__ __launch_bounds__(256) void attn_reduce_kernel(qavit_attn_args a, int nwaves) {
+  const int nE = (a.mode == 0) ? a.L * a.KC : 0;
+  const int nS = a.S * a.D;
+  const int per = 2 * nE + 2 * nS;
+  const int total = 2 * nE + 2 * nS * a.H;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float s = 0.f;
+  if (i < 2 * nE) {
+    for (int w = 0; w < nwaves; ++w) s += a.ws[(size_t)w * per + i];
+    float* dst = (i < nE) ? a.dE_k + i : a.dE_v + (i - nE);
+    if ((i < nE) ? (a.dE_k != nullptr) : (a.dE_v != nullptr)) *dst += s;
+  } else {
+    int r = i - 2 * nE;                 // [which(2)][h][s][d]
+    const int which = r / (nS * a.H); r -= which * nS * a.H;
+    const int h = r / nS; r -= h * nS;
+    const int srow = r / a.D, dd = r - srow * a.D;
+    for (int w = h; w < nwaves; w += a.H) s += a.ws[(size_t)w * per + 2 * nE + which * nS + srow * a.D + dd];
+    float* dst = which == 0 ? a.dsh_k : a.dsh_v;
+    if (dst) dst[(size_t)srow * a.H * a.D + h * a.D + dd] += s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nan_guard_kernel(T* x, int64_t n, int* flag) {
+  if (*flag == 0) return;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = from_f<T>(0.f);
+}
+__global__ void nan_flag_clear_kernel(int* flag) { *flag = 0; }
+
+static int attn_validate(const qavit_attn_args* a, bool bwd) {
+  if (!a) return set_error(QAVIT_EINVAL, "attn: null args");
+  if (a->G <= 0 || a->Nq <= 0 || a->H <= 0 || a->D <= 0 || a->S < 0 || a->L < 0) return set_error(QAVIT_EINVAL, "attn: bad dimensions");
+  if (a->mode != 0 && a->mode != 1) return set_error(QAVIT_EINVAL, "attn: mode must be 0 or 1");
+  if (a->mode == 0 && (a->KC <= 0 || a->L <= 0 || !a->E_k || !a->E_v)) return set_error(QAVIT_EINVAL, "attn: Linformer mode needs E_k/E_v, L and KC");
+  if (!a->q || !a->o || (a->L > 0 && (!a->k_tok || !a->v_tok)) || (a->S > 0 && (!a->sh_k || !a->sh_v)))
+    return set_error(QAVIT_EINVAL, "attn: null operand");
+  if (attn_dims(*a).NK <= 0) return set_error(QAVIT_EINVAL, "attn: no keys");
+  if (bwd) {
+    if (!a->d_o || !a->dq || (a->L > 0 && (!a->dk_tok || !a->dv_tok)) || !a->ws) return set_error(QAVIT_EINVAL, "attn_bwd: null operand");
+  }
+  const AttnLds L = attn_lds(*a, bwd);
+  if ((size_t)L.total * 4 > 160 * 1024) return set_error(QAVIT_EINVAL, "attn: problem does not fit one wave's LDS slice");
+  return QAVIT_OK;
+}
+
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" int64_t qavit_attn_ws_floats(const qavit_attn_args* a) {
+  if (!a) return 0;
+  return (int64_t)attn_grid(*a, true) * attn_ws_per_wave(*a);
+}
+
+template <typename T, bool BF>
+static int attn_launch(const qavit_attn_args& a, bool bwd, hipStream_t st) {
+  const AttnLds L = attn_lds(a, bwd);
+  const size_t smem = (size_t)L.total * sizeof(float);
+  const int grid = attn_grid(a, bwd);
+  if (!bwd) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<T, BF>), dim3(grid), dim3(64), smem, st, a);
+    return check_launch("attn_fwd");
+  }
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+  if (a.ws_floats < (int64_t)grid * attn_ws_per_wave(a)) return set_error(QAVIT_EINVAL, "attn_bwd: workspace too small");
+  hipLaunchKernelGGL((attn_bwd_kernel<T, BF>), dim3(grid), dim3(64), smem, st, a);
+  const int nE = (a.mode == 0) ? a.L * a.KC : 0;
+  const int total = 2 * nE + 2 * a.S * a.D * a.H;
+  if (total > 0) hipLaunchKernelGGL(attn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a, grid);
+  return check_launch("attn_bwd");
+}
+
+extern "C" int qavit_attn_fwd(const qavit_attn_args* a, void* stream) {
+  int rc = attn_validate(a, false);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == QAVIT_F32) return attn_launch<float, false>(*a, false, st);
+  if (a->dtype == QAVIT_BF16) return attn_launch<bf16, true>(*a, false, st);
+  return set_error(QAVIT_EINVAL, "attn_fwd: unknown dtype");
+}
+
+extern "C" int qavit_attn_bwd(const qavit_attn_args* a, void* stream) {
+  int rc = attn_validate(a, true);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == QAVIT_F32) return attn_launch<float, false>(*a, true, st);
+  if (a->dtype == QAVIT_BF16) return attn_launch<bf16, true>(*a, true, st);
+  return set_error(QAVIT_EINVAL, "attn_bwd: unknown dtype");
+}
+
+extern "C" int qavit_nan_guard(int dtype, void* x, int64_t n, int* flag, void* stream) {
+  if (!x || !flag || n <= 0) return set_error(QAVIT_EINVAL, "nan_guard: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int nb = (int)((n + 2047) / 2048);
+  if (nb > 2048) nb = 2048;
+  if (dtype == QAVIT_F32) hipLaunchKernelGGL((nan_guard_kernel<float>), dim3(nb), dim3(256), 0, st, (float*)x, n, flag);
+  else if (dtype == QAVIT_BF16) hipLaunchKernelGGL((nan_guard_kernel<bf16>), dim3(nb), dim3(256), 0, st, (bf16*)x, n, flag);
+  else return set_error(QAVIT_EINVAL, "nan_guard: unknown dtype");
+  hipLaunchKernelGGL(nan_flag_clear_kernel, dim3(1), dim3(1), 0, st, flag);
+  return check_launch("nan_guard");
+}

@@ -1,0 +1,169 @@
+// GlobalTokenBank.write (train mode, no gradient).  See include/qavit.h.
+//   stats : per image  tn = LN_write(LN_branch(tokens));  w = softmax_tokens(tn Wg^T + bg);  U += w^T tn
+//           (workgroup partials -> one reduction into acc[S,C])
+//   apply : U/B -> clamp -> bank update (+ the Linear(192,192) applied to the 16 mean rows instead of to
+//           every token: exact because each softmax column sums to one)
+#include "common.cuh"
+#include "mma_lds.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+
+namespace qv {
+
+constexpr int BANK_MAX_WG = 256;
+
+template <typename T, bool BF>
+__global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr,
+                                                         const float* Wg, const float* bg, float* ws, int B, int N, int C, int S, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* tn = sm;                    // [N][C]
+  float* lg = tn + N * C;            // [N][S] logits -> weights
+  float* U = lg + N * S;             // [S][C] accumulator over this workgroup's images
+  float* red = U + S * C;            // [256]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float invC = 1.f / (float)C;
+  for (int i = t; i < S * C; i += 256) U[i] = 0.f;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = t; i < N * C; i += 256) tn[i] = to_f<T>(tokens[(size_t)b * N * C + i]);
+    __syncthreads();
+    // two chained LayerNorms per row
+    for (int r = wave; r < N; r += 4) {
+      float* row = tn + r * C;
+      for (int pass = 0; pass < 2; ++pass) {
+        const float* g = pass == 0 ? gbr : gwr;
+        const float* bb = pass == 0 ? bbr : bwr;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += row[c];
+        const float mean = wave_sum(s) * invC;
+        float s2 = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = row[c] - mean; s2 += d * d; }
+        const float rstd = rsqrtf(wave_sum(s2) * invC + eps);
+        for (int c = lane; c < C; c += 64) row[c] = (row[c] - mean) * rstd * g[c] + bb[c];
+      }
+    }
+    __syncthreads();
+    // logits[n][s] = tn[n,:] . Wg[s,:] + bg[s]
+    {
+      const int nt_n = (N + 15) / 16, st_n = (S + 15) / 16;
+      for (int tile = wave; tile < nt_n * st_n; tile += 4) {
+        const int nt = tile / st_n, stt = tile - nt * st_n;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_tile<BF>(tn + nt * 16 * C, C, 1, N - nt * 16, Wg + (size_t)stt * 16 * C, 1, C, S - stt * 16, C, acc);
+        const int col = tile_col();
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = nt * 16 + tile_row(reg);
+          if (row < N && stt * 16 + col < S) lg[row * S + stt * 16 + col] = acc[reg] + bg[stt * 16 + col];
+        }
+      }
+    }
+    __syncthreads();
+    // softmax over tokens per slot: S columns, 256/S threads per column (S divides 256)
+    {
+      const int parts = 256 / S, s_ = t % S, part = t / S;
+      float mx = -INFINITY;
+      for (int n = part; n < N; n += parts) mx = fmaxf(mx, lg[n * S + s_]);
+      red[t] = mx; __syncthreads();
+      mx = -INFINITY;
+      for (int p = 0; p < parts; ++p) mx = fmaxf(mx, red[p * S + s_]);
+      __syncthreads();
+      float sum = 0.f;
+      for (int n = part; n < N; n += parts) { const float e = __expf(lg[n * S + s_] - mx); lg[n * S + s_] = e; sum += e; }
+      red[t] = sum; __syncthreads();
+      sum = 0.f;
+      for (int p = 0; p < parts; ++p) sum += red[p * S + s_];
+      const float inv = 1.f / sum;
+      for (int n = part; n < N; n += parts) lg[n * S + s_] *= inv;
+    }
+    __syncthreads();
+    // U[s][c] += sum_n w[n][s] tn[n][c]
+    {
+      const int st_n = (S + 15) / 16, ct_n = (C + 15) / 16;
+      for (int tile = wave; tile < st_n * ct_n; tile += 4) {
+        const int stt = tile / ct_n, ct = tile - stt * ct_n;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_tile<BF>(lg + stt * 16, 1, S, S - stt * 16, tn + ct * 16, C, 1, C - ct * 16, N, acc);
+        tile_to_f32<true>(U + stt * 16 * C + ct * 16, C, 1, S - stt * 16, C - ct * 16, acc);
+      }
+    }
+  }
+  __syncthreads();
+  float* out = ws + (size_t)blockIdx.x * S * C;
+  for (int i = t; i < S * C; i += 256) out[i] = U[i];
+}
+
+__global__ __launch_bounds__(256) void bank_reduce_kernel(const float* ws, float* acc, int nparts, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int w = 0; w < nparts; ++w) s += ws[(size_t)w * n + i];
+  acc[i] = s;
+}
+
+// one workgroup per slot s
+__global__ __launch_bounds__(256) void bank_apply_kernel(const float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
+                                                         const int64_t* update_count, int S, int C, float inv_batch, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float u[];   // [C]
+  const int s = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) u[c] = acc[s * C + c] * inv_batch;
+  __syncthreads();
+  float rate, cu, cb;
+  if (mode == 1) { rate = 0.01f; cu = 0.1f; cb = 1.0f; }
+  else { rate = (update_count && update_count[0] >= 1000) ? 0.01f : 0.005f; cu = 0.05f; cb = 0.5f; }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float dotk = bc[c];
+    const float* wr = Wc + (size_t)c * C;
+    for (int k = 0; k < C; ++k) dotk += u[k] * wr[k];
+    const float uk = fminf(fmaxf(dotk, -cu), cu);
+    const float uv = fminf(fmaxf(u[c], -cu), cu);
+    const float nk = bank_k[s * C + c] + rate * uk;
+    const float nv = bank_v[s * C + c] + rate * uv;
+    bank_k[s * C + c] = fminf(fmaxf(nk, -cb), cb);
+    bank_v[s * C + c] = fminf(fmaxf(nv, -cb), cb);
+  }
+}
+__global__ void bank_count_kernel(int64_t* update_count) { update_count[0] += 1; }
+
+static int bank_grid(int B) { return B < BANK_MAX_WG ? B : BANK_MAX_WG; }
+
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" int64_t qavit_bank_ws_floats(int B, int N, int C, int S) {
+  (void)N;
+  return (int64_t)bank_grid(B) * S * C;
+}
+
+extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const float* b_branch,
+                                const float* g_write, const float* b_write, const float* Wg, const float* bg,
+                                float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps, void* stream) {
+  if (!tokens || !g_branch || !b_branch || !g_write || !b_write || !Wg || !bg || !acc || !ws) return set_error(QAVIT_EINVAL, "bank_stats: null operand");
+  if (B <= 0 || N <= 0 || C <= 0 || S <= 0 || S > 256 || (256 % S) != 0) return set_error(QAVIT_EINVAL, "bank_stats: bad dimensions (S must divide 256)");
+  const int grid = bank_grid(B);
+  if (ws_floats < (int64_t)grid * S * C) return set_error(QAVIT_EINVAL, "bank_stats: workspace too small");
+  const size_t smem = ((size_t)N * C + (size_t)N * S + (size_t)S * C + 256) * sizeof(float);
+  if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "bank_stats: token tile too large for LDS");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_F32) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((bank_stats_kernel<float, false>), dim3(grid), dim3(256), smem, st, (const float*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);
+  } else if (dtype == QAVIT_BF16) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((bank_stats_kernel<bf16, true>), dim3(grid), dim3(256), smem, st, (const bf16*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);
+  } else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
+  const int n = S * C;
+  hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, acc, grid, n);
+  return check_launch("bank_stats");
+}
+
+extern "C" int qavit_bank_apply(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
+                                int64_t* update_count, int S, int C, float inv_batch, int mode, void* stream) {
+  if (!acc || !Wc || !bc || !bank_k || !bank_v || S <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "bank_apply: bad arguments");
+  if (mode == 0 && !update_count) return set_error(QAVIT_EINVAL, "bank_apply: mode 0 needs update_count");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(256), (size_t)C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode);
+  if (mode == 0) hipLaunchKernelGGL(bank_count_kernel, dim3(1), dim3(1), 0, st, update_count);
+  return check_launch("bank_apply");
+}

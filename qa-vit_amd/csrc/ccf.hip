@@ -1,0 +1,243 @@
+// CCF-FFN middle: h2 = LN2( scale * dwconv3x3( LN1(h) ) + bias ) on channel-last tokens [B, Hs*Ws, C].
+// HBM-bound: every activation element is read once and written once; the 3x3 depthwise stencil, both
+// LayerNorms and (in backward) all parameter-gradient partial sums stay in LDS.  One workgroup per image.
+#include "common.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+
+namespace qv {
+
+constexpr int F_LN = 1, F_BIAS = 2, F_SCALE = 4;
+
+// row-wise LN over C of buf[N][C] in place; optional stats out
+__device__ __forceinline__ void ln_rows(float* buf, int N, int C, const float* g, const float* b, float eps, float* mean_o, float* rstd_o) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  for (int r = wave; r < N; r += 4) {
+    float* row = buf + r * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += row[c];
+    const float mean = wave_sum(s) * invC;
+    float s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = row[c] - mean; s2 += d * d; }
+    const float rstd = rsqrtf(wave_sum(s2) * invC + eps);
+    for (int c = lane; c < C; c += 64) row[c] = (row[c] - mean) * rstd * g[c] + b[c];
+    if (lane == 0) { if (mean_o) mean_o[r] = mean; if (rstd_o) rstd_o[r] = rstd; }
+  }
+}
+
+// t[n][c] = scale[c] * sum_{dy,dx} w[c][dy][dx] * a[(y+dy-1, x+dx-1)][c] + bias[c]
+__device__ __forceinline__ void dwconv_rows(const float* a, float* t, const float* w, const float* cbias, const float* cscale,
+                                            int Hs, int Ws, int C, float* raw) {
+  const int N = Hs * Ws;
+  for (int i = threadIdx.x; i < N * C; i += 256) {
+    const int n = i / C, c = i - n * C;
+    const int y = n / Ws, x = n - y * Ws;
+    float s = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = y + dy - 1, xx = x + dx - 1;
+        if (yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) s += w[c * 9 + dy * 3 + dx] * a[(yy * Ws + xx) * C + c];
+      }
+    if (cbias) s += cbias[c];
+    if (raw) raw[i] = s;
+    if (cscale) s *= cscale[c];
+    t[i] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ccf_fwd_kernel(qavit_ccf_args p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = p.Hs * p.Ws, C = p.C;
+  float* a = sm;               // [N][C]
+  float* t = sm + N * C;       // [N][C]
+  const T* h = reinterpret_cast<const T*>(p.h);
+  T* out = reinterpret_cast<T*>(p.out);
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * C; i += 256) a[i] = to_f<T>(h[(size_t)b * N * C + i]);
+    __syncthreads();
+    if (p.flags & F_LN) { ln_rows(a, N, C, p.g1, p.b1, p.eps, p.mean1 + (size_t)b * N, p.rstd1 + (size_t)b * N); __syncthreads(); }
+    dwconv_rows(a, t, p.w, (p.flags & F_BIAS) ? p.cbias : nullptr, (p.flags & F_SCALE) ? p.cscale : nullptr, p.Hs, p.Ws, C, nullptr);
+    __syncthreads();
+    if (p.flags & F_LN) { ln_rows(t, N, C, p.g2, p.b2, p.eps, p.mean2 + (size_t)b * N, p.rstd2 + (size_t)b * N); __syncthreads(); }
+    for (int i = threadIdx.x; i < N * C; i += 256) out[(size_t)b * N * C + i] = from_f<T>(t[i]);
+  }
+}
+
+// LN backward over rows of LDS buffers: xin holds the LN INPUT rows, gy the output gradient (overwritten by dx).
+// pg/pb: [C] LDS partial sums (LDS atomics across the 4 waves)
+__device__ __forceinline__ void ln_rows_bwd(const float* xin, float* gy, int N, int C, const float* g, const float* mean, const float* rstd,
+                                            float* pg, float* pb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  for (int r = wave; r < N; r += 4) {
+    const float* xr = xin + r * C;
+    float* gr = gy + r * C;
+    const float mu = mean[r], rs = rstd[r];
+    float c1 = 0.f, c2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (xr[c] - mu) * rs, gg = gr[c] * g[c];
+      c1 += gg * xh; c2 += gg;
+    }
+    c1 = wave_sum(c1) * invC; c2 = wave_sum(c2) * invC;
+    for (int c = lane; c < C; c += 64) {
+      const float d = gr[c];
+      const float xh = (xr[c] - mu) * rs;
+      atomicAdd(pg + c, d * xh);
+      atomicAdd(pb + c, d);
+      gr[c] = rs * (d * g[c] - c2 - xh * c1);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ccf_bwd_kernel(qavit_ccf_args p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = p.Hs * p.Ws, C = p.C;
+  float* hin = sm;                 // [N][C] raw input h (LN1 input)
+  float* a = hin + N * C;          // [N][C] LN1 output
+  float* raw = a + N * C;          // [N][C] conv (+bias) before scale
+  float* t = raw + N * C;          // [N][C] LN2 input, then gradients in place
+  float* part = t + N * C;         // parameter partials: dg1,db1,dg2,db2 [C each], dcb [C], dcs [C], dw [9C]
+  float* pg1 = part, *pb1 = part + C, *pg2 = part + 2 * C, *pb2 = part + 3 * C, *pcb = part + 4 * C, *pcs = part + 5 * C, *pw = part + 6 * C;
+  const T* h = reinterpret_cast<const T*>(p.h);
+  const T* dout = reinterpret_cast<const T*>(p.d_out);
+  T* dh = reinterpret_cast<T*>(p.d_h);
+  const bool ln = p.flags & F_LN, hb = p.flags & F_BIAS, hs = p.flags & F_SCALE;
+  for (int i = threadIdx.x; i < 15 * C; i += 256) part[i] = 0.f;
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * C; i += 256) { const float v = to_f<T>(h[(size_t)b * N * C + i]); hin[i] = v; a[i] = v; }
+    __syncthreads();
+    if (ln) { ln_rows(a, N, C, p.g1, p.b1, p.eps, nullptr, nullptr); __syncthreads(); }
+    dwconv_rows(a, t, p.w, hb ? p.cbias : nullptr, hs ? p.cscale : nullptr, p.Hs, p.Ws, C, raw);
+    __syncthreads();
+    // gradient wrt LN2 output -> wrt t (in place in a scratch: reuse `a`?  a is still needed for dw) -> use t after copying LN2 input
+    // step 1: gy := dout ; LN2 backward needs its input t: keep t as xin and put gy into `hin`-independent buffer `raw`? raw is needed for dscale.
+    // => fold dscale / dbias first using raw, then reuse raw as the gradient buffer.
+    // load dout into registers-per-element order: we process element-wise passes over LDS buffers.
+    // pass A: gy (into raw2 = raw after consuming raw) requires dt first, so: gy -> tmp in `a2`:
+    // To keep LDS at 4 buffers we stage gy into `t`'s twin only after LN2-bwd; implement LN2-bwd with gy read from global.
+    {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const float invC = 1.f / (float)C;
+      for (int r = wave; r < N; r += 4) {
+        const T* gr = dout + ((size_t)b * N + r) * C;
+        float* tr = t + r * C;
+        if (ln) {
+          const float mu = p.mean2[(size_t)b * N + r], rs = p.rstd2[(size_t)b * N + r];
+          float c1 = 0.f, c2 = 0.f;
+          for (int c = lane; c < C; c += 64) {
+            const float xh = (tr[c] - mu) * rs, gg = to_f<T>(gr[c]) * p.g2[c];
+            c1 += gg * xh; c2 += gg;
+          }
+          c1 = wave_sum(c1) * invC; c2 = wave_sum(c2) * invC;
+          for (int c = lane; c < C; c += 64) {
+            const float d = to_f<T>(gr[c]);
+            const float xh = (tr[c] - mu) * rs;
+            atomicAdd(pg2 + c, d * xh);
+            atomicAdd(pb2 + c, d);
+            tr[c] = rs * (d * p.g2[c] - c2 - xh * c1);          // dt
+          }
+        } else {
+          for (int c = lane; c < C; c += 64) tr[c] = to_f<T>(gr[c]);
+        }
+      }
+    }
+    __syncthreads();
+    // dt -> dconv (gradient wrt conv+bias output), dscale, dbias
+    for (int i = threadIdx.x; i < N * C; i += 256) {
+      const int c = i % C;
+      const float dt = t[i];
+      if (hs) { atomicAdd(pcs + c, dt * raw[i]); t[i] = dt * p.cscale[c]; }
+      if (hb) atomicAdd(pcb + c, t[i]);
+    }
+    __syncthreads();
+    // dw[c][dy][dx] += sum_n dconv[n][c] * a[n + off][c] ;  da[n'][c] = sum_{dy,dx} w[c][dy][dx] dconv[n' - off][c]  (into raw)
+    for (int i = threadIdx.x; i < N * C; i += 256) {
+      const int n = i / C, c = i - n * C;
+      const int y = n / p.Ws, x = n - y * p.Ws;
+      const float dc = t[i];
+      float da = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int yy = y + dy - 1, xx = x + dx - 1;           // forward tap read by output (y,x)
+          if (yy >= 0 && yy < p.Hs && xx >= 0 && xx < p.Ws) atomicAdd(pw + c * 9 + dy * 3 + dx, dc * a[(yy * p.Ws + xx) * C + c]);
+          const int yo = y - dy + 1, xo = x - dx + 1;           // outputs that read input (y,x) through tap (dy,dx)
+          if (yo >= 0 && yo < p.Hs && xo >= 0 && xo < p.Ws) da += p.w[c * 9 + dy * 3 + dx] * t[(yo * p.Ws + xo) * C + c];
+        }
+      raw[i] = da;
+    }
+    __syncthreads();
+    if (ln) {
+      const float* m1 = p.mean1 + (size_t)b * N;
+      const float* r1 = p.rstd1 + (size_t)b * N;
+      ln_rows_bwd(hin, raw, N, C, p.g1, m1, r1, pg1, pb1);
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < N * C; i += 256) dh[(size_t)b * N * C + i] = from_f<T>(raw[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    if (ln) { atomic_add_f(p.dg1 + c, pg1[c]); atomic_add_f(p.db1 + c, pb1[c]); atomic_add_f(p.dg2 + c, pg2[c]); atomic_add_f(p.db2 + c, pb2[c]); }
+    if (hb && p.dcbias) atomic_add_f(p.dcbias + c, pcb[c]);
+    if (hs && p.dcscale) atomic_add_f(p.dcscale + c, pcs[c]);
+  }
+  for (int i = threadIdx.x; i < 9 * C; i += 256) atomic_add_f(p.dw + i, pw[i]);
+}
+
+}  // namespace qv
+
+using namespace qv;
+
+static int ccf_validate(const qavit_ccf_args* a, bool bwd) {
+  if (!a || !a->h || !a->w || a->B <= 0 || a->Hs <= 0 || a->Ws <= 0 || a->C <= 0) return set_error(QAVIT_EINVAL, "ccf_mid: bad arguments");
+  if ((a->flags & F_LN) && (!a->g1 || !a->b1 || !a->g2 || !a->b2 || !a->mean1 || !a->rstd1 || !a->mean2 || !a->rstd2))
+    return set_error(QAVIT_EINVAL, "ccf_mid: LayerNorm flag set but norm arguments missing");
+  if ((a->flags & F_BIAS) && !a->cbias) return set_error(QAVIT_EINVAL, "ccf_mid: bias flag set but bias missing");
+  if ((a->flags & F_SCALE) && !a->cscale) return set_error(QAVIT_EINVAL, "ccf_mid: scale flag set but scale missing");
+  if (!bwd && !a->out) return set_error(QAVIT_EINVAL, "ccf_mid_fwd: null output");
+  if (bwd && (!a->d_out || !a->d_h || !a->dw)) return set_error(QAVIT_EINVAL, "ccf_mid_bwd: null gradient buffers");
+  if (bwd && (a->flags & F_LN) && (!a->dg1 || !a->db1 || !a->dg2 || !a->db2)) return set_error(QAVIT_EINVAL, "ccf_mid_bwd: null norm gradient buffers");
+  return QAVIT_OK;
+}
+
+extern "C" int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream) {
+  int rc = ccf_validate(a, false);
+  if (rc) return rc;
+  const size_t smem = (size_t)2 * a->Hs * a->Ws * a->C * sizeof(float);
+  if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_fwd: image tile too large for LDS");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = a->B < 2048 ? a->B : 2048;
+  if (a->dtype == QAVIT_F32) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((ccf_fwd_kernel<float>), dim3(grid), dim3(256), smem, st, *a);
+  } else if (a->dtype == QAVIT_BF16) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((ccf_fwd_kernel<bf16>), dim3(grid), dim3(256), smem, st, *a);
+  } else return set_error(QAVIT_EINVAL, "ccf_mid_fwd: unknown dtype");
+  return check_launch("ccf_mid_fwd");
+}
+
+extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
+  int rc = ccf_validate(a, true);
+  if (rc) return rc;
+  const size_t smem = ((size_t)4 * a->Hs * a->Ws * a->C + 15 * (size_t)a->C) * sizeof(float);
+  if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_bwd: image tile too large for LDS");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = a->B < 512 ? a->B : 512;
+  if (a->dtype == QAVIT_F32) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((ccf_bwd_kernel<float>), dim3(grid), dim3(256), smem, st, *a);
+  } else if (a->dtype == QAVIT_BF16) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((ccf_bwd_kernel<bf16>), dim3(grid), dim3(256), smem, st, *a);
+  } else return set_error(QAVIT_EINVAL, "ccf_mid_bwd: unknown dtype");
+  return check_launch("ccf_mid_bwd");
+}

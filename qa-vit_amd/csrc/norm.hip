@@ -1,0 +1,148 @@
+// nn.LayerNorm over the channel axis, forward and backward.  HBM-bound streaming kernels: one wavefront
+// per row, 64 lanes stride the C <= 1024 channels, statistics by wave shuffles (no LDS in forward).
+#include "common.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+
+namespace qv {
+
+constexpr int LN_MAX_PER_LANE = 16;   // C <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, T* y, const float* gamma, const float* beta, float eps,
+                                                            int rows, int C, float* mean_o, float* rstd_o,
+                                                            const float* add, int add_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const T* xr = x + (size_t)row * C;
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < C) ? to_f<T>(xr[c]) : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) * invC;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      const float dlt = (c < C) ? v[i] - mean : 0.f;
+      s2 += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * invC + eps);
+    T* yr = y + (size_t)row * C;
+    const float* ar = add ? add + (size_t)(row % add_rows) * C : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (ar) o += ar[c];
+        yr[c] = from_f<T>(o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_o) mean_o[row] = mean;
+      if (rstd_o) rstd_o[row] = rstd;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                            const float* rstd, T* dx, float* dgamma, float* dbeta,
+                                                            int rows, int C, float* dadd, int add_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  float pg[LN_MAX_PER_LANE], pb[LN_MAX_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const T* xr = x + (size_t)row * C;
+    const T* gr = dy + (size_t)row * C;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[LN_MAX_PER_LANE], g[LN_MAX_PER_LANE];
+    float c1 = 0.f, c2 = 0.f;
+    float* dar = dadd ? dadd + (size_t)(row % add_rows) * C : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        const float d = to_f<T>(gr[c]);
+        xh[i] = (to_f<T>(xr[c]) - mu) * rs;
+        g[i] = d * gamma[c];
+        pg[i] += d * xh[i];
+        pb[i] += d;
+        c1 += g[i] * xh[i];
+        c2 += g[i];
+        if (dar) atomic_add_f(dar + c, d);
+      } else { xh[i] = 0.f; g[i] = 0.f; }
+    }
+    c1 = wave_sum(c1) * invC;
+    c2 = wave_sum(c2) * invC;
+    T* dxr = dx + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) dxr[c] = from_f<T>(rs * (g[i] - c2 - xh[i] * c1));
+    }
+  }
+  // reduce the 4 waves' partial dgamma / dbeta through LDS, one atomic per column per workgroup
+  __shared__ float red[2][4][64];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    if (64 * i >= C) break;
+    __syncthreads();
+    red[0][wave][lane] = pg[i];
+    red[1][wave][lane] = pb[i];
+    __syncthreads();
+    if (wave == 0) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        if (dgamma) atomic_add_f(dgamma + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+        if (dbeta) atomic_add_f(dbeta + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+      }
+    }
+  }
+}
+
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
+                                   float eps, int rows, int C, float* mean, float* rstd,
+                                   const float* add, int add_rows, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_fwd: bad arguments");
+  if (C > 64 * LN_MAX_PER_LANE) return set_error(QAVIT_EINVAL, "layernorm_fwd: C > 1024 unsupported");
+  if (add && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_fwd: add_rows must be positive");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = (rows + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  if (dtype == QAVIT_F32)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows);
+  else if (dtype == QAVIT_BF16)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows);
+  else return set_error(QAVIT_EINVAL, "layernorm_fwd: unknown dtype");
+  return check_launch("layernorm_fwd");
+}
+
+extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
+                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                   int rows, int C, float* dadd, int add_rows, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: bad arguments");
+  if (C > 64 * LN_MAX_PER_LANE) return set_error(QAVIT_EINVAL, "layernorm_bwd: C > 1024 unsupported");
+  if (dadd && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: add_rows must be positive");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = (rows + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  if (dtype == QAVIT_F32)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, C, dadd, add_rows);
+  else if (dtype == QAVIT_BF16)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, rows, C, dadd, add_rows);
+  else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
+  return check_launch("layernorm_bwd");
+}

@@ -1,0 +1,372 @@
+// Error state, version, and the small streaming kernels (weight packing, rng, dropout, token mean,
+// hybrid fuse, scale-add, patchify, optimizer).
+#include "common.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+#include <stdio.h>
+#include <string.h>
+
+namespace qv {
+
+static thread_local char g_err[256] = "";
+
+int set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return QAVIT_ELAUNCH;
+  }
+  return QAVIT_OK;
+}
+
+static inline int blocks_for(int64_t n, int per_block, int cap = 4096) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: dst = cast(src), dstT = cast(src)^T.  One workgroup column per 32x32 tile.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const qavit_pack_desc* descs, int tiles_per_desc) {
+  const qavit_pack_desc d = descs[blockIdx.y];
+  __shared__ float tile[32][33];
+  const int tcols = (d.cols + 31) / 32, trows = (d.rows + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int t = blockIdx.x; t < trows * tcols; t += tiles_per_desc) {
+    const int tr = t / tcols, tc = t - tr * tcols;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+      const int r = tr * 32 + ty + i, c = tc * 32 + tx;
+      const float v = (r < d.rows && c < d.cols) ? d.src[(size_t)r * d.cols + c] : 0.f;
+      tile[ty + i][tx] = v;
+      if (d.dst && r < d.rows && c < d.cols) reinterpret_cast<T*>(d.dst)[(size_t)r * d.cols + c] = from_f<T>(v);
+    }
+    __syncthreads();
+    if (d.dstT) {
+#pragma unroll
+      for (int i = 0; i < 32; i += 8) {
+        const int c = tc * 32 + ty + i, r = tr * 32 + tx;   // output row = c, output col = r
+        if (r < d.rows && c < d.cols) reinterpret_cast<T*>(d.dstT)[(size_t)c * d.rows + r] = from_f<T>(tile[tx][ty + i]);
+      }
+    }
+  }
+}
+
+__global__ void rng_advance_kernel(int64_t* rng) { rng[1] += 1; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, int64_t n, float p, int site, const int64_t* rng) {
+  const uint32_t key = rng_key(rng, site);
+  const float inv = 1.f / (1.f - p);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = from_f<T>(to_f<T>(x[i]) * drop_factor(key, (uint32_t)i, p, inv));
+}
+
+// y[b,c] = mean_n x[b,n,c]
+template <typename T>
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const T* x, T* y, int B, int N, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += to_f<T>(x[((size_t)b * N + n) * C + c]);
+    y[(size_t)b * C + c] = from_f<T>(s / (float)N);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const T* dy, T* dx, int B, int N, int C) {
+  const int b = blockIdx.x;
+  const float inv = 1.f / (float)N;
+  for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+    const int c = i % C;
+    dx[(size_t)b * N * C + i] = from_f<T>(to_f<T>(dy[(size_t)b * C + c]) * inv);
+  }
+}
+
+// HybridFusion: y = x * softmax(fw)[col / Cb]
+__device__ __forceinline__ void softmax_small(const float* fw, int nb, float* w) {
+  float mx = -INFINITY;
+  for (int i = 0; i < nb; ++i) mx = fmaxf(mx, fw[i]);
+  float s = 0.f;
+  for (int i = 0; i < nb; ++i) { w[i] = __expf(fw[i] - mx); s += w[i]; }
+  for (int i = 0; i < nb; ++i) w[i] /= s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void hybrid_fwd_kernel(const T* x, const float* fw, T* y, int64_t n, int nb, int Cb) {
+  float w[8];
+  softmax_small(fw, nb, w);
+  const int C = nb * Cb;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = from_f<T>(to_f<T>(x[i]) * w[(int)(i % C) / Cb]);
+}
+// dx = dy * w[b];  ds[b] = sum dy*x over branch b;  dfw[j] += sum_b ds[b] * w[b] * (delta_bj - w[j])
+template <typename T>
+__global__ __launch_bounds__(256) void hybrid_bwd_kernel(const T* dy, const T* x, const float* fw, T* dx, float* dfw,
+                                                         int64_t n, int nb, int Cb) {
+  float w[8], part[8];
+  softmax_small(fw, nb, w);
+  for (int i = 0; i < 8; ++i) part[i] = 0.f;
+  const int C = nb * Cb;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % C) / Cb;
+    const float g = to_f<T>(dy[i]);
+    dx[i] = from_f<T>(g * w[b]);
+    const float t = g * to_f<T>(x[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[j] += (j == b) ? t : 0.f;
+  }
+  __shared__ float red[8][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float s = wave_sum(part[j]);
+    if (lane == 0) red[j][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ds[8];
+    for (int j = 0; j < nb; ++j) ds[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
+    float dot = 0.f;
+    for (int j = 0; j < nb; ++j) dot += ds[j] * w[j];
+    for (int j = 0; j < nb; ++j) atomic_add_f(dfw + j, w[j] * (ds[j] - dot));
+  }
+}
+
+// y = x + droppath(gamma * u)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_add_fwd_kernel(const T* x, const T* u, const float* gamma, T* y, int64_t n, int C,
+                                                            float dp_p, int dp_site, int dp_rows, const int64_t* rng) {
+  const float gm = gamma ? gamma[0] : 1.f;
+  const uint32_t key = dp_p > 0.f ? rng_key(rng, dp_site) : 0u;
+  const float inv = dp_p > 0.f ? 1.f / (1.f - dp_p) : 1.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float f = gm;
+    if (dp_p > 0.f) f *= drop_factor(key, (uint32_t)((i / C) / dp_rows), dp_p, inv);
+    y[i] = from_f<T>(to_f<T>(x[i]) + f * to_f<T>(u[i]));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scale_add_bwd_kernel(const T* dy, const T* u, const float* gamma, T* du, float* dgamma,
+                                                            int64_t n, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng) {
+  const float gm = gamma ? gamma[0] : 1.f;
+  const uint32_t key = dp_p > 0.f ? rng_key(rng, dp_site) : 0u;
+  const float inv = dp_p > 0.f ? 1.f / (1.f - dp_p) : 1.f;
+  float part = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float f = 1.f;
+    if (dp_p > 0.f) f = drop_factor(key, (uint32_t)((i / C) / dp_rows), dp_p, inv);
+    const float g = to_f<T>(dy[i]) * f;
+    du[i] = from_f<T>(g * gm);
+    part += g * to_f<T>(u[i]);
+  }
+  if (dgamma) {
+    __shared__ float red[4];
+    const float s = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f(dgamma, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+// cols[(b*Hp*Wp + py*Wp + px), c*p*p + dy*p + dx] = img[b, c, py*p+dy, px*p+dx]
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* img, T* cols, int B, int Cin, int H, int W, int p) {
+  const int Hp = H / p, Wp = W / p, K = Cin * p * p;
+  const int64_t total = (int64_t)B * Cin * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int c = (int)((i / ((int64_t)W * H)) % Cin);
+    const int b = (int)(i / ((int64_t)W * H * Cin));
+    const int py = y / p, dy = y - py * p, px = x / p, dx = x - px * p;
+    if (py < Hp && px < Wp)
+      cols[((size_t)b * Hp * Wp + py * Wp + px) * K + c * p * p + dy * p + dx] = from_f<T>(img[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer: l2 norm + fused AdamW (decoupled weight decay, bias-corrected; torch.optim.AdamW semantics)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* g, int64_t n, float* partial) {
+  float s = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += g[i] * g[i];
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void l2_final_kernel(const float* partial, int nparts, float* out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partial[i];
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const uint8_t* skip, int64_t n,
+                                                    const float* lr_dev, float b1, float b2, float eps, float wd,
+                                                    const float* step_dev, const float* gnorm_dev, float max_norm) {
+  const float lr = lr_dev[0], step = step_dev[0];
+  float clip = 1.f;
+  if (gnorm_dev && max_norm > 0.f) { clip = max_norm / (gnorm_dev[0] + 1e-6f); if (clip > 1.f) clip = 1.f; }
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (skip && skip[i]) continue;
+    const float gi = g[i] * clip;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi;
+  }
+}
+
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" int qavit_version(void) { return 1; }
+extern "C" const char* qavit_last_error(void) { return g_err; }
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16, NAME)                   \
+  do {                                                                 \
+    if ((dtype) == QAVIT_F32) { CALL_F32; }                            \
+    else if ((dtype) == QAVIT_BF16) { CALL_BF16; }                     \
+    else return set_error(QAVIT_EINVAL, NAME ": unknown dtype");       \
+  } while (0)
+
+extern "C" int qavit_pack_weights(int dtype, const qavit_pack_desc* descs_dev, int n_desc, int max_elems, void* stream) {
+  if (!descs_dev || n_desc <= 0) return set_error(QAVIT_EINVAL, "pack_weights: empty descriptor table");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int tiles = (max_elems + 1023) / 1024;
+  if (tiles < 1) tiles = 1;
+  if (tiles > 64) tiles = 64;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((pack_kernel<float>), dim3(tiles, n_desc), dim3(256), 0, st, descs_dev, tiles),
+             hipLaunchKernelGGL((pack_kernel<bf16>), dim3(tiles, n_desc), dim3(256), 0, st, descs_dev, tiles), "pack_weights");
+  return check_launch("pack_weights");
+}
+
+extern "C" int qavit_rng_advance(int64_t* rng, void* stream) {
+  if (!rng) return set_error(QAVIT_EINVAL, "rng_advance: null");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), rng);
+  return check_launch("rng_advance");
+}
+
+extern "C" int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream) {
+  if (!x || !y || !rng || n <= 0 || p < 0.f || p >= 1.f) return set_error(QAVIT_EINVAL, "dropout: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nb = blocks_for(n, 1024);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((dropout_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, (float*)y, n, p, site, rng),
+             hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, p, site, rng), "dropout");
+  return check_launch("dropout");
+}
+
+extern "C" int qavit_token_mean_fwd(int dtype, const void* x, void* y, int B, int N, int C, void* stream) {
+  if (!x || !y || B <= 0 || N <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "token_mean_fwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((token_mean_fwd_kernel<float>), dim3(B), dim3(256), 0, st, (const float*)x, (float*)y, B, N, C),
+             hipLaunchKernelGGL((token_mean_fwd_kernel<bf16>), dim3(B), dim3(256), 0, st, (const bf16*)x, (bf16*)y, B, N, C), "token_mean_fwd");
+  return check_launch("token_mean_fwd");
+}
+extern "C" int qavit_token_mean_bwd(int dtype, const void* dy, void* dx, int B, int N, int C, void* stream) {
+  if (!dy || !dx || B <= 0 || N <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "token_mean_bwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((token_mean_bwd_kernel<float>), dim3(B), dim3(256), 0, st, (const float*)dy, (float*)dx, B, N, C),
+             hipLaunchKernelGGL((token_mean_bwd_kernel<bf16>), dim3(B), dim3(256), 0, st, (const bf16*)dy, (bf16*)dx, B, N, C), "token_mean_bwd");
+  return check_launch("token_mean_bwd");
+}
+
+extern "C" int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, void* y, int rows, int nb, int Cb, void* stream) {
+  if (!x || !fw || !y || rows <= 0 || nb <= 0 || nb > 8 || Cb <= 0) return set_error(QAVIT_EINVAL, "hybrid_fuse_fwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)rows * nb * Cb;
+  const int g = blocks_for(n, 1024);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((hybrid_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, fw, (float*)y, n, nb, Cb),
+             hipLaunchKernelGGL((hybrid_fwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)x, fw, (bf16*)y, n, nb, Cb), "hybrid_fuse_fwd");
+  return check_launch("hybrid_fuse_fwd");
+}
+extern "C" int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, const float* fw, void* dx, float* dfw,
+                                     int rows, int nb, int Cb, void* stream) {
+  if (!dy || !x || !fw || !dx || !dfw || rows <= 0 || nb <= 0 || nb > 8 || Cb <= 0) return set_error(QAVIT_EINVAL, "hybrid_fuse_bwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)rows * nb * Cb;
+  const int g = blocks_for(n, 4096, 1024);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb),
+             hipLaunchKernelGGL((hybrid_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, n, nb, Cb), "hybrid_fuse_bwd");
+  return check_launch("hybrid_fuse_bwd");
+}
+
+extern "C" int qavit_scale_add_fwd(int dtype, const void* x, const void* u, const float* gamma, void* y, int rows, int C,
+                                   float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream) {
+  if (!x || !u || !y || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "scale_add_fwd: bad arguments");
+  if (dp_p > 0.f && (!rng || dp_rows <= 0)) return set_error(QAVIT_EINVAL, "scale_add_fwd: drop-path needs rng and rows-per-sample");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)rows * C;
+  const int g = blocks_for(n, 1024);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((scale_add_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)u, gamma, (float*)y, n, C, dp_p, dp_site, dp_rows, rng),
+             hipLaunchKernelGGL((scale_add_fwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)x, (const bf16*)u, gamma, (bf16*)y, n, C, dp_p, dp_site, dp_rows, rng), "scale_add_fwd");
+  return check_launch("scale_add_fwd");
+}
+extern "C" int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, const float* gamma, void* du, float* dgamma,
+                                   int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream) {
+  if (!dy || !u || !du || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "scale_add_bwd: bad arguments");
+  if (dp_p > 0.f && (!rng || dp_rows <= 0)) return set_error(QAVIT_EINVAL, "scale_add_bwd: drop-path needs rng and rows-per-sample");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n = (int64_t)rows * C;
+  const int g = blocks_for(n, 4096, 1024);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((scale_add_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)u, gamma, (float*)du, dgamma, n, C, dp_p, dp_site, dp_rows, rng),
+             hipLaunchKernelGGL((scale_add_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)u, gamma, (bf16*)du, dgamma, n, C, dp_p, dp_site, dp_rows, rng), "scale_add_bwd");
+  return check_launch("scale_add_bwd");
+}
+
+extern "C" int qavit_patchify(int dtype, const float* img, void* cols, int B, int Cin, int H, int W, int p, void* stream) {
+  if (!img || !cols || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p)
+    return set_error(QAVIT_EINVAL, "patchify: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = blocks_for((int64_t)B * Cin * H * W, 1024);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((patchify_kernel<float>), dim3(g), dim3(256), 0, st, img, (float*)cols, B, Cin, H, W, p),
+             hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(g), dim3(256), 0, st, img, (bf16*)cols, B, Cin, H, W, p), "patchify");
+  return check_launch("patchify");
+}
+
+extern "C" int qavit_l2norm(const float* g, int64_t n, float* partial, float* out, void* stream) {
+  if (!g || !partial || !out || n <= 0) return set_error(QAVIT_EINVAL, "l2norm: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nb = blocks_for(n, 4096, 1024);   // partial must hold 1024 floats
+  hipLaunchKernelGGL(l2_partial_kernel, dim3(nb), dim3(256), 0, st, g, n, partial);
+  hipLaunchKernelGGL(l2_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, out);
+  return check_launch("l2norm");
+}
+
+extern "C" int qavit_adamw(float* p, const float* g, float* m, float* v, const uint8_t* skip, int64_t n,
+                           const float* lr_dev, float beta1, float beta2, float eps, float wd,
+                           const float* step_dev, const float* gnorm_dev, float max_norm, void* stream) {
+  if (!p || !g || !m || !v || !lr_dev || !step_dev || n <= 0) return set_error(QAVIT_EINVAL, "adamw: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nb = blocks_for(n, 1024);
+  hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, st, p, g, m, v, skip, n, lr_dev, beta1, beta2, eps, wd, step_dev, gnorm_dev, max_norm);
+  return check_launch("adamw");
+}
