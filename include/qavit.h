@@ -118,11 +118,11 @@ int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
  * seq_len is skipped algebraically: only the first L rows of E contribute), :584-587 (CGA, D=4),
  * :616-621 (cross), :355-397 (efficient_attention, default scale 1/sqrt(D), no mask).
  * One wavefront per (g,h); MFMA tiles read their operands from LDS.
- *   q      : element (g,i,h,d) at q[(g*Nq+i)*ldq + h*D + d]          (activation dtype)
- *   k_tok  : element (g,l,h,d) at k_tok[(g*L+l)*ldk + h*D + d]; v_tok likewise
+ *   q      : element (g,i,h,d) at q[qrow(g,i)*ldq + h*D + d]          (activation dtype; qrow: see struct)
+ *   k_tok  : element (g,l,h,d) at k_tok[krow(g,l)*ldk + h*D + d]; v_tok likewise
  *   E_k/E_v: fp32 [*, KC] row-major (mode 0), first L rows used
  *   sh_k/sh_v: fp32 [S, H*D] shared rows (the bank, or a Linear of the bank)
- *   o      : element (g,i,h,d) at o[(g*Nq+i)*ldo + h*D + d]
+ *   o      : element (g,i,h,d) at o[qrow(g,i)*ldo + h*D + d]
  *   nan_flag (optional): set to 1 if any q/k/v input or output element is NaN (the reference then returns
  *   zeros for the WHOLE tensor: call qavit_nan_guard afterwards).
  * bwd: writes dq / dk_tok / dv_tok, and per-wave partial sums of dE_k, dE_v [L,KC] and dsh_k, dsh_v
@@ -132,6 +132,13 @@ int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
 typedef struct qavit_attn_args {
   int dtype; int mode;
   int G, Nq, L, H, D, KC, S;
+  /* row addressing: group g = b*groups_per_b + gi.  Query/output row of (g,i) is
+   *   b*q_rows_per_b + (q_tbl ? q_tbl[gi*Nq+i] : gi*Nq+i); key-token row of (g,l) is
+   *   b*k_rows_per_b + (k_tbl ? k_tbl[gi*L+l] : gi*L+l).  Tables (device int32) express the SWA window
+   *   partition (HQAViT_CIFAR100.py:419-439) and the CGA channel-group regrouping (:562-564, :588-589)
+   *   without permute+contiguous copies.  groups_per_b == 0 means "one flat group axis" (row = g*Nq+i). */
+  int groups_per_b; int q_rows_per_b; int k_rows_per_b;
+  const int32_t* q_tbl; const int32_t* k_tbl;
   const void* q; int64_t ldq;
   const void* k_tok; int64_t ldk;
   const void* v_tok; int64_t ldv;
@@ -244,7 +251,9 @@ int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, const float* g
 /* y = dropout(x) (pos_drop, HQAViT_CIFAR100.py:1251); bwd is the same call on dy */
 int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream);
 /* packed weights: dst = cast(src) and dstT = cast(src)^T for 2-D [rows, cols] fp32 params; descriptor table on device */
-typedef struct qavit_pack_desc { const float* src; void* dst; void* dstT; int rows; int cols; } qavit_pack_desc;
+typedef struct qavit_pack_desc { const float* src; void* dst; void* dstT; int rows; int cols; int ldT; int pad; } qavit_pack_desc;
+/* dst[r*cols + c] = src[r][c]; dstT[c*ldT + r] = src[r][c] (ldT >= rows lets several sources stack into one
+ * transposed matrix, e.g. CGA's q/k/v projections) */
 int qavit_pack_weights(int dtype, const qavit_pack_desc* descs_dev, int n_desc, int max_elems, void* stream);
 /* rng[1] += 1 */
 int qavit_rng_advance(int64_t* rng, void* stream);

@@ -68,6 +68,17 @@ static inline int attn_grid(const qavit_attn_args& a, bool bwd) {
   return (int)g;
 }
 
+__device__ __forceinline__ int64_t qrow(const qavit_attn_args& a, int g, int i) {
+  if (a.groups_per_b <= 0) return (int64_t)g * a.Nq + i;
+  const int b = g / a.groups_per_b, gi = g - b * a.groups_per_b;
+  return (int64_t)b * a.q_rows_per_b + (a.q_tbl ? a.q_tbl[gi * a.Nq + i] : gi * a.Nq + i);
+}
+__device__ __forceinline__ int64_t krow(const qavit_attn_args& a, int g, int l) {
+  if (a.groups_per_b <= 0) return (int64_t)g * a.L + l;
+  const int b = g / a.groups_per_b, gi = g - b * a.groups_per_b;
+  return (int64_t)b * a.k_rows_per_b + (a.k_tbl ? a.k_tbl[gi * a.L + l] : gi * a.L + l);
+}
+
 // ---- shared staging: builds Kf / Vf (and keeps kt/vt/ek/ev for bwd) for problem (g,h) ----
 template <typename T, bool BF>
 __device__ __forceinline__ bool stage_keys(const qavit_attn_args& a, const AttnDims& d, const AttnLds& L, float* sm, int g, int h) {
@@ -88,8 +99,9 @@ __device__ __forceinline__ bool stage_keys(const qavit_attn_args& a, const AttnD
   if (a.mode == 0) {
     for (int i = lane; i < a.L * D; i += 64) {
       const int l = i / D, dd = i - l * D;
-      const float k = to_f<T>(kt[((size_t)g * a.L + l) * a.ldk + h * D + dd]);
-      const float v = to_f<T>(vt[((size_t)g * a.L + l) * a.ldv + h * D + dd]);
+      const int64_t kr = krow(a, g, l);
+      const float k = to_f<T>(kt[kr * a.ldk + h * D + dd]);
+      const float v = to_f<T>(vt[kr * a.ldv + h * D + dd]);
       bad |= (k != k) | (v != v);
       sm[L.kt + i] = k;
       sm[L.vt + i] = v;
@@ -108,8 +120,9 @@ __device__ __forceinline__ bool stage_keys(const qavit_attn_args& a, const AttnD
   } else {
     for (int i = lane; i < a.L * D; i += 64) {
       const int l = i / D, dd = i - l * D;
-      const float k = to_f<T>(kt[((size_t)g * a.L + l) * a.ldk + h * D + dd]);
-      const float v = to_f<T>(vt[((size_t)g * a.L + l) * a.ldv + h * D + dd]);
+      const int64_t kr = krow(a, g, l);
+      const float k = to_f<T>(kt[kr * a.ldk + h * D + dd]);
+      const float v = to_f<T>(vt[kr * a.ldv + h * D + dd]);
       bad |= (k != k) | (v != v);
       sm[L.kf + i] = k;
       sm[L.vf + i] = v;
@@ -145,15 +158,35 @@ __device__ __forceinline__ void scores_softmax(const qavit_attn_args& a, const A
 }
 
 template <typename T>
-__device__ __forceinline__ bool load_rows16(const T* src, int64_t ld, int rows, int D, float* dst) {
+__device__ __forceinline__ bool load_rows16(const qavit_attn_args& a, int g, int q0, const T* src, int64_t ld, int h, int rows, int D, float* dst) {
   bool bad = false;
   for (int i = threadIdx.x; i < 16 * D; i += 64) {
     const int r = i / D, dd = i - r * D;
-    const float v = (r < rows) ? to_f<T>(src[(size_t)r * ld + dd]) : 0.f;
+    const float v = (r < rows) ? to_f<T>(src[qrow(a, g, q0 + r) * ld + h * D + dd]) : 0.f;
     bad |= (v != v);
     dst[i] = v;
   }
   return bad;
+}
+
+// accumulator tile -> rows qrow(g, q0 + row) / krow(g, l0 + row) of a global matrix
+template <typename T>
+__device__ __forceinline__ void store_qrows(const qavit_attn_args& a, int g, int q0, T* dst, int64_t ld, int coff, int rows, int cols, const f32x4& acc) {
+  const int col = tile_col();
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = tile_row(reg);
+    if (row < rows && col < cols) dst[qrow(a, g, q0 + row) * ld + coff + col] = from_f<T>(acc[reg]);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_krows(const qavit_attn_args& a, int g, int l0, T* dst, int64_t ld, int coff, int rows, int cols, const f32x4& acc) {
+  const int col = tile_col();
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = tile_row(reg);
+    if (row < rows && col < cols) dst[krow(a, g, l0 + row) * ld + coff + col] = from_f<T>(acc[reg]);
+  }
 }
 
 template <typename T, bool BF>
@@ -173,14 +206,14 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(qavit_attn_args a) {
     for (int q0 = 0; q0 < a.Nq; q0 += 16) {
       const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
       __syncthreads();
-      bad |= load_rows16<T>(q + ((size_t)g * a.Nq + q0) * a.ldq + h * D, a.ldq, rows, D, sm + L.q);
+      bad |= load_rows16<T>(a, g, q0, q, a.ldq, h, rows, D, sm + L.q);
       __syncthreads();
       scores_softmax<BF>(a, d, L, sm, rows, scale);
       for (int dt = 0; dt * 16 < D; ++dt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mma_tile<BF>(sm + L.s, d.NKp, 1, rows, sm + L.vf + dt * 16, D, 1, D - dt * 16, d.NK, acc);
         bad |= (acc[0] != acc[0]) | (acc[1] != acc[1]) | (acc[2] != acc[2]) | (acc[3] != acc[3]);
-        tile_to_global<T>(o + ((size_t)g * a.Nq + q0) * a.ldo + h * D + dt * 16, a.ldo, rows, D - dt * 16, acc);
+        store_qrows<T>(a, g, q0, o, a.ldo, h * D + dt * 16, rows, D - dt * 16, acc);
       }
     }
   }
@@ -212,8 +245,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
     for (int q0 = 0; q0 < a.Nq; q0 += 16) {
       const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
       __syncthreads();
-      load_rows16<T>(q + ((size_t)g * a.Nq + q0) * a.ldq + h * D, a.ldq, rows, D, sm + L.q);
-      load_rows16<T>(dO + ((size_t)g * a.Nq + q0) * a.lddo + h * D, a.lddo, rows, D, sm + L.d_o);
+      load_rows16<T>(a, g, q0, q, a.ldq, h, rows, D, sm + L.q);
+      load_rows16<T>(a, g, q0, dO, a.lddo, h, rows, D, sm + L.d_o);
       __syncthreads();
       scores_softmax<BF>(a, d, L, sm, rows, scale);                          // P in sm[L.s]
       // dP = dO . Vf^T ;  dVf += P^T . dO
@@ -242,7 +275,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
       for (int dt = 0; dt * 16 < D; ++dt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mma_tile<BF>(sm + L.dp, d.NKp, 1, rows, sm + L.kf + dt * 16, D, 1, D - dt * 16, d.NK, acc);
-        tile_to_global<T>(dq + ((size_t)g * a.Nq + q0) * a.lddq + h * D + dt * 16, a.lddq, rows, D - dt * 16, acc);
+        store_qrows<T>(a, g, q0, dq, a.lddq, h * D + dt * 16, rows, D - dt * 16, acc);
         for (int nt = 0; nt * 16 < d.NK; ++nt) {
           f32x4 ak = {0.f, 0.f, 0.f, 0.f};
           ak = mma_tile<BF>(sm + L.dp + nt * 16, 1, d.NKp, d.NK - nt * 16, sm + L.q + dt * 16, D, 1, D - dt * 16, rows, ak);
@@ -263,8 +296,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
           f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
           ak = mma_tile<BF>(sm + L.ek + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dkf + dt * 16, D, 1, D - dt * 16, a.KC, ak);
           av = mma_tile<BF>(sm + L.ev + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dvf + dt * 16, D, 1, D - dt * 16, a.KC, av);
-          tile_to_global<T>(dkt + ((size_t)g * a.L + lt * 16) * a.lddk + h * D + dt * 16, a.lddk, a.L - lt * 16, D - dt * 16, ak);
-          tile_to_global<T>(dvt + ((size_t)g * a.L + lt * 16) * a.lddv + h * D + dt * 16, a.lddv, a.L - lt * 16, D - dt * 16, av);
+          store_krows<T>(a, g, lt * 16, dkt, a.lddk, h * D + dt * 16, a.L - lt * 16, D - dt * 16, ak);
+          store_krows<T>(a, g, lt * 16, dvt, a.lddv, h * D + dt * 16, a.L - lt * 16, D - dt * 16, av);
         }
         for (int jt = 0; jt * 16 < a.KC; ++jt) {
           f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
@@ -277,8 +310,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
     } else {
       for (int i = lane; i < a.L * D; i += 64) {
         const int l = i / D, dd = i - l * D;
-        dkt[((size_t)g * a.L + l) * a.lddk + h * D + dd] = from_f<T>(sm[L.dkf + i]);
-        dvt[((size_t)g * a.L + l) * a.lddv + h * D + dd] = from_f<T>(sm[L.dvf + i]);
+        const int64_t kr = krow(a, g, l);
+        dkt[kr * a.lddk + h * D + dd] = from_f<T>(sm[L.dkf + i]);
+        dvt[kr * a.lddv + h * D + dd] = from_f<T>(sm[L.dvf + i]);
       }
     }
   }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const qavit_pack_desc* descs,
 #pragma unroll
       for (int i = 0; i < 32; i += 8) {
         const int c = tc * 32 + ty + i, r = tr * 32 + tx;   // output row = c, output col = r
-        if (r < d.rows && c < d.cols) reinterpret_cast<T*>(d.dstT)[(size_t)c * d.rows + r] = from_f<T>(tile[tx][ty + i]);
+        if (r < d.rows && c < d.cols) reinterpret_cast<T*>(d.dstT)[(size_t)c * d.ldT + r] = from_f<T>(tile[tx][ty + i]);
       }
     }
   }

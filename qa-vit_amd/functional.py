@@ -1,0 +1,662 @@
+"""Autograd operators of the QA-ViT hot path, each a thin torch.autograd.Function over the HIP kernels.
+
+Conventions
+  * activations are fp32 or bf16 (the "compute dtype"); parameters stay fp32 (master weights); 2-D weights
+    are read through a WeightPack (compute-dtype copy + transposed copy, refreshed by one kernel launch);
+  * parameter gradients are accumulated by the kernels DIRECTLY into ``param.grad`` (fp32, created on
+    demand) and the Function returns None for them -- no per-parameter add kernels.  ``.grad`` is therefore
+    correct after ``loss.backward()``, which is what the reference's training loops consume;
+  * dropout / drop-path masks are regenerated in backward from (seed, step, site, index).
+"""
+import ctypes as C
+import math
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from . import lib as L
+
+
+# ---------------------------------------------------------------------------------------------------
+# packed weights
+# ---------------------------------------------------------------------------------------------------
+class _PackEntry:
+    __slots__ = ("params", "versions", "dst", "dstT", "rows", "cols", "desc_rows")
+
+
+class WeightPack:
+    """Compute-dtype copies of 2-D weights: ``W`` (as stored, [N,K]) and ``W^T`` ([K,N]).
+
+    One ``refresh()`` launch re-packs every registered weight (the descriptor table lives on the device),
+    so a training step pays one kernel for all ~200 weights; it is also what a captured hipGraph replays
+    at the top of each step."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}      # (ids, dtype) -> _PackEntry
+        self._tables = {}      # dtype -> (device bytes tensor, n_desc, max_elems)
+
+    @staticmethod
+    def _as2d(w):
+        return w.reshape(w.shape[0], -1)
+
+    def _make(self, params, dtype):
+        e = _PackEntry()
+        e.params = params
+        rows = sum(p.shape[0] for p in params)
+        cols = self._as2d(params[0]).shape[1]
+        e.rows, e.cols = rows, cols
+        single_f32 = dtype == torch.float32 and len(params) == 1
+        e.dst = None if single_f32 else torch.empty(rows, cols, dtype=dtype, device=self.device)
+        e.dstT = torch.empty(cols, rows, dtype=dtype, device=self.device)
+        e.versions = [-1] * len(params)
+        return e
+
+    def _descs(self, e):
+        out, off = [], 0
+        esz = e.dstT.element_size()
+        for p in e.params:
+            r = p.shape[0]
+            d = L.PackDesc()
+            d.src = self._as2d(p).data_ptr()
+            d.dst = 0 if e.dst is None else e.dst.data_ptr() + off * e.cols * esz
+            d.dstT = e.dstT.data_ptr() + off * esz
+            d.rows, d.cols, d.ldT, d.pad = r, e.cols, e.rows, 0
+            out.append(d)
+            off += r
+        return out
+
+    def _launch(self, descs, dtype):
+        arr = (L.PackDesc * len(descs))(*descs)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        mx = max(d.rows * d.cols for d in descs)
+        K.pack_weights(dtype, raw, len(descs), mx)
+        return raw, len(descs), mx
+
+    def refresh(self, dtype=None):
+        """Re-pack every registered weight (one launch per compute dtype in use)."""
+        dts = {k[1] for k in self.entries} if dtype is None else {dtype}
+        for dt in dts:
+            tab = self._tables.get(dt)
+            if tab is None:
+                descs = []
+                for (ids, d), e in self.entries.items():
+                    if d == dt:
+                        descs.extend(self._descs(e))
+                if not descs:
+                    continue
+                self._tables[dt] = self._launch(descs, dt)
+            else:
+                K.pack_weights(dt, tab[0], tab[1], tab[2])
+            for (ids, d), e in self.entries.items():
+                if d == dt:
+                    e.versions = [p._version for p in e.params]
+
+    def get(self, params, dtype):
+        """-> (W [rows, cols], W^T [cols, rows]) in ``dtype`` for a weight or a row-stack of weights."""
+        if isinstance(params, torch.Tensor):
+            params = [params]
+        key = (tuple(id(p) for p in params), dtype)
+        e = self.entries.get(key)
+        if e is None:
+            e = self._make(params, dtype)
+            self.entries[key] = e
+            self._tables.pop(dtype, None)
+            self._launch(self._descs(e), dtype)          # first use: pack just this one
+            e.versions = [p._version for p in e.params]
+        elif any(v != p._version for v, p in zip(e.versions, e.params)):
+            self.refresh(dtype)                           # an optimizer stepped: re-pack everything once
+        W = e.dst if e.dst is not None else self._as2d(e.params[0]).detach()
+        return W, e.dstT
+
+
+_packs = {}
+
+
+def pack_for(device) -> WeightPack:
+    key = torch.device(device).index or 0
+    if key not in _packs:
+        _packs[key] = WeightPack(torch.device("cuda", key))
+    return _packs[key]
+
+
+# ---------------------------------------------------------------------------------------------------
+# gradient sinks
+# ---------------------------------------------------------------------------------------------------
+def grad_sink(t: Optional[torch.Tensor]):
+    """-> (fp32 accumulation buffer, value to return from backward).  Leaf parameters accumulate in
+    place into ``.grad``; anything else gets a fresh zero buffer that is returned to autograd."""
+    if t is None or not t.requires_grad:
+        return None, None
+    if t.is_leaf:
+        if t.grad is None:
+            t.grad = torch.zeros_like(t, dtype=torch.float32)
+        return t.grad, None
+    buf = torch.zeros(t.shape, dtype=torch.float32, device=t.device)
+    return buf, buf
+
+
+def _ret(buf_ret, like):
+    if buf_ret is None:
+        return None
+    return buf_ret if buf_ret.dtype == like.dtype else buf_ret.to(like.dtype)
+
+
+def _rt(x):
+    return K.Runtime.get(x.device)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Linear (+ fused LayerNorm prologue, GELU / dropout / drop-path / residual epilogue)
+# ---------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = resid + droppath(dropout(act(LN(x) @ W[rows]^T + b[rows])))"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, ln_g, ln_b, resid, opts):
+        K._require_cuda(x, w)
+        rt = _rt(x)
+        Kd = x.shape[-1]
+        x2 = x.reshape(-1, Kd)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        off, n = opts.get("rows") or (0, w.shape[0])
+        Wc, Wt = pack_for(x.device).get(w, x.dtype)
+        y = torch.empty(M, n, dtype=x.dtype, device=x.device)
+        act = 1 if opts.get("act") == "gelu" else 0
+        drop = opts.get("drop") or (0.0, 0)
+        dp = opts.get("dp") or (0.0, 0, 1)
+        Z = torch.empty_like(y) if (act and any(ctx.needs_input_grad)) else None
+        ln = None
+        stats = None
+        if ln_g is not None:
+            ln = (ln_g, ln_b, opts.get("eps", 1e-5))
+            stats = (torch.empty(M, dtype=torch.float32, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device))
+        r2 = None
+        if resid is not None:
+            r2 = resid.reshape(-1, n)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+        esz = Wc.element_size()
+        bias_ptr = None if b is None else b.data_ptr() + off * 4
+        a = dict(a_mode=1 if ln else 0, ln=ln, ln_stats=stats, Z=Z, act=act, drop=drop, dp=dp, R=r2, ldr=n, rng=rt.rng)
+        # bias pointer offset: pass a narrow view tensor to keep kernels.gemm_nt simple
+        bview = None if b is None else b.detach()[off:off + n]
+        K.gemm_nt(x2, Wc, y, M, n, Kd, Kd, Kd, n, bview, B_ptr=Wc.data_ptr() + off * Kd * esz, **a)
+        ctx.opts = dict(opts)
+        ctx.meta = (M, n, Kd, off, act, drop, dp, x.shape, resid is not None)
+        ctx.save_for_backward(x2, w, b, ln_g, ln_b, Z, stats[0] if stats else None, stats[1] if stats else None)
+        return y.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, b, ln_g, ln_b, Z, mean, rstd = ctx.saved_tensors
+        M, n, Kd, off, act, drop, dp, xshape, has_res = ctx.meta
+        rt = _rt(x2)
+        dy2 = dy.reshape(M, n)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        need_t = bool(act) or drop[0] > 0.0 or dp[0] > 0.0
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = w.requires_grad
+        Wc, Wt = pack_for(x2.device).get(w, x2.dtype)
+        esz = Wt.element_size()
+        dz = dy2
+        dx = None
+        if need_dx or need_t:
+            dz = torch.empty_like(dy2) if (need_t and (need_dw or (b is not None and b.requires_grad))) else dy2
+            dxn = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
+            bwd = None
+            if need_t:
+                bwd = dict(Z=Z, ldz=n, act=act, drop=drop, dp=dp, out=dz if dz is not dy2 else None, ldo=n)
+            K.gemm_nt(dy2, Wt, dxn, M, Kd, n, n, Wt.shape[1], Kd, None, a_mode=2 if need_t else 0, bwd=bwd, rng=rt.rng,
+                      B_ptr=Wt.data_ptr() + off * esz)
+            if ln_g is not None:
+                gbuf, _ = grad_sink(ln_g)
+                bbuf, _ = grad_sink(ln_b)
+                dx = torch.empty_like(dxn)
+                K.layernorm_bwd(dxn, x2, ln_g, mean, rstd, dx, gbuf, bbuf, M, Kd)
+            else:
+                dx = dxn
+        if need_dw or (b is not None and b.requires_grad):
+            wbuf, _ = grad_sink(w)
+            bbuf2, _ = grad_sink(b)
+            if wbuf is None:   # bias-only gradient: still use the kernel with a scratch C
+                wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+            lnarg = (ln_g, ln_b, mean, rstd) if ln_g is not None else None
+            K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
+                      C_ptr=wbuf.data_ptr() + off * Kd * 4,
+                      colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
+        dres = dy if has_res else None
+        return (dx.reshape(xshape) if (dx is not None and need_dx) else None), None, None, None, None, dres, None
+
+
+def linear(x, w, b=None, *, ln=None, act=None, drop=None, dp=None, resid=None, rows=None, eps=1e-5, train=True):
+    ln_g, ln_b = ln if ln is not None else (None, None)
+    opts = dict(act=act, drop=drop, dp=dp, rows=rows, eps=eps, train=train)
+    return LinearFn.apply(x, w, b, ln_g, ln_b, resid, opts)
+
+
+class LinearStack3Fn(Function):
+    """y = x @ [W1;W2;W3]^T + [b1;b2;b3] (CGA q/k/v projections, HQAViT_CIFAR100.py:566-568) as ONE GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3):
+        Kd = x.shape[-1]
+        x2 = x.reshape(-1, Kd)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        ws = [w1, w2, w3]
+        Wc, Wt = pack_for(x.device).get(ws, x.dtype)
+        n = Wc.shape[0]
+        bias = torch.cat([b1.detach(), b2.detach(), b3.detach()])
+        y = torch.empty(M, n, dtype=x.dtype, device=x.device)
+        K.gemm_nt(x2, Wc, y, M, n, Kd, Kd, Kd, n, bias)
+        ctx.save_for_backward(x2, w1, b1, w2, b2, w3, b3)
+        ctx.xshape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, b1, w2, b2, w3, b3 = ctx.saved_tensors
+        M, Kd = x2.shape
+        ws, bs = [w1, w2, w3], [b1, b2, b3]
+        Wc, Wt = pack_for(x2.device).get(ws, x2.dtype)
+        n = Wc.shape[0]
+        dy2 = dy.reshape(M, n)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
+            K.gemm_nt(dy2, Wt, dx, M, Kd, n, n, n, Kd, None)
+        off = 0
+        esz = dy2.element_size()
+        for w, b in zip(ws, bs):
+            ni = w.shape[0]
+            wbuf, _ = grad_sink(w)
+            bbuf, _ = grad_sink(b)
+            if wbuf is not None:
+                K.gemm_tn(dy2, x2, wbuf, M, ni, Kd, n, Kd, Kd, bbuf, A_ptr=dy2.data_ptr() + off * esz)
+            off += ni
+        return (dx.reshape(ctx.xshape) if dx is not None else None), None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# LayerNorm (stand-alone) with optional broadcast add (pos_embed)
+# ---------------------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, g, b, add, eps):
+        Cc = x.shape[-1]
+        x2 = x.reshape(-1, Cc)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        add_rows = 0 if add is None else add.numel() // Cc
+        K.layernorm_fwd(x2, y, g, b, eps, rows, Cc, mean, rstd, None if add is None else add.detach(), add_rows)
+        ctx.save_for_backward(x2, g, b, add, mean, rstd)
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, b, add, mean, rstd = ctx.saved_tensors
+        rows, Cc = x2.shape
+        dy2 = dy.reshape(rows, Cc)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        gbuf, _ = grad_sink(g)
+        bbuf, _ = grad_sink(b)
+        abuf, _ = grad_sink(add)
+        dx = torch.empty_like(x2)
+        K.layernorm_bwd(dy2, x2, g, mean, rstd, dx, gbuf, bbuf, rows, Cc, abuf, 0 if add is None else add.numel() // Cc)
+        return dx.reshape(ctx.xshape), None, None, None, None
+
+
+def layer_norm(x, g, b, eps=1e-5, add=None):
+    return LayerNormFn.apply(x, g, b, add, eps)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention core
+# ---------------------------------------------------------------------------------------------------
+class AttnFn(Function):
+    """See include/qavit.h (qavit_attn_args).  ``q_t`` is a 2-D row matrix holding q (and, when ``kv_t`` is
+    None and L > 0, also k and v) at column offsets; gradients come back as whole matrices."""
+
+    @staticmethod
+    def forward(ctx, q_t, kv_t, E_k, E_v, sh_k, sh_v, spec):
+        rt = _rt(q_t)
+        s = spec
+        HD = s["H"] * s["D"]
+        src_kv = q_t if kv_t is None else kv_t
+        a = K.attn_args(q_t.dtype, s["mode"], s["G"], s["Nq"], s["L"], s["H"], s["D"], s.get("KC", 0), s["S"],
+                        s.get("groups_per_b", 0), s.get("q_rows_per_b", 0), s.get("k_rows_per_b", 0), s.get("q_tbl"), s.get("k_tbl"))
+        esz = q_t.element_size()
+        o = torch.empty(s["q_rows"], HD, dtype=q_t.dtype, device=q_t.device)
+        a.q, a.ldq = q_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]
+        if s["L"] > 0:
+            a.k_tok, a.ldk = src_kv.data_ptr() + s["k_off"] * esz, src_kv.shape[1]
+            a.v_tok, a.ldv = src_kv.data_ptr() + s["v_off"] * esz, src_kv.shape[1]
+        if s["mode"] == 0:
+            a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
+        a.sh_k, a.sh_v = sh_k.data_ptr(), sh_v.data_ptr()
+        a.o, a.ldo = o.data_ptr(), HD
+        guard = rt.nan_guard
+        if guard:
+            a.nan_flag = rt.nan_flag.data_ptr()
+        K.attn_fwd(a)
+        if guard:
+            K.nan_guard(o, rt.nan_flag)
+        ctx.spec = s
+        ctx.save_for_backward(q_t, kv_t, E_k, E_v, sh_k, sh_v)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q_t, kv_t, E_k, E_v, sh_k, sh_v = ctx.saved_tensors
+        s = ctx.spec
+        rt = _rt(q_t)
+        HD = s["H"] * s["D"]
+        if not d_o.is_contiguous():
+            d_o = d_o.contiguous()
+        src_kv = q_t if kv_t is None else kv_t
+        a = K.attn_args(q_t.dtype, s["mode"], s["G"], s["Nq"], s["L"], s["H"], s["D"], s.get("KC", 0), s["S"],
+                        s.get("groups_per_b", 0), s.get("q_rows_per_b", 0), s.get("k_rows_per_b", 0), s.get("q_tbl"), s.get("k_tbl"))
+        esz = q_t.element_size()
+        a.q, a.ldq = q_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]
+        if s["L"] > 0:
+            a.k_tok, a.ldk = src_kv.data_ptr() + s["k_off"] * esz, src_kv.shape[1]
+            a.v_tok, a.ldv = src_kv.data_ptr() + s["v_off"] * esz, src_kv.shape[1]
+        if s["mode"] == 0:
+            a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
+        a.sh_k, a.sh_v = sh_k.data_ptr(), sh_v.data_ptr()
+        a.d_o, a.lddo = d_o.data_ptr(), HD
+        covered_q = HD * (3 if (kv_t is None and s["L"] > 0) else 1) == q_t.shape[1]
+        dq_t = torch.empty_like(q_t) if covered_q else torch.zeros_like(q_t)
+        a.dq, a.lddq = dq_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]
+        dkv_t = None
+        if s["L"] > 0:
+            if kv_t is None:
+                dst = dq_t
+            else:
+                dkv_t = torch.empty_like(kv_t) if 2 * HD == kv_t.shape[1] else torch.zeros_like(kv_t)
+                dst = dkv_t
+            a.dk_tok, a.lddk = dst.data_ptr() + s["k_off"] * esz, dst.shape[1]
+            a.dv_tok, a.lddv = dst.data_ptr() + s["v_off"] * esz, dst.shape[1]
+        ek_buf, ek_ret = grad_sink(E_k) if s["mode"] == 0 else (None, None)
+        ev_buf, ev_ret = grad_sink(E_v) if s["mode"] == 0 else (None, None)
+        sk_buf, sk_ret = grad_sink(sh_k)
+        sv_buf, sv_ret = grad_sink(sh_v)
+        a.dE_k, a.dE_v = K._p(ek_buf), K._p(ev_buf)
+        a.dsh_k, a.dsh_v = K._p(sk_buf), K._p(sv_buf)
+        nws = K.attn_ws_floats(a)
+        ws = rt.workspace("attn_bwd", nws)
+        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+        K.attn_bwd(a)
+        return dq_t, dkv_t, _ret(ek_ret, E_k) if ek_ret is not None else None, _ret(ev_ret, E_v) if ev_ret is not None else None, \
+            _ret(sk_ret, sh_k), _ret(sv_ret, sh_v), None
+
+
+# ---------------------------------------------------------------------------------------------------
+# token-axis operators
+# ---------------------------------------------------------------------------------------------------
+class TokMixFn(Function):
+    @staticmethod
+    def forward(ctx, scores, x):
+        B, N, M = scores.shape
+        Cc = x.shape[-1]
+        scores = scores.contiguous()
+        x = x.contiguous()
+        p = torch.empty_like(scores)
+        xc = torch.empty(B, M, Cc, dtype=x.dtype, device=x.device)
+        K.tokmix_fwd(scores, x, p, xc, B, N, M, Cc)
+        ctx.save_for_backward(p, x)
+        return xc
+
+    @staticmethod
+    def backward(ctx, dxc):
+        p, x = ctx.saved_tensors
+        B, N, M = p.shape
+        Cc = x.shape[-1]
+        dxc = dxc.contiguous()
+        dx = torch.empty_like(x)
+        ds = torch.empty_like(p)
+        K.tokmix_bwd(p, x, dxc, dx, ds, B, N, M, Cc)
+        return ds, dx
+
+
+class UpMixFn(Function):
+    @staticmethod
+    def forward(ctx, xc, W, bias, g, b, eps):
+        B, M, Cc = xc.shape
+        N = W.shape[0]
+        xc = xc.contiguous()
+        y = torch.empty(B, N, Cc, dtype=xc.dtype, device=xc.device)
+        mean = torch.empty(B * N, dtype=torch.float32, device=xc.device)
+        rstd = torch.empty(B * N, dtype=torch.float32, device=xc.device)
+        K.upmix_fwd(xc, W.detach(), bias.detach(), g.detach(), b.detach(), eps, y, mean, rstd, B, N, M, Cc)
+        ctx.save_for_backward(xc, W, bias, g, b, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, W, bias, g, b, mean, rstd = ctx.saved_tensors
+        B, M, Cc = xc.shape
+        N = W.shape[0]
+        dy = dy.contiguous()
+        dxc = torch.empty_like(xc)
+        wbuf, _ = grad_sink(W)
+        bbuf, _ = grad_sink(bias)
+        gbuf, _ = grad_sink(g)
+        bebuf, _ = grad_sink(b)
+        if wbuf is None:
+            wbuf = torch.zeros_like(W, dtype=torch.float32)
+        if gbuf is None:
+            gbuf = torch.zeros_like(g, dtype=torch.float32)
+        if bebuf is None:
+            bebuf = torch.zeros_like(b, dtype=torch.float32)
+        K.upmix_bwd(dy, xc, W.detach(), bias.detach(), g.detach(), mean, rstd, dxc, wbuf, bbuf, gbuf, bebuf, B, N, M, Cc)
+        return dxc, None, None, None, None, None
+
+
+class GatherPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, idx, stride):
+        B, N, Cc = x.shape
+        NP = idx.numel() // stride
+        x = x.contiguous()
+        y = torch.empty(B, NP, Cc, dtype=x.dtype, device=x.device)
+        K.gather_pool_fwd(x, idx, y, B, N, NP, stride, Cc)
+        ctx.idx, ctx.dims = idx, (B, N, NP, stride, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, NP, stride, Cc = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(B, N, Cc, dtype=dy.dtype, device=dy.device)
+        K.gather_pool_bwd(dy, ctx.idx, dx, B, N, NP, stride, Cc)
+        return dx, None, None
+
+
+class TokenMeanFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, N, Cc = x.shape
+        x = x.contiguous()
+        y = torch.empty(B, Cc, dtype=x.dtype, device=x.device)
+        K.token_mean_fwd(x, y, B, N, Cc)
+        ctx.dims = (B, N, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, Cc = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(B, N, Cc, dtype=dy.dtype, device=dy.device)
+        K.token_mean_bwd(dy, dx, B, N, Cc)
+        return dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# CCF-FFN middle
+# ---------------------------------------------------------------------------------------------------
+class CcfMidFn(Function):
+    @staticmethod
+    def forward(ctx, h, g1, b1, g2, b2, w, cbias, cscale, Hs, Ws, eps):
+        B, N, Cc = h.shape
+        h = h.contiguous()
+        flags = (1 if g1 is not None else 0) | (2 if cbias is not None else 0) | (4 if cscale is not None else 0)
+        a = K.ccf_args(h.dtype, flags, B, Hs, Ws, Cc, eps)
+        out = torch.empty_like(h)
+        stats = [torch.empty(B * N, dtype=torch.float32, device=h.device) for _ in range(4)] if flags & 1 else [None] * 4
+        a.h, a.out = h.data_ptr(), out.data_ptr()
+        a.g1, a.b1, a.g2, a.b2 = K._p(g1), K._p(b1), K._p(g2), K._p(b2)
+        a.w, a.cbias, a.cscale = w.data_ptr(), K._p(cbias), K._p(cscale)
+        a.mean1, a.rstd1, a.mean2, a.rstd2 = [K._p(t) for t in stats]
+        K.ccf_fwd(a)
+        ctx.dims = (B, Hs, Ws, Cc, eps, flags)
+        ctx.save_for_backward(h, g1, b1, g2, b2, w, cbias, cscale, *stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        h, g1, b1, g2, b2, w, cbias, cscale, m1, r1, m2, r2 = ctx.saved_tensors
+        B, Hs, Ws, Cc, eps, flags = ctx.dims
+        d_out = d_out.contiguous()
+        a = K.ccf_args(h.dtype, flags, B, Hs, Ws, Cc, eps)
+        d_h = torch.empty_like(h)
+        a.h, a.d_out, a.d_h = h.data_ptr(), d_out.data_ptr(), d_h.data_ptr()
+        a.g1, a.b1, a.g2, a.b2 = K._p(g1), K._p(b1), K._p(g2), K._p(b2)
+        a.w, a.cbias, a.cscale = w.data_ptr(), K._p(cbias), K._p(cscale)
+        a.mean1, a.rstd1, a.mean2, a.rstd2 = K._p(m1), K._p(r1), K._p(m2), K._p(r2)
+        sinks = [grad_sink(t)[0] for t in (g1, b1, g2, b2, w, cbias, cscale)]
+        a.dg1, a.db1, a.dg2, a.db2, a.dw, a.dcbias, a.dcscale = [K._p(t) for t in sinks]
+        if a.dw is None:
+            scratch = torch.zeros_like(w, dtype=torch.float32)
+            a.dw = scratch.data_ptr()
+        K.ccf_bwd(a)
+        return (d_h,) + (None,) * 10
+
+
+# ---------------------------------------------------------------------------------------------------
+# elementwise helpers
+# ---------------------------------------------------------------------------------------------------
+class HybridFuseFn(Function):
+    @staticmethod
+    def forward(ctx, x, fw):
+        nb = fw.numel()
+        Cc = x.shape[-1]
+        x = x.contiguous()
+        rows = x.numel() // Cc
+        y = torch.empty_like(x)
+        K.hybrid_fuse_fwd(x, fw.detach(), y, rows, nb, Cc // nb)
+        ctx.save_for_backward(x, fw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, fw = ctx.saved_tensors
+        nb = fw.numel()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        fbuf, fret = grad_sink(fw)
+        if fbuf is None:
+            fbuf = torch.zeros(nb, dtype=torch.float32, device=x.device)
+        K.hybrid_fuse_bwd(dy, x, fw.detach(), dx, fbuf, rows, nb, Cc // nb)
+        return dx, fret
+
+
+class ScaleAddFn(Function):
+    """y = x + droppath(gamma * u)"""
+
+    @staticmethod
+    def forward(ctx, x, u, gamma, dp):
+        rt = _rt(x)
+        Cc = x.shape[-1]
+        x = x.contiguous()
+        u = u.contiguous()
+        rows = x.numel() // Cc
+        y = torch.empty_like(x)
+        K.scale_add_fwd(x, u, None if gamma is None else gamma.detach(), y, rows, Cc, dp, rt.rng)
+        ctx.save_for_backward(u, gamma)
+        ctx.dp = dp
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, gamma = ctx.saved_tensors
+        rt = _rt(u)
+        Cc = u.shape[-1]
+        rows = u.numel() // Cc
+        dy = dy.contiguous()
+        du = torch.empty_like(u)
+        gbuf, gret = grad_sink(gamma)
+        K.scale_add_bwd(dy, u, None if gamma is None else gamma.detach(), du, gbuf, rows, Cc, ctx.dp, rt.rng)
+        return dy, du, gret, None
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, site):
+        rt = _rt(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        K.dropout(x, y, p, site, rt.rng)
+        ctx.ps = (p, site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt = _rt(dy)
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        K.dropout(dy, dx, ctx.ps[0], ctx.ps[1], rt.rng)
+        return dx, None, None
+
+
+def dropout(x, p, site, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p, site)
+
+
+@torch.no_grad()
+def patchify(img, patch, dtype):
+    """[B,C,H,W] fp32 image -> [B*(H/p)*(W/p), C*p*p] rows in the compute dtype (no gradient to pixels)."""
+    B, Cin, H, W = img.shape
+    img = img.contiguous().float()
+    cols = torch.empty(B * (H // patch) * (W // patch), Cin * patch * patch, dtype=dtype, device=img.device)
+    K.patchify(img, cols, B, Cin, H, W, patch)
+    return cols
+
+
+@torch.no_grad()
+def bank_write(tokens, norm_g, norm_b, bank, mode, sync=None):
+    """GlobalTokenBank.write(norm(tokens)) -- see csrc/bank.hip.  ``bank`` is the GlobalTokenBank module.
+    ``sync(acc)`` (optional) all-reduces the [S,C] batch sum across data-parallel ranks and returns the
+    global batch size divisor."""
+    B, N, Cc = tokens.shape
+    rt = _rt(tokens)
+    S = bank.bank_size
+    tokens = tokens.contiguous()
+    acc = rt.workspace("bank_acc", S * Cc)
+    ws = rt.workspace("bank_ws", K.bank_ws_floats(B, N, Cc, S))
+    K.bank_stats(tokens, norm_g, norm_b, bank.write_norm.weight, bank.write_norm.bias, bank.write_gate.weight, bank.write_gate.bias,
+                 acc, ws, B, N, Cc, S, 1e-5)
+    total = B
+    if sync is not None:
+        total = sync(acc[: S * Cc], B)
+    K.bank_apply(acc, bank.write_compression.weight, bank.write_compression.bias, bank.global_k.data, bank.global_v.data,
+                 getattr(bank, "update_count", None), S, Cc, 1.0 / float(total), mode)

@@ -1,0 +1,224 @@
+"""Lean training harness: the counterpart of the reference's ``train_epoch`` (HQAViT_CIFAR100.py:1366-1458)
+and optimiser set-up (:1566-1583) without its host-sync storm.
+
+What is reproduced: AdamW(betas .9/.999, wd 0.06) over ``model.parameters()`` --
+tensors that never receive a gradient are skipped exactly as torch skips ``grad is None``; OneCycleLR
+(max_lr, pct_start = warmup/total, cos, div 25, final_div 1e4) stepped per iteration; CrossEntropy with label
+smoothing; per-tensor clip 0.1 for names containing ``cnn_stem`` / ``dwconv`` then global clip 0.5; EMA
+``p_ema = d*p_ema + (1-d)*p`` with buffers copied.
+
+MI355X-first structure: parameters, gradients and Adam moments live in FLAT fp32 buffers (parameters and
+``.grad`` are views), so clipping + AdamW is two kernels, gradient all-reduce works on contiguous buckets, and
+the whole step (weight re-pack, forward, backward, optimiser) is capturable in one hipGraph.
+"""
+import math
+from copy import deepcopy
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import functional as F
+from . import kernels as K
+
+
+@dataclass
+class TrainingConfig:
+    """Subset of HQAViT_CIFAR100.TrainingConfig (:81-122) that the step consumes, same names/defaults."""
+    batch_size: int = 256
+    epochs: int = 450
+    warmup_epochs: int = 20
+    base_lr: float = 6e-4
+    weight_decay: float = 0.06
+    label_smoothing: float = 0.12
+    max_grad_norm: float = 0.5
+    local_clip: float = 0.1          # per-tensor clip for 'cnn_stem' / 'dwconv' (:1416-1418)
+    use_amp: bool = True
+    amp_dtype: str = "bfloat16"
+    use_ema: bool = False
+    ema_decay: float = 0.999
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+
+
+def never_trained(name: str) -> bool:
+    """Parameters the reference's forward never puts on the autograd path: every ``global_bank.write_*`` (the
+    write runs on ``.data`` under no consumers) and the branch ``norm`` that only feeds the bank write
+    (SURVEY.md section 7 'Unused parameters': 54 tensors on HQA-ViT C100)."""
+    if "global_bank.write_" in name:
+        return True
+    for br in (".swa.norm.", ".msda.norm.", ".cga.norm."):
+        if br in name:
+            return True
+    return False
+
+
+def onecycle_lr(step: int, total: int, max_lr: float, pct_start: float, div: float = 25.0, final_div: float = 1e4) -> float:
+    """torch.optim.lr_scheduler.OneCycleLR (cos, two phases) in closed form; ``step`` = number of scheduler steps taken."""
+    initial, minimum = max_lr / div, max_lr / div / final_div
+    up_end = float(pct_start * total) - 1.0
+    down_end = float(total) - 1.0
+
+    def cos(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+    if step <= up_end:
+        return cos(initial, max_lr, step / up_end if up_end > 0 else 1.0)
+    return cos(max_lr, minimum, (step - up_end) / (down_end - up_end))
+
+
+class ModelEMA:
+    """HQAViT_CIFAR100.py:128-184."""
+
+    def __init__(self, model: nn.Module, decay: float = 0.9999, device: Optional[str] = None):
+        self.ema = deepcopy(model).eval()
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        self.decay = decay
+        if device is not None:
+            self.ema.to(device)
+
+    @torch.no_grad()
+    def update(self, model: nn.Module):
+        ep = [p for _, p in self.ema.named_parameters()]
+        mp = [p.detach() for _, p in model.named_parameters()]
+        torch._foreach_mul_(ep, self.decay)
+        torch._foreach_add_(ep, mp, alpha=1.0 - self.decay)
+        mb = dict(model.named_buffers())
+        for n, b in self.ema.named_buffers():
+            if n in mb:
+                b.copy_(mb[n])
+
+    def set_decay(self, decay: float):
+        self.decay = decay
+
+
+class Trainer:
+    """One object = model + flat optimiser state + (optional) data-parallel reducer + (optional) hipGraph."""
+
+    def __init__(self, model: nn.Module, cfg: TrainingConfig, total_steps: int, warmup_steps: Optional[int] = None,
+                 reducer=None, compute_dtype: Optional[torch.dtype] = None, order=None):
+        self.model, self.cfg, self.reducer = model, cfg, reducer
+        dev = next(model.parameters()).device
+        self.device = dev
+        if compute_dtype is None:
+            compute_dtype = torch.bfloat16 if (cfg.use_amp and cfg.amp_dtype == "bfloat16") else torch.float32
+        if hasattr(model, "compute_dtype"):
+            model.compute_dtype = compute_dtype
+        named = list(model.named_parameters())
+        if order is not None:                           # bucket-friendly ordering (parallel.bucket_order)
+            named = order(named)
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        sizes = [p.numel() for p in self.params]
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        n = self.offsets[-1]
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        skip = torch.zeros(n, dtype=torch.uint8, device=dev)
+        with torch.no_grad():
+            for p, name, o, s in zip(self.params, self.names, self.offsets, sizes):
+                self.flat_p[o:o + s].copy_(p.reshape(-1))
+                p.data = self.flat_p[o:o + s].view_as(p)
+                p.grad = self.flat_g[o:o + s].view_as(p)
+                if never_trained(name) or not p.requires_grad:
+                    skip[o:o + s] = 1
+        self.skip = skip
+        self.local_clip_params = [p for p, nme in zip(self.params, self.names) if ("cnn_stem" in nme or "dwconv" in nme)]
+        self.total_steps = total_steps
+        warm = warmup_steps if warmup_steps is not None else max(1, int(total_steps * cfg.warmup_epochs / max(cfg.epochs, 1)))
+        table = [onecycle_lr(i, total_steps, cfg.base_lr, warm / total_steps) for i in range(total_steps)]
+        self.lr_table = torch.tensor(table, dtype=torch.float32, device=dev)
+        self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)       # scheduler steps taken
+        self.step_f = torch.zeros(1, dtype=torch.float32, device=dev)       # Adam step count (1-based at use)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.partial = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.ema = None
+        if cfg.use_ema:
+            self.ema_flat = self.flat_p.clone()
+        self.graph = None
+        self._static_x = self._static_y = None
+        self.rt = K.Runtime.get(dev) if dev.type == "cuda" else None
+
+    # ------------------------------------------------------------------------------------------
+    def _fwd_bwd(self, x, y):
+        self.rt.advance()
+        F.pack_for(self.device).refresh()
+        self.flat_g.zero_()
+        if self.reducer is not None:
+            self.reducer.begin_step()
+        logits = self.model(x)
+        loss = TF.cross_entropy(logits.float(), y, label_smoothing=self.cfg.label_smoothing)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish(self.flat_g)
+        return loss.detach()
+
+    def _optim(self):
+        cfg = self.cfg
+        if cfg.local_clip > 0 and self.local_clip_params:
+            grads = [p.grad for p in self.local_clip_params]
+            norms = torch._foreach_norm(grads)
+            scale = torch.clamp(cfg.local_clip / (torch.stack(norms) + 1e-6), max=1.0)
+            torch._foreach_mul_(grads, list(scale.unbind(0)))
+        K.l2norm(self.flat_g, self.partial, self.gnorm)
+        torch.index_select(self.lr_table, 0, torch.clamp(self.step_idx, max=self.total_steps - 1), out=self.lr_dev)
+        self.step_f += 1.0
+        K.adamw(self.flat_p, self.flat_g, self.m, self.v, self.skip, self.lr_dev, cfg.beta1, cfg.beta2, cfg.eps,
+                cfg.weight_decay, self.step_f, self.gnorm, cfg.max_grad_norm)
+        self.step_idx += 1
+        if cfg.use_ema:
+            self.ema_flat.lerp_(self.flat_p, 1.0 - cfg.ema_decay)
+
+    def fwd_bwd(self, x, y):
+        """forward + loss + backward (+ gradient all-reduce): the unit BASELINE.json's metric times."""
+        self.model.train()
+        return self._fwd_bwd(x, y)
+
+    def step(self, x, y):
+        """Full optimiser step, eager.  Returns the (device) loss tensor."""
+        self.model.train()
+        loss = self._fwd_bwd(x, y)
+        self._optim()
+        return loss
+
+    # ------------------------------------------------------------------------------------------
+    def capture(self, x, y, with_optim: bool = True, warmup: int = 3):
+        """Capture the whole step into one hipGraph (torch.cuda.CUDAGraph).  ``x``/``y`` give the static shapes."""
+        self.model.train()
+        self._static_x, self._static_y = x.clone(), y.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                loss = self._fwd_bwd(self._static_x, self._static_y)
+                if with_optim:
+                    self._optim()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._fwd_bwd(self._static_x, self._static_y)
+            if with_optim:
+                self._optim()
+            self.loss.copy_(loss)
+        self.graph = g
+        return g
+
+    def replay(self, x=None, y=None):
+        if x is not None:
+            self._static_x.copy_(x, non_blocking=True)
+            self._static_y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+    def grad_norm(self) -> float:
+        return float(self.gnorm.item())

@@ -1,0 +1,294 @@
+"""Raw (non-autograd) Python wrappers over the C-ABI: tensors in, kernels enqueued on torch's current
+stream.  PyTorch is plumbing here -- device memory, streams -- the arithmetic is in libqavit_hip.so."""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return L.F32
+    if dtype == torch.bfloat16:
+        return L.BF16
+    raise TypeError(f"qavit kernels support float32 and bfloat16 activations, got {dtype}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("qavit HIP kernels need tensors on the GPU (there is no CPU fallback)")
+
+
+class Runtime:
+    """Per-device state: RNG words, NaN flag, dropout-site ids, scratch workspaces."""
+    _inst = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.rng = torch.tensor([0x5EED, 0], dtype=torch.int64, device=device)
+        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self._ws = {}
+        self._tbl = {}
+        self.nan_guard = True
+
+    @classmethod
+    def get(cls, device) -> "Runtime":
+        key = torch.device(device).index or 0
+        if key not in cls._inst:
+            cls._inst[key] = Runtime(torch.device("cuda", key))
+        return cls._inst[key]
+
+    def seed(self, s: int):
+        self.rng[0] = int(s)
+        self.rng[1] = 0
+
+    def advance(self):
+        L.check(L.load().qavit_rng_advance(self.rng.data_ptr(), stream()), "rng_advance")
+
+    def workspace(self, name: str, n_floats: int) -> torch.Tensor:
+        w = self._ws.get(name)
+        if w is None or w.numel() < n_floats:
+            w = torch.empty(max(int(n_floats), 1), dtype=torch.float32, device=self.device)
+            self._ws[name] = w
+        return w
+
+    def table(self, key, builder) -> torch.Tensor:
+        t = self._tbl.get(key)
+        if t is None:
+            t = torch.tensor(builder(), dtype=torch.int32, device=self.device)
+            self._tbl[key] = t
+        return t
+
+
+_site_counter = [0]
+
+
+def new_site() -> int:
+    """Unique id of a dropout / drop-path site (mixed into the RNG key)."""
+    _site_counter[0] += 1
+    return _site_counter[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMMs
+# ---------------------------------------------------------------------------------------------------
+def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None, ln_stats=None,
+            bwd=None, Z=None, act=0, drop=(0.0, 0), scale=1.0, dp=(0.0, 0, 1), R=None, ldr=0, rng=None,
+            A_ptr=None, B_ptr=None, C_ptr=None):
+    """C[M,N] = epi(pro(A)[M,K] @ B[N,K]^T + bias).  A/B/Cout are tensors used for dtype/liveness; *_ptr
+    override the base address (column-offset views)."""
+    a = L.GemmArgs()
+    a.dtype = dt_code(A.dtype)
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda = (A_ptr or A.data_ptr()), lda
+    a.B, a.ldb = (B_ptr or B.data_ptr()), ldb
+    a.C, a.ldc = (C_ptr or Cout.data_ptr()), ldc
+    a.bias = _p(bias)
+    a.a_mode = a_mode
+    a.a_scale = 1.0
+    if a_mode == 1:
+        g, b_, eps = ln
+        a.ln_gamma, a.ln_beta, a.ln_eps = g.data_ptr(), b_.data_ptr(), eps
+        if ln_stats is not None:
+            a.ln_mean, a.ln_rstd = ln_stats[0].data_ptr(), ln_stats[1].data_ptr()
+    if a_mode == 2:
+        a.a_Z = _p(bwd.get("Z"))
+        a.a_ldz = bwd.get("ldz", 0)
+        a.a_act = bwd.get("act", 0)
+        a.a_drop_p, a.a_drop_site = bwd.get("drop", (0.0, 0))
+        a.a_dp_p, a.a_dp_site, a.a_dp_rows = bwd.get("dp", (0.0, 0, 1))
+        a.a_scale = bwd.get("scale", 1.0)
+        a.a_out = _p(bwd.get("out"))
+        a.a_ldo = bwd.get("ldo", 0)
+    if Z is not None:
+        a.Z, a.ldz = Z.data_ptr(), N
+    a.act = act
+    a.drop_p, a.drop_site = drop
+    a.scale = scale
+    a.dp_p, a.dp_site, a.dp_rows = dp
+    if R is not None:
+        a.R, a.ldr = R.data_ptr(), (ldr or N)
+    a.rng = _p(rng)
+    L.check(L.load().qavit_gemm_nt(C.byref(a), stream()), "gemm_nt")
+
+
+def gemm_tn(A, Bm, Cgrad, M, N, K, lda, ldb, ldc, colsum=None, ln=None, A_ptr=None, B_ptr=None, C_ptr=None, colsum_ptr=None):
+    """Cgrad[N,K] += A[M,N]^T @ B[M,K] (fp32), colsum[N] += sum_m A."""
+    a = L.GemmTnArgs()
+    a.dtype = dt_code(A.dtype)
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda = (A_ptr or A.data_ptr()), lda
+    a.B, a.ldb = (B_ptr or Bm.data_ptr()), ldb
+    a.C, a.ldc = (C_ptr or Cgrad.data_ptr()), ldc
+    a.colsum = colsum_ptr or _p(colsum)
+    if ln is not None:
+        g, b_, mean, rstd = ln
+        a.ln_gamma, a.ln_beta, a.ln_mean, a.ln_rstd = g.data_ptr(), b_.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    a.splits = 0
+    L.check(L.load().qavit_gemm_tn(C.byref(a), stream()), "gemm_tn")
+
+
+# ---------------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, y, gamma, beta, eps, rows, Cc, mean, rstd, add=None, add_rows=0):
+    L.check(L.load().qavit_layernorm_fwd(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                         eps, rows, Cc, _p(mean), _p(rstd), _p(add), add_rows, stream()), "layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0):
+    L.check(L.load().qavit_layernorm_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, Cc, _p(dadd), add_rows,
+                                         stream()), "layernorm_bwd")
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------
+def attn_args(dtype, mode, G, Nq, Lk, H, D, KC, S, groups_per_b=0, q_rows_per_b=0, k_rows_per_b=0, q_tbl=None, k_tbl=None):
+    a = L.AttnArgs()
+    a.dtype, a.mode = dt_code(dtype), mode
+    a.G, a.Nq, a.L, a.H, a.D, a.KC, a.S = G, Nq, Lk, H, D, KC, S
+    a.groups_per_b, a.q_rows_per_b, a.k_rows_per_b = groups_per_b, q_rows_per_b, k_rows_per_b
+    a.q_tbl, a.k_tbl = _p(q_tbl), _p(k_tbl)
+    return a
+
+
+def attn_fwd(a):
+    L.check(L.load().qavit_attn_fwd(C.byref(a), stream()), "attn_fwd")
+
+
+def attn_bwd(a):
+    L.check(L.load().qavit_attn_bwd(C.byref(a), stream()), "attn_bwd")
+
+
+def attn_ws_floats(a) -> int:
+    return int(L.load().qavit_attn_ws_floats(C.byref(a)))
+
+
+def nan_guard(x, flag):
+    L.check(L.load().qavit_nan_guard(dt_code(x.dtype), x.data_ptr(), x.numel(), flag.data_ptr(), stream()), "nan_guard")
+
+
+# ---------------------------------------------------------------------------------------------------
+# token kernels
+# ---------------------------------------------------------------------------------------------------
+def tokmix_fwd(scores, x, p, xc, B, N, M, Cc):
+    L.check(L.load().qavit_tokmix_fwd(dt_code(x.dtype), scores.data_ptr(), x.data_ptr(), p.data_ptr(), xc.data_ptr(), B, N, M, Cc, stream()), "tokmix_fwd")
+
+
+def tokmix_bwd(p, x, dxc, dx, dscores, B, N, M, Cc):
+    L.check(L.load().qavit_tokmix_bwd(dt_code(x.dtype), p.data_ptr(), x.data_ptr(), dxc.data_ptr(), dx.data_ptr(), dscores.data_ptr(), B, N, M, Cc, stream()), "tokmix_bwd")
+
+
+def upmix_fwd(xc, W, bias, gamma, beta, eps, y, mean, rstd, B, N, M, Cc):
+    L.check(L.load().qavit_upmix_fwd(dt_code(xc.dtype), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
+                                     y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, M, Cc, stream()), "upmix_fwd")
+
+
+def upmix_bwd(dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta, B, N, M, Cc):
+    L.check(L.load().qavit_upmix_bwd(dt_code(xc.dtype), dy.data_ptr(), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                                     mean.data_ptr(), rstd.data_ptr(), dxc.data_ptr(), dW.data_ptr(), _p(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
+                                     B, N, M, Cc, stream()), "upmix_bwd")
+
+
+def gather_pool_fwd(x, idx, y, B, N, NP, stride, Cc):
+    L.check(L.load().qavit_gather_pool_fwd(dt_code(x.dtype), x.data_ptr(), idx.data_ptr(), y.data_ptr(), B, N, NP, stride, Cc, stream()), "gather_pool_fwd")
+
+
+def gather_pool_bwd(dy, idx, dx, B, N, NP, stride, Cc):
+    L.check(L.load().qavit_gather_pool_bwd(dt_code(dy.dtype), dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, N, NP, stride, Cc, stream()), "gather_pool_bwd")
+
+
+def token_mean_fwd(x, y, B, N, Cc):
+    L.check(L.load().qavit_token_mean_fwd(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), B, N, Cc, stream()), "token_mean_fwd")
+
+
+def token_mean_bwd(dy, dx, B, N, Cc):
+    L.check(L.load().qavit_token_mean_bwd(dt_code(dy.dtype), dy.data_ptr(), dx.data_ptr(), B, N, Cc, stream()), "token_mean_bwd")
+
+
+# ---------------------------------------------------------------------------------------------------
+# CCF-FFN middle
+# ---------------------------------------------------------------------------------------------------
+def ccf_args(dtype, flags, B, Hs, Ws, Cc, eps):
+    a = L.CcfArgs()
+    a.dtype, a.flags, a.B, a.Hs, a.Ws, a.C, a.eps = dt_code(dtype), flags, B, Hs, Ws, Cc, eps
+    return a
+
+
+def ccf_fwd(a):
+    L.check(L.load().qavit_ccf_mid_fwd(C.byref(a), stream()), "ccf_mid_fwd")
+
+
+def ccf_bwd(a):
+    L.check(L.load().qavit_ccf_mid_bwd(C.byref(a), stream()), "ccf_mid_bwd")
+
+
+# ---------------------------------------------------------------------------------------------------
+# bank
+# ---------------------------------------------------------------------------------------------------
+def bank_stats(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, acc, ws, B, N, Cc, S, eps):
+    L.check(L.load().qavit_bank_stats(dt_code(tokens.dtype), tokens.data_ptr(), g_branch.data_ptr(), b_branch.data_ptr(), g_write.data_ptr(),
+                                      b_write.data_ptr(), Wg.data_ptr(), bg.data_ptr(), acc.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      B, N, Cc, S, eps, stream()), "bank_stats")
+
+
+def bank_ws_floats(B, N, Cc, S) -> int:
+    return int(L.load().qavit_bank_ws_floats(B, N, Cc, S))
+
+
+def bank_apply(acc, Wc, bc, bank_k, bank_v, update_count, S, Cc, inv_batch, mode):
+    L.check(L.load().qavit_bank_apply(acc.data_ptr(), Wc.data_ptr(), bc.data_ptr(), bank_k.data_ptr(), bank_v.data_ptr(), _p(update_count),
+                                      S, Cc, inv_batch, mode, stream()), "bank_apply")
+
+
+# ---------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------
+def patchify(img, cols, B, Cin, H, W, p):
+    L.check(L.load().qavit_patchify(dt_code(cols.dtype), img.data_ptr(), cols.data_ptr(), B, Cin, H, W, p, stream()), "patchify")
+
+
+def hybrid_fuse_fwd(x, fw, y, rows, nb, Cb):
+    L.check(L.load().qavit_hybrid_fuse_fwd(dt_code(x.dtype), x.data_ptr(), fw.data_ptr(), y.data_ptr(), rows, nb, Cb, stream()), "hybrid_fuse_fwd")
+
+
+def hybrid_fuse_bwd(dy, x, fw, dx, dfw, rows, nb, Cb):
+    L.check(L.load().qavit_hybrid_fuse_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), fw.data_ptr(), dx.data_ptr(), dfw.data_ptr(), rows, nb, Cb, stream()), "hybrid_fuse_bwd")
+
+
+def scale_add_fwd(x, u, gamma, y, rows, Cc, dp, rng):
+    L.check(L.load().qavit_scale_add_fwd(dt_code(x.dtype), x.data_ptr(), u.data_ptr(), _p(gamma), y.data_ptr(), rows, Cc, dp[0], dp[1], dp[2], _p(rng), stream()), "scale_add_fwd")
+
+
+def scale_add_bwd(dy, u, gamma, du, dgamma, rows, Cc, dp, rng):
+    L.check(L.load().qavit_scale_add_bwd(dt_code(dy.dtype), dy.data_ptr(), u.data_ptr(), _p(gamma), du.data_ptr(), _p(dgamma), rows, Cc, dp[0], dp[1], dp[2], _p(rng), stream()), "scale_add_bwd")
+
+
+def dropout(x, y, p, site, rng):
+    L.check(L.load().qavit_dropout(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), x.numel(), p, site, rng.data_ptr(), stream()), "dropout")
+
+
+def pack_weights(dtype, descs_dev, n_desc, max_elems):
+    L.check(L.load().qavit_pack_weights(dt_code(dtype), descs_dev.data_ptr(), n_desc, max_elems, stream()), "pack_weights")
+
+
+def adamw(p, g, m, v, skip, lr_dev, b1, b2, eps, wd, step_dev, gnorm_dev, max_norm):
+    L.check(L.load().qavit_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(skip), p.numel(), lr_dev.data_ptr(), b1, b2, eps, wd,
+                                 step_dev.data_ptr(), _p(gnorm_dev), max_norm, stream()), "adamw")
+
+
+def l2norm(g, partial, out):
+    L.check(L.load().qavit_l2norm(g.data_ptr(), g.numel(), partial.data_ptr(), out.data_ptr(), stream()), "l2norm")

@@ -1,0 +1,122 @@
+"""ctypes binding of libqavit_hip.so (include/qavit.h).  No fallback: if the library is missing or a call
+fails, a RuntimeError is raised -- the product path never computes on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqavit_hip.so")
+
+F32, BF16 = 0, 1
+
+i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("M", i32), ("N", i32), ("K", i32),
+        ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("bias", vp),
+        ("a_mode", i32), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32), ("ln_mean", vp), ("ln_rstd", vp),
+        ("a_Z", vp), ("a_ldz", i64), ("a_act", i32), ("a_drop_p", f32), ("a_drop_site", i32),
+        ("a_dp_p", f32), ("a_dp_site", i32), ("a_dp_rows", i32), ("a_scale", f32), ("a_out", vp), ("a_ldo", i64),
+        ("Z", vp), ("ldz", i64), ("act", i32), ("drop_p", f32), ("drop_site", i32), ("scale", f32),
+        ("dp_p", f32), ("dp_site", i32), ("dp_rows", i32), ("R", vp), ("ldr", i64), ("rng", vp),
+    ]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("M", i32), ("N", i32), ("K", i32),
+        ("A", vp), ("lda", i64), ("B", vp), ("ldb", i64), ("C", vp), ("ldc", i64), ("colsum", vp),
+        ("ln_gamma", vp), ("ln_beta", vp), ("ln_mean", vp), ("ln_rstd", vp), ("splits", i32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("mode", i32),
+        ("G", i32), ("Nq", i32), ("L", i32), ("H", i32), ("D", i32), ("KC", i32), ("S", i32),
+        ("groups_per_b", i32), ("q_rows_per_b", i32), ("k_rows_per_b", i32), ("q_tbl", vp), ("k_tbl", vp),
+        ("q", vp), ("ldq", i64), ("k_tok", vp), ("ldk", i64), ("v_tok", vp), ("ldv", i64),
+        ("E_k", vp), ("E_v", vp), ("sh_k", vp), ("sh_v", vp), ("o", vp), ("ldo", i64), ("nan_flag", vp),
+        ("d_o", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk_tok", vp), ("lddk", i64), ("dv_tok", vp), ("lddv", i64),
+        ("ws", vp), ("ws_floats", i64), ("dE_k", vp), ("dE_v", vp), ("dsh_k", vp), ("dsh_v", vp),
+    ]
+
+
+class CcfArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("flags", i32), ("B", i32), ("Hs", i32), ("Ws", i32), ("C", i32),
+        ("h", vp), ("out", vp), ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp), ("eps", f32),
+        ("w", vp), ("cbias", vp), ("cscale", vp), ("mean1", vp), ("rstd1", vp), ("mean2", vp), ("rstd2", vp),
+        ("d_out", vp), ("d_h", vp), ("dg1", vp), ("db1", vp), ("dg2", vp), ("db2", vp), ("dw", vp), ("dcbias", vp), ("dcscale", vp),
+    ]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("dstT", vp), ("rows", i32), ("cols", i32), ("ldT", i32), ("pad", i32)]
+
+
+_SIGS = {
+    "qavit_version": (i32, []),
+    "qavit_last_error": (C.c_char_p, []),
+    "qavit_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
+    "qavit_gemm_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
+    "qavit_layernorm_fwd": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, i32, vp]),
+    "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
+    "qavit_attn_fwd": (i32, [C.POINTER(AttnArgs), vp]),
+    "qavit_attn_bwd": (i32, [C.POINTER(AttnArgs), vp]),
+    "qavit_attn_ws_floats": (i64, [C.POINTER(AttnArgs)]),
+    "qavit_nan_guard": (i32, [i32, vp, i64, vp, vp]),
+    "qavit_tokmix_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "qavit_tokmix_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "qavit_upmix_fwd": (i32, [i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "qavit_upmix_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "qavit_gather_pool_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "qavit_gather_pool_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "qavit_ccf_mid_fwd": (i32, [C.POINTER(CcfArgs), vp]),
+    "qavit_ccf_mid_bwd": (i32, [C.POINTER(CcfArgs), vp]),
+    "qavit_bank_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]),
+    "qavit_bank_ws_floats": (i64, [i32, i32, i32, i32]),
+    "qavit_bank_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
+    "qavit_patchify": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "qavit_token_mean_fwd": (i32, [i32, vp, vp, i32, i32, i32, vp]),
+    "qavit_token_mean_bwd": (i32, [i32, vp, vp, i32, i32, i32, vp]),
+    "qavit_hybrid_fuse_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
+    "qavit_hybrid_fuse_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "qavit_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "qavit_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "qavit_dropout": (i32, [i32, vp, vp, i64, f32, i32, vp, vp]),
+    "qavit_pack_weights": (i32, [i32, vp, i32, i32, vp]),
+    "qavit_rng_advance": (i32, [vp, vp]),
+    "qavit_adamw": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, f32, vp]),
+    "qavit_l2norm": (i32, [vp, i64, vp, vp, vp]),
+}
+
+# every symbol include/qavit.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once).  Raises RuntimeError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `python qa-vit_amd/build.py`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().qavit_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

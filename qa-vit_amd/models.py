@@ -1,0 +1,154 @@
+"""Top-level models: ``HQAViT`` (HQAViT_CIFAR100.py:1141-1277, HQAViT_IN_Tiny.py:1362-1494) and ``QAViT``
+(QAViT.py:654-699, QAViTv2.py:1011-1055).  ``Model(config)``, ``forward(x[B,3,H,W]) -> logits``,
+``state_dict`` layout, attribute surface (``patch_embed.proj``, ``pos_embed``, ``head``, ``global_bank``,
+``cnn_stem`` / ``lmfa*`` / ``rrcv*`` / ``fuse*``, ``blocks``) follow the reference; the arithmetic runs in
+libqavit_hip.so.
+
+Compute dtype: under ``torch.autocast(dtype=bf16)`` (what the reference's training loops use,
+HQAViT_CIFAR100.py:1401-1403) activations are bf16 with fp32 accumulation; otherwise fp32 (exact-fp32 MFMA),
+which is the parity path.  ``model.compute_dtype = torch.bfloat16`` forces bf16 without autocast.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from . import kernels as K
+from . import modules as M
+from .config import HQAViTConfig, QAViTConfig  # noqa: F401
+
+
+def _init_weights(m):
+    """HQAViT._init_weights, HQAViT_CIFAR100.py:1215-1224."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+    elif isinstance(m, nn.Conv2d):
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class _Base(nn.Module):
+    compute_dtype = None
+    _sync_reducer = None          # parallel.GradReducer when data-parallel (see parallel.SyncPoint)
+
+    def _sync(self, T, tag):
+        if self._sync_reducer is not None and torch.is_grad_enabled():
+            from .parallel import SyncPoint
+            return SyncPoint.apply(T, self._sync_reducer, tag)
+        return T
+
+    def _dtype(self, x):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled():
+            return torch.get_autocast_gpu_dtype()
+        return torch.float32
+
+    def _check(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("qavit_amd models run on the GPU only (HIP kernels; there is no CPU fallback). "
+                               "Move the model and the input to cuda.")
+
+    def set_bank_sync(self, fn):
+        """Data-parallel hook: ``fn(acc[S*C], local_batch) -> global_batch`` all-reduces the bank statistics."""
+        self._rt.bank_sync = fn
+
+    def _head(self, T):
+        T = F.layer_norm(T, self.norm.weight, self.norm.bias, self.norm.eps)
+        return F.linear(F.TokenMeanFn.apply(T), self.head.weight, self.head.bias)
+
+
+class HQAViT(_Base):
+    def __init__(self, config: HQAViTConfig, variant: str = "hqa"):
+        super().__init__()
+        self.config = config
+        self._rt = M._Ctx(variant)
+        self.num_patches = (config.img_size // config.patch_size) ** 2
+        self.H = self.W = config.img_size // config.patch_size
+        d = config.embed_dim
+        self.patch_embed = M.PatchEmbed(config.img_size, config.patch_size, config.in_channels, d)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, d))
+        self.pos_drop = nn.Dropout(config.dropout)
+        self.global_bank = M.GlobalTokenBank(config.global_bank_size, d)
+        self.cnn_stem = M.CNNStemModel(config.in_channels, config.cnn_c2, config.cnn_c3, config.cnn_c4)
+        for i, c in ((2, config.cnn_c2), (3, config.cnn_c3), (4, config.cnn_c4)):
+            setattr(self, f"lmfa{i}", M.LMFAdapter(c, d, target_hw=self.H))
+        for i in (2, 3, 4):
+            setattr(self, f"rrcv{i}", M.RRCV(d, config.rrcv_channels, config.rrcv_num_blocks))
+        for i in (2, 3, 4):
+            setattr(self, f"fuse{i}", M.SplitFusion(d))
+        dpr = [v.item() for v in torch.linspace(0, config.drop_path, config.depth)]
+        sizes = (2, 2, config.depth - 6, 2)          # [2,2,2,2] at depth 8, [2,2,6,2] at depth 12
+        k = 0
+        for si, n in enumerate(sizes, start=1):
+            blocks = nn.ModuleList([
+                M.QuadBlockWithTokenLearner(config, self.global_bank, dpr[k + j], config.use_token_learner, self._rt)
+                for j in range(n)])
+            setattr(self, f"stage{si}_blocks", blocks)
+            k += n
+        self.norm = nn.LayerNorm(d)
+        self.head = nn.Linear(d, config.num_classes)
+        self._pos_site = K.new_site()
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        self.apply(_init_weights)
+
+    def forward(self, x):
+        self._check(x)
+        cdt = self._dtype(x)
+        self.patch_embed.proj.compute_dtype = cdt
+        lowp = cdt != torch.float32
+        # CNN lateral path: stock ROCm convolutions, in the compute dtype via autocast
+        with torch.autocast("cuda", dtype=cdt if lowp else torch.bfloat16, enabled=lowp):
+            f2, f3, f4 = self.cnn_stem(x)
+            R = {}
+            for i, f in ((2, f2), (3, f3), (4, f4)):
+                a = getattr(self, f"lmfa{i}")(f)
+                R[i] = getattr(self, f"rrcv{i}")(a.to(cdt), self.H, self.W).to(cdt)
+        with torch.autocast("cuda", enabled=False):
+            T = self.patch_embed(x, self.pos_embed)
+            T = F.dropout(T, self.pos_drop.p, self._pos_site, self.training)
+            for si in (1, 2, 3, 4):
+                if si >= 2:
+                    T = self._sync(T, f"fuse{si}")
+                    T = getattr(self, f"fuse{si}")(T, R[si])
+                T = self._sync(T, f"stage{si}_blocks")
+                for blk in getattr(self, f"stage{si}_blocks"):
+                    T = blk(T)
+            return self._head(T)
+
+
+class QAViT(_Base):
+    """variant 'v1' = QAViT.py, 'v2' = QAViTv2.py (stabilised CCF-FFN + depthwise bias + bank update_count),
+    'hqa' = QAViTv2_CIFAR100.py (v2 without the depthwise bias)."""
+
+    def __init__(self, config: QAViTConfig, variant: str = "v1"):
+        super().__init__()
+        self.config = config
+        self._rt = M._Ctx(variant)
+        self.num_patches = (config.img_size // config.patch_size) ** 2
+        d = config.embed_dim
+        self.patch_embed = M.PatchEmbed(config.img_size, config.patch_size, config.in_channels, d)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, d))
+        self.pos_drop = nn.Dropout(config.dropout)
+        self.global_bank = M.GlobalTokenBank(config.global_bank_size, d, with_counter=(variant != "v1"))
+        dpr = [v.item() for v in torch.linspace(0, config.drop_path, config.depth)]
+        self.blocks = nn.ModuleList([M.QuadAttentionBlock(config, self.global_bank, dpr[i], self._rt) for i in range(config.depth)])
+        self.norm = nn.LayerNorm(d)
+        self.head = nn.Linear(d, config.num_classes)
+        self._pos_site = K.new_site()
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        self.apply(_init_weights)
+
+    def forward(self, x):
+        self._check(x)
+        cdt = self._dtype(x)
+        self.patch_embed.proj.compute_dtype = cdt
+        with torch.autocast("cuda", enabled=False):
+            T = self.patch_embed(x, self.pos_embed)
+            T = F.dropout(T, self.pos_drop.p, self._pos_site, self.training)
+            for blk in self.blocks:
+                T = blk(T)
+            return self._head(T)

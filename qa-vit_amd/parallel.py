@@ -1,0 +1,205 @@
+"""Data parallelism for the training path -- NEW functionality (the reference has no distributed code at all,
+SURVEY.md section 2): one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" on CPU for tests).
+
+Design (SURVEY.md sections 5 and 8e):
+  * the global batch is sharded, weights replicated; the one exchange step is a SUM all-reduce of the flat
+    fp32 gradient buffer, cut into contiguous buckets ordered by backward completion (head and last stage
+    first, CNN stem / bank / embeddings last).  ``SyncPoint`` autograd nodes placed between stages fire during
+    backward and launch the buckets whose gradients are complete on a side stream, overlapping the remaining
+    backward; ``finish()`` launches the rest, waits, and divides by the world size.  25.7 MB of gradients
+    are tiny against 7 x 153 GB/s of xGMI per GPU, so a handful of >= 4 MB buckets keeps every collective
+    bandwidth- rather than latency-bound.
+  * exception 1, ``GlobalTokenBank.write``: its batch mean spans the GLOBAL batch, so the [S,C] statistics
+    are all-reduced (SUM) before the clamp/update -- 24 (C100) sequential 12 KB collectives per forward,
+    latency-bound; exact mode is the default, ``bank_sync="local"`` keeps per-rank banks and re-broadcasts
+    rank 0's bank every ``bank_broadcast_every`` steps.
+  * exception 2, BatchNorm in the CNN stem: per-rank statistics (standard DDP semantics); buffers are broadcast
+    from rank 0 at construction.
+  * dropout / drop-path RNG streams differ per rank (seed + rank).
+"""
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def bucket_order(named: Sequence[Tuple[str, torch.nn.Parameter]]):
+    """Order parameters by when their gradient completes in backward: head/norm, stage4, fuse4, stage3, ...,
+    stage1, then everything that stays live until the very end (embeddings, bank, CNN lateral path)."""
+    def key(name: str) -> int:
+        if name.startswith(("head.", "norm.")):
+            return 0
+        for i, tag in enumerate(("stage4_blocks", "fuse4", "stage3_blocks", "fuse3", "stage2_blocks", "fuse2", "stage1_blocks")):
+            if name.startswith(tag):
+                return 1 + i
+        if name.startswith("blocks."):                      # QAViT: blocks.<i>, later blocks finish first
+            try:
+                return 1 + (1000 - int(name.split(".")[1]))
+            except ValueError:
+                return 1
+        return 10_000
+    return sorted(named, key=lambda kv: key(kv[0]))
+
+
+class SyncPoint(torch.autograd.Function):
+    """Identity in forward; in backward tells the reducer that every parameter used AFTER this point in the
+    forward pass has its complete gradient."""
+
+    @staticmethod
+    def forward(ctx, x, reducer, tag):
+        ctx.reducer, ctx.tag = reducer, tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.reducer.reached(ctx.tag)
+        return g, None, None
+
+
+class GradReducer:
+    """Bucketed all-reduce of a flat gradient buffer, overlapped with backward on a side stream."""
+
+    def __init__(self, group=None, bucket_bytes: int = 4 << 20):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.bucket_bytes = bucket_bytes
+        self.bounds: List[Tuple[int, int]] = []       # element ranges, in launch order
+        self.ready_at = {}                            # tag -> number of buckets complete when the tag fires
+        self._next = 0
+        self._flat = None
+        self._side = None
+        self._works = []
+
+    def plan(self, names: Sequence[str], offsets: Sequence[int], tags: Sequence[Tuple[str, Callable[[str], bool]]]):
+        """``names/offsets`` describe the flat buffer (already in bucket_order).  ``tags`` lists, in backward
+        firing order, (tag, predicate(name) -> "complete once this tag has fired")."""
+        total = offsets[-1]
+        per = max(1, self.bucket_bytes // 4)
+        # tag boundaries in elements: parameters complete at tag k form a prefix of the flat buffer
+        done_upto = []
+        pos = 0
+        for tag, pred in tags:
+            while pos < len(names) and pred(names[pos]):
+                pos += 1
+            done_upto.append((tag, offsets[pos]))
+        # cut buckets: never across a tag boundary's "ready" prefix unless the piece is small
+        cuts = sorted({0, total, *[e for _, e in done_upto]})
+        bounds = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            s = a
+            while s < b:
+                e = min(b, s + per)
+                if b - e < per // 4:
+                    e = b
+                bounds.append((s, e))
+                s = e
+        merged = []
+        for s, e in bounds:                            # merge slivers into their predecessor
+            if merged and (e - s) < per // 8:
+                merged[-1] = (merged[-1][0], e)
+            else:
+                merged.append((s, e))
+        self.bounds = merged
+        self.ready_at = {}
+        for tag, upto in done_upto:
+            self.ready_at[tag] = sum(1 for (_, e) in merged if e <= upto)
+        return merged
+
+    def attach(self, flat: torch.Tensor):
+        self._flat = flat
+        if flat.is_cuda:
+            self._side = torch.cuda.Stream(device=flat.device)
+
+    def begin_step(self):
+        self._next = 0
+        self._works = []
+
+    def _launch(self, upto_bucket: int):
+        if self._flat is None or upto_bucket <= self._next:
+            return
+        flat = self._flat
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._side):
+                for s, e in self.bounds[self._next:upto_bucket]:
+                    dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            for s, e in self.bounds[self._next:upto_bucket]:
+                self._works.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._next = upto_bucket
+
+    def reached(self, tag):
+        self._launch(self.ready_at.get(tag, 0))
+
+    def finish(self, flat: torch.Tensor):
+        if self._flat is None:
+            self.attach(flat)
+        self._launch(len(self.bounds))
+        if self._side is not None:
+            torch.cuda.current_stream(flat.device).wait_stream(self._side)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        flat.mul_(1.0 / self.world)
+
+
+class DataParallel:
+    """Wires a model + Trainer for data-parallel training.
+
+        dp = DataParallel(model)                       # broadcast weights/buffers, per-rank RNG, bank hook
+        trainer = Trainer(model, cfg, steps, reducer=dp.reducer, order=bucket_order)
+        dp.bind(trainer)                               # plan buckets over the trainer's flat gradient buffer
+    """
+
+    def __init__(self, model: torch.nn.Module, group=None, bucket_bytes: int = 4 << 20, bank_sync: str = "exact",
+                 bank_broadcast_every: int = 50, seed: int = 0x5EED):
+        if not dist.is_initialized():
+            raise RuntimeError("DataParallel needs torch.distributed.init_process_group first")
+        self.model, self.group = model, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.bank_sync, self.bank_every, self._steps = bank_sync, bank_broadcast_every, 0
+        with torch.no_grad():
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=group)
+        self.reducer = GradReducer(group, bucket_bytes)
+        dev = next(model.parameters()).device
+        if dev.type == "cuda":
+            from . import kernels as K
+            K.Runtime.get(dev).seed(seed + self.rank)
+        if hasattr(model, "set_bank_sync"):
+            model.set_bank_sync(self._bank_all_reduce if bank_sync == "exact" else None)
+        if hasattr(model, "_sync_reducer"):
+            model._sync_reducer = self.reducer
+
+    def _bank_all_reduce(self, acc: torch.Tensor, local_batch: int) -> int:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+        return local_batch * self.world
+
+    def bind(self, trainer):
+        names, offsets = trainer.names, trainer.offsets
+        stage_tags = []
+        for tag in ("stage4_blocks", "fuse4", "stage3_blocks", "fuse3", "stage2_blocks", "fuse2", "stage1_blocks"):
+            # gradients of everything ordered at or before `tag` are complete when backward passes the sync
+            # point placed BEFORE that module group in forward
+            stage_tags.append((tag, _prefix_pred(tag)))
+        self.reducer.plan(names, offsets, stage_tags)
+        self.reducer.attach(trainer.flat_g)
+
+    def after_step(self):
+        self._steps += 1
+        if self.bank_sync == "local" and self._steps % self.bank_every == 0 and hasattr(self.model, "global_bank"):
+            dist.broadcast(self.model.global_bank.global_k.data, src=0, group=self.group)
+            dist.broadcast(self.model.global_bank.global_v.data, src=0, group=self.group)
+
+
+_ORDER = ("head.", "norm.", "stage4_blocks", "fuse4", "stage3_blocks", "fuse3", "stage2_blocks", "fuse2", "stage1_blocks")
+
+
+def _prefix_pred(tag: str):
+    upto = _ORDER.index(tag)
+    ok = _ORDER[: upto + 1]
+
+    def pred(name: str) -> bool:
+        return name.startswith(ok)
+    return pred

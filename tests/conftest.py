@@ -1,0 +1,68 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are selected explicitly with -m gpu; without a GPU they are skipped, never silently passed
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="session")
+def Q():
+    import qavit_amd
+    return qavit_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    return importlib.import_module("qavit_oracle")
+
+
+MODELS = {
+    # tag -> (builder(Q, **cfg_overrides), oracle forward name, oracle variant, label smoothing)
+    "c100": (lambda Q, **kw: Q.HQAViT(Q.HQAViTConfig(**kw)), "hqavit_forward", "hqa", 0.12),
+    "tin": (lambda Q, **kw: Q.HQAViT(Q.HQAViTTinyINConfig(**kw)), "hqavit_forward", "hqa", 0.12),
+    "q32": (lambda Q, **kw: Q.QAViT(Q.qavit32_config(**kw), "v1"), "qavit_forward", "v1", 0.1),
+    "v2_32": (lambda Q, **kw: Q.QAViT(Q.qavit32_config(**kw), "v2"), "qavit_forward", "v2", 0.1),
+}
+
+
+def sig(t: torch.Tensor) -> np.ndarray:
+    """Same activation signature as tests/golden/make_golden.py."""
+    t = t.detach().float().cpu()
+    flat = t.reshape(t.shape[0], -1)
+    corner = flat[:2, :96].reshape(-1)
+    stride = max(1, flat.shape[1] // 64)
+    strided = flat[:, ::stride][:, :64].reshape(-1)
+    mom = torch.stack([t.mean(), t.std(), t.abs().max(), t.abs().mean()])
+    return torch.cat([corner, strided, mom]).numpy().astype(np.float32)
+
+
+def max_rel(a, b) -> float:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

@@ -1,0 +1,447 @@
+"""Operator-level parity of the HIP kernels (through the C-ABI) against plain PyTorch fp32 math on the same
+inputs.  fp32 path: <= 2e-5 max-rel forward, <= 2e-4 for gradients reduced with atomics; bf16 path: loose
+(bf16 has 8 mantissa bits) -- the parity gate of BASELINE.json is on fp32."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def tol(dtype, fwd=True):
+    if dtype == torch.float32:
+        return 3e-5 if fwd else 3e-4
+    return 3e-2 if fwd else 6e-2
+
+
+def leaf(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).requires_grad_(True)
+
+
+@pytest.fixture(scope="module")
+def F(Q):
+    Q.lib.load()
+    import importlib
+    return importlib.import_module("qa-vit_amd.functional")
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(1000, 192, 576), (4096, 48, 192), (777, 96, 100), (64, 192, 16), (300, 384, 192), (130, 1024, 256), (50, 100, 192)])
+def test_linear_plain(F, dtype, M, K, N):
+    x = leaf(M, K, seed=1)
+    w = leaf(N, K, scale=0.05, seed=2)
+    b = leaf(N, scale=0.1, seed=3)
+    xr, wr, br = [t.detach().clone().requires_grad_(True) for t in (x, w, b)]
+    y = F.linear(x.to(dtype) if dtype != torch.float32 else x, w, b)
+    ref = TF.linear(xr, wr, br)
+    assert y.dtype == dtype
+    assert rel(y, ref) <= tol(dtype)
+    g = torch.randn_like(ref)
+    y.backward(g.to(dtype))
+    ref.backward(g)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+    assert rel(w.grad, wr.grad) <= tol(dtype, False)
+    assert rel(b.grad, br.grad) <= tol(dtype, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_ln_gelu_residual(F, dtype):
+    M, K, N = 2048, 192, 96
+    x0 = leaf(M, K, seed=5)
+    w, b = leaf(N, K, scale=0.05, seed=6), leaf(N, scale=0.1, seed=7)
+    g_, be = leaf(K, scale=0.1, seed=8), leaf(K, scale=0.1, seed=9)
+    with torch.no_grad():
+        g_.add_(1.0)
+    res0 = leaf(M, N, seed=10)
+    x = x0.detach().to(dtype).requires_grad_(True)
+    res = res0.detach().to(dtype).requires_grad_(True)
+    refs = [t.detach().clone().float().requires_grad_(True) for t in (x, w, b, g_, be, res)]
+    y = F.linear(x, w, b, ln=(g_, be), act="gelu", resid=res)
+    xr, wr, br, gr, ber, rr = refs
+    ref = rr + TF.gelu(TF.linear(TF.layer_norm(xr, (K,), gr, ber), wr, br))
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    for a, r, name in ((x, xr, "x"), (w, wr, "w"), (b, br, "b"), (g_, gr, "gamma"), (be, ber, "beta"), (res, rr, "res")):
+        assert rel(a.grad, r.grad) <= tol(dtype, False) * (3 if name in ("gamma", "beta") else 1), name
+
+
+def test_linear_rows_slice_and_stack(F):
+    M, K = 512, 32
+    x = leaf(M, K, seed=11)
+    w, b = leaf(48, K, scale=0.1, seed=12), leaf(48, scale=0.1, seed=13)
+    y = F.linear(x, w, b, rows=(16, 32))
+    ref = TF.linear(x.detach(), w.detach()[16:48], b.detach()[16:48])
+    assert rel(y, ref) <= 3e-5
+    y.sum().backward()
+    assert float(w.grad[:16].abs().max()) == 0.0 and float(w.grad[16:].abs().max()) > 0
+    ws = [leaf(16, K, scale=0.1, seed=20 + i) for i in range(3)]
+    bs = [leaf(16, scale=0.1, seed=30 + i) for i in range(3)]
+    x2 = leaf(M, K, seed=14)
+    ys = F.LinearStack3Fn.apply(x2, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])
+    xr = x2.detach().clone().requires_grad_(True)
+    wr = [t.detach().clone().requires_grad_(True) for t in ws]
+    brr = [t.detach().clone().requires_grad_(True) for t in bs]
+    refs = torch.cat([TF.linear(xr, wr[i], brr[i]) for i in range(3)], -1)
+    assert rel(ys, refs) <= 3e-5
+    go = torch.randn_like(refs)
+    ys.backward(go)
+    refs.backward(go)
+    assert rel(x2.grad, xr.grad) <= 3e-4
+    for i in range(3):
+        assert rel(ws[i].grad, wr[i].grad) <= 3e-4
+        assert rel(bs[i].grad, brr[i].grad) <= 3e-4
+
+
+def test_dropout_and_droppath_masks(F, Q):
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    M, Kd, N = 4096, 64, 128
+    x = leaf(M, Kd, seed=40)
+    w = leaf(N, Kd, scale=0.1, seed=41)
+    s1, s2 = K.new_site(), K.new_site()
+    y = F.linear(x, w, None, drop=(0.25, s1))
+    y0 = TF.linear(x.detach(), w.detach())
+    kept = (y != 0)
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.75) < 0.01
+    assert rel(y[kept], (y0 / 0.75)[kept]) <= 3e-5
+    y.backward(torch.ones_like(y))
+    # backward regenerates the same mask: dL/dx = (mask/keep) @ W
+    ref_dx = (kept.float() / 0.75) @ w.detach()
+    assert rel(x.grad, ref_dx) <= 3e-4
+    # drop path: whole samples (rows_per_sample rows) share one factor
+    x2 = leaf(M, Kd, seed=42)
+    y2 = F.linear(x2, w, None, dp=(0.5, s2, 16))
+    ratio = (y2 / TF.linear(x2.detach(), w.detach())).reshape(M // 16, -1)
+    per_sample = ratio[:, 0]
+    assert torch.all((ratio - per_sample[:, None]).abs() < 1e-3)
+    assert set(torch.round(per_sample).tolist()) <= {0.0, 2.0}
+    f = (per_sample > 1).float().mean().item()
+    assert 0.35 < f < 0.65
+    # a new step gives a new mask
+    K.Runtime.get(0).advance()
+    y3 = F.linear(x.detach(), w.detach(), None, drop=(0.25, s1))
+    assert (y3 != 0).ne(kept).any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(F, dtype):
+    B, N, C = 33, 64, 192
+    x = leaf(B, N, C, seed=50).detach().to(dtype).requires_grad_(True)
+    g_, b = leaf(C, scale=0.2, seed=51), leaf(C, scale=0.2, seed=52)
+    pos = leaf(1, N, C, scale=0.3, seed=53)
+    y = F.layer_norm(x, g_, b, 1e-5, add=pos)
+    xr, gr, br, pr = [t.detach().clone().float().requires_grad_(True) for t in (x, g_, b, pos)]
+    ref = TF.layer_norm(xr, (C,), gr, br) + pr
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+    assert rel(g_.grad, gr.grad) <= tol(dtype, False)
+    assert rel(b.grad, br.grad) <= tol(dtype, False)
+    assert rel(pos.grad, pr.grad) <= tol(dtype, False)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _ref_attn(q, k, v):
+    return TF.scaled_dot_product_attention(q, k, v)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Hs,ws", [(37, 4, 4), (9, 8, 4)])
+def test_attn_swa_like(F, Q, dtype, B, Hs, ws):
+    """mode 0 with the window table: qkv [B*N,3C] -> windows -> Linformer(16->32) + 16 bank rows."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    N, C, H, KC, S = Hs * Hs, 192, 4, 32, 16
+    D = C // H
+    nw = Hs // ws
+    qkv = leaf(B * N, 3 * C, seed=60).detach().to(dtype).requires_grad_(True)
+    Ek, Ev = leaf(ws * ws, KC, scale=0.3, seed=61), leaf(ws * ws, KC, scale=0.3, seed=62)
+    bk, bv = leaf(1, S, C, scale=0.5, seed=63), leaf(1, S, C, scale=0.5, seed=64)
+    tbl = None
+    if nw > 1:
+        t = [(wy * ws + ty) * Hs + wx * ws + tx for wy in range(nw) for wx in range(nw) for ty in range(ws) for tx in range(ws)]
+        tbl = torch.tensor(t, dtype=torch.int32, device=DEV)
+    spec = dict(mode=0, G=B * nw * nw, Nq=ws * ws, L=ws * ws, H=H, D=D, KC=KC, S=S, groups_per_b=nw * nw, q_rows_per_b=N,
+                k_rows_per_b=N, q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=C, v_off=2 * C, q_rows=B * N)
+    o = F.AttnFn.apply(qkv, None, Ek, Ev, bk, bv, spec)
+    # reference (same math as oracle.swa without the projections)
+    r = [t.detach().clone().float().requires_grad_(True) for t in (qkv, Ek, Ev, bk, bv)]
+    qr, Ekr, Evr, bkr, bvr = r
+    x = qr.view(B, Hs, Hs, 3 * C).view(B, nw, ws, nw, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, 3, H, D).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    BW = q.shape[0]
+    kc = torch.matmul(Ekr.T, k.reshape(BW * H, ws * ws, D)).reshape(BW, H, KC, D)
+    vc = torch.matmul(Evr.T, v.reshape(BW * H, ws * ws, D)).reshape(BW, H, KC, D)
+    kb = bkr.expand(BW, -1, -1).reshape(BW, S, H, D).transpose(1, 2)
+    vb = bvr.expand(BW, -1, -1).reshape(BW, S, H, D).transpose(1, 2)
+    ro = _ref_attn(q, torch.cat([kc, kb], 2), torch.cat([vc, vb], 2)).transpose(1, 2).reshape(BW, ws * ws, C)
+    ro = ro.view(B, nw, nw, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B * N, C)
+    assert rel(o, ro) <= tol(dtype)
+    go = torch.randn_like(ro)
+    o.backward(go.to(dtype))
+    ro.backward(go)
+    assert rel(qkv.grad, qr.grad) <= tol(dtype, False)
+    for a, rr, nme in ((Ek, Ekr, "Ek"), (Ev, Evr, "Ev"), (bk, bkr, "bank_k"), (bv, bvr, "bank_v")):
+        assert rel(a.grad, rr.grad) <= tol(dtype, False), nme
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,NP", [(16, 10), (64, 40)])
+def test_attn_msda_like(F, dtype, N, NP):
+    """mode 0, separate q and kv matrices, ragged L (10 / 40 of a 128-row Linformer)."""
+    B, C, H, KC, S = 21, 192, 4, 32, 16
+    D = C // H
+    q_t = leaf(B * N, C, seed=70).detach().to(dtype).requires_grad_(True)
+    kv_t = leaf(B * NP, 2 * C, seed=71).detach().to(dtype).requires_grad_(True)
+    Ek, Ev = leaf(128, KC, scale=0.3, seed=72), leaf(128, KC, scale=0.3, seed=73)
+    bk, bv = leaf(1, S, C, scale=0.5, seed=74), leaf(1, S, C, scale=0.5, seed=75)
+    spec = dict(mode=0, G=B, Nq=N, L=NP, H=H, D=D, KC=KC, S=S, groups_per_b=1, q_rows_per_b=N, k_rows_per_b=NP,
+                q_off=0, k_off=0, v_off=C, q_rows=B * N)
+    o = F.AttnFn.apply(q_t, kv_t, Ek, Ev, bk, bv, spec)
+    qr, kvr, Ekr, Evr, bkr, bvr = [t.detach().clone().float().requires_grad_(True) for t in (q_t, kv_t, Ek, Ev, bk, bv)]
+    q = qr.view(B, N, H, D).transpose(1, 2)
+    kv = kvr.view(B, NP, 2, H, D).permute(2, 0, 3, 1, 4)
+    k = TF.pad(kv[0], (0, 0, 0, 128 - NP))
+    v = TF.pad(kv[1], (0, 0, 0, 128 - NP))
+    kc = torch.matmul(Ekr.T, k.reshape(B * H, 128, D)).reshape(B, H, KC, D)
+    vc = torch.matmul(Evr.T, v.reshape(B * H, 128, D)).reshape(B, H, KC, D)
+    kb = bkr.expand(B, -1, -1).reshape(B, S, H, D).transpose(1, 2)
+    vb = bvr.expand(B, -1, -1).reshape(B, S, H, D).transpose(1, 2)
+    ro = _ref_attn(q, torch.cat([kc, kb], 2), torch.cat([vc, vb], 2)).transpose(1, 2).reshape(B * N, C)
+    assert rel(o, ro) <= tol(dtype)
+    go = torch.randn_like(ro)
+    o.backward(go.to(dtype))
+    ro.backward(go)
+    assert rel(q_t.grad, qr.grad) <= tol(dtype, False)
+    assert rel(kv_t.grad, kvr.grad) <= tol(dtype, False)
+    assert rel(Ek.grad, Ekr.grad) <= tol(dtype, False)
+    assert rel(Ev.grad, Evr.grad) <= tol(dtype, False)
+    assert float(Ek.grad[NP:].abs().max()) == 0.0          # zero-padded rows get no gradient
+    assert rel(bk.grad, bkr.grad) <= tol(dtype, False)
+    assert rel(bv.grad, bvr.grad) <= tol(dtype, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [16, 64])
+def test_attn_cga_like(F, dtype, N):
+    """mode 1, D=4, keys = own tokens + 16 shared rows, channel-group row table."""
+    B, G, H, S, ccg = 13, 6, 4, 16, 16
+    D = ccg // H
+    qkv = leaf(B * N * G, 3 * ccg, seed=80).detach().to(dtype).requires_grad_(True)
+    shk = (leaf(S, ccg, seed=81) * 1.0)
+    shv = (leaf(S, ccg, seed=82) * 1.0)
+    shk_l, shv_l = shk.detach().clone().requires_grad_(True), shv.detach().clone().requires_grad_(True)
+    tbl = torch.tensor([n * G + g for g in range(G) for n in range(N)], dtype=torch.int32, device=DEV)
+    spec = dict(mode=1, G=B * G, Nq=N, L=N, H=H, D=D, S=S, groups_per_b=G, q_rows_per_b=N * G, k_rows_per_b=N * G,
+                q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=ccg, v_off=2 * ccg, q_rows=B * N * G)
+    # non-leaf shared rows (as in the model: outputs of a Linear on the bank)
+    sk, sv = shk_l * 1.0, shv_l * 1.0
+    o = F.AttnFn.apply(qkv, None, None, None, sk, sv, spec)
+    qr = qkv.detach().clone().float().requires_grad_(True)
+    skr, svr = shk.detach().clone().requires_grad_(True), shv.detach().clone().requires_grad_(True)
+    x = qr.view(B, N, G, 3, H, D).permute(3, 0, 2, 4, 1, 5).reshape(3, B * G, H, N, D)
+    kb = skr.view(1, S, H, D).transpose(1, 2).expand(B * G, -1, -1, -1)
+    vb = svr.view(1, S, H, D).transpose(1, 2).expand(B * G, -1, -1, -1)
+    ro = _ref_attn(x[0], torch.cat([x[1], kb], 2), torch.cat([x[2], vb], 2))       # [BG,H,N,D]
+    ro = ro.transpose(1, 2).reshape(B, G, N, ccg).permute(0, 2, 1, 3).reshape(B * N * G, ccg)
+    assert rel(o, ro) <= tol(dtype)
+    go = torch.randn_like(ro)
+    o.backward(go.to(dtype))
+    ro.backward(go)
+    assert rel(qkv.grad, qr.grad) <= tol(dtype, False)
+    assert rel(shk_l.grad, skr.grad) <= tol(dtype, False)
+    assert rel(shv_l.grad, svr.grad) <= tol(dtype, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_cross_like_and_nan_guard(F, dtype):
+    B, N, C, H, S = 19, 16, 192, 4, 16
+    D = C // H
+    q_t = leaf(B * N, C, seed=90).detach().to(dtype).requires_grad_(True)
+    shk, shv = leaf(S, C, seed=91), leaf(S, C, seed=92)
+    spec = dict(mode=1, G=B, Nq=N, L=0, H=H, D=D, S=S, q_off=0, k_off=0, v_off=0, q_rows=B * N)
+    o = F.AttnFn.apply(q_t, None, None, None, shk, shv, spec)
+    qr, kr, vr = [t.detach().clone().float().requires_grad_(True) for t in (q_t, shk, shv)]
+    q = qr.view(B, N, H, D).transpose(1, 2)
+    k = kr.view(1, S, H, D).transpose(1, 2).expand(B, -1, -1, -1)
+    v = vr.view(1, S, H, D).transpose(1, 2).expand(B, -1, -1, -1)
+    ro = _ref_attn(q, k, v).transpose(1, 2).reshape(B * N, C)
+    assert rel(o, ro) <= tol(dtype)
+    go = torch.randn_like(ro)
+    o.backward(go.to(dtype))
+    ro.backward(go)
+    assert rel(q_t.grad, qr.grad) <= tol(dtype, False)
+    assert rel(shk.grad, kr.grad) <= tol(dtype, False)
+    assert rel(shv.grad, vr.grad) <= tol(dtype, False)
+    # efficient_attention: any NaN in the inputs -> the WHOLE output is zeros (HQAViT_CIFAR100.py:356-357)
+    bad = q_t.detach().clone()
+    bad[5, 7] = float("nan")
+    ob = F.AttnFn.apply(bad, None, None, None, shk.detach(), shv.detach(), spec)
+    assert float(ob.float().abs().max()) == 0.0
+    ok = F.AttnFn.apply(q_t.detach(), None, None, None, shk.detach(), shv.detach(), spec)   # flag was cleared
+    assert rel(ok, ro) <= tol(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,M", [(64, 16), (256, 64)])
+def test_tokmix_upmix(F, dtype, N, M):
+    B, C = 11, 192
+    scores = leaf(B, N, M, seed=100).detach().to(dtype).requires_grad_(True)
+    x = leaf(B, N, C, seed=101).detach().to(dtype).requires_grad_(True)
+    xc = F.TokMixFn.apply(scores, x)
+    sr, xr = [t.detach().clone().float().requires_grad_(True) for t in (scores, x)]
+    ref = torch.bmm(torch.softmax(sr, 1).transpose(1, 2), xr)
+    assert rel(xc, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    xc.backward(go.to(dtype))
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+    assert rel(scores.grad, sr.grad) <= tol(dtype, False)
+    # up-mix
+    xc2 = leaf(B, M, C, seed=102).detach().to(dtype).requires_grad_(True)
+    W, bias = leaf(N, M, scale=0.2, seed=103), leaf(N, scale=0.2, seed=104)
+    g_, b = leaf(C, scale=0.2, seed=105), leaf(C, scale=0.2, seed=106)
+    with torch.no_grad():
+        g_.add_(1.0)
+    y = F.UpMixFn.apply(xc2, W, bias, g_, b, 1e-5)
+    r = [t.detach().clone().float().requires_grad_(True) for t in (xc2, W, bias, g_, b)]
+    up = TF.linear(r[0].transpose(1, 2), r[1], r[2]).transpose(1, 2)
+    ref = TF.layer_norm(up, (C,), r[3], r[4])
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    for a, rr, nme in zip((xc2, W, bias, g_, b), r, ("xc", "W", "bias", "gamma", "beta")):
+        assert rel(a.grad, rr.grad) <= tol(dtype, False) * 2, nme
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Hs,flags", [(4, "hqa"), (8, "hqa"), (8, "v1"), (4, "v2")])
+def test_ccf_mid(F, dtype, Hs, flags):
+    B, C = 29, 96
+    N = Hs * Hs
+    h = leaf(B, N, C, seed=110).detach().to(dtype).requires_grad_(True)
+    w = leaf(C, 1, 3, 3, scale=0.3, seed=111)
+    ln = flags != "v1"
+    bias = leaf(C, scale=0.2, seed=112) if flags in ("v1", "v2") else None
+    scale = (leaf(1, C, 1, 1, scale=0.05, seed=113).detach() + 0.1).requires_grad_(True) if flags != "v1" else None
+    g1, b1, g2, b2 = [leaf(C, scale=0.2, seed=114 + i) if ln else None for i in range(4)]
+    out = F.CcfMidFn.apply(h, g1, b1, g2, b2, w, bias, scale, Hs, Hs, 1e-5)
+    params = [t for t in (h, w, bias, scale, g1, b1, g2, b2)]
+    r = [None if t is None else t.detach().clone().float().requires_grad_(True) for t in params]
+    hr, wr, br, sr, g1r, b1r, g2r, b2r = r
+    a = TF.layer_norm(hr, (C,), g1r, b1r) if ln else hr
+    img = TF.conv2d(a.transpose(1, 2).reshape(B, C, Hs, Hs), wr, br, padding=1, groups=C)
+    if sr is not None:
+        img = img * sr
+    t = img.flatten(2).transpose(1, 2)
+    ref = TF.layer_norm(t, (C,), g2r, b2r) if ln else t
+    assert rel(out, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    out.backward(go.to(dtype))
+    ref.backward(go)
+    for a_, rr in zip(params, r):
+        if a_ is not None:
+            assert rel(a_.grad, rr.grad) <= tol(dtype, False) * 2
+
+
+def test_small_ops(F):
+    B, N, C = 17, 16, 192
+    x = leaf(B, N, C, seed=120)
+    fw = leaf(4, scale=0.5, seed=121)
+    y = F.HybridFuseFn.apply(x, fw)
+    xr, fr = x.detach().clone().requires_grad_(True), fw.detach().clone().requires_grad_(True)
+    wsm = torch.softmax(fr, 0)
+    ref = torch.cat([xr[..., 48 * i:48 * (i + 1)] * wsm[i] for i in range(4)], -1)
+    assert rel(y, ref) <= 3e-5
+    go = torch.randn_like(ref)
+    y.backward(go)
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= 3e-5 and rel(fw.grad, fr.grad) <= 3e-4
+    # scale-add
+    u, gamma = leaf(B, N, C, seed=122), leaf(1, scale=0.1, seed=123)
+    x2 = leaf(B, N, C, seed=124)
+    y2 = F.ScaleAddFn.apply(x2, u, gamma, (0.0, 0, N))
+    r = [t.detach().clone().requires_grad_(True) for t in (x2, u, gamma)]
+    ref2 = r[0] + r[2] * r[1]
+    assert rel(y2, ref2) <= 3e-5
+    y2.backward(go)
+    ref2.backward(go)
+    assert rel(u.grad, r[1].grad) <= 3e-5 and rel(gamma.grad, r[2].grad) <= 3e-4 and rel(x2.grad, r[0].grad) <= 1e-6
+    # token mean, gather-pool
+    x3 = leaf(B, 64, C, seed=125)
+    m = F.TokenMeanFn.apply(x3)
+    assert rel(m, x3.detach().mean(1)) <= 3e-5
+    idx_l = [y_ * 8 + x_ for d in (1, 2) for y_ in range(0, 8, d) for x_ in range(0, 8, d)]
+    idx = torch.tensor(idx_l, dtype=torch.int32, device=DEV)
+    pooled = F.GatherPoolFn.apply(x3, idx, 2)
+    xr3 = x3.detach().clone().requires_grad_(True)
+    refp = TF.avg_pool1d(xr3[:, idx.long()].transpose(1, 2), 2, 2).transpose(1, 2)
+    assert rel(pooled, refp) <= 3e-5
+    gp = torch.randn_like(refp)
+    pooled.backward(gp)
+    refp.backward(gp)
+    assert rel(x3.grad, xr3.grad) <= 3e-5
+    # patchify == unfold of the conv
+    img = torch.randn(5, 3, 32, 32, device=DEV)
+    cols = F.patchify(img, 4, torch.float32)
+    refc = TF.unfold(img, 4, stride=4).transpose(1, 2).reshape(5 * 64, 48)
+    assert rel(cols, refc) <= 1e-7
+
+
+def test_bank_write_matches_oracle(F, Q, oracle):
+    cfg = Q.HQAViTConfig()
+    bank = Q.HQAViT(cfg).global_bank
+    Q.fill_module(bank)
+    P = {("global_bank." + k): v.clone() for k, v in bank.state_dict().items()}
+    bank = bank.cuda()
+    tokens = torch.randn(37, 16, 192)
+    ng, nb = torch.randn(192) * 0.1 + 1, torch.randn(192) * 0.1
+    for step in range(3):
+        pre = torch.nn.functional.layer_norm(tokens + step, (192,), ng, nb)
+        oracle.bank_write(P, pre, oracle.VARIANTS["hqa"], True)
+        F.bank_write((tokens + step).cuda(), ng.cuda(), nb.cuda(), bank, 0)
+    assert rel(bank.global_k, P["global_bank.global_k"]) <= 1e-5
+    assert rel(bank.global_v, P["global_bank.global_v"]) <= 1e-5
+    assert int(bank.update_count) == 3 == int(P["global_bank.update_count"])
+
+
+def test_adamw_and_l2norm_match_torch(Q):
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    n = 100_003
+    p0 = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV) * 0.01
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=6e-4, weight_decay=0.06, betas=(0.9, 0.999))
+    lr = torch.tensor([6e-4], device=DEV)
+    step = torch.zeros(1, device=DEV)
+    gn, part = torch.zeros(1, device=DEV), torch.zeros(1024, device=DEV)
+    for i in range(3):
+        step += 1
+        K.l2norm(g, part, gn)
+        assert abs(gn.item() - g.norm().item()) <= 1e-5 * g.norm().item()
+        K.adamw(p, g, m, v, None, lr, 0.9, 0.999, 1e-8, 0.06, step, gn, 0.5)
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 0.5)
+        opt.step()
+    assert rel(p, pr) <= 1e-6
