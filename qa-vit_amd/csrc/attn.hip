@@ -357,7 +357,7 @@ static int attn_validate(const qavit_attn_args* a, bool bwd) {
   if (a->G <= 0 || a->Nq <= 0 || a->H <= 0 || a->D <= 0 || a->S < 0 || a->L < 0) return set_error(QAVIT_EINVAL, "attn: bad dimensions");
   if (a->mode != 0 && a->mode != 1) return set_error(QAVIT_EINVAL, "attn: mode must be 0 or 1");
   if (a->mode == 0 && (a->KC <= 0 || a->L <= 0 || !a->E_k || !a->E_v)) return set_error(QAVIT_EINVAL, "attn: Linformer mode needs E_k/E_v, L and KC");
-  if (!a->q || !a->o || (a->L > 0 && (!a->k_tok || !a->v_tok)) || (a->S > 0 && (!a->sh_k || !a->sh_v)))
+  if (!a->q || (!bwd && !a->o) || (a->L > 0 && (!a->k_tok || !a->v_tok)) || (a->S > 0 && (!a->sh_k || !a->sh_v)))
     return set_error(QAVIT_EINVAL, "attn: null operand");
   if (attn_dims(*a).NK <= 0) return set_error(QAVIT_EINVAL, "attn: no keys");
   if (bwd) {

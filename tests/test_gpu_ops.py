@@ -126,10 +126,11 @@ def test_dropout_and_droppath_masks(F, Q):
     # drop path: whole samples (rows_per_sample rows) share one factor
     x2 = leaf(M, Kd, seed=42)
     y2 = F.linear(x2, w, None, dp=(0.5, s2, 16))
-    ratio = (y2 / TF.linear(x2.detach(), w.detach())).reshape(M // 16, -1)
-    per_sample = ratio[:, 0]
-    assert torch.all((ratio - per_sample[:, None]).abs() < 1e-3)
-    assert set(torch.round(per_sample).tolist()) <= {0.0, 2.0}
+    y20 = TF.linear(x2.detach(), w.detach()).reshape(M // 16, -1)
+    y2r = y2.detach().reshape(M // 16, -1)
+    per_sample = torch.round((y2r.abs().sum(1) / y20.abs().sum(1)))
+    assert set(per_sample.tolist()) <= {0.0, 2.0}
+    assert rel(y2r, y20 * per_sample[:, None]) <= 3e-5
     f = (per_sample > 1).float().mean().item()
     assert 0.35 < f < 0.65
     # a new step gives a new mask
@@ -330,6 +331,9 @@ def test_tokmix_upmix(F, dtype, N, M):
     y.backward(go.to(dtype))
     ref.backward(go)
     for a, rr, nme in zip((xc2, W, bias, g_, b), r, ("xc", "W", "bias", "gamma", "beta")):
+        if nme == "bias":      # d/dbias of LN(up + bias) is identically 0 (LN removes the row mean): both are round-off
+            assert float(a.grad.abs().max()) <= 1e-3 * float(W.grad.abs().max())
+            continue
         assert rel(a.grad, rr.grad) <= tol(dtype, False) * 2, nme
 
 
