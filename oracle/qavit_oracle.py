@@ -207,8 +207,10 @@ def cga(P, pre: str, x: Tensor, cfg, var: Variant, train: bool, sync=None) -> Te
     v = _lin(P, pre + ".v_proj", xf).reshape(B * G, N, heads, dh).transpose(1, 2)
     gk, gv = P["global_bank.global_k"], P["global_bank.global_v"]
     S = gk.shape[1]
-    bk = _lin(P, pre + ".bank_k_proj", gk).reshape(1, S, heads, dh).transpose(1, 2).expand(B * G, -1, -1, -1)
-    bv = _lin(P, pre + ".bank_v_proj", gv).reshape(1, S, heads, dh).transpose(1, 2).expand(B * G, -1, -1, -1)
+    # The reference projects the EXPANDED bank (:576-577).  That matters for autograd: linear's flatten of a
+    # stride-0 view copies, so the saved input holds the forward-time bank, not the later in-place writes.
+    bk = _lin(P, pre + ".bank_k_proj", gk.expand(B, -1, -1)).unsqueeze(1).expand(-1, G, -1, -1).reshape(B * G, S, heads, dh).transpose(1, 2)
+    bv = _lin(P, pre + ".bank_v_proj", gv.expand(B, -1, -1)).unsqueeze(1).expand(-1, G, -1, -1).reshape(B * G, S, heads, dh).transpose(1, 2)
     o = _sdpa(q, torch.cat([k, bk], 2), torch.cat([v, bv], 2), cfg.dropout, train)
     o = o.transpose(1, 2).reshape(B, G, N, ccg).permute(0, 2, 1, 3).reshape(B, N, cc)
     o = _drop(_lin(P, pre + ".proj", o), cfg.dropout, train)
@@ -224,8 +226,9 @@ def cross(P, pre: str, x: Tensor, cfg, train: bool) -> Tensor:
     q = _lin(P, pre + ".q_proj", x).reshape(B, N, heads, D).transpose(1, 2)
     gk, gv = P["global_bank.global_k"], P["global_bank.global_v"]
     S = gk.shape[1]
-    k = _lin(P, pre + ".k_proj", gk).reshape(1, S, heads, D).transpose(1, 2).expand(B, -1, -1, -1)
-    v = _lin(P, pre + ".v_proj", gv).reshape(1, S, heads, D).transpose(1, 2).expand(B, -1, -1, -1)
+    # projected AFTER expansion, as the reference does (:617-619) -- see the note in cga()
+    k = _lin(P, pre + ".k_proj", gk.expand(B, -1, -1)).reshape(B, S, heads, D).transpose(1, 2)
+    v = _lin(P, pre + ".v_proj", gv.expand(B, -1, -1)).reshape(B, S, heads, D).transpose(1, 2)
     o = _sdpa(q, k, v, cfg.dropout, train)
     o = o.transpose(1, 2).reshape(B, N, C)
     return _drop(_lin(P, pre + ".proj", o), cfg.dropout, train)

@@ -357,12 +357,20 @@ class AttnFn(Function):
         if guard:
             K.nan_guard(o, rt.nan_flag)
         ctx.spec = s
-        ctx.save_for_backward(q_t, kv_t, E_k, E_v, sh_k, sh_v)
+        # The bank is mutated in place later in the same forward (GlobalTokenBank.write); the reference's SDPA
+        # backward sees the values its forward used (torch.cat made a copy), so snapshot shared rows that alias
+        # a parameter.
+        ctx.sh_alias = (sh_k, sh_v)
+        need = any(ctx.needs_input_grad)
+        sk_s = sh_k.detach().clone() if (need and sh_k.is_leaf) else sh_k
+        sv_s = sh_v.detach().clone() if (need and sh_v.is_leaf) else sh_v
+        ctx.save_for_backward(q_t, kv_t, E_k, E_v, sk_s, sv_s)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         q_t, kv_t, E_k, E_v, sh_k, sh_v = ctx.saved_tensors
+        sh_k_in, sh_v_in = ctx.sh_alias
         s = ctx.spec
         rt = _rt(q_t)
         HD = s["H"] * s["D"]
@@ -394,8 +402,8 @@ class AttnFn(Function):
             a.dv_tok, a.lddv = dst.data_ptr() + s["v_off"] * esz, dst.shape[1]
         ek_buf, ek_ret = grad_sink(E_k) if s["mode"] == 0 else (None, None)
         ev_buf, ev_ret = grad_sink(E_v) if s["mode"] == 0 else (None, None)
-        sk_buf, sk_ret = grad_sink(sh_k)
-        sv_buf, sv_ret = grad_sink(sh_v)
+        sk_buf, sk_ret = grad_sink(sh_k_in)
+        sv_buf, sv_ret = grad_sink(sh_v_in)
         a.dE_k, a.dE_v = K._p(ek_buf), K._p(ev_buf)
         a.dsh_k, a.dsh_v = K._p(sk_buf), K._p(sv_buf)
         nws = K.attn_ws_floats(a)
@@ -403,7 +411,7 @@ class AttnFn(Function):
         a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
         K.attn_bwd(a)
         return dq_t, dkv_t, _ret(ek_ret, E_k) if ek_ret is not None else None, _ret(ev_ret, E_v) if ev_ret is not None else None, \
-            _ret(sk_ret, sh_k), _ret(sv_ret, sh_v), None
+            _ret(sk_ret, sh_k_in), _ret(sv_ret, sh_v_in), None
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import MODELS, max_rel, sig
+from conftest import MODELS, max_rel, sig, zero_by_construction
 
 TOL = 1e-5
 
@@ -81,6 +81,14 @@ def test_train_forward_backward_matches_reference(tag, golden, Q, oracle):
     names = golden[f"{tag}/grad_names"].tolist()
     norms = np.array([P[n].grad.norm().item() for n in names])
     ref = golden[f"{tag}/grad_norms"]
-    assert np.abs(norms - ref).max() <= 2e-5 * ref.max() + 1e-9
+    # per-parameter relative error (small-gradient tensors are not hidden behind the largest norm)
+    err = np.abs(norms - ref) / (ref + 1e-5 * ref.max())   # floor: d/d(upsample bias) is exactly 0 (LN), pure round-off
+    # d/d(token_upmix.upsample_attn.bias) is identically 0 (the LayerNorm that follows removes the row mean):
+    # the reference's value is pure round-off, so it is not compared
+    for i, n in enumerate(names):
+        if zero_by_construction(n):
+            err[i] = 0.0
+    worst = [(float(err[i]), names[i]) for i in np.argsort(-err)[:3]]
+    assert err.max() <= 2e-4, worst
     for n in ("head.weight", "pos_embed", "global_bank.global_k", "patch_embed.proj.weight"):
         assert max_rel(P[n].grad.reshape(-1)[:256].numpy(), golden[f"{tag}/grad/{n}"]) <= 5e-5, n
