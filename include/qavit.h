@@ -214,6 +214,16 @@ int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream);
 int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Depthwise k x k convolution, stride 1, pad k/2, on channel-last tokens x[B, H*W, C] (k in {3,5,7}):
+ * ConvNeXtBlock.dwconv (HQAViT_CIFAR100.py:722, dw7x7), LMFAdapter.dwconv_3x3 / dwconv_5x5 (:811-812).
+ * w is the nn.Conv2d weight [C,1,k,k] fp32; bias [C] or NULL.  bwd: dx, dw += , dbias += (fp32 atomics).
+ * ------------------------------------------------------------------------------------------------- */
+int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias, void* y,
+                     int B, int H, int W, int C, int ks, void* stream);
+int qavit_dwconv_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
+                     int B, int H, int W, int C, int ks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * GlobalTokenBank.write (HQAViT_CIFAR100.py:296-321; QAViT.py:205-224), train mode only, no gradient.
  * stats: acc[S,C] = sum_b  softmax_tokens( tn Wg^T + bg )^T tn,  tn = LN_write(LN_branch(tokens))
  *        (per-wave partials in `ws`, then one reduction; under data parallelism `acc` is what gets

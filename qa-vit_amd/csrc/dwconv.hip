@@ -1,0 +1,170 @@
+// Depthwise k x k convolution (stride 1, pad k/2) on channel-last tokens [B, H*W, C]: the dw3x3 / dw5x5 / dw7x7
+// of the CNN lateral path (ConvNeXtBlock.dwconv HQAViT_CIFAR100.py:722, LMFAdapter.dwconv_3x3/_5x5 :811-812).
+// HBM-bound: one pass over x (and dy); the image tile of 64 channels lives in LDS, each thread owns one
+// channel column (lane = channel -> conflict-free LDS, coalesced HBM) and a strip of tokens.
+// Weight / bias gradients are accumulated in registers over all images a workgroup visits, reduced through
+// LDS, and flushed with one fp32 atomic per element per workgroup.
+#include "common.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+
+namespace qv {
+
+constexpr int DW_CH = 64;   // channels per workgroup tile
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = H * W;
+  float* xs = sm;                      // [N][DW_CH]
+  float* ws = sm + N * DW_CH;          // [KS*KS][DW_CH]
+  const int c0 = blockIdx.x * DW_CH;
+  const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  const bool cok = c < C;
+  for (int i = threadIdx.x; i < KS * KS * DW_CH; i += 256) {
+    const int t = i / DW_CH, cc = i - t * DW_CH;
+    ws[i] = (c0 + cc < C) ? w[(size_t)(c0 + cc) * KS * KS + t] : 0.f;
+  }
+  const float bv = (bias && cok) ? bias[c] : 0.f;
+  constexpr int R = KS / 2;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    __syncthreads();
+    for (int n = tg; n < N; n += 4) xs[n * DW_CH + cl] = cok ? to_f<T>(x[((size_t)b * N + n) * C + c]) : 0.f;
+    __syncthreads();
+    for (int n = tg; n < N; n += 4) {
+      const int yy = n / W, xx = n - yy * W;
+      float s = bv;
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) {
+        const int y2 = yy + dy - R;
+        if (y2 < 0 || y2 >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+          const int x2 = xx + dx - R;
+          if (x2 >= 0 && x2 < W) s += ws[(dy * KS + dx) * DW_CH + cl] * xs[(y2 * W + x2) * DW_CH + cl];
+        }
+      }
+      if (cok) y[((size_t)b * N + n) * C + c] = from_f<T>(s);
+    }
+  }
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias,
+                                                         int B, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = H * W;
+  float* xs = sm;                       // [N][DW_CH]
+  float* gs = xs + N * DW_CH;           // [N][DW_CH]  dy
+  float* ws = gs + N * DW_CH;           // [KS*KS][DW_CH]
+  float* red = ws + KS * KS * DW_CH;    // [4][DW_CH] cross-strip reduction scratch
+  const int c0 = blockIdx.x * DW_CH;
+  const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  const bool cok = c < C;
+  for (int i = threadIdx.x; i < KS * KS * DW_CH; i += 256) {
+    const int t = i / DW_CH, cc = i - t * DW_CH;
+    ws[i] = (c0 + cc < C) ? w[(size_t)(c0 + cc) * KS * KS + t] : 0.f;
+  }
+  constexpr int R = KS / 2;
+  float aw[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) aw[i] = 0.f;
+  float ab = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    __syncthreads();
+    for (int n = tg; n < N; n += 4) {
+      const size_t o = ((size_t)b * N + n) * C + c;
+      xs[n * DW_CH + cl] = cok ? to_f<T>(x[o]) : 0.f;
+      gs[n * DW_CH + cl] = cok ? to_f<T>(dy[o]) : 0.f;
+    }
+    __syncthreads();
+    for (int n = tg; n < N; n += 4) {
+      const int yy = n / W, xx = n - yy * W;
+      const float g = gs[n * DW_CH + cl];
+      ab += g;
+      float s = 0.f;
+#pragma unroll
+      for (int dyy = 0; dyy < KS; ++dyy) {
+#pragma unroll
+        for (int dxx = 0; dxx < KS; ++dxx) {
+          const int y2 = yy + dyy - R, x2 = xx + dxx - R;      // input read by output n through tap (dyy,dxx)
+          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) aw[dyy * KS + dxx] += g * xs[(y2 * W + x2) * DW_CH + cl];
+          const int yo = yy - dyy + R, xo = xx - dxx + R;      // output that reads input n through tap (dyy,dxx)
+          if (yo >= 0 && yo < H && xo >= 0 && xo < W) s += ws[(dyy * KS + dxx) * DW_CH + cl] * gs[(yo * W + xo) * DW_CH + cl];
+        }
+      }
+      if (cok) dx[((size_t)b * N + n) * C + c] = from_f<T>(s);
+    }
+  }
+  // reduce the 4 token strips, then one atomic per (channel, tap) per workgroup
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) {
+    __syncthreads();
+    red[tg * DW_CH + cl] = aw[i];
+    __syncthreads();
+    if (tg == 0 && cok) atomic_add_f(dw + (size_t)c * KS * KS + i, red[cl] + red[DW_CH + cl] + red[2 * DW_CH + cl] + red[3 * DW_CH + cl]);
+  }
+  if (dbias) {
+    __syncthreads();
+    red[tg * DW_CH + cl] = ab;
+    __syncthreads();
+    if (tg == 0 && cok) atomic_add_f(dbias + c, red[cl] + red[DW_CH + cl] + red[2 * DW_CH + cl] + red[3 * DW_CH + cl]);
+  }
+}
+
+template <typename T, int KS>
+static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, const float* bias, void* o0, float* dw, float* dbias,
+                     int B, int H, int W, int C, hipStream_t st) {
+  const int N = H * W;
+  const int chunks = (C + DW_CH - 1) / DW_CH;
+  if (!bwd) {
+    const size_t smem = ((size_t)N * DW_CH + KS * KS * DW_CH) * sizeof(float);
+    if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "dwconv_fwd: feature map too large for LDS");
+    int gy = B < 2048 / chunks ? B : 2048 / chunks;
+    if (gy < 1) gy = 1;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((dwconv_fwd_kernel<T, KS>), dim3(chunks, gy), dim3(256), smem, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
+    return check_launch("dwconv_fwd");
+  }
+  const size_t smem = ((size_t)2 * N * DW_CH + KS * KS * DW_CH + 4 * DW_CH) * sizeof(float);
+  if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "dwconv_bwd: feature map too large for LDS");
+  int gy = B < 1024 / chunks ? B : 1024 / chunks;
+  if (gy < 1) gy = 1;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_bwd_kernel<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((dwconv_bwd_kernel<T, KS>), dim3(chunks, gy), dim3(256), smem, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
+  return check_launch("dwconv_bwd");
+}
+
+template <typename T>
+static int dispatch_dw(int ks, bool bwd, const void* a0, const void* a1, const float* w, const float* bias, void* o0, float* dw, float* dbias,
+                       int B, int H, int W, int C, hipStream_t st) {
+  switch (ks) {
+    case 3: return launch_dw<T, 3>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st);
+    case 5: return launch_dw<T, 5>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st);
+    case 7: return launch_dw<T, 7>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st);
+    default: return set_error(QAVIT_EINVAL, "dwconv: kernel size must be 3, 5 or 7");
+  }
+}
+
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int ks, void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "dwconv_fwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st);
+  if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st);
+  return set_error(QAVIT_EINVAL, "dwconv_fwd: unknown dtype");
+}
+
+extern "C" int qavit_dwconv_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
+                                int B, int H, int W, int C, int ks, void* stream) {
+  if (!dy || !x || !w || !dx || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "dwconv_bwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, true, dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, st);
+  if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, true, dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, st);
+  return set_error(QAVIT_EINVAL, "dwconv_bwd: unknown dtype");
+}

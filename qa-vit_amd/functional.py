@@ -556,6 +556,34 @@ class CcfMidFn(Function):
         return (d_h,) + (None,) * 10
 
 
+class DwConvFn(Function):
+    """Depthwise k x k conv on channel-last tokens [B, H*W, C] (csrc/dwconv.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, H, W):
+        B, N, Cc = x.shape
+        ks = w.shape[-1]
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        K.dwconv_fwd(x, w.detach(), None if bias is None else bias.detach(), y, B, H, W, Cc, ks)
+        ctx.save_for_backward(x, w, bias)
+        ctx.dims = (B, H, W, Cc, ks)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, bias = ctx.saved_tensors
+        B, H, W, Cc, ks = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        wbuf, _ = grad_sink(w)
+        bbuf, _ = grad_sink(bias)
+        if wbuf is None:
+            wbuf = torch.zeros_like(w, dtype=torch.float32)
+        K.dwconv_bwd(dy, x, w.detach(), dx, wbuf, bbuf, B, H, W, Cc, ks)
+        return dx, None, None, None, None
+
+
 # ---------------------------------------------------------------------------------------------------
 # elementwise helpers
 # ---------------------------------------------------------------------------------------------------

@@ -236,6 +236,15 @@ def ccf_bwd(a):
     L.check(L.load().qavit_ccf_mid_bwd(C.byref(a), stream()), "ccf_mid_bwd")
 
 
+def dwconv_fwd(x, w, bias, y, B, H, W, Cc, ks):
+    L.check(L.load().qavit_dwconv_fwd(dt_code(x.dtype), x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cc, ks, stream()), "dwconv_fwd")
+
+
+def dwconv_bwd(dy, x, w, dx, dw, dbias, B, H, W, Cc, ks):
+    L.check(L.load().qavit_dwconv_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw.data_ptr(), _p(dbias),
+                                      B, H, W, Cc, ks, stream()), "dwconv_bwd")
+
+
 # ---------------------------------------------------------------------------------------------------
 # bank
 # ---------------------------------------------------------------------------------------------------

@@ -100,14 +100,15 @@ class HQAViT(_Base):
         cdt = self._dtype(x)
         self.patch_embed.proj.compute_dtype = cdt
         lowp = cdt != torch.float32
-        # CNN lateral path: stock ROCm convolutions, in the compute dtype via autocast
+        # CNN lateral path: only the two strided 3x3 stem convolutions (+BN+GELU) are stock ROCm ops (autocast gives
+        # them the compute dtype); the 8x8 part is channel-last on the HIP kernels
         with torch.autocast("cuda", dtype=cdt if lowp else torch.bfloat16, enabled=lowp):
-            f2, f3, f4 = self.cnn_stem(x)
-            R = {}
-            for i, f in ((2, f2), (3, f3), (4, f4)):
-                a = getattr(self, f"lmfa{i}")(f)
-                R[i] = getattr(self, f"rrcv{i}")(a.to(cdt), self.H, self.W).to(cdt)
+            feats, (fh, fw) = self.cnn_stem.forward_tokens(x, cdt)
         with torch.autocast("cuda", enabled=False):
+            R = {}
+            for i, f in zip((2, 3, 4), feats):
+                a = getattr(self, f"lmfa{i}").forward_tokens(f, fh, fw)
+                R[i] = getattr(self, f"rrcv{i}")(a, self.H, self.W)
             T = self.patch_embed(x, self.pos_embed)
             T = F.dropout(T, self.pos_drop.p, self._pos_site, self.training)
             for si in (1, 2, 3, 4):

@@ -422,8 +422,28 @@ class PatchEmbed(nn.Module):
 # CNN lateral path (second tier, SURVEY.md section 8f N1): convolutions / BatchNorm run on stock PyTorch-ROCm
 # ops (MIOpen) for now; every LayerNorm / Linear inside it already goes through the HIP kernels.
 # ---------------------------------------------------------------------------------------------------
+def _to_tokens(x):
+    """[B,C,H,W] -> channel-last tokens [B, H*W, C] (one copy; everything downstream stays channel-last)."""
+    B, C, H, W = x.shape
+    return x.flatten(2).transpose(1, 2).contiguous()
+
+
+def _conv1x1_tokens(t, conv: nn.Conv2d):
+    """A 1x1 nn.Conv2d applied to channel-last tokens is a GEMM over the channel axis (weight [Cout,Cin,1,1])."""
+    return F.linear(t, conv.weight, conv.bias)
+
+
+def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool):
+    """nn.BatchNorm2d on channel-last tokens == batch_norm over the rows of [B*H*W, C] (per-rank batch statistics)."""
+    B, N, C = t.shape
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    y = TF.batch_norm(t.reshape(B * N, C), bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+    return y.reshape(B, N, C)
+
+
 class ConvNeXtBlock(nn.Module):
-    """HQAViT_CIFAR100.py:718-739."""
+    """HQAViT_CIFAR100.py:718-739 on channel-last tokens: dw7x7 (csrc/dwconv.hip) -> LN+Linear+GELU -> Linear+residual."""
 
     def __init__(self, dim, drop_path=0.0):
         super().__init__()
@@ -434,15 +454,19 @@ class ConvNeXtBlock(nn.Module):
         self.pwconv2 = nn.Linear(4 * dim, dim)
         self.drop_path = nn.Identity()
 
-    def forward(self, x):
-        h = self.dwconv(x).permute(0, 2, 3, 1).contiguous()
+    def forward_tokens(self, t, H, W):
+        h = F.DwConvFn.apply(t, self.dwconv.weight, self.dwconv.bias, H, W)
         h = F.linear(h, self.pwconv1.weight, self.pwconv1.bias, ln=(self.norm.weight, self.norm.bias), eps=self.norm.eps, act="gelu")
-        h = F.linear(h, self.pwconv2.weight, self.pwconv2.bias)
-        return x + h.permute(0, 3, 1, 2)
+        return F.linear(h, self.pwconv2.weight, self.pwconv2.bias, resid=t)
+
+    def forward(self, x):                                   # NCHW surface of the reference class
+        B, C, H, W = x.shape
+        return self.forward_tokens(_to_tokens(x), H, W).transpose(1, 2).reshape(B, C, H, W)
 
 
 class CNNStemModel(nn.Module):
-    """HQAViT_CIFAR100.py:742-793."""
+    """HQAViT_CIFAR100.py:742-793.  The two strided 3x3 convolutions (+BatchNorm+GELU) still run on MIOpen; from the
+    8x8 (16x16) feature map on everything is channel-last and on the HIP kernels."""
 
     def __init__(self, in_ch=3, c2=64, c3=128, c4=256, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -451,16 +475,26 @@ class CNNStemModel(nn.Module):
         self.stage2 = nn.Sequential(nn.Conv2d(c2, c3, 1), nn.BatchNorm2d(c3), ConvNeXtBlock(c3))
         self.stage3 = nn.Sequential(nn.Conv2d(c3, c4, 1), nn.BatchNorm2d(c4), ConvNeXtBlock(c4))
 
-    def forward(self, x):
+    def forward_tokens(self, x, cdt):
+        """-> (F2, F3, F4) as channel-last tokens [B, h*w, c] in the compute dtype, and (h, w)."""
         x = self.stem(x)
-        f2 = self.stage1(x)
-        f3 = self.stage2(f2)
-        f4 = self.stage3(f3)
-        return f2, f3, f4
+        x = self.stage1[2](self.stage1[1](self.stage1[0](x)))
+        h, w = x.shape[2], x.shape[3]
+        t = _to_tokens(x).to(cdt)
+        with torch.autocast("cuda", enabled=False):
+            f2 = self.stage1[3].forward_tokens(t, h, w)
+            f3 = self.stage2[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f2, self.stage2[0]), self.stage2[1], self.training), h, w)
+            f4 = self.stage3[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f3, self.stage3[0]), self.stage3[1], self.training), h, w)
+        return (f2, f3, f4), (h, w)
+
+    def forward(self, x):                                   # NCHW surface of the reference class
+        (f2, f3, f4), (h, w) = self.forward_tokens(x, x.dtype)
+        B = x.shape[0]
+        return tuple(f.transpose(1, 2).reshape(B, -1, h, w) for f in (f2, f3, f4))
 
 
 class LMFAdapter(nn.Module):
-    """HQAViT_CIFAR100.py:799-849."""
+    """HQAViT_CIFAR100.py:799-849 on channel-last tokens."""
 
     def __init__(self, in_channels: int, embed_dim: int, target_hw: int = 8):
         super().__init__()
@@ -471,16 +505,24 @@ class LMFAdapter(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)
         self.act = nn.GELU()
 
+    def forward_tokens(self, t, H, W):
+        f1 = F.DwConvFn.apply(t, self.dwconv_3x3.weight, self.dwconv_3x3.bias, H, W)
+        f2 = F.DwConvFn.apply(t, self.dwconv_5x5.weight, self.dwconv_5x5.bias, H, W)
+        h = _conv1x1_tokens(torch.cat([f1, f2, t], -1), self.proj)
+        if H != self.target_hw or W != self.target_hw:      # :840-842 (not hit by the in-scope configs)
+            B = h.shape[0]
+            img = TF.interpolate(h.transpose(1, 2).reshape(B, -1, H, W).float(), size=(self.target_hw, self.target_hw),
+                                 mode="bilinear", align_corners=False)
+            h = _to_tokens(img).to(t.dtype)
+        return TF.gelu(F.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps))
+
     def forward(self, feat):
-        h = self.proj(torch.cat([self.dwconv_3x3(feat), self.dwconv_5x5(feat), feat], 1))
-        if h.shape[2] != self.target_hw or h.shape[3] != self.target_hw:
-            h = TF.interpolate(h, size=(self.target_hw, self.target_hw), mode="bilinear", align_corners=False)
-        a = h.flatten(2).transpose(1, 2).contiguous()
-        return TF.gelu(F.layer_norm(a, self.norm.weight, self.norm.bias, self.norm.eps))
+        B, C, H, W = feat.shape
+        return self.forward_tokens(_to_tokens(feat), H, W)
 
 
 class RRCV(nn.Module):
-    """HQAViT_CIFAR100.py:855-907."""
+    """HQAViT_CIFAR100.py:855-907 on channel-last tokens (the reverse / re-embed 1x1 convolutions are GEMMs)."""
 
     def __init__(self, embed_dim: int, rec_channels: int = 64, num_blocks: int = 1):
         super().__init__()
@@ -492,11 +534,10 @@ class RRCV(nn.Module):
         self.beta = nn.Parameter(torch.tensor(0.1))
 
     def forward(self, A, H: int, W: int):
-        B, N, C = A.shape
-        h = self.reverse_proj(A.permute(0, 2, 1).reshape(B, C, H, W))
+        h = _conv1x1_tokens(A, self.reverse_proj)
         for blk in self.blocks:
-            h = blk(h)
-        t = self.reembed_proj(h).flatten(2).transpose(1, 2).contiguous()
+            h = blk.forward_tokens(h, H, W)
+        t = _conv1x1_tokens(h, self.reembed_proj)
         return A + self.beta.to(A.dtype) * F.layer_norm(t, self.norm.weight, self.norm.bias, self.norm.eps)
 
 

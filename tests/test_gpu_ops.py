@@ -367,6 +367,25 @@ def test_ccf_mid(F, dtype, Hs, flags):
             assert rel(a_.grad, rr.grad) <= tol(dtype, False) * 2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ks,C,H", [(7, 64, 8), (7, 256, 8), (3, 128, 8), (5, 100, 8), (7, 64, 16)])
+def test_dwconv_tokens(F, dtype, ks, C, H):
+    B = 21
+    x = leaf(B, H * H, C, seed=130).detach().to(dtype).requires_grad_(True)
+    w = leaf(C, 1, ks, ks, scale=0.2, seed=131)
+    b = leaf(C, scale=0.2, seed=132)
+    y = F.DwConvFn.apply(x, w, b, H, H)
+    xr, wr, br = [t.detach().clone().float().requires_grad_(True) for t in (x, w, b)]
+    ref = TF.conv2d(xr.transpose(1, 2).reshape(B, C, H, H), wr, br, padding=ks // 2, groups=C).flatten(2).transpose(1, 2)
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+    assert rel(w.grad, wr.grad) <= tol(dtype, False)
+    assert rel(b.grad, br.grad) <= tol(dtype, False)
+
+
 def test_small_ops(F):
     B, N, C = 17, 16, 192
     x = leaf(B, N, C, seed=120)
