@@ -106,7 +106,10 @@ def cpu_baseline(batch=32, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a 1-GPU box exposes a 16-core CPU share whatever the affinity mask says; oversubscribing it stalls for minutes
+    cores = max(1, min(cores, int(os.environ.get("QAVIT_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
+    print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
     cfg = Q.HQAViTConfig()
     model = Q.HQAViT(cfg)
     Q.fill_module(model)
@@ -194,6 +197,8 @@ def main():
             torch.cuda.synchronize()
             tr.graph = None
 
+    if rank == 0:
+        print(f"[bench] mode={mode}, warm-up ...", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()

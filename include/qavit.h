@@ -223,6 +223,13 @@ int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias
 int qavit_dwconv_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
                      int B, int H, int W, int C, int ks, void* stream);
 
+/* im2col / col2im for the strided 3x3 stem convolutions (HQAViT_CIFAR100.py:752, :759) so that they run on
+ * qavit_gemm_nt: cols[(b,oy,ox), c*k*k+dy*k+dx] = src[b, c, oy*s+dy-p, ox*s+dx-p].  src is the fp32 NCHW image
+ * (src_nchw_f32 != 0) or channel-last tokens [B,H*W,Cin] in `dtype`; col2im scatters dcols back to tokens. */
+int qavit_im2col(int dtype, const void* src, int src_nchw_f32, void* cols, int B, int Cin, int H, int W,
+                 int k, int stride, int pad, void* stream);
+int qavit_col2im(int dtype, const void* dcols, void* dx, int B, int Cin, int H, int W, int k, int stride, int pad, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * GlobalTokenBank.write (HQAViT_CIFAR100.py:296-321; QAViT.py:205-224), train mode only, no gradient.
  * stats: acc[S,C] = sum_b  softmax_tokens( tn Wg^T + bg )^T tn,  tn = LN_write(LN_branch(tokens))

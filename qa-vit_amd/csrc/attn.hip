@@ -321,7 +321,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
   for (int i = lane; i < n_acc; i += 64) ws[i] = sm[acc0 + i];
 }
 
-// fold the per-wave partials into the gradient buffers: one thread per output element
+// fold the per-wave partials into the gradient buffers: thread = output element, blockIdx.y = slice of 32 waves
+// (coalesced reads across the element axis, one fp32 atomic per thread)
+constexpr int RED_WAVES = 32;
 __global__ __launch_bounds__(256) void attn_reduce_kernel(qavit_attn_args a, int nwaves) {
   const int nE = (a.mode == 0) ? a.L * a.KC : 0;
   const int nS = a.S * a.D;
@@ -329,19 +331,22 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(qavit_attn_args a, int
   const int total = 2 * nE + 2 * nS * a.H;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  const int w0 = blockIdx.y * RED_WAVES * a.H;            // slices are multiples of H waves: head alignment is kept
+  int w1 = w0 + RED_WAVES * a.H;
+  if (w1 > nwaves) w1 = nwaves;
   float s = 0.f;
   if (i < 2 * nE) {
-    for (int w = 0; w < nwaves; ++w) s += a.ws[(size_t)w * per + i];
-    float* dst = (i < nE) ? a.dE_k + i : a.dE_v + (i - nE);
-    if ((i < nE) ? (a.dE_k != nullptr) : (a.dE_v != nullptr)) *dst += s;
+    for (int w = w0; w < w1; ++w) s += a.ws[(size_t)w * per + i];
+    float* dst = (i < nE) ? a.dE_k : a.dE_v;
+    if (dst) atomic_add_f(dst + (i < nE ? i : i - nE), s);
   } else {
     int r = i - 2 * nE;                 // [which(2)][h][s][d]
     const int which = r / (nS * a.H); r -= which * nS * a.H;
     const int h = r / nS; r -= h * nS;
     const int srow = r / a.D, dd = r - srow * a.D;
-    for (int w = h; w < nwaves; w += a.H) s += a.ws[(size_t)w * per + 2 * nE + which * nS + srow * a.D + dd];
+    for (int w = w0 + h; w < w1; w += a.H) s += a.ws[(size_t)w * per + 2 * nE + which * nS + srow * a.D + dd];
     float* dst = which == 0 ? a.dsh_k : a.dsh_v;
-    if (dst) dst[(size_t)srow * a.H * a.D + h * a.D + dd] += s;
+    if (dst) atomic_add_f(dst + (size_t)srow * a.H * a.D + h * a.D + dd, s);
   }
 }
 
@@ -394,7 +399,10 @@ static int attn_launch(const qavit_attn_args& a, bool bwd, hipStream_t st) {
   hipLaunchKernelGGL((attn_bwd_kernel<T, BF>), dim3(grid), dim3(64), smem, st, a);
   const int nE = (a.mode == 0) ? a.L * a.KC : 0;
   const int total = 2 * nE + 2 * a.S * a.D * a.H;
-  if (total > 0) hipLaunchKernelGGL(attn_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a, grid);
+  if (total > 0) {
+    const int slices = (grid + RED_WAVES * a.H - 1) / (RED_WAVES * a.H);
+    hipLaunchKernelGGL(attn_reduce_kernel, dim3((total + 255) / 256, slices), dim3(256), 0, st, a, grid);
+  }
   return check_launch("attn_bwd");
 }
 

@@ -93,12 +93,15 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
   for (int i = t; i < S * C; i += 256) out[i] = U[i];
 }
 
+// acc (zeroed by the launcher) += partials; blockIdx.y = slice of 16 partials
 __global__ __launch_bounds__(256) void bank_reduce_kernel(const float* ws, float* acc, int nparts, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int w0 = blockIdx.y * 16;
+  const int w1 = (w0 + 16 < nparts) ? w0 + 16 : nparts;
   float s = 0.f;
-  for (int w = 0; w < nparts; ++w) s += ws[(size_t)w * n + i];
-  acc[i] = s;
+  for (int w = w0; w < w1; ++w) s += ws[(size_t)w * n + i];
+  atomic_add_f(acc + i, s);
 }
 
 // one workgroup per slot s
@@ -154,7 +157,8 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
     hipLaunchKernelGGL((bank_stats_kernel<bf16, true>), dim3(grid), dim3(256), smem, st, (const bf16*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);
   } else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
   const int n = S * C;
-  hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, acc, grid, n);
+  (void)hipMemsetAsync(acc, 0, (size_t)n * sizeof(float), st);
+  hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n);
   return check_launch("bank_stats");
 }
 

@@ -148,9 +148,87 @@ static int dispatch_dw(int ks, bool bwd, const void* a0, const void* a1, const f
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// im2col / col2im for the two strided 3x3 stem convolutions (HQAViT_CIFAR100.py:752, :759): the conv becomes a
+// GEMM over rows (b, oy, ox) with K = Cin*k*k in the nn.Conv2d weight's own (c, dy, dx) order.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool NCHW_F32>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* src_, T* cols, int B, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
+  const int Kc = Cin * k * k;
+  const int64_t total = (int64_t)B * Ho * Wo * Kc;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % Kc);
+    const int64_t row = i / Kc;
+    const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho), b = (int)(row / ((int64_t)Wo * Ho));
+    const int c = col / (k * k), r = col - c * k * k, dy = r / k, dx = r - dy * k;
+    const int y = oy * stride + dy - pad, x = ox * stride + dx - pad;
+    float v = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      if (NCHW_F32) v = reinterpret_cast<const float*>(src_)[(((size_t)b * Cin + c) * H + y) * W + x];
+      else v = to_f<T>(reinterpret_cast<const T*>(src_)[((size_t)b * H * W + y * W + x) * Cin + c]);
+    }
+    cols[i] = from_f<T>(v);
+  }
+}
+
+// dx[b, y*W+x, c] = sum over taps of dcols[(b,oy,ox), c*k*k + dy*k + dx]  (channel-last destination)
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* dcols, T* dx, int B, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
+  const int Kc = Cin * k * k;
+  const int64_t total = (int64_t)B * H * W * Cin;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin);
+    const int64_t pix = i / Cin;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    float s = 0.f;
+    for (int dy = 0; dy < k; ++dy) {
+      const int ty = y + pad - dy;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= Ho) continue;
+      for (int dxx = 0; dxx < k; ++dxx) {
+        const int tx = x + pad - dxx;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= Wo) continue;
+        s += to_f<T>(dcols[(((size_t)b * Ho + oy) * Wo + ox) * Kc + c * k * k + dy * k + dxx]);
+      }
+    }
+    dx[i] = from_f<T>(s);
+  }
+}
+
 }  // namespace qv
 
 using namespace qv;
+
+extern "C" int qavit_im2col(int dtype, const void* src, int src_nchw_f32, void* cols, int B, int Cin, int H, int W, int k, int stride, int pad, void* stream) {
+  if (!src || !cols || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0) return set_error(QAVIT_EINVAL, "im2col: bad arguments");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int64_t total = (int64_t)B * Ho * Wo * Cin * k * k;
+  int grid = (int)((total + 1023) / 1024); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_F32) {
+    if (src_nchw_f32) hipLaunchKernelGGL((im2col_kernel<float, true>), dim3(grid), dim3(256), 0, st, src, (float*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
+    else hipLaunchKernelGGL((im2col_kernel<float, false>), dim3(grid), dim3(256), 0, st, src, (float*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
+  } else if (dtype == QAVIT_BF16) {
+    if (src_nchw_f32) hipLaunchKernelGGL((im2col_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, src, (bf16*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
+    else hipLaunchKernelGGL((im2col_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, src, (bf16*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
+  } else return set_error(QAVIT_EINVAL, "im2col: unknown dtype");
+  return check_launch("im2col");
+}
+
+extern "C" int qavit_col2im(int dtype, const void* dcols, void* dx, int B, int Cin, int H, int W, int k, int stride, int pad, void* stream) {
+  if (!dcols || !dx || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0) return set_error(QAVIT_EINVAL, "col2im: bad arguments");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int64_t total = (int64_t)B * H * W * Cin;
+  int grid = (int)((total + 1023) / 1024); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_F32) hipLaunchKernelGGL((col2im_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)dcols, (float*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
+  else if (dtype == QAVIT_BF16) hipLaunchKernelGGL((col2im_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)dcols, (bf16*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
+  else return set_error(QAVIT_EINVAL, "col2im: unknown dtype");
+  return check_launch("col2im");
+}
 
 extern "C" int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int ks, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "dwconv_fwd: bad arguments");

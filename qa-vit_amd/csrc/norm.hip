@@ -6,9 +6,9 @@
 
 namespace qv {
 
-constexpr int LN_MAX_PER_LANE = 16;   // C <= 1024
+constexpr int LN_MAX_C = 1024;
 
-template <typename T>
+template <typename T, int LN_MAX_PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, T* y, const float* gamma, const float* beta, float eps,
                                                             int rows, int C, float* mean_o, float* rstd_o,
                                                             const float* add, int add_rows) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, T* y, co
   }
 }
 
-template <typename T>
+template <typename T, int LN_MAX_PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                             const float* rstd, T* dx, float* dgamma, float* dbeta,
                                                             int rows, int C, float* dadd, int add_rows) {
@@ -113,20 +113,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
 
 using namespace qv;
 
+static int ln_pl(int C) { const int p = (C + 63) / 64; return p <= 1 ? 1 : p <= 2 ? 2 : p <= 3 ? 3 : p <= 4 ? 4 : p <= 8 ? 8 : 16; }
+
+#define LN_DISPATCH(PL, CALL)            \
+  switch (PL) {                          \
+    case 1: { constexpr int P = 1; CALL; } break;   \
+    case 2: { constexpr int P = 2; CALL; } break;   \
+    case 3: { constexpr int P = 3; CALL; } break;   \
+    case 4: { constexpr int P = 4; CALL; } break;   \
+    case 8: { constexpr int P = 8; CALL; } break;   \
+    default: { constexpr int P = 16; CALL; } break; \
+  }
+
 extern "C" int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                                    float eps, int rows, int C, float* mean, float* rstd,
                                    const float* add, int add_rows, void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_fwd: bad arguments");
-  if (C > 64 * LN_MAX_PER_LANE) return set_error(QAVIT_EINVAL, "layernorm_fwd: C > 1024 unsupported");
+  if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "layernorm_fwd: C > 1024 unsupported");
   if (add && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_fwd: add_rows must be positive");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = (rows + 3) / 4;
   if (grid > 4096) grid = 4096;
-  if (dtype == QAVIT_F32)
-    hipLaunchKernelGGL((layernorm_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows);
-  else if (dtype == QAVIT_BF16)
-    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows);
-  else return set_error(QAVIT_EINVAL, "layernorm_fwd: unknown dtype");
+  const int pl = ln_pl(C);
+  if (dtype == QAVIT_F32) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_fwd_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows))
+  } else if (dtype == QAVIT_BF16) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows))
+  } else return set_error(QAVIT_EINVAL, "layernorm_fwd: unknown dtype");
   return check_launch("layernorm_fwd");
 }
 
@@ -134,15 +147,16 @@ extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, con
                                    const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                    int rows, int C, float* dadd, int add_rows, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: bad arguments");
-  if (C > 64 * LN_MAX_PER_LANE) return set_error(QAVIT_EINVAL, "layernorm_bwd: C > 1024 unsupported");
+  if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "layernorm_bwd: C > 1024 unsupported");
   if (dadd && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: add_rows must be positive");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = (rows + 3) / 4;
-  if (grid > 1024) grid = 1024;
-  if (dtype == QAVIT_F32)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, C, dadd, add_rows);
-  else if (dtype == QAVIT_BF16)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, rows, C, dadd, add_rows);
-  else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
+  if (grid > 512) grid = 512;     // every workgroup ends with 2*C same-address atomics: keep the flush small
+  const int pl = ln_pl(C);
+  if (dtype == QAVIT_F32) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, C, dadd, add_rows))
+  } else if (dtype == QAVIT_BF16) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, rows, C, dadd, add_rows))
+  } else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
   return check_launch("layernorm_bwd");
 }

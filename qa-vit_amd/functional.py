@@ -556,6 +556,34 @@ class CcfMidFn(Function):
         return (d_h,) + (None,) * 10
 
 
+class Im2ColFn(Function):
+    """Rows (b,oy,ox) x columns (c,dy,dx) of a k x k / stride / pad convolution.  ``src`` is the fp32 NCHW image
+    (no gradient) or channel-last tokens [B,H*W,Cin] (gradient by col2im)."""
+
+    @staticmethod
+    def forward(ctx, src, dims, dtype):
+        B, Cin, H, W, k, stride, pad = dims
+        nchw = src.dim() == 4
+        src = src.contiguous()
+        if nchw:
+            src = src.float()
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        cols = torch.empty(B * Ho * Wo, Cin * k * k, dtype=dtype, device=src.device)
+        K.im2col(src, nchw, cols, B, Cin, H, W, k, stride, pad)
+        ctx.dims, ctx.nchw = dims, nchw
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        if ctx.nchw:
+            return None, None, None
+        B, Cin, H, W, k, stride, pad = ctx.dims
+        dcols = dcols.contiguous()
+        dx = torch.empty(B, H * W, Cin, dtype=dcols.dtype, device=dcols.device)
+        K.col2im(dcols, dx, B, Cin, H, W, k, stride, pad)
+        return dx, None, None
+
+
 class DwConvFn(Function):
     """Depthwise k x k conv on channel-last tokens [B, H*W, C] (csrc/dwconv.hip)."""
 

@@ -236,6 +236,14 @@ def ccf_bwd(a):
     L.check(L.load().qavit_ccf_mid_bwd(C.byref(a), stream()), "ccf_mid_bwd")
 
 
+def im2col(src, nchw_f32, cols, B, Cin, H, W, k, stride, pad):
+    L.check(L.load().qavit_im2col(dt_code(cols.dtype), src.data_ptr(), 1 if nchw_f32 else 0, cols.data_ptr(), B, Cin, H, W, k, stride, pad, stream()), "im2col")
+
+
+def col2im(dcols, dx, B, Cin, H, W, k, stride, pad):
+    L.check(L.load().qavit_col2im(dt_code(dcols.dtype), dcols.data_ptr(), dx.data_ptr(), B, Cin, H, W, k, stride, pad, stream()), "col2im")
+
+
 def dwconv_fwd(x, w, bias, y, B, H, W, Cc, ks):
     L.check(L.load().qavit_dwconv_fwd(dt_code(x.dtype), x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cc, ks, stream()), "dwconv_fwd")
 

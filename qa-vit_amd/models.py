@@ -99,12 +99,9 @@ class HQAViT(_Base):
         self._check(x)
         cdt = self._dtype(x)
         self.patch_embed.proj.compute_dtype = cdt
-        lowp = cdt != torch.float32
-        # CNN lateral path: only the two strided 3x3 stem convolutions (+BN+GELU) are stock ROCm ops (autocast gives
-        # them the compute dtype); the 8x8 part is channel-last on the HIP kernels
-        with torch.autocast("cuda", dtype=cdt if lowp else torch.bfloat16, enabled=lowp):
-            feats, (fh, fw) = self.cnn_stem.forward_tokens(x, cdt)
+        # CNN lateral path: channel-last on the HIP kernels (no MIOpen convolution anywhere)
         with torch.autocast("cuda", enabled=False):
+            feats, (fh, fw) = self.cnn_stem.forward_tokens(x, cdt)
             R = {}
             for i, f in zip((2, 3, 4), feats):
                 a = getattr(self, f"lmfa{i}").forward_tokens(f, fh, fw)

@@ -465,8 +465,8 @@ class ConvNeXtBlock(nn.Module):
 
 
 class CNNStemModel(nn.Module):
-    """HQAViT_CIFAR100.py:742-793.  The two strided 3x3 convolutions (+BatchNorm+GELU) still run on MIOpen; from the
-    8x8 (16x16) feature map on everything is channel-last and on the HIP kernels."""
+    """HQAViT_CIFAR100.py:742-793, channel-last throughout: the two strided 3x3 convolutions are im2col + MFMA GEMM,
+    the 1x1 convolutions are GEMMs, the depthwise 7x7 is csrc/dwconv.hip; only BatchNorm / GELU are stock ops."""
 
     def __init__(self, in_ch=3, c2=64, c3=128, c4=256, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -475,13 +475,21 @@ class CNNStemModel(nn.Module):
         self.stage2 = nn.Sequential(nn.Conv2d(c2, c3, 1), nn.BatchNorm2d(c3), ConvNeXtBlock(c3))
         self.stage3 = nn.Sequential(nn.Conv2d(c3, c4, 1), nn.BatchNorm2d(c4), ConvNeXtBlock(c4))
 
+    def _conv3x3s2_tokens(self, src, conv: nn.Conv2d, bn: nn.BatchNorm2d, dims, cdt):
+        """conv3x3/s2/p1 as im2col + MFMA GEMM, then BatchNorm + GELU, channel-last in and out."""
+        B = dims[0]
+        cols = F.Im2ColFn.apply(src, dims, cdt)
+        t = F.linear(cols, conv.weight, conv.bias).reshape(B, -1, conv.out_channels)
+        return TF.gelu(_bn_tokens(t, bn, self.training))
+
     def forward_tokens(self, x, cdt):
         """-> (F2, F3, F4) as channel-last tokens [B, h*w, c] in the compute dtype, and (h, w)."""
-        x = self.stem(x)
-        x = self.stage1[2](self.stage1[1](self.stage1[0](x)))
-        h, w = x.shape[2], x.shape[3]
-        t = _to_tokens(x).to(cdt)
+        B, Cin, H, W = x.shape
         with torch.autocast("cuda", enabled=False):
+            t = self._conv3x3s2_tokens(x, self.stem[0], self.stem[1], (B, Cin, H, W, 3, 2, 1), cdt)
+            H1, W1 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            t = self._conv3x3s2_tokens(t, self.stage1[0], self.stage1[1], (B, self.stem[0].out_channels, H1, W1, 3, 2, 1), cdt)
+            h, w = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
             f2 = self.stage1[3].forward_tokens(t, h, w)
             f3 = self.stage2[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f2, self.stage2[0]), self.stage2[1], self.training), h, w)
             f4 = self.stage3[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f3, self.stage3[0]), self.stage3[1], self.training), h, w)

@@ -386,6 +386,30 @@ def test_dwconv_tokens(F, dtype, ks, C, H):
     assert rel(b.grad, br.grad) <= tol(dtype, False)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3_s2_as_im2col_gemm(F, dtype):
+    """Both stem convolutions: NCHW fp32 image source (no input grad) and channel-last token source (col2im grad)."""
+    B = 9
+    img = torch.randn(B, 3, 32, 32, device=DEV)
+    w0, b0 = leaf(32, 3, 3, 3, scale=0.2, seed=140), leaf(32, scale=0.1, seed=141)
+    cols = F.Im2ColFn.apply(img, (B, 3, 32, 32, 3, 2, 1), dtype)
+    y0 = F.linear(cols, w0, b0).reshape(B, 256, 32)
+    ref0 = TF.conv2d(img, w0.detach(), b0.detach(), stride=2, padding=1).flatten(2).transpose(1, 2)
+    assert rel(y0, ref0) <= tol(dtype)
+    t = leaf(B, 256, 32, seed=142).detach().to(dtype).requires_grad_(True)
+    w1, b1 = leaf(64, 32, 3, 3, scale=0.1, seed=143), leaf(64, scale=0.1, seed=144)
+    y1 = F.linear(F.Im2ColFn.apply(t, (B, 32, 16, 16, 3, 2, 1), dtype), w1, b1).reshape(B, 64, 64)
+    tr, wr, br = [v.detach().clone().float().requires_grad_(True) for v in (t, w1, b1)]
+    ref1 = TF.conv2d(tr.transpose(1, 2).reshape(B, 32, 16, 16), wr, br, stride=2, padding=1).flatten(2).transpose(1, 2)
+    assert rel(y1, ref1) <= tol(dtype)
+    go = torch.randn_like(ref1)
+    y1.backward(go.to(dtype))
+    ref1.backward(go)
+    assert rel(t.grad, tr.grad) <= tol(dtype, False)
+    assert rel(w1.grad, wr.grad) <= tol(dtype, False)
+    assert rel(b1.grad, br.grad) <= tol(dtype, False)
+
+
 def test_small_ops(F):
     B, N, C = 17, 16, 192
     x = leaf(B, N, C, seed=120)
