@@ -11,6 +11,7 @@
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
+#include <stdlib.h>
 
 namespace qv {
 
@@ -53,263 +54,363 @@ __device__ __forceinline__ void store_vec_zero(T* p) {
 
 // ------------------------------------------------------------------------------------------------
 // gemm_nt
+//
+// A workgroup owns a BN-column slice of the output: its weight slice B[n0:n0+BN, 0:K] is staged into LDS ONCE
+// and stays resident while the workgroup walks row tiles of BM = 64 rows (blockIdx.y strides the tiles).  The
+// activation rows stream through LDS in K-chunks of <= KC elements with a register prefetch of the next chunk
+// issued before the MFMAs of the current one, so L2/HBM latency hides under the matrix work.  4 waves form a
+// 2 (M) x 2 (N) grid; each wave accumulates 2 x (BN/32) 16x16 tiles.  The fused LayerNorm prologue runs on the
+// staged rows in LDS (K <= KC: whole rows resident), the backward transform on the prefetched registers.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g) {
+constexpr int BM = 64;
+
+template <typename T> __host__ __device__ constexpr int kca_elems() { return sizeof(T) == 2 ? 256 : 128; }
+
+// AMODE: 0 plain rows, 1 fused LayerNorm, 2 backward transform.  EPI: 0 = bias only, 1 = full epilogue.
+template <typename T, int BNT, int AMODE, int EPI, int KC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g, int n_tiles_m) {
   using M_ = Mma<T>;
   constexpr int VN = Vec<T>::N;
   constexpr int FK = M_::FK;
-  constexpr int KC = kc_elems<T>();
-  constexpr int WM = (BM / 16 < 4) ? BM / 16 : 4;   // waves along M
-  constexpr int WN = 4 / WM;                        // waves along N
-  constexpr int MT = BM / 16 / WM;                  // 16-row tiles per wave
-  constexpr int NT = 4 / WN;                        // 16-col tiles per wave
+  constexpr int NT = BNT / 32;                       // 16-col tiles per wave
+  constexpr int PRE = BM * KC / VN / GEMM_THREADS;   // prefetch vectors per thread
+  constexpr int CLD = BNT + 4;                       // epilogue scratch row stride (floats)
   typedef typename Vec<T>::type vec_t;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Kp = (g.K + FK - 1) / FK * FK;
-  const int lda_s = Kp + VN;                         // LDS row stride of As (elements)
-  constexpr int ldb_s = KC + VN;
-  T* As = reinterpret_cast<T*>(smem);
-  char* region2 = smem + (size_t)BM * lda_s * sizeof(T);
-  T* Bs = reinterpret_cast<T*>(region2);
-  float* Cs = reinterpret_cast<float*>(region2);     // aliases Bs (used only between barriers)
+  const int ldb_s = Kp + VN;
+  const int lda_s = ((Kp < KC) ? Kp : KC) + VN;
+  T* Bs = reinterpret_cast<T*>(smem);
+  T* As = reinterpret_cast<T*>(smem + (size_t)BNT * ldb_s * sizeof(T));
+  float* Cs = reinterpret_cast<float*>(smem + (size_t)BNT * ldb_s * sizeof(T) + (size_t)BM * lda_s * sizeof(T));
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int m0 = blockIdx.x * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * BNT;
+  const bool first_slice = blockIdx.x == 0;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
   T* C = reinterpret_cast<T*>(g.C);
+  const T* Zin = reinterpret_cast<const T*>(g.a_Z);
+  T* Aout = reinterpret_cast<T*>(g.a_out);
+  const T* Rr = reinterpret_cast<const T*>(g.R);
+  T* Zo = reinterpret_cast<T*>(g.Z);
+  constexpr bool bwd = AMODE == 2;
+  const bool use_z = bwd && Zin && g.a_act;
 
   uint32_t key_adrop = 0, key_adp = 0, key_drop = 0, key_dp = 0;
-  if (g.rng) {
+  if ((AMODE == 2 || EPI == 1) && g.rng) {
     key_adrop = rng_key(g.rng, g.a_drop_site);
     key_adp = rng_key(g.rng, g.a_dp_site);
     key_drop = rng_key(g.rng, g.drop_site);
     key_dp = rng_key(g.rng, g.dp_site);
   }
-
-  // ---------------- stage A rows (with the backward transform when a_mode == 2) ----------------
-  {
-    const int kv = Kp / VN;                          // vectors per LDS row
-    const bool vec_ok = (g.K % VN == 0) && (g.lda % VN == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-    const bool bwd = g.a_mode == 2;
-    const T* Zin = reinterpret_cast<const T*>(g.a_Z);
-    T* Aout = reinterpret_cast<T*>(g.a_out);
-    const bool vec_ok2 = vec_ok && (!bwd || ((!Zin || (g.a_ldz % VN == 0 && (reinterpret_cast<uintptr_t>(Zin) & 15) == 0)) &&
-                                             (!Aout || (g.a_ldo % VN == 0 && (reinterpret_cast<uintptr_t>(Aout) & 15) == 0))));
-    const float a_inv_keep = g.a_drop_p > 0.f ? 1.f / (1.f - g.a_drop_p) : 1.f;
-    const float a_dp_inv = g.a_dp_p > 0.f ? 1.f / (1.f - g.a_dp_p) : 1.f;
-    for (int idx = tid; idx < BM * kv; idx += GEMM_THREADS) {
-      const int r = idx / kv, v = idx - r * kv;
-      const int m = m0 + r, k = v * VN;
-      T* dst = As + (size_t)r * lda_s + k;
-      if (m >= g.M || k >= g.K) { store_vec_zero<T>(dst); continue; }
-      float f[VN];
-      if (vec_ok2) {
-        vec_t x = *reinterpret_cast<const vec_t*>(A + (size_t)m * g.lda + k);
-#pragma unroll
-        for (int i = 0; i < VN; ++i) f[i] = to_f<T>(x[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < VN; ++i) f[i] = (k + i < g.K) ? to_f<T>(A[(size_t)m * g.lda + k + i]) : 0.f;
-      }
-      if (bwd) {
-        float rowf = g.a_scale;
-        if (g.a_dp_p > 0.f) rowf *= drop_factor(key_adp, (uint32_t)(m / g.a_dp_rows), g.a_dp_p, a_dp_inv);
-        float z[VN];
-        if (Zin && g.a_act) {
-          if (vec_ok2) {
-            vec_t zz = *reinterpret_cast<const vec_t*>(Zin + (size_t)m * g.a_ldz + k);
-#pragma unroll
-            for (int i = 0; i < VN; ++i) z[i] = to_f<T>(zz[i]);
-          } else {
-#pragma unroll
-            for (int i = 0; i < VN; ++i) z[i] = (k + i < g.K) ? to_f<T>(Zin[(size_t)m * g.a_ldz + k + i]) : 0.f;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < VN; ++i) {
-          float v_ = f[i] * rowf;
-          if (g.a_drop_p > 0.f) v_ *= drop_factor(key_adrop, (uint32_t)m * (uint32_t)g.K + (uint32_t)(k + i), g.a_drop_p, a_inv_keep);
-          if (Zin && g.a_act) v_ *= gelu_grad_f(z[i]);
-          f[i] = v_;
-        }
-      }
-      vec_t o;
-#pragma unroll
-      for (int i = 0; i < VN; ++i) o[i] = from_f<T>(f[i]);
-      *reinterpret_cast<vec_t*>(dst) = o;
-      if (bwd && Aout) {
-        if (vec_ok2) {
-          *reinterpret_cast<vec_t*>(Aout + (size_t)m * g.a_ldo + k) = o;
-        } else {
-#pragma unroll
-          for (int i = 0; i < VN; ++i) if (k + i < g.K) Aout[(size_t)m * g.a_ldo + k + i] = o[i];
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---------------- fused LayerNorm over K on the resident rows ----------------
-  if (g.a_mode == 1) {
-    const float invK = 1.f / (float)g.K;
-    for (int r = wave; r < BM; r += 4) {
-      const int m = m0 + r;
-      if (m >= g.M) continue;                         // wave-uniform
-      T* row = As + (size_t)r * lda_s;
-      float s = 0.f;
-      for (int k = lane; k < g.K; k += 64) s += to_f<T>(row[k]);
-      const float mean = wave_sum(s) * invK;
-      float s2 = 0.f;
-      for (int k = lane; k < g.K; k += 64) { const float d = to_f<T>(row[k]) - mean; s2 += d * d; }
-      const float rstd = rsqrtf(wave_sum(s2) * invK + g.ln_eps);
-      for (int k = lane; k < g.K; k += 64)
-        row[k] = from_f<T>((to_f<T>(row[k]) - mean) * rstd * g.ln_gamma[k] + g.ln_beta[k]);
-      if (lane == 0) {
-        if (g.ln_mean) g.ln_mean[m] = mean;
-        if (g.ln_rstd) g.ln_rstd[m] = rstd;
-      }
-    }
-    __syncthreads();
-  }
-
-  const int wm = wave % WM, wn = wave / WM;
-  const int fr = lane & 15, fq = lane >> 4;
+  const float a_inv_keep = g.a_drop_p > 0.f ? 1.f / (1.f - g.a_drop_p) : 1.f;
+  const float a_dp_inv = g.a_dp_p > 0.f ? 1.f / (1.f - g.a_dp_p) : 1.f;
   const float inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
   const float dp_inv = g.dp_p > 0.f ? 1.f / (1.f - g.dp_p) : 1.f;
-  const T* Rr = reinterpret_cast<const T*>(g.R);
-  T* Zo = reinterpret_cast<T*>(g.Z);
 
-  for (int n0 = 0; n0 < g.N; n0 += BN) {
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool a_vec = (g.K % VN == 0) && (g.lda % VN == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                     (!use_z || (g.a_ldz % VN == 0 && (reinterpret_cast<uintptr_t>(Zin) & 15) == 0)) &&
+                     (!(bwd && Aout) || (g.a_ldo % VN == 0 && (reinterpret_cast<uintptr_t>(Aout) & 15) == 0));
 
-    for (int k0 = 0; k0 < Kp; k0 += KC) {
-      const int kc = (Kp - k0 < KC) ? (Kp - k0) : KC;   // multiple of FK
-      __syncthreads();                                   // previous readers of Bs / Cs done
-      {  // stage B[n0:n0+64, k0:k0+kc] (rows = output columns)
-        const int kv = kc / VN;
-        const bool vec_ok = (g.K % VN == 0) && (g.ldb % VN == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-        for (int idx = tid; idx < BN * kv; idx += GEMM_THREADS) {
-          const int r = idx / kv, v = idx - r * kv;
-          const int n = n0 + r, k = k0 + v * VN;
-          T* dst = Bs + r * ldb_s + v * VN;
-          if (n >= g.N || k >= g.K) { store_vec_zero<T>(dst); continue; }
-          if (vec_ok) {
-            *reinterpret_cast<vec_t*>(dst) = *reinterpret_cast<const vec_t*>(B + (size_t)n * g.ldb + k);
-          } else {
-            vec_t o;
+  // ---------------- resident weight slice ----------------
+  {
+    const int kv = Kp / VN;
+    const bool b_vec = (g.K % VN == 0) && (g.ldb % VN == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    for (int idx = tid; idx < BNT * kv; idx += GEMM_THREADS) {
+      const int r = idx / kv, v = idx - r * kv;
+      const int n = n0 + r, k = v * VN;
+      T* dst = Bs + (size_t)r * ldb_s + k;
+      if (n >= g.N || k >= g.K) { store_vec_zero<T>(dst); continue; }
+      if (b_vec) {
+        *reinterpret_cast<vec_t*>(dst) = *reinterpret_cast<const vec_t*>(B + (size_t)n * g.ldb + k);
+      } else {
+        vec_t o;
 #pragma unroll
-            for (int i = 0; i < VN; ++i) o[i] = (k + i < g.K) ? B[(size_t)n * g.ldb + k + i] : from_f<T>(0.f);
-            *reinterpret_cast<vec_t*>(dst) = o;
+        for (int i = 0; i < VN; ++i) o[i] = (k + i < g.K) ? B[(size_t)n * g.ldb + k + i] : from_f<T>(0.f);
+        *reinterpret_cast<vec_t*>(dst) = o;
+      }
+    }
+  }
+
+  const int n_chunks = (Kp + KC - 1) / KC;
+  vec_t pre[PRE], prez[PRE];
+
+  // issue the global loads of (tile, chunk) into registers
+  auto prefetch = [&](int tile, int chunk) {
+    const int k0 = chunk * KC;
+    const int kc = (Kp - k0 < KC) ? (Kp - k0) : KC;
+    const int kv = kc / VN;
+    const int m0 = tile * BM;
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+      const int idx = tid + i * GEMM_THREADS;
+      if (idx >= BM * kv) break;
+      const int r = idx / kv, v = idx - r * kv;
+      const int m = m0 + r, k = k0 + v * VN;
+      vec_t x, z;
+#pragma unroll
+      for (int j = 0; j < VN; ++j) { x[j] = from_f<T>(0.f); z[j] = from_f<T>(0.f); }
+      if (m < g.M && k < g.K) {
+        if (a_vec) {
+          x = *reinterpret_cast<const vec_t*>(A + (size_t)m * g.lda + k);
+          if (use_z) z = *reinterpret_cast<const vec_t*>(Zin + (size_t)m * g.a_ldz + k);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            if (k + j < g.K) {
+              x[j] = A[(size_t)m * g.lda + k + j];
+              if (use_z) z[j] = Zin[(size_t)m * g.a_ldz + k + j];
+            }
           }
+        }
+      }
+      pre[i] = x;
+      prez[i] = z;
+    }
+  };
+
+  // registers -> LDS (applying the backward transform; n-slice 0 also writes dZ back)
+  auto commit = [&](int tile, int chunk) {
+    const int k0 = chunk * KC;
+    const int kc = (Kp - k0 < KC) ? (Kp - k0) : KC;
+    const int kv = kc / VN;
+    const int m0 = tile * BM;
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+      const int idx = tid + i * GEMM_THREADS;
+      if (idx >= BM * kv) break;
+      const int r = idx / kv, v = idx - r * kv;
+      const int m = m0 + r, k = k0 + v * VN;
+      vec_t o = pre[i];
+      if (bwd && m < g.M && k < g.K) {
+        float rowf = g.a_scale;
+        if (g.a_dp_p > 0.f) rowf *= drop_factor(key_adp, (uint32_t)(m / g.a_dp_rows), g.a_dp_p, a_dp_inv);
+        float f[VN];
+#pragma unroll
+        for (int j = 0; j < VN; ++j) f[j] = to_f<T>(o[j]) * rowf;
+        if (g.a_drop_p > 0.f) {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) f[j] *= drop_factor(key_adrop, (uint32_t)m * (uint32_t)g.K + (uint32_t)(k + j), g.a_drop_p, a_inv_keep);
+        }
+        if (use_z) {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) f[j] *= gelu_grad_f(to_f<T>(prez[i][j]));
+        }
+#pragma unroll
+        for (int j = 0; j < VN; ++j) o[j] = from_f<T>(f[j]);
+        if (Aout && first_slice) {
+          if (a_vec) *reinterpret_cast<vec_t*>(Aout + (size_t)m * g.a_ldo + k) = o;
+          else {
+#pragma unroll
+            for (int j = 0; j < VN; ++j) if (k + j < g.K) Aout[(size_t)m * g.a_ldo + k + j] = o[j];
+          }
+        }
+      }
+      *reinterpret_cast<vec_t*>(As + (size_t)r * lda_s + v * VN) = o;
+    }
+  };
+
+  f32x4 acc[2][NT];
+  int tile = blockIdx.y, chunk = 0;
+  if (tile < n_tiles_m) prefetch(tile, 0);
+  while (tile < n_tiles_m) {
+    __syncthreads();                                   // previous MFMAs done with As, previous epilogue done with Cs
+    commit(tile, chunk);
+    __syncthreads();
+    const int k0 = chunk * KC;
+    const int kc = (Kp - k0 < KC) ? (Kp - k0) : KC;
+    const int m0 = tile * BM;
+    if (AMODE == 1) {                                  // fused LayerNorm (host guarantees a single chunk)
+      const float invK = 1.f / (float)g.K;
+      for (int r = wave; r < BM; r += 4) {
+        const int m = m0 + r;
+        if (m >= g.M) continue;                        // wave-uniform
+        T* row = As + (size_t)r * lda_s;
+        float s = 0.f;
+        for (int k = lane; k < g.K; k += 64) s += to_f<T>(row[k]);
+        const float mean = wave_sum(s) * invK;
+        float s2 = 0.f;
+        for (int k = lane; k < g.K; k += 64) { const float d = to_f<T>(row[k]) - mean; s2 += d * d; }
+        const float rstd = rsqrtf(wave_sum(s2) * invK + g.ln_eps);
+        for (int k = lane; k < g.K; k += 64)
+          row[k] = from_f<T>((to_f<T>(row[k]) - mean) * rstd * g.ln_gamma[k] + g.ln_beta[k]);
+        if (lane == 0 && first_slice) {
+          if (g.ln_mean) g.ln_mean[m] = mean;
+          if (g.ln_rstd) g.ln_rstd[m] = rstd;
         }
       }
       __syncthreads();
-      const int nf = kc / FK;
-      for (int kf = 0; kf < nf; ++kf) {
-        typename M_::frag af[MT], bfr[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int row = (wm * MT + i) * 16 + fr;
-          af[i] = *reinterpret_cast<const typename M_::frag*>(As + (size_t)row * lda_s + k0 + kf * FK + fq * VN);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int col = (wn * NT + j) * 16 + fr;
-          bfr[j] = *reinterpret_cast<const typename M_::frag*>(Bs + col * ldb_s + kf * FK + fq * VN);
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) M_::mma(af[i], bfr[j], acc[i][j]);
-      }
     }
-    __syncthreads();   // all waves finished reading Bs -> reuse as Cs
-    // accumulator (col = lane&15, row = 4*(lane>>4)+reg) -> Cs[row][col]
+    // next (tile, chunk) in the stream: its loads fly while this chunk's MFMAs run
+    int ntile = tile, nchunk = chunk + 1;
+    if (nchunk == n_chunks) { nchunk = 0; ntile = tile + gridDim.y; }
+    if (ntile < n_tiles_m) prefetch(ntile, nchunk);
+
+    if (chunk == 0) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nf = kc / FK;
+    for (int kf = 0; kf < nf; ++kf) {
+      typename M_::frag af[2], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const typename M_::frag*>(As + (size_t)((wm * 2 + i) * 16 + fr) * lda_s + kf * FK + fq * VN);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
+        bfr[j] = *reinterpret_cast<const typename M_::frag*>(Bs + (size_t)((wn * NT + j) * 16 + fr) * ldb_s + k0 + kf * FK + fq * VN);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (wm * MT + i) * 16 + fq * 4 + r;
-          const int col = (wn * NT + j) * 16 + fr;
-          Cs[row * CS_LD + col] = acc[i][j][r];
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) M_::mma(af[i], bfr[j], acc[i][j]);
+    }
+
+    if (chunk == n_chunks - 1) {
+      // accumulators -> Cs (col = lane&15, row = 4*(lane>>4)+reg), then row-contiguous epilogue
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Cs[((wm * 2 + i) * 16 + fq * 4 + r) * CLD + (wn * NT + j) * 16 + fr] = acc[i][j][r];
+      __syncthreads();
+      constexpr int CG = BNT / 16;                     // 16-column groups per row
+      for (int idx = tid; idx < BM * CG; idx += GEMM_THREADS) {
+        const int r = idx / CG, cg = idx - r * CG;
+        const int m = m0 + r;
+        const int n = n0 + cg * 16;
+        if (m >= g.M || n >= g.N) continue;
+        const int nv = (g.N - n < 16) ? (g.N - n) : 16;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + r * CLD + cg * 16 + i);
+          v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
         }
-    __syncthreads();
-    // epilogue: each thread owns 16 consecutive columns of one row
-    for (int idx = tid; idx < BM * 4; idx += GEMM_THREADS) {
-      const int r = idx >> 2, cg = idx & 3;
-      const int m = m0 + r;
-      const int n = n0 + cg * 16;
-      if (m >= g.M || n >= g.N) continue;
-      const int nv = (g.N - n < 16) ? (g.N - n) : 16;
-      float v[16];
+        const bool full = (nv == 16) && (n % VN == 0);
+        if (g.bias) {
+          if (nv == 16 && ((reinterpret_cast<uintptr_t>(g.bias + n) & 15) == 0)) {
 #pragma unroll
-      for (int i = 0; i < 16; i += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + r * CS_LD + cg * 16 + i);
-        v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
-      }
-      float rowf = g.scale;
-      if (g.dp_p > 0.f) rowf *= drop_factor(key_dp, (uint32_t)(m / g.dp_rows), g.dp_p, dp_inv);
+            for (int i = 0; i < 16; i += 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(g.bias + n + i);
+              v[i] += t[0]; v[i + 1] += t[1]; v[i + 2] += t[2]; v[i + 3] += t[3];
+            }
+          } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i < nv) {
-          float x = v[i];
-          if (g.bias) x += g.bias[n + i];
-          if (Zo) Zo[(size_t)m * g.ldz + n + i] = from_f<T>(x);
-          if (g.act == 1) x = gelu_f(x);
-          if (g.drop_p > 0.f) x *= drop_factor(key_drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(n + i), g.drop_p, inv_keep);
-          x *= rowf;
-          if (Rr) x += to_f<T>(Rr[(size_t)m * g.ldr + n + i]);
-          v[i] = x;
+            for (int i = 0; i < 16; ++i) if (i < nv) v[i] += g.bias[n + i];
+          }
         }
-      }
-      T* crow = C + (size_t)m * g.ldc + n;
-      const bool cvec = (nv == 16) && (g.ldc % VN == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (n % VN == 0);
-      if (cvec) {
+        float zv[16];
+        if (EPI == 1) {
 #pragma unroll
-        for (int i = 0; i < 16; i += VN) {
-          vec_t o;
+          for (int i = 0; i < 16; ++i) zv[i] = v[i];
+          if (g.act == 1) {
 #pragma unroll
-          for (int j = 0; j < VN; ++j) o[j] = from_f<T>(v[i + j]);
-          *reinterpret_cast<vec_t*>(crow + i) = o;
+            for (int i = 0; i < 16; ++i) v[i] = gelu_f(v[i]);
+          }
+          if (g.drop_p > 0.f) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] *= drop_factor(key_drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(n + i), g.drop_p, inv_keep);
+          }
+          float rowf = g.scale;
+          if (g.dp_p > 0.f) rowf *= drop_factor(key_dp, (uint32_t)(m / g.dp_rows), g.dp_p, dp_inv);
+          if (rowf != 1.f) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] *= rowf;
+          }
+          if (Rr) {
+            if (full && (g.ldr % VN == 0) && ((reinterpret_cast<uintptr_t>(Rr) & 15) == 0)) {
+#pragma unroll
+              for (int i = 0; i < 16; i += VN) {
+                const vec_t t = *reinterpret_cast<const vec_t*>(Rr + (size_t)m * g.ldr + n + i);
+#pragma unroll
+                for (int j = 0; j < VN; ++j) v[i + j] += to_f<T>(t[j]);
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) if (i < nv) v[i] += to_f<T>(Rr[(size_t)m * g.ldr + n + i]);
+            }
+          }
         }
-      } else {
+        T* crow = C + (size_t)m * g.ldc + n;
+        if (full && (g.ldc % VN == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) if (i < nv) crow[i] = from_f<T>(v[i]);
+          for (int i = 0; i < 16; i += VN) {
+            vec_t o;
+#pragma unroll
+            for (int j = 0; j < VN; ++j) o[j] = from_f<T>(v[i + j]);
+            *reinterpret_cast<vec_t*>(crow + i) = o;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) if (i < nv) crow[i] = from_f<T>(v[i]);
+        }
+        if (EPI == 1 && Zo) {
+          T* zrow = Zo + (size_t)m * g.ldz + n;
+          if (full && (g.ldz % VN == 0) && ((reinterpret_cast<uintptr_t>(Zo) & 15) == 0)) {
+#pragma unroll
+            for (int i = 0; i < 16; i += VN) {
+              vec_t o;
+#pragma unroll
+              for (int j = 0; j < VN; ++j) o[j] = from_f<T>(zv[i + j]);
+              *reinterpret_cast<vec_t*>(zrow + i) = o;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (i < nv) zrow[i] = from_f<T>(zv[i]);
+          }
+        }
       }
     }
+    tile = ntile;
+    chunk = nchunk;
   }
 }
 
-template <typename T, int BM>
-static int launch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
+template <typename T, int BNT, int AMODE, int EPI, int KC>
+static int launch_gemm_nt3(const qavit_gemm_args& g, hipStream_t st) {
   constexpr int VN = Vec<T>::N;
   constexpr int FK = Mma<T>::FK;
-  constexpr int KC = kc_elems<T>();
   const int Kp = round_up(g.K, FK);
-  const size_t a_bytes = (size_t)BM * (Kp + VN) * sizeof(T);
-  const size_t b_bytes = (size_t)BN * (KC + VN) * sizeof(T);
-  const size_t c_bytes = (size_t)BM * CS_LD * sizeof(float);
-  const size_t smem = a_bytes + (b_bytes > c_bytes ? b_bytes : c_bytes);
-  if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "gemm_nt: K too large for the resident-row tile");
+  const size_t b_bytes = (size_t)BNT * (Kp + VN) * sizeof(T);
+  const size_t a_bytes = (size_t)BM * ((Kp < KC ? Kp : KC) + VN) * sizeof(T);
+  const size_t c_bytes = (size_t)BM * (BNT + 4) * sizeof(float);
+  const size_t smem = b_bytes + a_bytes + c_bytes;
+  if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "gemm_nt: K too large for the resident weight slice");
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BNT, AMODE, EPI, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const int grid = (g.M + BM - 1) / BM;
-  hipLaunchKernelGGL((gemm_nt_kernel<T, BM>), dim3(grid), dim3(GEMM_THREADS), smem, st, g);
+  const int n_slices = (g.N + BNT - 1) / BNT;
+  const int n_tiles_m = (g.M + BM - 1) / BM;
+  int gy = (768 + n_slices - 1) / n_slices;          // ~3 workgroups per CU across the chip
+  if (gy > n_tiles_m) gy = n_tiles_m;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BNT, AMODE, EPI, KC>), dim3(n_slices, gy), dim3(GEMM_THREADS), smem, st, g, n_tiles_m);
   return check_launch("gemm_nt");
+}
+
+// fp32 with a long K: the resident fp32 weight slice is large, so the row tile streams in 64-wide chunks
+template <typename T, int BNT, int AMODE, int EPI>
+static int launch_gemm_nt2(const qavit_gemm_args& g, hipStream_t st) {
+  if (sizeof(T) == 4 && AMODE != 1 && g.K > 256) return launch_gemm_nt3<T, BNT, AMODE, EPI, 64>(g, st);
+  return launch_gemm_nt3<T, BNT, AMODE, EPI, 256>(g, st);
+}
+
+template <typename T, int BNT>
+static int launch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
+  const bool full = g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f;
+  if (g.a_mode == 1) return full ? launch_gemm_nt2<T, BNT, 1, 1>(g, st) : launch_gemm_nt2<T, BNT, 1, 0>(g, st);
+  if (g.a_mode == 2) return full ? launch_gemm_nt2<T, BNT, 2, 1>(g, st) : launch_gemm_nt2<T, BNT, 2, 0>(g, st);
+  return full ? launch_gemm_nt2<T, BNT, 0, 1>(g, st) : launch_gemm_nt2<T, BNT, 0, 0>(g, st);
 }
 
 template <typename T>
@@ -317,18 +418,20 @@ static int dispatch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
   constexpr int VN = Vec<T>::N;
   constexpr int FK = Mma<T>::FK;
   const int Kp = round_up(g.K, FK);
+  if (g.a_mode == 1 && Kp > 256) return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm prologue needs K <= 256");
   const size_t row_bytes = (size_t)(Kp + VN) * sizeof(T);
-  const size_t budget = 96 * 1024;   // resident A rows; leaves room for the B / C region and 1 WG/CU
-  // prefer tall tiles (weight tile reuse) but keep >= ~2 waves of workgroups on 256 CUs
-  int bm = 128;
-  while (bm > 16 && (bm * row_bytes > budget)) bm >>= 1;
-  while (bm > 32 && (g.M + bm - 1) / bm < 384) bm >>= 1;
-  if (bm * row_bytes > 140 * 1024) return set_error(QAVIT_EINVAL, "gemm_nt: K too large");
-  switch (bm) {
+  // slice width: weights <= ~28 KB so that two workgroups share a CU (slice + row tile + epilogue scratch < 80 KB)
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("QAVIT_GEMM_BN"); forced = e ? atoi(e) : 0; }
+  int bn = forced > 0 ? forced : 64;
+  const size_t cap = (forced > 0 ? 100 : (sizeof(T) == 4 ? 52 : 28)) * 1024;
+  while (bn > 32 && (size_t)bn * row_bytes > cap) bn >>= 1;
+  if (bn > 32 && g.N <= bn / 2) bn = (g.N <= 32) ? 32 : 64;
+  if ((size_t)bn * row_bytes > 132 * 1024) return set_error(QAVIT_EINVAL, "gemm_nt: K too large");
+  switch (bn) {
     case 128: return launch_gemm_nt<T, 128>(g, st);
     case 64: return launch_gemm_nt<T, 64>(g, st);
-    case 32: return launch_gemm_nt<T, 32>(g, st);
-    default: return launch_gemm_nt<T, 16>(g, st);
+    default: return launch_gemm_nt<T, 32>(g, st);
   }
 }
 
@@ -417,6 +520,126 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(qavit_gemm_tn_arg
   if (g.colsum && blockIdx.y == 0 && tid < 64 && n0 + tid < g.N) atomic_add_f(g.colsum + n0 + tid, csum);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 gemm_tn with hardware-transposed LDS reads.  Both operands are staged ROW-MAJOR ([m][n], [m][k]: 16-byte
+// coalesced loads, register-prefetched one chunk ahead) and the m-contiguous MFMA fragments are produced by
+// ds_read_b64_tr_b16: per 16-lane group it reads a 4-row x 16-column block and hands lane i column i of the
+// four rows -- exactly the k-contiguous fragment of an operand stored with its reduction axis along rows.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int ld, int m0, int c0) {
+  // fragment for lane l: rows m0 + 8*(l>>4) + j (j = 0..7), column c0 + (l & 15)
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const bf16* a0 = tile + (size_t)(m0 + 8 * g + q) * ld + c0 + 4 * p;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * ld));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_bf16_kernel(qavit_gemm_tn_args g, int rows_per_split) {
+  constexpr int LD = 64 + 8;                          // elements; 144-byte rows keep every tr read 8-byte aligned
+  __shared__ __attribute__((aligned(16))) bf16 At[TN_MC * LD];   // [m][n]
+  __shared__ __attribute__((aligned(16))) bf16 Bt[TN_MC * LD];   // [m][k]
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int wa = wave & 1, wb = wave >> 1;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int mbeg = blockIdx.z * rows_per_split;
+  const int mend = (mbeg + rows_per_split < g.M) ? mbeg + rows_per_split : g.M;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A);
+  const bf16* B = reinterpret_cast<const bf16*>(g.B);
+  const bool ln = g.ln_mean != nullptr;
+  const bool a_vec = (g.lda % 8 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (n0 + 64 <= g.N);
+  const bool b_vec = (g.ldb % 8 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (k0 + 64 <= g.K);
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
+
+  // thread -> two 16-byte vectors per operand: rows r0 and r0 + 32, columns 8*vc .. 8*vc+7
+  const int r0 = tid >> 3, vc = tid & 7;
+  bf16x8 pa[2], pb[2];
+  auto prefetch = [&](int mc) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = mc + r0 + 32 * h;
+      bf16x8 va, vb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { va[j] = (bf16)0.f; vb[j] = (bf16)0.f; }
+      if (m < mend) {
+        if (a_vec) va = *reinterpret_cast<const bf16x8*>(A + (size_t)m * g.lda + n0 + 8 * vc);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n0 + 8 * vc + j < g.N) va[j] = A[(size_t)m * g.lda + n0 + 8 * vc + j];
+        }
+        if (b_vec) vb = *reinterpret_cast<const bf16x8*>(B + (size_t)m * g.ldb + k0 + 8 * vc);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (k0 + 8 * vc + j < g.K) vb[j] = B[(size_t)m * g.ldb + k0 + 8 * vc + j];
+        }
+        if (ln) {
+          const float mu = g.ln_mean[m], rs = g.ln_rstd[m];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int kk = k0 + 8 * vc + j;
+            if (kk < g.K) vb[j] = (bf16)(((float)vb[j] - mu) * rs * g.ln_gamma[kk] + g.ln_beta[kk]);
+          }
+        }
+      }
+      pa[h] = va;
+      pb[h] = vb;
+    }
+  };
+
+  if (mbeg < mend) prefetch(mbeg);
+  for (int mc = mbeg; mc < mend; mc += TN_MC) {
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<bf16x8*>(At + (r0 + 32 * h) * LD + 8 * vc) = pa[h];
+      *reinterpret_cast<bf16x8*>(Bt + (r0 + 32 * h) * LD + 8 * vc) = pb[h];
+    }
+    __syncthreads();
+    if (mc + TN_MC < mend) prefetch(mc + TN_MC);
+    if (g.colsum && blockIdx.y == 0 && tid < 64) {
+      float s_ = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < TN_MC; ++m) s_ += (float)At[m * LD + tid];
+      csum += s_;
+    }
+#pragma unroll
+    for (int kf = 0; kf < TN_MC / 32; ++kf) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = tr_frag(At, LD, kf * 32, (wa * 2 + i) * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = tr_frag(Bt, LD, kf * 32, (wb * 2 + j) * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  const int lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wa * 2 + i) * 16 + fq * 4 + r, k = k0 + (wb * 2 + j) * 16 + fr;
+        if (n < g.N && k < g.K) atomic_add_f(g.C + (size_t)n * g.ldc + k, acc[i][j][r]);
+      }
+  if (g.colsum && blockIdx.y == 0 && tid < 64 && n0 + tid < g.N) atomic_add_f(g.colsum + n0 + tid, csum);
+}
+
 template <typename T>
 static int launch_gemm_tn(const qavit_gemm_tn_args& g, hipStream_t st) {
   const int tn = (g.N + 63) / 64, tk = (g.K + 63) / 64;
@@ -431,7 +654,8 @@ static int launch_gemm_tn(const qavit_gemm_tn_args& g, hipStream_t st) {
   int rows = (g.M + splits - 1) / splits;
   rows = (rows + TN_MC - 1) / TN_MC * TN_MC;
   splits = (g.M + rows - 1) / rows;
-  hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(tn, tk, splits), dim3(GEMM_THREADS), 0, st, g, rows);
+  if (sizeof(T) == 2) hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tn, tk, splits), dim3(GEMM_THREADS), 0, st, g, rows);
+  else hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(tn, tk, splits), dim3(GEMM_THREADS), 0, st, g, rows);
   return check_launch("gemm_tn");
 }
 
