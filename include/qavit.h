@@ -46,7 +46,8 @@ const char* qavit_last_error(void);
  * (CCF-FFN fc1/fc2), and their autograd input-gradients (dX = dZ . W with B := W^T packed).
  *
  * a_mode 0: A as stored.
- * a_mode 1: A := LayerNorm_K(A) * ln_gamma + ln_beta (nn.LayerNorm fused as prologue; writes ln_mean/ln_rstd).
+ * a_mode 1: A := (A - ln_mean[m]) * ln_rstd[m] * ln_gamma + ln_beta (nn.LayerNorm fused as prologue: the row
+ *           statistics are INPUTS, produced by qavit_row_stats; the normalised rows are never written to HBM).
  * a_mode 2: A := A * droppath(a_dp) * dropout(a_drop) * gelu'(a_Z)   -- the backward of a layer's epilogue
  *           applied to its incoming gradient; the transformed tile is also written to a_out (dZ).
  * epilogue: v = acc + bias; Z := v (if Z); v = gelu(v) (act==1); v *= dropout; v *= scale; v *= droppath; v += R.
@@ -106,6 +107,8 @@ int qavit_gemm_tn(const qavit_gemm_tn_args* a, void* stream);
 int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                         float eps, int rows, int C, float* mean, float* rstd,
                         const float* add, int add_rows, void* stream);
+/* mean / rstd of each row only: the statistics half of a LayerNorm whose normalisation is fused into qavit_gemm_nt */
+int qavit_row_stats(int dtype, const void* x, float eps, int rows, int C, float* mean, float* rstd, void* stream);
 int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                         const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                         int rows, int C, float* dadd, int add_rows, void* stream);

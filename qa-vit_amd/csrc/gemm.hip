@@ -186,6 +186,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
       const int r = idx / kv, v = idx - r * kv;
       const int m = m0 + r, k = k0 + v * VN;
       vec_t o = pre[i];
+      if (AMODE == 1 && m < g.M && k < g.K) {
+        // LayerNorm prologue: statistics come from qavit_row_stats; normalise while the row goes to LDS
+        const float mu = g.ln_mean[m], rs = g.ln_rstd[m];
+#pragma unroll
+        for (int j = 0; j < VN; ++j)
+          if (k + j < g.K) o[j] = from_f<T>((to_f<T>(o[j]) - mu) * rs * g.ln_gamma[k + j] + g.ln_beta[k + j]);
+      }
       if (bwd && m < g.M && k < g.K) {
         float rowf = g.a_scale;
         if (g.a_dp_p > 0.f) rowf *= drop_factor(key_adp, (uint32_t)(m / g.a_dp_rows), g.a_dp_p, a_dp_inv);
@@ -224,27 +231,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
     const int k0 = chunk * KC;
     const int kc = (Kp - k0 < KC) ? (Kp - k0) : KC;
     const int m0 = tile * BM;
-    if (AMODE == 1) {                                  // fused LayerNorm (host guarantees a single chunk)
-      const float invK = 1.f / (float)g.K;
-      for (int r = wave; r < BM; r += 4) {
-        const int m = m0 + r;
-        if (m >= g.M) continue;                        // wave-uniform
-        T* row = As + (size_t)r * lda_s;
-        float s = 0.f;
-        for (int k = lane; k < g.K; k += 64) s += to_f<T>(row[k]);
-        const float mean = wave_sum(s) * invK;
-        float s2 = 0.f;
-        for (int k = lane; k < g.K; k += 64) { const float d = to_f<T>(row[k]) - mean; s2 += d * d; }
-        const float rstd = rsqrtf(wave_sum(s2) * invK + g.ln_eps);
-        for (int k = lane; k < g.K; k += 64)
-          row[k] = from_f<T>((to_f<T>(row[k]) - mean) * rstd * g.ln_gamma[k] + g.ln_beta[k]);
-        if (lane == 0 && first_slice) {
-          if (g.ln_mean) g.ln_mean[m] = mean;
-          if (g.ln_rstd) g.ln_rstd[m] = rstd;
-        }
-      }
-      __syncthreads();
-    }
     // next (tile, chunk) in the stream: its loads fly while this chunk's MFMAs run
     int ntile = tile, nchunk = chunk + 1;
     if (nchunk == n_chunks) { nchunk = 0; ntile = tile + gridDim.y; }
@@ -401,7 +387,7 @@ static int launch_gemm_nt3(const qavit_gemm_args& g, hipStream_t st) {
 // fp32 with a long K: the resident fp32 weight slice is large, so the row tile streams in 64-wide chunks
 template <typename T, int BNT, int AMODE, int EPI>
 static int launch_gemm_nt2(const qavit_gemm_args& g, hipStream_t st) {
-  if (sizeof(T) == 4 && AMODE != 1 && g.K > 256) return launch_gemm_nt3<T, BNT, AMODE, EPI, 64>(g, st);
+  if (sizeof(T) == 4 && g.K > 256) return launch_gemm_nt3<T, BNT, AMODE, EPI, 64>(g, st);
   return launch_gemm_nt3<T, BNT, AMODE, EPI, 256>(g, st);
 }
 
@@ -418,7 +404,6 @@ static int dispatch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
   constexpr int VN = Vec<T>::N;
   constexpr int FK = Mma<T>::FK;
   const int Kp = round_up(g.K, FK);
-  if (g.a_mode == 1 && Kp > 256) return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm prologue needs K <= 256");
   const size_t row_bytes = (size_t)(Kp + VN) * sizeof(T);
   // slice width: weights <= ~28 KB so that two workgroups share a CU (slice + row tile + epilogue scratch < 80 KB)
   static int forced = -1;
@@ -666,7 +651,8 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return set_error(QAVIT_EINVAL, "gemm_nt: null operand");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return set_error(QAVIT_EINVAL, "gemm_nt: non-positive dimension");
   if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N) return set_error(QAVIT_EINVAL, "gemm_nt: leading dimension too small");
-  if (a->a_mode == 1 && (!a->ln_gamma || !a->ln_beta)) return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm prologue needs gamma/beta");
+  if (a->a_mode == 1 && (!a->ln_gamma || !a->ln_beta || !a->ln_mean || !a->ln_rstd))
+    return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm prologue needs gamma/beta and the row statistics (qavit_row_stats)");
   if ((a->drop_p > 0.f || a->dp_p > 0.f || a->a_drop_p > 0.f || a->a_dp_p > 0.f) && !a->rng)
     return set_error(QAVIT_EINVAL, "gemm_nt: dropout requested without rng state");
   if ((a->dp_p > 0.f && a->dp_rows <= 0) || (a->a_dp_p > 0.f && a->a_dp_rows <= 0))

@@ -51,6 +51,34 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, T* y, co
   }
 }
 
+// mean / rstd only (the statistics half of a LayerNorm whose normalisation is fused into the consumer GEMM)
+template <typename T, int LN_MAX_PER_LANE>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* x, float eps, int rows, int C, float* mean_o, float* rstd_o) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const T* xr = x + (size_t)row * C;
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < C) ? to_f<T>(xr[c]) : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) * invC;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      const float dlt = (c < C) ? v[i] - mean : 0.f;
+      s2 += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * invC + eps);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  }
+}
+
 template <typename T, int LN_MAX_PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                             const float* rstd, T* dx, float* dgamma, float* dbeta,
@@ -141,6 +169,21 @@ extern "C" int qavit_layernorm_fwd(int dtype, const void* x, void* y, const floa
     LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows))
   } else return set_error(QAVIT_EINVAL, "layernorm_fwd: unknown dtype");
   return check_launch("layernorm_fwd");
+}
+
+extern "C" int qavit_row_stats(int dtype, const void* x, float eps, int rows, int C, float* mean, float* rstd, void* stream) {
+  if (!x || !mean || !rstd || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "row_stats: bad arguments");
+  if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "row_stats: C > 1024 unsupported");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = (rows + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  const int pl = ln_pl(C);
+  if (dtype == QAVIT_F32) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((row_stats_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)x, eps, rows, C, mean, rstd))
+  } else if (dtype == QAVIT_BF16) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((row_stats_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)x, eps, rows, C, mean, rstd))
+  } else return set_error(QAVIT_EINVAL, "row_stats: unknown dtype");
+  return check_launch("row_stats");
 }
 
 extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,

@@ -175,6 +175,7 @@ class LinearFn(Function):
         if ln_g is not None:
             ln = (ln_g, ln_b, opts.get("eps", 1e-5))
             stats = (torch.empty(M, dtype=torch.float32, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device))
+            K.row_stats(x2, ln[2], M, Kd, stats[0], stats[1])
         r2 = None
         if resid is not None:
             r2 = resid.reshape(-1, n)

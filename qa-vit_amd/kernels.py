@@ -147,6 +147,10 @@ def layernorm_fwd(x, y, gamma, beta, eps, rows, Cc, mean, rstd, add=None, add_ro
                                          eps, rows, Cc, _p(mean), _p(rstd), _p(add), add_rows, stream()), "layernorm_fwd")
 
 
+def row_stats(x, eps, rows, Cc, mean, rstd):
+    L.check(L.load().qavit_row_stats(dt_code(x.dtype), x.data_ptr(), eps, rows, Cc, mean.data_ptr(), rstd.data_ptr(), stream()), "row_stats")
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0):
     L.check(L.load().qavit_layernorm_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, Cc, _p(dadd), add_rows,
