@@ -6,6 +6,8 @@
 #include "mma_lds.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
+#include "attn_shared.h"
+#include <stdlib.h>
 
 namespace qv {
 
@@ -368,8 +370,6 @@ static int attn_validate(const qavit_attn_args* a, bool bwd) {
   if (bwd) {
     if (!a->d_o || !a->dq || (a->L > 0 && (!a->dk_tok || !a->dv_tok)) || !a->ws) return set_error(QAVIT_EINVAL, "attn_bwd: null operand");
   }
-  const AttnLds L = attn_lds(*a, bwd);
-  if ((size_t)L.total * 4 > 160 * 1024) return set_error(QAVIT_EINVAL, "attn: problem does not fit one wave's LDS slice");
   return QAVIT_OK;
 }
 
@@ -382,11 +382,32 @@ extern "C" int64_t qavit_attn_ws_floats(const qavit_attn_args* a) {
   return (int64_t)attn_grid(*a, true) * attn_ws_per_wave(*a);
 }
 
+static void launch_reduce(const qavit_attn_args& a, int grid, hipStream_t st) {
+  const int nE = (a.mode == 0) ? a.L * a.KC : 0;
+  const int total = 2 * nE + 2 * a.S * a.D * a.H;
+  if (total > 0) {
+    const int slices = (grid + RED_WAVES * a.H - 1) / (RED_WAVES * a.H);
+    hipLaunchKernelGGL(attn_reduce_kernel, dim3((total + 255) / 256, slices), dim3(256), 0, st, a, grid);
+  }
+}
+
 template <typename T, bool BF>
 static int attn_launch(const qavit_attn_args& a, bool bwd, hipStream_t st) {
-  const AttnLds L = attn_lds(a, bwd);
-  const size_t smem = (size_t)L.total * sizeof(float);
   const int grid = attn_grid(a, bwd);
+  if (bwd && a.ws_floats < (int64_t)grid * attn_ws_per_wave(a)) return set_error(QAVIT_EINVAL, "attn_bwd: workspace too small");
+  if (BF) {
+    static int use_fast = -1;
+    if (use_fast < 0) { const char* e = getenv("QAVIT_ATTN_GENERIC"); use_fast = (e && atoi(e)) ? 0 : 1; }
+    const int took = use_fast ? attn_bf16_try(a, bwd, grid, st) : 0;
+    if (took < 0) return took;
+    if (took == 1) {
+      if (bwd) launch_reduce(a, grid, st);
+      return check_launch(bwd ? "attn_bwd(bf16)" : "attn_fwd(bf16)");
+    }
+  }
+  const AttnLds L = attn_lds(a, bwd);
+  if ((size_t)L.total * 4 > 160 * 1024) return set_error(QAVIT_EINVAL, "attn: problem does not fit one wave's LDS slice");
+  const size_t smem = (size_t)L.total * sizeof(float);
   if (!bwd) {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
@@ -395,14 +416,8 @@ static int attn_launch(const qavit_attn_args& a, bool bwd, hipStream_t st) {
   }
   static bool done = false;
   if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-  if (a.ws_floats < (int64_t)grid * attn_ws_per_wave(a)) return set_error(QAVIT_EINVAL, "attn_bwd: workspace too small");
   hipLaunchKernelGGL((attn_bwd_kernel<T, BF>), dim3(grid), dim3(64), smem, st, a);
-  const int nE = (a.mode == 0) ? a.L * a.KC : 0;
-  const int total = 2 * nE + 2 * a.S * a.D * a.H;
-  if (total > 0) {
-    const int slices = (grid + RED_WAVES * a.H - 1) / (RED_WAVES * a.H);
-    hipLaunchKernelGGL(attn_reduce_kernel, dim3((total + 255) / 256, slices), dim3(256), 0, st, a, grid);
-  }
+  launch_reduce(a, grid, st);
   return check_launch("attn_bwd");
 }
 

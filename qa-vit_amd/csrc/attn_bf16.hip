@@ -1,0 +1,396 @@
+// bf16 attention core (forward + backward) for the four QA-ViT branches -- the fast path behind qavit_attn_fwd /
+// qavit_attn_bwd when dtype == QAVIT_BF16 (the fp32 parity path stays in attn.hip).
+//
+// One wavefront per (group, head) problem.  Every operand lives in the wave's LDS slice as a row-major bf16 tile
+// and feeds v_mfma_f32_16x16x16_bf16 (k = 16: D = 48, 48 keys, 16 window tokens, 32 Linformer rows are all
+// multiples of 16, so no k padding).  A fragment whose reduction axis runs along the tile's COLUMNS is one
+// ds_read_b64 per lane; one whose reduction axis runs along the ROWS is one ds_read_b64_tr_b16 (hardware
+// transpose) -- so Q.Kf^T, P.Vf, P^T.dO, dS^T.Q, E^T.k_tok ... all read the same images with no transposed
+// copies.  Softmax runs on the accumulator registers (16-lane row reductions); only P / dS go back to LDS (bf16)
+// as the next product's operand.  dKf/dVf accumulate in registers across the query tiles of a problem; dE and
+// the shared-row (bank) gradients accumulate in fp32 LDS across the problems a wave visits and leave as one
+// partial per wave (folded by attn_reduce_kernel in attn.hip).
+#include "common.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+#include "attn_shared.h"
+
+namespace qv {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+__device__ __forceinline__ s16x4 as_s16(bf16x4 v) { return __builtin_bit_cast(s16x4, v); }
+
+// operand fragment, reduction axis along the tile's columns: element (idx = lane&15, k = k0 + 4*(lane>>4) + j)
+__device__ __forceinline__ s16x4 rowfrag(const bf16* tile, int ld, int r0, int k0) {
+  const int lane = threadIdx.x & 63;
+  return as_s16(*reinterpret_cast<const bf16x4*>(tile + (r0 + (lane & 15)) * ld + k0 + 4 * (lane >> 4)));
+}
+// operand fragment, reduction axis along the tile's rows: element (k = k0 + 4*(lane>>4) + j, idx = c0 + (lane&15))
+__device__ __forceinline__ s16x4 trfrag(const bf16* tile, int ld, int k0, int c0) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  return as_s16(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tile + (k0 + 4 * g + q) * ld + c0 + 4 * p)));
+}
+__device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+// accumulator tile (row = 4*(lane>>4)+r, col = lane&15) -> bf16 LDS tile
+__device__ __forceinline__ void acc_to_lds(bf16* tile, int ld, int r0, int c0, const f32x4& acc, float scale = 1.f) {
+  const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[(r0 + 4 * q + r) * ld + c0 + col] = (bf16)(acc[r] * scale);
+}
+
+template <int W> __device__ __forceinline__ float grp_max(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+template <int W> __device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct A2Lds {   // offsets in bf16 elements unless noted
+  int ldd, ldk, lde;
+  int q, d_o, p, ds, kt, vt, ek, ev, kf, vf, dkf, dvf;
+  int accf;                 // float offset (from the float view of the base) of the fp32 accumulators
+  int bytes;
+};
+
+// nk16 / d16: the kernel instantiation's padded key count and head dim (NKT*16, DT*16), not the problem's own
+__host__ __device__ inline A2Lds a2_lds(const qavit_attn_args& a, bool bwd, int NK16, int D16) {
+  A2Lds L;
+  const int L16 = (a.L + 15) / 16 * 16;
+  L.ldd = D16 + 4; L.ldk = NK16 + 4; L.lde = a.KC + 4;
+  int o = 0;
+  L.q = o; o += 16 * L.ldd;
+  L.p = o; o += 16 * L.ldk;
+  L.kf = o; o += NK16 * L.ldd;
+  L.vf = o; o += NK16 * L.ldd;
+  L.kt = L.vt = L.ek = L.ev = 0;
+  if (a.mode == 0) {
+    L.kt = o; o += L16 * L.ldd;
+    L.vt = o; o += L16 * L.ldd;
+    L.ek = o; o += L16 * L.lde;
+    L.ev = o; o += L16 * L.lde;
+  }
+  L.d_o = L.ds = L.dkf = L.dvf = 0;
+  if (bwd) {
+    L.d_o = o; o += 16 * L.ldd;
+    L.ds = o; o += 16 * L.ldk;
+    L.dkf = o; o += NK16 * L.ldd;
+    L.dvf = o; o += NK16 * L.ldd;
+  }
+  o = (o + 7) / 8 * 8;                         // 16-byte boundary
+  L.accf = o / 2;
+  int fl = 0;
+  if (bwd) fl = (a.mode == 0 ? 2 * a.L * a.KC : 0) + 2 * a.S * a.D;
+  L.bytes = o * 2 + fl * 4;
+  return L;
+}
+
+template <int MODE, int NKT, int DT, bool BWD>
+__global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  bf16* sm = reinterpret_cast<bf16*>(smraw);
+  float* smf = reinterpret_cast<float*>(smraw);
+  const A2Lds L = a2_lds(a, BWD, NKT * 16, DT * 16);
+  const int lane = threadIdx.x, col = lane & 15, q4 = lane >> 4;
+  const int D = a.D;
+  const int NKo = (MODE == 0) ? a.KC : a.L;
+  const int NK = NKo + a.S, NK16 = NKT * 16;
+  const int L16 = (a.L + 15) / 16 * 16;
+  const float scale = rsqrtf((float)D);
+  const bf16* qg = reinterpret_cast<const bf16*>(a.q);
+  const bf16* ktg = reinterpret_cast<const bf16*>(a.k_tok);
+  const bf16* vtg = reinterpret_cast<const bf16*>(a.v_tok);
+  bf16* og = reinterpret_cast<bf16*>(a.o);
+  const bf16* dog = reinterpret_cast<const bf16*>(a.d_o);
+  bf16* dqg = reinterpret_cast<bf16*>(a.dq);
+  bf16* dktg = reinterpret_cast<bf16*>(a.dk_tok);
+  bf16* dvtg = reinterpret_cast<bf16*>(a.dv_tok);
+  bool bad = false;
+
+  const int nE = (MODE == 0) ? a.L * a.KC : 0;
+  const int nS = a.S * D;
+  float* accEk = smf + L.accf;
+  float* accEv = accEk + nE;
+  float* accSk = accEv + nE;
+  float* accSv = accSk + nS;
+  if (BWD) for (int i = lane; i < 2 * nE + 2 * nS; i += 64) accEk[i] = 0.f;
+
+  // zero the padded tiles once: rows / columns beyond the valid extents must read as 0 in every product
+  {
+    const int total = (BWD ? L.dvf + NK16 * L.ldd : (MODE == 0 ? L.ev + L16 * L.lde : L.vf + NK16 * L.ldd));
+    for (int i = lane; i < total; i += 64) sm[i] = (bf16)0.f;
+  }
+
+  for (int pid = blockIdx.x; pid < a.G * a.H; pid += gridDim.x) {
+    const int g = pid / a.H, h = pid - g * a.H;
+    __syncthreads();
+    // ---------------- key side ----------------
+    for (int i = lane; i < a.S * D; i += 64) {
+      const int s = i / D, dd = i - s * D;
+      const float k = a.sh_k[(size_t)s * a.H * D + h * D + dd];
+      const float v = a.sh_v[(size_t)s * a.H * D + h * D + dd];
+      bad |= (k != k) | (v != v);
+      sm[L.kf + (NKo + s) * L.ldd + dd] = (bf16)k;
+      sm[L.vf + (NKo + s) * L.ldd + dd] = (bf16)v;
+    }
+    {
+      const int kdst = (MODE == 0) ? L.kt : L.kf, vdst = (MODE == 0) ? L.vt : L.vf;
+      for (int i = lane; i < a.L * D; i += 64) {
+        const int l = i / D, dd = i - l * D;
+        const int64_t kr = attn_krow(a, g, l);
+        const bf16 k = ktg[kr * a.ldk + h * D + dd];
+        const bf16 v = vtg[kr * a.ldv + h * D + dd];
+        bad |= ((float)k != (float)k) | ((float)v != (float)v);
+        sm[kdst + l * L.ldd + dd] = k;
+        sm[vdst + l * L.ldd + dd] = v;
+      }
+    }
+    if (MODE == 0) {
+      for (int i = lane; i < a.L * a.KC; i += 64) {
+        const int l = i / a.KC, j = i - l * a.KC;
+        sm[L.ek + l * L.lde + j] = (bf16)a.E_k[i];
+        sm[L.ev + l * L.lde + j] = (bf16)a.E_v[i];
+      }
+      __syncthreads();
+      // Kf[j][d] = sum_l E_k[l][j] kt[l][d]   (both operands reduce along their rows -> transposed reads)
+      for (int jt = 0; jt * 16 < a.KC; ++jt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+          for (int l0 = 0; l0 < L16; l0 += 16) {
+            ak = mma16(trfrag(sm + L.ek, L.lde, l0, jt * 16), trfrag(sm + L.kt, L.ldd, l0, dt * 16), ak);
+            av = mma16(trfrag(sm + L.ev, L.lde, l0, jt * 16), trfrag(sm + L.vt, L.ldd, l0, dt * 16), av);
+          }
+          acc_to_lds(sm + L.kf, L.ldd, jt * 16, dt * 16, ak);
+          acc_to_lds(sm + L.vf, L.ldd, jt * 16, dt * 16, av);
+        }
+    }
+    __syncthreads();
+
+    f32x4 gK[NKT][DT], gV[NKT][DT];
+    if (BWD) {
+#pragma unroll
+      for (int i = 0; i < NKT; ++i)
+#pragma unroll
+        for (int j = 0; j < DT; ++j) { gK[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; gV[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+
+    for (int q0 = 0; q0 < a.Nq; q0 += 16) {
+      const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
+      __syncthreads();
+      for (int i = lane; i < 16 * D; i += 64) {
+        const int r = i / D, dd = i - r * D;
+        bf16 v = (bf16)0.f, gvv = (bf16)0.f;
+        if (r < rows) {
+          const int64_t qr = attn_qrow(a, g, q0 + r);
+          v = qg[qr * a.ldq + h * D + dd];
+          if (BWD) gvv = dog[qr * a.lddo + h * D + dd];
+        }
+        bad |= ((float)v != (float)v);
+        sm[L.q + r * L.ldd + dd] = v;
+        if (BWD) sm[L.d_o + r * L.ldd + dd] = gvv;
+      }
+      __syncthreads();
+      // ---------------- scores + softmax on registers ----------------
+      f32x4 s[NKT];
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          acc = mma16(rowfrag(sm + L.q, L.ldd, 0, dt * 16), rowfrag(sm + L.kf, L.ldd, nt * 16, dt * 16), acc);
+        s[nt] = acc;
+      }
+      float inv_sum[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) {
+          const bool ok = nt * 16 + col < NK;
+          s[nt][r] = ok ? s[nt][r] * scale : -INFINITY;
+          mx = fmaxf(mx, s[nt][r]);
+        }
+        mx = grp_max<16>(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) { const float e = __expf(s[nt][r] - mx); s[nt][r] = e; sum += e; }
+        sum = grp_sum<16>(sum);
+        inv_sum[r] = 1.f / sum;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[nt][r] *= inv_sum[r];
+        acc_to_lds(sm + L.p, L.ldk, 0, nt * 16, s[nt]);
+      }
+      __syncthreads();
+      if (!BWD) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int nt = 0; nt < NKT; ++nt)
+            acc = mma16(rowfrag(sm + L.p, L.ldk, 0, nt * 16), trfrag(sm + L.vf, L.ldd, nt * 16, dt * 16), acc);
+          bad |= (acc[0] != acc[0]) | (acc[1] != acc[1]) | (acc[2] != acc[2]) | (acc[3] != acc[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * q4 + r;
+            if (row < rows && dt * 16 + col < D)
+              og[attn_qrow(a, g, q0 + row) * a.ldo + h * D + dt * 16 + col] = (bf16)acc[r];
+          }
+        }
+      } else {
+        // dP = dO . Vf^T ; dS = P * (dP - rowdot) * scale
+        f32x4 dp[NKT];
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            acc = mma16(rowfrag(sm + L.d_o, L.ldd, 0, dt * 16), rowfrag(sm + L.vf, L.ldd, nt * 16, dt * 16), acc);
+          dp[nt] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float dot = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NKT; ++nt) dot += s[nt][r] * dp[nt][r];
+          dot = grp_sum<16>(dot);
+#pragma unroll
+          for (int nt = 0; nt < NKT; ++nt) dp[nt][r] = s[nt][r] * (dp[nt][r] - dot) * scale;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) acc_to_lds(sm + L.ds, L.ldk, 0, nt * 16, dp[nt]);
+        __syncthreads();
+        // dQ = dS . Kf ; dKf += dS^T . Q ; dVf += P^T . dO
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int nt = 0; nt < NKT; ++nt)
+            acc = mma16(rowfrag(sm + L.ds, L.ldk, 0, nt * 16), trfrag(sm + L.kf, L.ldd, nt * 16, dt * 16), acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * q4 + r;
+            if (row < rows && dt * 16 + col < D)
+              dqg[attn_qrow(a, g, q0 + row) * a.lddq + h * D + dt * 16 + col] = (bf16)acc[r];
+          }
+          const s16x4 bq = trfrag(sm + L.q, L.ldd, 0, dt * 16);
+          const s16x4 bo = trfrag(sm + L.d_o, L.ldd, 0, dt * 16);
+#pragma unroll
+          for (int nt = 0; nt < NKT; ++nt) {
+            gK[nt][dt] = mma16(trfrag(sm + L.ds, L.ldk, 0, nt * 16), bq, gK[nt][dt]);
+            gV[nt][dt] = mma16(trfrag(sm + L.p, L.ldk, 0, nt * 16), bo, gV[nt][dt]);
+          }
+        }
+      }
+    }
+
+    if (BWD) {
+      __syncthreads();
+      // key-side gradients: to LDS (bf16, operands of the Linformer products) and into the shared-row accumulators
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          acc_to_lds(sm + L.dkf, L.ldd, nt * 16, dt * 16, gK[nt][dt]);
+          acc_to_lds(sm + L.dvf, L.ldd, nt * 16, dt * 16, gV[nt][dt]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = nt * 16 + 4 * q4 + r, cc = dt * 16 + col;
+            if (row >= NKo && row < NK && cc < D) {
+              accSk[(row - NKo) * D + cc] += gK[nt][dt][r];
+              accSv[(row - NKo) * D + cc] += gV[nt][dt][r];
+            }
+            if (MODE == 1 && row < NKo && cc < D) {
+              const int64_t kr = attn_krow(a, g, row);
+              dktg[kr * a.lddk + h * D + cc] = (bf16)gK[nt][dt][r];
+              dvtg[kr * a.lddv + h * D + cc] = (bf16)gV[nt][dt][r];
+            }
+          }
+        }
+      if (MODE == 0) {
+        __syncthreads();
+        for (int lt = 0; lt * 16 < L16; ++lt) {
+          // dk_tok[l][d] = sum_j E_k[l][j] dKf[j][d]
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+            for (int j0 = 0; j0 < a.KC; j0 += 16) {
+              ak = mma16(rowfrag(sm + L.ek, L.lde, lt * 16, j0), trfrag(sm + L.dkf, L.ldd, j0, dt * 16), ak);
+              av = mma16(rowfrag(sm + L.ev, L.lde, lt * 16, j0), trfrag(sm + L.dvf, L.ldd, j0, dt * 16), av);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int l = lt * 16 + 4 * q4 + r, cc = dt * 16 + col;
+              if (l < a.L && cc < D) {
+                const int64_t kr = attn_krow(a, g, l);
+                dktg[kr * a.lddk + h * D + cc] = (bf16)ak[r];
+                dvtg[kr * a.lddv + h * D + cc] = (bf16)av[r];
+              }
+            }
+          }
+          // dE_k[l][j] += sum_d kt[l][d] dKf[j][d]
+          for (int jt = 0; jt * 16 < a.KC; ++jt) {
+            f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              ak = mma16(rowfrag(sm + L.kt, L.ldd, lt * 16, dt * 16), rowfrag(sm + L.dkf, L.ldd, jt * 16, dt * 16), ak);
+              av = mma16(rowfrag(sm + L.vt, L.ldd, lt * 16, dt * 16), rowfrag(sm + L.dvf, L.ldd, jt * 16, dt * 16), av);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int l = lt * 16 + 4 * q4 + r, j = jt * 16 + col;
+              if (l < a.L && j < a.KC) { accEk[l * a.KC + j] += ak[r]; accEv[l * a.KC + j] += av[r]; }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (BWD) {
+    __syncthreads();
+    float* ws = a.ws + (size_t)blockIdx.x * (2 * nE + 2 * nS);
+    for (int i = lane; i < 2 * nE + 2 * nS; i += 64) ws[i] = accEk[i];
+  } else {
+    if (a.nan_flag && __any(bad) && lane == 0) atomicOr(a.nan_flag, 1);
+  }
+}
+
+template <int MODE, int NKT, int DT>
+static int a2_launch(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) {
+  const A2Lds L = a2_lds(a, bwd, NKT * 16, DT * 16);
+  if (L.bytes > 160 * 1024) return set_error(QAVIT_EINVAL, "attn(bf16): problem does not fit one wave's LDS slice");
+  if (bwd) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<MODE, NKT, DT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((attn2_kernel<MODE, NKT, DT, true>), dim3(grid), dim3(64), L.bytes, st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel<MODE, NKT, DT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((attn2_kernel<MODE, NKT, DT, false>), dim3(grid), dim3(64), L.bytes, st, a);
+  }
+  return QAVIT_OK;
+}
+
+// returns 1 if this fast path took the launch, 0 if the shape is not covered (caller falls back), <0 on error
+int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) {
+  const int NKo = (a.mode == 0) ? a.KC : a.L;
+  const int nkt = (NKo + a.S + 15) / 16, dt = (a.D + 15) / 16;
+  if (a.mode == 0 && (a.KC % 16 != 0)) return 0;
+  int rc = -100;
+  if (a.mode == 0 && nkt <= 3 && dt == 3) rc = a2_launch<0, 3, 3>(a, bwd, grid, st);
+  else if (a.mode == 1 && nkt == 1 && dt == 3) rc = a2_launch<1, 1, 3>(a, bwd, grid, st);
+  else if (a.mode == 1 && nkt <= 2 && dt == 1) rc = a2_launch<1, 2, 1>(a, bwd, grid, st);
+  else if (a.mode == 1 && nkt <= 5 && dt == 1) rc = a2_launch<1, 5, 1>(a, bwd, grid, st);
+  if (rc == -100) return 0;
+  return rc == QAVIT_OK ? 1 : rc;
+}
+
+}  // namespace qv
