@@ -84,6 +84,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
   T* Bs = reinterpret_cast<T*>(smem);
   T* As = reinterpret_cast<T*>(smem + (size_t)BNT * ldb_s * sizeof(T));
   float* Cs = reinterpret_cast<float*>(smem + (size_t)BNT * ldb_s * sizeof(T) + (size_t)BM * lda_s * sizeof(T));
+  float* Gs = Cs + BM * (BNT + 4);                   // [2][Kp] LayerNorm gamma / beta (AMODE 1 only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -136,6 +137,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
     }
   }
 
+  if (AMODE == 1) {
+    for (int k = tid; k < Kp; k += GEMM_THREADS) {
+      Gs[k] = (k < g.K) ? g.ln_gamma[k] : 0.f;
+      Gs[Kp + k] = (k < g.K) ? g.ln_beta[k] : 0.f;
+    }
+    __syncthreads();
+  }
   const int n_chunks = (Kp + KC - 1) / KC;
   vec_t pre[PRE], prez[PRE];
 
@@ -190,8 +198,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
         // LayerNorm prologue: statistics come from qavit_row_stats; normalise while the row goes to LDS
         const float mu = g.ln_mean[m], rs = g.ln_rstd[m];
 #pragma unroll
-        for (int j = 0; j < VN; ++j)
-          if (k + j < g.K) o[j] = from_f<T>((to_f<T>(o[j]) - mu) * rs * g.ln_gamma[k + j] + g.ln_beta[k + j]);
+        for (int j = 0; j < VN; j += 4) {
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(Gs + k + j);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(Gs + Kp + k + j);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) o[j + jj] = from_f<T>((to_f<T>(o[j + jj]) - mu) * rs * ga[jj] + be[jj]);
+        }
       }
       if (bwd && m < g.M && k < g.K) {
         float rowf = g.a_scale;
@@ -367,7 +379,7 @@ static int launch_gemm_nt3(const qavit_gemm_args& g, hipStream_t st) {
   const int Kp = round_up(g.K, FK);
   const size_t b_bytes = (size_t)BNT * (Kp + VN) * sizeof(T);
   const size_t a_bytes = (size_t)BM * ((Kp < KC ? Kp : KC) + VN) * sizeof(T);
-  const size_t c_bytes = (size_t)BM * (BNT + 4) * sizeof(float);
+  const size_t c_bytes = (size_t)BM * (BNT + 4) * sizeof(float) + (AMODE == 1 ? (size_t)2 * Kp * sizeof(float) : 0);
   const size_t smem = b_bytes + a_bytes + c_bytes;
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "gemm_nt: K too large for the resident weight slice");
   static bool attr_done = false;   // per instantiation
@@ -630,10 +642,10 @@ static int launch_gemm_tn(const qavit_gemm_tn_args& g, hipStream_t st) {
   const int tn = (g.N + 63) / 64, tk = (g.K + 63) / 64;
   int splits = g.splits;
   if (splits <= 0) {
-    splits = 768 / (tn * tk);
+    splits = 1024 / (tn * tk);                        // short per-workgroup chains: the kernel is latency-, not atomic-bound
     if (splits < 1) splits = 1;
   }
-  int max_splits = (g.M + 255) / 256;                 // at least 256 rows per split
+  int max_splits = (g.M + 127) / 128;                 // at least 128 rows (two staged chunks) per split
   if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
   int rows = (g.M + splits - 1) / splits;

@@ -141,6 +141,79 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
 
 using namespace qv;
 
+// ---- vector variant (C % 4 == 0, 16-byte aligned rows for bf16 x4 = 8 B / fp32 x4 = 16 B): lane owns channels
+// 4*lane .. 4*lane+3 (+256 per extra pass) -> 8/16-byte loads instead of 2/4-byte ones
+template <typename T> struct V4;
+template <> struct V4<float> { typedef f32x4 type; };
+template <> struct V4<bf16> { typedef bf16x4 type; };
+
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                               const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C) {
+  typedef typename V4<T>::type v4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  float pg[NP][4], pb[NP][4], gm[NP][4];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = 4 * lane + 256 * i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; gm[i][j] = (c + j < C) ? gamma[c + j] : 0.f; }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NP][4], g[NP][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = 4 * lane + 256 * i;
+      if (c < C) {
+        const v4 xv = *reinterpret_cast<const v4*>(x + (size_t)row * C + c);
+        const v4 dv = *reinterpret_cast<const v4*>(dy + (size_t)row * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = to_f<T>(dv[j]);
+          xh[i][j] = (to_f<T>(xv[j]) - mu) * rs;
+          g[i][j] = d * gm[i][j];
+          pg[i][j] += d * xh[i][j];
+          pb[i][j] += d;
+          c1 += g[i][j] * xh[i][j];
+          c2 += g[i][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+      }
+    }
+    c1 = wave_sum(c1) * invC;
+    c2 = wave_sum(c2) * invC;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = 4 * lane + 256 * i;
+      if (c < C) {
+        v4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = from_f<T>(rs * (g[i][j] - c2 - xh[i][j] * c1));
+        *reinterpret_cast<v4*>(dx + (size_t)row * C + c) = o;
+      }
+    }
+  }
+  __shared__ float red[2][4][256];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][wave][4 * lane + j] = pg[i][j]; red[1][wave][4 * lane + j] = pb[i][j]; }
+    __syncthreads();
+    const int c = threadIdx.x + 256 * i;
+    if (c < C) {
+      const int t = threadIdx.x;
+      if (dgamma) atomic_add_f(dgamma + c, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+      if (dbeta) atomic_add_f(dbeta + c, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+    }
+  }
+}
+
 static int ln_pl(int C) { const int p = (C + 63) / 64; return p <= 1 ? 1 : p <= 2 ? 2 : p <= 3 ? 3 : p <= 4 ? 4 : p <= 8 ? 8 : 16; }
 
 #define LN_DISPATCH(PL, CALL)            \
@@ -195,6 +268,18 @@ extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, con
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = (rows + 3) / 4;
   if (grid > 512) grid = 512;     // every workgroup ends with 2*C same-address atomics: keep the flush small
+  const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
+  const bool v4ok = !dadd && (C % 4 == 0) && C <= 1024 &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) % (4 * esz) == 0);
+  if (v4ok) {
+    const int np = (C + 255) / 256;
+#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_>), dim3(grid), dim3(256), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C)
+    if (dtype == QAVIT_F32) { if (np == 1) LNV(float, 1); else if (np == 2) LNV(float, 2); else LNV(float, 4); }
+    else if (dtype == QAVIT_BF16) { if (np == 1) LNV(bf16, 1); else if (np == 2) LNV(bf16, 2); else LNV(bf16, 4); }
+    else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
+#undef LNV
+    return check_launch("layernorm_bwd");
+  }
   const int pl = ln_pl(C);
   if (dtype == QAVIT_F32) {
     LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, C, dadd, add_rows))

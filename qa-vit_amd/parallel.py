@@ -96,7 +96,7 @@ class GradReducer:
                 s = e
         merged = []
         for s, e in bounds:                            # merge slivers into their predecessor
-            if merged and (e - s) < per // 8:
+            if merged and (e - s) < per // 16:
                 merged[-1] = (merged[-1][0], e)
             else:
                 merged.append((s, e))

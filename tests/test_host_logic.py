@@ -1,0 +1,136 @@
+"""CPU-side logic of the product: module tree / state_dict contract, filler, schedules, parameter bookkeeping."""
+import math
+
+import numpy as np
+import torch
+
+from conftest import MODELS
+
+
+def test_state_dict_layout_matches_reference(golden, Q):
+    for tag, (build, *_rest) in MODELS.items():
+        m = build(Q)
+        keys = sorted(m.state_dict().keys())
+        assert keys == golden[f"{tag}/state_keys"].tolist(), tag
+        assert sum(p.numel() for p in m.parameters()) == int(golden[f"{tag}/n_params"]), tag
+    m = MODELS["c100"][0](Q)
+    assert len(m.state_dict()) == 1116                      # SURVEY.md section 8b [probe]
+    assert len(list(m.parameters())) == 815
+    # the bank is ONE module aliased under every branch (strict load_state_dict needs the aliased keys)
+    assert m.stage1_blocks[0].quad_block.swa.global_bank is m.global_bank
+    assert m.stage4_blocks[1].quad_block.cross_attn.global_bank.global_k is m.global_bank.global_k
+
+
+def test_param_group_sizes_known_answers(golden, Q):
+    """Name-pattern grouping of HQAViT_C100_Finetune.py:201-221 reproduces the group sizes printed in the reference's
+    own fine-tune log ("log hqavit. finetunetxt.txt":19-27), including the 'stage1' substring quirk."""
+    m = MODELS["c100"][0](Q)
+    groups = {k: 0 for k in ("head", "stage4", "stage3", "stage2", "stage1", "fusion", "cnn_stem", "embeddings", "remaining")}
+    for n, p in m.named_parameters():
+        if "head" in n:
+            groups["head"] += p.numel()
+        elif "stage4" in n:
+            groups["stage4"] += p.numel()
+        elif "stage3" in n:
+            groups["stage3"] += p.numel()
+        elif "stage2" in n:
+            groups["stage2"] += p.numel()
+        elif "stage1" in n:
+            groups["stage1"] += p.numel()
+        elif "fuse" in n or "rrcv" in n or "lmfa" in n:
+            groups["fusion"] += p.numel()
+        elif "cnn_stem" in n:
+            groups["cnn_stem"] += p.numel()
+        elif "patch_embed" in n or "pos_embed" in n or "global_bank" in n:
+            groups["embeddings"] += p.numel()
+        else:
+            groups["remaining"] += p.numel()
+    assert list(groups.values()) == golden["c100/known_group_sizes"].tolist()
+    assert sum(groups.values()) == 6472037
+
+
+def test_filler_is_deterministic_and_key_seeded(Q):
+    a, b = MODELS["c100"][0](Q), MODELS["c100"][0](Q)
+    Q.fill_module(a)
+    Q.fill_module(b)
+    for (n, p), (_, q) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(p, q), n
+    assert not torch.equal(a.head.weight, a.stage1_blocks[0].quad_block.swa.proj.weight[:100])
+    assert int(a.global_bank.update_count) == 0
+    assert float(a.cnn_stem.stem[1].running_var.min()) >= 0.5
+
+
+def test_never_trained_matches_reference_nograd_set(golden, Q):
+    harness = __import__("importlib").import_module("qa-vit_amd.harness")
+    for tag in ("c100", "tin", "v2_32"):
+        m = MODELS[tag][0](Q)
+        mine = sorted(n for n, _ in m.named_parameters() if harness.never_trained(n))
+        assert mine == sorted(golden[f"{tag}/nograd_names"].tolist()), tag
+    assert len([n for n, _ in MODELS["c100"][0](Q).named_parameters() if harness.never_trained(n)]) == 54
+
+
+def test_onecycle_closed_form_matches_torch(golden, Q):
+    harness = __import__("importlib").import_module("qa-vit_amd.harness")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=6e-4)
+    total, warm = 100, 10
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=6e-4, total_steps=total, pct_start=warm / total,
+                                                anneal_strategy="cos", div_factor=25.0, final_div_factor=1e4)
+    for i in range(total):
+        assert math.isclose(harness.onecycle_lr(i, total, 6e-4, warm / total), opt.param_groups[0]["lr"], rel_tol=1e-9, abs_tol=1e-15), i
+        opt.step()
+        if i < total - 1:
+            sched.step()
+    assert np.allclose([harness.onecycle_lr(i, 100, 6e-4, 0.1) for i in range(3)], golden["harness/lr"], rtol=1e-9)
+
+
+def test_config_defaults_match_reference_dataclasses(Q):
+    c = Q.HQAViTConfig()
+    assert (c.img_size, c.patch_size, c.embed_dim, c.depth, c.num_heads, c.num_learned_tokens, c.linformer_k) == (32, 4, 192, 8, 4, 16, 32)
+    assert (c.dropout, c.drop_path, c.window_size, c.dilation_factors, c.num_channel_groups) == (0.1, 0.1, 4, (1, 2), 6)
+    t = Q.HQAViTTinyINConfig()
+    assert (t.img_size, t.num_classes, t.depth, t.drop_path, t.num_learned_tokens) == (64, 200, 12, 0.2, 64)
+    q = Q.QAViTConfig()
+    assert (q.img_size, q.patch_size, q.window_size, q.dilation_factors, q.linformer_k) == (224, 16, 7, (1, 2, 3), 64)
+
+
+def test_model_refuses_cpu_tensors(Q):
+    m = MODELS["c100"][0](Q)
+    try:
+        m(torch.randn(1, 3, 32, 32))
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("a CPU forward must fail loudly")
+
+
+def test_bucket_plan_covers_flat_buffer_in_backward_order(Q):
+    par = __import__("importlib").import_module("qa-vit_amd.parallel")
+    m = MODELS["c100"][0](Q)
+    named = par.bucket_order(list(m.named_parameters()))
+    names = [n for n, _ in named]
+    # head first, stage4 before stage1, bank / stem / embeddings last
+    assert names[0].startswith(("head.", "norm."))
+    assert names.index("stage4_blocks.0.quad_block.norm1.weight") < names.index("stage1_blocks.0.quad_block.norm1.weight")
+    assert names.index("stage1_blocks.1.token_upmix.norm.bias") < names.index("global_bank.global_k")
+    offs = [0]
+    for _, p in named:
+        offs.append(offs[-1] + p.numel())
+
+    class FakeGroup:
+        pass
+    red = par.GradReducer.__new__(par.GradReducer)
+    red.bucket_bytes, red.bounds, red.ready_at = 4 << 20, [], {}
+    tags = [(t, par._prefix_pred(t)) for t in ("stage4_blocks", "fuse4", "stage3_blocks", "fuse3", "stage2_blocks", "fuse2", "stage1_blocks")]
+    bounds = red.plan(names, offs, tags)
+    assert bounds[0][0] == 0 and bounds[-1][1] == offs[-1]
+    assert all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:]))
+    ready = [red.ready_at[t] for t, _ in tags]
+    assert ready == sorted(ready) and ready[0] >= 1 and ready[-1] <= len(bounds)
+    # a bucket released at tag k only holds parameters whose gradients are complete at tag k
+    for (t, pred) in tags:
+        upto = bounds[red.ready_at[t] - 1][1] if red.ready_at[t] else 0
+        i = 0
+        while offs[i + 1] <= upto:
+            assert pred(names[i]), (t, names[i])
+            i += 1
