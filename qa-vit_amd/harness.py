@@ -95,6 +95,43 @@ class ModelEMA:
         self.decay = decay
 
 
+class GradientMonitor:
+    """HQAViT_CIFAR100.py:190-250 surface (``log_gradients`` / ``check_explosion``) without the ~3 k host syncs per
+    call: one fused norm over all gradients and one over all parameters (2 syncs); per-layer statistics only when
+    ``detailed`` is requested."""
+
+    def __init__(self):
+        self.grad_norms, self.param_norms, self.layer_grad_history, self.explosion_count = [], [], {}, 0
+
+    @torch.no_grad()
+    def log_gradients(self, model, detailed=False):
+        named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+        if not named:
+            return 0.0, 0.0, {}, {}
+        gn = torch.stack(torch._foreach_norm([p.grad for _, p in named]))
+        pn = torch.stack(torch._foreach_norm([p.detach() for _, p in named]))
+        total, param = float(gn.norm()), float(pn.norm())
+        self.grad_norms.append(total)
+        self.param_norms.append(param)
+        layer_stats = {}
+        if detailed:
+            g, q = gn.tolist(), pn.tolist()
+            for (n, _), a, b in zip(named, g, q):
+                k = ".".join(n.split(".")[:2])
+                st = layer_stats.setdefault(k, {"grad_norm": 0.0, "param_norm": 0.0, "count": 0})
+                st["grad_norm"] += a
+                st["param_norm"] += b
+                st["count"] += 1
+            for k, st in layer_stats.items():
+                self.layer_grad_history.setdefault(k, []).append(st["grad_norm"] / max(st["count"], 1))
+        return total, param, {}, layer_stats
+
+    def check_explosion(self, threshold=50.0):
+        bad = bool(self.grad_norms) and self.grad_norms[-1] > threshold
+        self.explosion_count += int(bad)
+        return bad
+
+
 class Trainer:
     """One object = model + flat optimiser state + (optional) data-parallel reducer + (optional) hipGraph."""
 
