@@ -97,6 +97,9 @@ typedef struct qavit_gemm_tn_args {
 } qavit_gemm_tn_args;
 
 int qavit_gemm_tn(const qavit_gemm_tn_args* a, void* stream);
+/* n independent problems (host array) in as few grids as possible: the weight-gradient GEMMs of a backward pass are
+ * off the critical path and individually too small to fill the chip, so the autograd layer defers and batches them */
+int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * nn.LayerNorm over the last dim C (HQAViT_CIFAR100.py:1072 norm1, :1083 norm2, :1273 norm, :1029 ...).

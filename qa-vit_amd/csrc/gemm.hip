@@ -117,26 +117,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
                      (!use_z || (g.a_ldz % VN == 0 && (reinterpret_cast<uintptr_t>(Zin) & 15) == 0)) &&
                      (!(bwd && Aout) || (g.a_ldo % VN == 0 && (reinterpret_cast<uintptr_t>(Aout) & 15) == 0));
 
-  // ---------------- resident weight slice ----------------
-  {
-    const int kv = Kp / VN;
-    const bool b_vec = (g.K % VN == 0) && (g.ldb % VN == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-    for (int idx = tid; idx < BNT * kv; idx += GEMM_THREADS) {
-      const int r = idx / kv, v = idx - r * kv;
-      const int n = n0 + r, k = v * VN;
-      T* dst = Bs + (size_t)r * ldb_s + k;
-      if (n >= g.N || k >= g.K) { store_vec_zero<T>(dst); continue; }
-      if (b_vec) {
-        *reinterpret_cast<vec_t*>(dst) = *reinterpret_cast<const vec_t*>(B + (size_t)n * g.ldb + k);
-      } else {
-        vec_t o;
-#pragma unroll
-        for (int i = 0; i < VN; ++i) o[i] = (k + i < g.K) ? B[(size_t)n * g.ldb + k + i] : from_f<T>(0.f);
-        *reinterpret_cast<vec_t*>(dst) = o;
-      }
-    }
-  }
-
   if (AMODE == 1) {
     for (int k = tid; k < Kp; k += GEMM_THREADS) {
       Gs[k] = (k < g.K) ? g.ln_gamma[k] : 0.f;
@@ -235,7 +215,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
 
   f32x4 acc[2][NT];
   int tile = blockIdx.y, chunk = 0;
-  if (tile < n_tiles_m) prefetch(tile, 0);
+  if (tile < n_tiles_m) prefetch(tile, 0);           // first row tile's loads fly while the weight slice is staged
+  // ---------------- resident weight slice ----------------
+  {
+    const int kv = Kp / VN;
+    const bool b_vec = (g.K % VN == 0) && (g.ldb % VN == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    for (int idx = tid; idx < BNT * kv; idx += GEMM_THREADS) {
+      const int r = idx / kv, v = idx - r * kv;
+      const int n = n0 + r, k = v * VN;
+      T* dst = Bs + (size_t)r * ldb_s + k;
+      if (n >= g.N || k >= g.K) { store_vec_zero<T>(dst); continue; }
+      if (b_vec) {
+        *reinterpret_cast<vec_t*>(dst) = *reinterpret_cast<const vec_t*>(B + (size_t)n * g.ldb + k);
+      } else {
+        vec_t o;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) o[i] = (k + i < g.K) ? B[(size_t)n * g.ldb + k + i] : from_f<T>(0.f);
+        *reinterpret_cast<vec_t*>(dst) = o;
+      }
+    }
+  }
+
+
   while (tile < n_tiles_m) {
     __syncthreads();                                   // previous MFMAs done with As, previous epilogue done with Cs
     commit(tile, chunk);
@@ -389,7 +390,9 @@ static int launch_gemm_nt3(const qavit_gemm_args& g, hipStream_t st) {
   }
   const int n_slices = (g.N + BNT - 1) / BNT;
   const int n_tiles_m = (g.M + BM - 1) / BM;
-  int gy = (768 + n_slices - 1) / n_slices;          // ~3 workgroups per CU across the chip
+  static int wg_target = -1;
+  if (wg_target < 0) { const char* e = getenv("QAVIT_GEMM_WGS"); wg_target = e ? atoi(e) : 768; }
+  int gy = (wg_target + n_slices - 1) / n_slices;    // ~3 workgroups per CU across the chip
   if (gy > n_tiles_m) gy = n_tiles_m;
   if (gy < 1) gy = 1;
   hipLaunchKernelGGL((gemm_nt_kernel<T, BNT, AMODE, EPI, KC>), dim3(n_slices, gy), dim3(GEMM_THREADS), smem, st, g, n_tiles_m);
@@ -538,14 +541,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int ld, int m0, int 
   return r;
 }
 
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_bf16_kernel(qavit_gemm_tn_args g, int rows_per_split) {
-  constexpr int LD = 64 + 8;                          // elements; 144-byte rows keep every tr read 8-byte aligned
-  __shared__ __attribute__((aligned(16))) bf16 At[TN_MC * LD];   // [m][n]
-  __shared__ __attribute__((aligned(16))) bf16 Bt[TN_MC * LD];   // [m][k]
+constexpr int TN_LD = 64 + 8;                          // elements; 144-byte rows keep every tr read 8-byte aligned
+
+__device__ __forceinline__ void gemm_tn_bf16_body(const qavit_gemm_tn_args& g, bf16* At, bf16* Bt, int bx, int by, int bz, int rows_per_split) {
+  constexpr int LD = TN_LD;
   const int tid = threadIdx.x, wave = tid >> 6;
   const int wa = wave & 1, wb = wave >> 1;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int mbeg = blockIdx.z * rows_per_split;
+  const int n0 = bx * 64, k0 = by * 64;
+  const int mbeg = bz * rows_per_split;
   const int mend = (mbeg + rows_per_split < g.M) ? mbeg + rows_per_split : g.M;
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_bf16_kernel(qavit_gemm_t
     }
     __syncthreads();
     if (mc + TN_MC < mend) prefetch(mc + TN_MC);
-    if (g.colsum && blockIdx.y == 0 && tid < 64) {
+    if (g.colsum && by == 0 && tid < 64) {
       float s_ = 0.f;
 #pragma unroll 8
       for (int m = 0; m < TN_MC; ++m) s_ += (float)At[m * LD + tid];
@@ -634,7 +637,50 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_bf16_kernel(qavit_gemm_t
         const int n = n0 + (wa * 2 + i) * 16 + fq * 4 + r, k = k0 + (wb * 2 + j) * 16 + fr;
         if (n < g.N && k < g.K) atomic_add_f(g.C + (size_t)n * g.ldc + k, acc[i][j][r]);
       }
-  if (g.colsum && blockIdx.y == 0 && tid < 64 && n0 + tid < g.N) atomic_add_f(g.colsum + n0 + tid, csum);
+  if (g.colsum && by == 0 && tid < 64 && n0 + tid < g.N) atomic_add_f(g.colsum + n0 + tid, csum);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_bf16_kernel(qavit_gemm_tn_args g, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) bf16 At[TN_MC * TN_LD];   // [m][n]
+  __shared__ __attribute__((aligned(16))) bf16 Bt[TN_MC * TN_LD];   // [m][k]
+  gemm_tn_bf16_body(g, At, Bt, blockIdx.x, blockIdx.y, blockIdx.z, rows_per_split);
+}
+
+// Grouped launch: up to TN_GROUP independent weight-gradient GEMMs in ONE grid.  The dW GEMMs of a backward pass
+// are off the critical path and individually too small to fill 256 CUs (latency-bound ~25-50 us each); batching
+// a dozen of them keeps every CU busy and removes the per-launch gaps.
+constexpr int TN_GROUP = 12;
+struct TnGroup {
+  int n;
+  int wg_start[TN_GROUP + 1];
+  int tn[TN_GROUP], tk[TN_GROUP], rows[TN_GROUP];
+  qavit_gemm_tn_args p[TN_GROUP];
+};
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_bf16_grouped_kernel(TnGroup G) {
+  __shared__ __attribute__((aligned(16))) bf16 At[TN_MC * TN_LD];
+  __shared__ __attribute__((aligned(16))) bf16 Bt[TN_MC * TN_LD];
+  const int bid = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < TN_GROUP; ++j) if (j < G.n && bid >= G.wg_start[j]) i = j;
+  const int local = bid - G.wg_start[i];
+  const int tiles = G.tn[i] * G.tk[i];
+  const int bz = local / tiles, t = local - bz * tiles;
+  const int by = t / G.tn[i], bx = t - by * G.tn[i];
+  gemm_tn_bf16_body(G.p[i], At, Bt, bx, by, bz, G.rows[i]);
+}
+
+static void tn_split_plan(const qavit_gemm_tn_args& g, int budget, int& tn, int& tk, int& splits, int& rows) {
+  tn = (g.N + 63) / 64; tk = (g.K + 63) / 64;
+  splits = g.splits;
+  if (splits <= 0) { splits = budget / (tn * tk); if (splits < 1) splits = 1; }
+  int max_splits = (g.M + 127) / 128;
+  if (max_splits < 1) max_splits = 1;
+  if (splits > max_splits) splits = max_splits;
+  rows = (g.M + splits - 1) / splits;
+  rows = (rows + TN_MC - 1) / TN_MC * TN_MC;
+  splits = (g.M + rows - 1) / rows;
 }
 
 template <typename T>
@@ -673,6 +719,41 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   if (a->dtype == QAVIT_F32) return dispatch_gemm_nt<float>(*a, st);
   if (a->dtype == QAVIT_BF16) return dispatch_gemm_nt<bf16>(*a, st);
   return set_error(QAVIT_EINVAL, "gemm_nt: unknown dtype");
+}
+
+extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* stream) {
+  using namespace qv;
+  if (!a || n <= 0) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: empty group");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int done = 0;
+  while (done < n) {
+    TnGroup G;
+    G.n = 0;
+    int wg = 0;
+    while (done < n && G.n < TN_GROUP) {
+      const qavit_gemm_tn_args& g = a[done];
+      if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: bad problem");
+      if (g.lda < g.N || g.ldb < g.K || g.ldc < g.K) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: leading dimension too small");
+      if (g.dtype != QAVIT_BF16) {            // fp32 problems run through the single-problem path
+        int rc = qavit_gemm_tn(&g, stream);
+        if (rc) return rc;
+        ++done;
+        continue;
+      }
+      int tn, tk, splits, rows;
+      tn_split_plan(g, 256, tn, tk, splits, rows);
+      const int i = G.n++;
+      G.p[i] = g; G.tn[i] = tn; G.tk[i] = tk; G.rows[i] = rows;
+      G.wg_start[i] = wg;
+      wg += tn * tk * splits;
+      ++done;
+    }
+    if (G.n > 0) {
+      G.wg_start[G.n] = wg;
+      hipLaunchKernelGGL(gemm_tn_bf16_grouped_kernel, dim3(wg), dim3(GEMM_THREADS), 0, st, G);
+    }
+  }
+  return check_launch("gemm_tn_grouped");
 }
 
 extern "C" int qavit_gemm_tn(const qavit_gemm_tn_args* a, void* stream) {

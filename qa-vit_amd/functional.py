@@ -10,6 +10,7 @@ Conventions
 """
 import ctypes as C
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -148,6 +149,88 @@ def _rt(x):
     return K.Runtime.get(x.device)
 
 
+class DeferDW:
+    """Defer the weight-gradient GEMMs of a backward pass and launch them in grouped kernels (kernels.DeferredTN).
+    The first deferral of a pass registers an autograd-engine callback that flushes when backward ends, so
+    ``loss.backward(); optimizer.step()`` sees complete gradients; ``flush()`` can be called earlier (DDP sync points)."""
+    enabled = os.environ.get("QAVIT_DEFER_DW", "1") != "0"
+    _armed = False
+
+    @classmethod
+    def arm(cls):
+        if not cls.enabled or cls._armed:
+            return cls.enabled
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(cls.finish)
+        except RuntimeError:
+            return False                                    # not inside a backward pass
+        cls._armed = True
+        K.DeferredTN.enabled = True
+        return True
+
+    @classmethod
+    def flush(cls):
+        K.DeferredTN.flush()
+
+    @classmethod
+    def finish(cls):
+        K.DeferredTN.flush()
+        K.DeferredTN.enabled = False
+        cls._armed = False
+
+
+class SideStream:
+    """Weight-gradient GEMMs are independent of the activation-gradient chain: they run on a second HIP stream
+    (fork after their inputs exist, join before anyone reads ``.grad``) so their latency hides under the dX /
+    LayerNorm-backward kernels.  Works eagerly and under hipGraph capture (fork/join become graph edges)."""
+    enabled = os.environ.get("QAVIT_DW_STREAM", "0") != "0"   # measured slower under hipGraph (fork/join edges): opt-in
+    _streams = {}
+    _dirty = {}
+    _main = {}
+
+    @classmethod
+    def get(cls, device):
+        key = torch.device(device).index or 0
+        st = cls._streams.get(key)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            cls._streams[key] = st
+        return st
+
+    @classmethod
+    def fork(cls, device, *tensors):
+        """-> context manager running on the side stream after everything enqueued so far on the current stream."""
+        st = cls.get(device)
+        key = torch.device(device).index or 0
+        main = torch.cuda.current_stream(device)
+        st.wait_stream(main)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(st)
+        if not cls._dirty.get(key):
+            # first fork of this backward pass: join automatically when the autograd engine finishes, on the
+            # stream the backward kernels run on, so `loss.backward(); optimizer.step()` stays correct
+            cls._dirty[key] = True
+            cls._main[key] = main
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda d=device: cls.join(d))
+            except RuntimeError:
+                pass                                        # not inside a backward pass: caller joins explicitly
+        return torch.cuda.stream(st)
+
+    @classmethod
+    def join(cls, device):
+        """Make the current stream wait for all side-stream work (call before gradients are consumed)."""
+        key = torch.device(device).index or 0
+        if cls._dirty.get(key):
+            main = cls._main.get(key) or torch.cuda.current_stream(device)
+            main.wait_stream(cls.get(device))
+            cur = torch.cuda.current_stream(device)
+            if cur != main:
+                cur.wait_stream(cls.get(device))
+            cls._dirty[key] = False
+
+
 # ---------------------------------------------------------------------------------------------------
 # Linear (+ fused LayerNorm prologue, GELU / dropout / drop-path / residual epilogue)
 # ---------------------------------------------------------------------------------------------------
@@ -228,9 +311,16 @@ class LinearFn(Function):
             if wbuf is None:   # bias-only gradient: still use the kernel with a scratch C
                 wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
             lnarg = (ln_g, ln_b, mean, rstd) if ln_g is not None else None
-            K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
-                      C_ptr=wbuf.data_ptr() + off * Kd * 4,
-                      colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
+            DeferDW.arm()
+            if SideStream.enabled:
+                with SideStream.fork(x2.device, dz, x2, mean, rstd):
+                    K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
+                              C_ptr=wbuf.data_ptr() + off * Kd * 4,
+                              colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
+            else:
+                K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
+                          C_ptr=wbuf.data_ptr() + off * Kd * 4,
+                          colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
         dres = dy if has_res else None
         return (dx.reshape(xshape) if (dx is not None and need_dx) else None), None, None, None, None, dres, None
 

@@ -195,6 +195,7 @@ class Trainer:
         logits = self.model(x)
         loss = TF.cross_entropy(logits.float(), y, label_smoothing=self.cfg.label_smoothing)
         loss.backward()
+        F.SideStream.join(self.device)                     # weight-gradient GEMMs ran on the side stream
         if self.reducer is not None:
             self.reducer.finish(self.flat_g)
         return loss.detach()

@@ -123,6 +123,22 @@ def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None,
     L.check(L.load().qavit_gemm_nt(C.byref(a), stream()), "gemm_nt")
 
 
+class DeferredTN:
+    """Queue of weight-gradient GEMMs (see qavit_gemm_tn_grouped).  ``enabled`` is switched on by the autograd layer
+    for the duration of a backward pass; queued problems keep their operand tensors alive until ``flush``."""
+    enabled = False
+    queue = []          # (GemmTnArgs, keepalive tuple)
+    MAX = 48
+
+    @classmethod
+    def flush(cls):
+        if not cls.queue:
+            return
+        q, cls.queue = cls.queue, []
+        arr = (L.GemmTnArgs * len(q))(*[a for a, _ in q])
+        L.check(L.load().qavit_gemm_tn_grouped(arr, len(q), stream()), "gemm_tn_grouped")
+
+
 def gemm_tn(A, Bm, Cgrad, M, N, K, lda, ldb, ldc, colsum=None, ln=None, A_ptr=None, B_ptr=None, C_ptr=None, colsum_ptr=None):
     """Cgrad[N,K] += A[M,N]^T @ B[M,K] (fp32), colsum[N] += sum_m A."""
     a = L.GemmTnArgs()
@@ -136,6 +152,11 @@ def gemm_tn(A, Bm, Cgrad, M, N, K, lda, ldb, ldc, colsum=None, ln=None, A_ptr=No
         g, b_, mean, rstd = ln
         a.ln_gamma, a.ln_beta, a.ln_mean, a.ln_rstd = g.data_ptr(), b_.data_ptr(), mean.data_ptr(), rstd.data_ptr()
     a.splits = 0
+    if DeferredTN.enabled:
+        DeferredTN.queue.append((a, (A, Bm, Cgrad, colsum, ln)))
+        if len(DeferredTN.queue) >= DeferredTN.MAX:
+            DeferredTN.flush()
+        return
     L.check(L.load().qavit_gemm_tn(C.byref(a), stream()), "gemm_tn")
 
 

@@ -53,6 +53,11 @@ class SyncPoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        try:                                   # deferred weight-gradient GEMMs must land before their bucket is reduced
+            from .functional import DeferDW
+            DeferDW.flush()
+        except ImportError:
+            pass
         ctx.reducer.reached(ctx.tag)
         return g, None, None
 
