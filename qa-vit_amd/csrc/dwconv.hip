@@ -114,6 +114,92 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* dy, const T* x
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 8x8 feature maps (the CIFAR lateral path): the whole map of one channel fits a lane's registers.  One lane =
+// one channel of one image; taps, rows and columns are compile-time loops, so every index is a register name and
+// the border tests fold away -- no LDS traffic inside the 49-tap loops.  4 waves of a workgroup take different
+// images of the same 64 channels; dw/dbias partials are reduced across them in LDS, one atomic per element per WG.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KS>
+__global__ __launch_bounds__(256, 1) void dwconv_bwd8_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int C) {
+  constexpr int HW = 8, N = 64, R = KS / 2;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const bool cok = c < C;
+  float wt[KS * KS], aw[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) { wt[t] = cok ? w[(size_t)c * KS * KS + t] : 0.f; aw[t] = 0.f; }
+  float ab = 0.f;
+  for (int b = blockIdx.y * 4 + wave; b < B; b += gridDim.y * 4) {
+    float g[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) g[n] = cok ? to_f<T>(dy[((size_t)b * N + n) * C + c]) : 0.f;
+    // dx = full correlation of dy with the flipped taps
+#pragma unroll
+    for (int yy = 0; yy < HW; ++yy) {
+      float o[HW];
+#pragma unroll
+      for (int xx = 0; xx < HW; ++xx) {
+        float s = 0.f;
+#pragma unroll
+        for (int dyy = 0; dyy < KS; ++dyy) {
+          const int yo = yy - dyy + R;
+          if (yo < 0 || yo >= HW) continue;
+#pragma unroll
+          for (int dxx = 0; dxx < KS; ++dxx) {
+            const int xo = xx - dxx + R;
+            if (xo < 0 || xo >= HW) continue;
+            s += wt[dyy * KS + dxx] * g[yo * HW + xo];
+          }
+        }
+        o[xx] = s;
+      }
+      if (cok) {
+#pragma unroll
+        for (int xx = 0; xx < HW; ++xx) dx[((size_t)b * N + yy * HW + xx) * C + c] = from_f<T>(o[xx]);
+      }
+    }
+    // dw[tap] += sum_n dy[n] * x[n + off(tap)]
+    float xi[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) xi[n] = cok ? to_f<T>(x[((size_t)b * N + n) * C + c]) : 0.f;
+#pragma unroll
+    for (int n = 0; n < N; ++n) ab += g[n];
+#pragma unroll
+    for (int dyy = 0; dyy < KS; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < KS; ++dxx) {
+        float s = 0.f;
+#pragma unroll
+        for (int yy = 0; yy < HW; ++yy) {
+          const int y2 = yy + dyy - R;
+          if (y2 < 0 || y2 >= HW) continue;
+#pragma unroll
+          for (int xx = 0; xx < HW; ++xx) {
+            const int x2 = xx + dxx - R;
+            if (x2 < 0 || x2 >= HW) continue;
+            s += g[yy * HW + xx] * xi[y2 * HW + x2];
+          }
+        }
+        aw[dyy * KS + dxx] += s;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) {
+    __syncthreads();
+    red[wave][lane] = aw[t];
+    __syncthreads();
+    if (wave == 0 && cok) atomic_add_f(dw + (size_t)c * KS * KS + t, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  }
+  if (dbias) {
+    __syncthreads();
+    red[wave][lane] = ab;
+    __syncthreads();
+    if (wave == 0 && cok) atomic_add_f(dbias + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  }
+}
+
 template <typename T, int KS>
 static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, const float* bias, void* o0, float* dw, float* dbias,
                      int B, int H, int W, int C, hipStream_t st) {
@@ -127,6 +213,13 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((dwconv_fwd_kernel<T, KS>), dim3(chunks, gy), dim3(256), smem, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
     return check_launch("dwconv_fwd");
+  }
+  if (H == 8 && W == 8) {
+    int gy8 = (B + 3) / 4;
+    const int cap = 512 / chunks > 0 ? 512 / chunks : 1;
+    if (gy8 > cap) gy8 = cap;
+    hipLaunchKernelGGL((dwconv_bwd8_kernel<T, KS>), dim3(chunks, gy8), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, C);
+    return check_launch("dwconv_bwd8");
   }
   const size_t smem = ((size_t)2 * N * DW_CH + KS * KS * DW_CH + 4 * DW_CH) * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "dwconv_bwd: feature map too large for LDS");
