@@ -159,9 +159,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_ddp = os.environ.get("QAVIT_FORCE_DDP", "0") != "0"      # exercise the data-parallel path on one rank
+    if world > 1 or force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -175,7 +177,7 @@ def main():
     y = torch.randint(0, cfg.num_classes, (B,), generator=g).to(dev)
 
     dp = None
-    if world > 1:
+    if world > 1 or force_ddp:
         dp = par.DataParallel(model)
     tcfg = Q.TrainingConfig(batch_size=B * world, use_amp=(cdt == torch.bfloat16))
     tr = Q.Trainer(model, tcfg, total_steps=100000, warmup_steps=1000, reducer=(dp.reducer if dp else None),

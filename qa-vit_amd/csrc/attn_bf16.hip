@@ -131,32 +131,42 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
   for (int pid = blockIdx.x; pid < a.G * a.H; pid += gridDim.x) {
     const int g = pid / a.H, h = pid - g * a.H;
     __syncthreads();
-    // ---------------- key side ----------------
-    for (int i = lane; i < a.S * D; i += 64) {
-      const int s = i / D, dd = i - s * D;
-      const float k = a.sh_k[(size_t)s * a.H * D + h * D + dd];
-      const float v = a.sh_v[(size_t)s * a.H * D + h * D + dd];
-      bad |= (k != k) | (v != v);
-      sm[L.kf + (NKo + s) * L.ldd + dd] = (bf16)k;
-      sm[L.vf + (NKo + s) * L.ldd + dd] = (bf16)v;
+    // ---------------- key side (4-element chunks: 16-byte fp32 / 8-byte bf16 loads, 8-byte LDS stores) ----------------
+    const int DC = D >> 2;                               // chunks per row (D % 4 == 0, checked on the host)
+    for (int i = lane; i < a.S * DC; i += 64) {
+      const int s = i / DC, ch = i - s * DC;
+      const f32x4 k = *reinterpret_cast<const f32x4*>(a.sh_k + (size_t)s * a.H * D + h * D + 4 * ch);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.sh_v + (size_t)s * a.H * D + h * D + 4 * ch);
+      bf16x4 kb, vb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bad |= (k[j] != k[j]) | (v[j] != v[j]); kb[j] = (bf16)k[j]; vb[j] = (bf16)v[j]; }
+      *reinterpret_cast<bf16x4*>(sm + L.kf + (NKo + s) * L.ldd + 4 * ch) = kb;
+      *reinterpret_cast<bf16x4*>(sm + L.vf + (NKo + s) * L.ldd + 4 * ch) = vb;
     }
     {
       const int kdst = (MODE == 0) ? L.kt : L.kf, vdst = (MODE == 0) ? L.vt : L.vf;
-      for (int i = lane; i < a.L * D; i += 64) {
-        const int l = i / D, dd = i - l * D;
+      for (int i = lane; i < a.L * DC; i += 64) {
+        const int l = i / DC, ch = i - l * DC;
         const int64_t kr = attn_krow(a, g, l);
-        const bf16 k = ktg[kr * a.ldk + h * D + dd];
-        const bf16 v = vtg[kr * a.ldv + h * D + dd];
-        bad |= ((float)k != (float)k) | ((float)v != (float)v);
-        sm[kdst + l * L.ldd + dd] = k;
-        sm[vdst + l * L.ldd + dd] = v;
+        const bf16x4 k = *reinterpret_cast<const bf16x4*>(ktg + kr * a.ldk + h * D + 4 * ch);
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(vtg + kr * a.ldv + h * D + 4 * ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= ((float)k[j] != (float)k[j]) | ((float)v[j] != (float)v[j]);
+        *reinterpret_cast<bf16x4*>(sm + kdst + l * L.ldd + 4 * ch) = k;
+        *reinterpret_cast<bf16x4*>(sm + vdst + l * L.ldd + 4 * ch) = v;
       }
     }
     if (MODE == 0) {
-      for (int i = lane; i < a.L * a.KC; i += 64) {
-        const int l = i / a.KC, j = i - l * a.KC;
-        sm[L.ek + l * L.lde + j] = (bf16)a.E_k[i];
-        sm[L.ev + l * L.lde + j] = (bf16)a.E_v[i];
+      const int EC = a.KC >> 2;
+      for (int i = lane; i < a.L * EC; i += 64) {
+        const int l = i / EC, ch = i - l * EC;
+        const f32x4 ek = *reinterpret_cast<const f32x4*>(a.E_k + (size_t)l * a.KC + 4 * ch);
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(a.E_v + (size_t)l * a.KC + 4 * ch);
+        bf16x4 kb, vb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kb[j] = (bf16)ek[j]; vb[j] = (bf16)ev[j]; }
+        *reinterpret_cast<bf16x4*>(sm + L.ek + l * L.lde + 4 * ch) = kb;
+        *reinterpret_cast<bf16x4*>(sm + L.ev + l * L.lde + 4 * ch) = vb;
       }
       __syncthreads();
       // Kf[j][d] = sum_l E_k[l][j] kt[l][d]   (both operands reduce along their rows -> transposed reads)
@@ -185,17 +195,20 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
     for (int q0 = 0; q0 < a.Nq; q0 += 16) {
       const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
       __syncthreads();
-      for (int i = lane; i < 16 * D; i += 64) {
-        const int r = i / D, dd = i - r * D;
-        bf16 v = (bf16)0.f, gvv = (bf16)0.f;
+      for (int i = lane; i < 16 * DC; i += 64) {
+        const int r = i / DC, ch = i - r * DC;
+        bf16x4 v, gvv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = (bf16)0.f; gvv[j] = (bf16)0.f; }
         if (r < rows) {
           const int64_t qr = attn_qrow(a, g, q0 + r);
-          v = qg[qr * a.ldq + h * D + dd];
-          if (BWD) gvv = dog[qr * a.lddo + h * D + dd];
+          v = *reinterpret_cast<const bf16x4*>(qg + qr * a.ldq + h * D + 4 * ch);
+          if (BWD) gvv = *reinterpret_cast<const bf16x4*>(dog + qr * a.lddo + h * D + 4 * ch);
         }
-        bad |= ((float)v != (float)v);
-        sm[L.q + r * L.ldd + dd] = v;
-        if (BWD) sm[L.d_o + r * L.ldd + dd] = gvv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= ((float)v[j] != (float)v[j]);
+        *reinterpret_cast<bf16x4*>(sm + L.q + r * L.ldd + 4 * ch) = v;
+        if (BWD) *reinterpret_cast<bf16x4*>(sm + L.d_o + r * L.ldd + 4 * ch) = gvv;
       }
       __syncthreads();
       // ---------------- scores + softmax on registers ----------------
@@ -384,6 +397,12 @@ int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) 
   const int NKo = (a.mode == 0) ? a.KC : a.L;
   const int nkt = (NKo + a.S + 15) / 16, dt = (a.D + 15) / 16;
   if (a.mode == 0 && (a.KC % 16 != 0)) return 0;
+  // 8-byte / 16-byte vector staging: head dim and every leading dimension a multiple of 4 elements, aligned bases
+  auto al = [](const void* p, size_t n) { return (reinterpret_cast<uintptr_t>(p) % n) == 0; };
+  if (a.D % 4 || a.ldq % 4 || (a.L > 0 && (a.ldk % 4 || a.ldv % 4)) || !al(a.q, 8) || !al(a.sh_k, 16) || !al(a.sh_v, 16)) return 0;
+  if (a.L > 0 && (!al(a.k_tok, 8) || !al(a.v_tok, 8))) return 0;
+  if (a.mode == 0 && (!al(a.E_k, 16) || !al(a.E_v, 16))) return 0;
+  if (bwd && (a.lddo % 4 || !al(a.d_o, 8))) return 0;
   int rc = -100;
   if (a.mode == 0 && nkt <= 3 && dt == 3) rc = a2_launch<0, 3, 3>(a, bwd, grid, st);
   else if (a.mode == 1 && nkt == 1 && dt == 3) rc = a2_launch<1, 1, 3>(a, bwd, grid, st);

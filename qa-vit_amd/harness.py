@@ -150,22 +150,25 @@ class Trainer:
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
         sizes = [p.numel() for p in self.params]
+        # every tensor starts on a 256-byte boundary of the flat buffers: the kernels' 16-byte vector loads of weights,
+        # bank rows and Linformer matrices need aligned bases (padding elements stay 0 through AdamW / all-reduce)
+        ALIGN = 64
         self.offsets = [0]
         for s in sizes:
-            self.offsets.append(self.offsets[-1] + s)
+            self.offsets.append((self.offsets[-1] + s + ALIGN - 1) // ALIGN * ALIGN)
         n = self.offsets[-1]
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        skip = torch.zeros(n, dtype=torch.uint8, device=dev)
+        skip = torch.ones(n, dtype=torch.uint8, device=dev)          # padding between tensors is never touched
         with torch.no_grad():
             for p, name, o, s in zip(self.params, self.names, self.offsets, sizes):
                 self.flat_p[o:o + s].copy_(p.reshape(-1))
                 p.data = self.flat_p[o:o + s].view_as(p)
                 p.grad = self.flat_g[o:o + s].view_as(p)
-                if never_trained(name) or not p.requires_grad:
-                    skip[o:o + s] = 1
+                if not (never_trained(name) or not p.requires_grad):
+                    skip[o:o + s] = 0
         self.skip = skip
         self.local_clip_params = [p for p, nme in zip(self.params, self.names) if ("cnn_stem" in nme or "dwconv" in nme)]
         self.total_steps = total_steps
