@@ -7,6 +7,7 @@
 #include "mma_lds.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
+#include "tokens_shared.h"
 
 namespace qv {
 
@@ -149,6 +150,16 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
   const size_t smem = ((size_t)N * C + (size_t)N * S + (size_t)S * C + 256) * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "bank_stats: token tile too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int n_acc = S * C;
+  if (dtype == QAVIT_BF16) {
+    const int took = bank_stats_bf16_try(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, grid, eps, st);
+    if (took < 0) return took;
+    if (took == 1) {
+      (void)hipMemsetAsync(acc, 0, (size_t)n_acc * sizeof(float), st);
+      hipLaunchKernelGGL(bank_reduce_kernel, dim3((n_acc + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n_acc);
+      return check_launch("bank_stats(bf16)");
+    }
+  }
   if (dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((bank_stats_kernel<float, false>), dim3(grid), dim3(256), smem, st, (const float*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);

@@ -471,6 +471,28 @@ def test_bank_write_matches_oracle(F, Q, oracle):
     assert int(bank.update_count) == 3 == int(P["global_bank.update_count"])
 
 
+@pytest.mark.parametrize("N", [16, 64])
+def test_bank_write_bf16_path_close_to_fp32(F, Q, N):
+    """The bf16 fast path of the bank statistics (tokens_bf16.hip) against the fp32 kernel on the same tokens."""
+    banks = []
+    tokens = torch.randn(53, N, 192, device=DEV)
+    ng, nb = (torch.randn(192, device=DEV) * 0.1 + 1), torch.randn(192, device=DEV) * 0.1
+    for dtype in (torch.float32, torch.bfloat16):
+        bank = Q.HQAViT(Q.HQAViTConfig()).global_bank
+        Q.fill_module(bank)
+        bank = bank.cuda()
+        for step in range(3):
+            F.bank_write((tokens + step).to(dtype), ng, nb, bank, 0)
+        banks.append((bank.global_k.detach().clone(), bank.global_v.detach().clone(), int(bank.update_count)))
+    # the bank moves by <= 3 * 0.005 * 0.05; compare the MOVEMENT, not the (much larger) bank itself
+    ref = Q.HQAViT(Q.HQAViTConfig()).global_bank
+    Q.fill_module(ref)
+    k0, v0 = ref.global_k.cuda(), ref.global_v.cuda()
+    assert rel(banks[1][0] - k0, banks[0][0] - k0) <= 5e-2
+    assert rel(banks[1][1] - v0, banks[0][1] - v0) <= 5e-2
+    assert banks[0][2] == banks[1][2] == 3
+
+
 def test_adamw_and_l2norm_match_torch(Q):
     import importlib
     K = importlib.import_module("qa-vit_amd.kernels")
