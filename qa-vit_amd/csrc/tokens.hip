@@ -5,6 +5,7 @@
 #include "mma_lds.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
+#include "tokens_shared.h"
 
 namespace qv {
 
@@ -287,6 +288,11 @@ extern "C" int qavit_tokmix_fwd(int dtype, const void* scores, const void* x, vo
   const size_t smem = ((size_t)N * M + 256) * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "tokmix_fwd: N*M too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_BF16) {
+    const int took = qv::tokmix_bf16_try(false, scores, x, nullptr, p, xc, B, N, M, C, st);
+    if (took < 0) return took;
+    if (took == 1) return check_launch("tokmix_fwd(bf16)");
+  }
   if (dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokmix_fwd_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((tokmix_fwd_kernel<float, false>), dim3(B), dim3(256), smem, st, (const float*)scores, (const float*)x, (float*)p, (float*)xc, B, N, M, C);
@@ -302,6 +308,11 @@ extern "C" int qavit_tokmix_bwd(int dtype, const void* p, const void* x, const v
   const size_t smem = ((size_t)2 * N * M + 256) * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "tokmix_bwd: N*M too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_BF16) {
+    const int took = qv::tokmix_bf16_try(true, p, x, dxc, dx, dscores, B, N, M, C, st);
+    if (took < 0) return took;
+    if (took == 1) return check_launch("tokmix_bwd(bf16)");
+  }
   if (dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokmix_bwd_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((tokmix_bwd_kernel<float, false>), dim3(B), dim3(256), smem, st, (const float*)p, (const float*)x, (const float*)dxc, (float*)dx, (float*)dscores, B, N, M, C);
@@ -318,6 +329,11 @@ extern "C" int qavit_upmix_fwd(int dtype, const void* xc, const float* W, const 
   const size_t smem = (size_t)UP_ROWS * C * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "upmix_fwd: C too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_BF16) {
+    const int took = qv::upmix_bf16_try(false, nullptr, xc, W, bias, gamma, beta, eps, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, B, N, M, C, st);
+    if (took < 0) return took;
+    if (took == 1) return check_launch("upmix_fwd(bf16)");
+  }
   if (dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix_fwd_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((upmix_fwd_kernel<float, false>), dim3(B), dim3(256), smem, st, (const float*)xc, W, bias, gamma, beta, eps, (float*)y, mean, rstd, B, N, M, C);
@@ -338,6 +354,11 @@ extern "C" int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const 
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "upmix_bwd: problem too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = B < 512 ? B : 512;
+  if (dtype == QAVIT_BF16) {
+    const int took = qv::upmix_bf16_try(true, dy, xc, W, bias, gamma, nullptr, 0.f, dxc, const_cast<float*>(mean), const_cast<float*>(rstd), dW, dbias, dgamma, dbeta, B, N, M, C, st);
+    if (took < 0) return took;
+    if (took == 1) return check_launch("upmix_bwd(bf16)");
+  }
   if (dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix_bwd_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((upmix_bwd_kernel<float, false>), dim3(grid), dim3(256), smem, st, (const float*)dy, (const float*)xc, W, bias, gamma, mean, rstd, (float*)dxc, dW, dbias, dgamma, dbeta, B, N, M, C, lds_dw);

@@ -158,4 +158,374 @@ int bank_stats_bf16_try(const void* tokens, const float* gbr, const float* bbr, 
   return rc == QAVIT_OK ? 1 : rc;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// TokenUpMix: up[n][c] = sum_m W[n][m] xc[m][c] + bias[n];  y = LN_c(up).   One workgroup per image, one wave per
+// 16-row tile; the 192 columns of a row live in 12 accumulator tiles of ONE wave, so the LayerNorm (and, in backward,
+// its gradient) is a 16-lane register reduction -- `up` never touches memory.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int MT, int CT>
+struct UpLds {
+  static constexpr int N = 16 * NT, M = 16 * MT, C = 16 * CT;
+  static constexpr int LDM = M + 4, LDC = C + 4;
+  static constexpr int wt = 0;                               // bf16 [N][LDM]
+  static constexpr int xc = wt + N * LDM;                    // bf16 [M][LDC]
+  static constexpr int dup = xc + M * LDC;                   // bf16 [N][LDC]   (backward only)
+  static constexpr int fwd_bf16 = dup;
+  static constexpr int bwd_bf16 = dup + N * LDC;
+};
+
+template <int NT, int MT, int CT>
+__device__ __forceinline__ void up_stage_w(bf16* Wt, const float* W) {
+  using L = UpLds<NT, MT, CT>;
+  for (int i = threadIdx.x; i < L::N * L::M; i += 256) { const int n = i / L::M, m = i - n * L::M; Wt[n * L::LDM + m] = (bf16)W[i]; }
+}
+template <int NT, int MT, int CT>
+__device__ __forceinline__ void up_stage_xc(bf16* Xs, const bf16* xcb) {
+  using L = UpLds<NT, MT, CT>;
+  constexpr int CH = L::C / 4;
+  for (int i = threadIdx.x; i < L::M * CH; i += 256) {
+    const int m = i / CH, ch = i - m * CH;
+    *reinterpret_cast<bf16x4*>(Xs + m * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(xcb + (size_t)m * L::C + 4 * ch);
+  }
+}
+// accumulators of one 16-row tile: acc[ct][r] = up[nt*16 + 4q + r][ct*16 + col]
+template <int NT, int MT, int CT>
+__device__ __forceinline__ void up_tile(const bf16* Wt, const bf16* Xs, const float* bias, int nt, f32x4 (&acc)[CT]) {
+  using L = UpLds<NT, MT, CT>;
+  const int q4 = (threadIdx.x & 63) >> 4;
+  f32x4 bi;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bi[r] = bias[nt * 16 + 4 * q4 + r];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    f32x4 a = bi;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a = mma16(rowfrag(Wt, L::LDM, nt * 16, mt * 16), trfrag(Xs, L::LDC, mt * 16, ct * 16), a);
+    acc[ct] = a;
+  }
+}
+
+template <int NT, int MT, int CT>
+__global__ __launch_bounds__(256) void upmix2_fwd_kernel(const bf16* xc, const float* W, const float* bias, const float* gamma, const float* beta,
+                                                         float eps, bf16* y, float* mean_o, float* rstd_o, int B) {
+  using L = UpLds<NT, MT, CT>;
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  bf16* sm = reinterpret_cast<bf16*>(smraw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q4 = lane >> 4;
+  up_stage_w<NT, MT, CT>(sm + L::wt, W);
+  float ga[CT], be[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) { ga[ct] = gamma[ct * 16 + col]; be[ct] = beta[ct * 16 + col]; }
+  const float invC = 1.f / (float)L::C;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
+    __syncthreads();
+    for (int nt = wave; nt < NT; nt += 4) {
+      f32x4 acc[CT];
+      up_tile<NT, MT, CT>(sm + L::wt, sm + L::xc, bias, nt, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) s += acc[ct][r];
+        const float mean = grp_sum<16>(s) * invC;
+        float s2 = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { const float d = acc[ct][r] - mean; s2 += d * d; }
+        const float rstd = rsqrtf(grp_sum<16>(s2) * invC + eps);
+        const size_t row = (size_t)b * L::N + nt * 16 + 4 * q4 + r;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) y[row * L::C + ct * 16 + col] = (bf16)((acc[ct][r] - mean) * rstd * ga[ct] + be[ct]);
+        if (col == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+      }
+    }
+  }
+}
+
+template <int NT, int MT, int CT>
+__global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const bf16* xc, const float* W, const float* bias, const float* gamma,
+                                                         const float* mean, const float* rstd, bf16* dxc, float* dW, float* dbias,
+                                                         float* dgamma, float* dbeta, int B) {
+  using L = UpLds<NT, MT, CT>;
+  constexpr int NTW = (NT + 3) / 4;                           // row tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  bf16* sm = reinterpret_cast<bf16*>(smraw);
+  float* fl = reinterpret_cast<float*>(smraw + (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2);   // [N] dbias + [4][2][C] gamma/beta partials
+  float* dba = fl;
+  float* gred = fl + L::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q4 = lane >> 4;
+  up_stage_w<NT, MT, CT>(sm + L::wt, W);
+  for (int i = threadIdx.x; i < L::N; i += 256) dba[i] = 0.f;
+  float ga[CT], pg[CT], pb[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) { ga[ct] = gamma[ct * 16 + col]; pg[ct] = 0.f; pb[ct] = 0.f; }
+  f32x4 dwacc[NTW][MT];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) dwacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float invC = 1.f / (float)L::C;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
+    __syncthreads();
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+      const int nt = wave + 4 * tw;
+      if (nt < NT) {
+        f32x4 acc[CT];
+        up_tile<NT, MT, CT>(sm + L::wt, sm + L::xc, bias, nt, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t row = (size_t)b * L::N + nt * 16 + 4 * q4 + r;
+          const float mu = mean[row], rs = rstd[row];
+          float g[CT];
+          float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const float d = (float)dy[row * L::C + ct * 16 + col];
+            const float xh = (acc[ct][r] - mu) * rs;
+            acc[ct][r] = xh;
+            g[ct] = d * ga[ct];
+            pg[ct] += d * xh;
+            pb[ct] += d;
+            c1 += g[ct] * xh; c2 += g[ct];
+          }
+          c1 = grp_sum<16>(c1) * invC; c2 = grp_sum<16>(c2) * invC;
+          float rsum = 0.f;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) { const float du = rs * (g[ct] - c2 - acc[ct][r] * c1); acc[ct][r] = du; rsum += du; }
+          rsum = grp_sum<16>(rsum);
+          if (col == 0) dba[nt * 16 + 4 * q4 + r] += rsum;       // this row belongs to this wave only
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc_to_lds(sm + L::dup, L::LDC, nt * 16, ct * 16, acc[ct]);
+      }
+    }
+    __syncthreads();
+    // dxc[m][c] = sum_n W[n][m] dup[n][c]
+    for (int tile = wave; tile < MT * CT; tile += 4) {
+      const int mt = tile / CT, ct = tile - mt * CT;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) a = mma16(trfrag(sm + L::wt, L::LDM, nt * 16, mt * 16), trfrag(sm + L::dup, L::LDC, nt * 16, ct * 16), a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dxc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)a[r];
+    }
+    // dW[n][m] += sum_c dup[n][c] xc[m][c]
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+      const int nt = wave + 4 * tw;
+      if (nt < NT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            dwacc[tw][mt] = mma16(rowfrag(sm + L::dup, L::LDC, nt * 16, ct * 16), rowfrag(sm + L::xc, L::LDC, mt * 16, ct * 16), dwacc[tw][mt]);
+      }
+    }
+  }
+  __syncthreads();
+  // flush: dW tiles, dbias, dgamma / dbeta
+#pragma unroll
+  for (int tw = 0; tw < NTW; ++tw) {
+    const int nt = wave + 4 * tw;
+    if (nt < NT) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomic_add_f(dW + (size_t)(nt * 16 + 4 * q4 + r) * L::M + mt * 16 + col, dwacc[tw][mt][r]);
+    }
+  }
+  if (dbias) for (int i = threadIdx.x; i < L::N; i += 256) atomic_add_f(dbias + i, dba[i]);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float a = pg[ct], c = pb[ct];
+    a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+    c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+    if (q4 == 0) { gred[(wave * 2 + 0) * L::C + ct * 16 + col] = a; gred[(wave * 2 + 1) * L::C + ct * 16 + col] = c; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L::C; i += 256) {
+    atomic_add_f(dgamma + i, gred[(0 * 2 + 0) * L::C + i] + gred[(1 * 2 + 0) * L::C + i] + gred[(2 * 2 + 0) * L::C + i] + gred[(3 * 2 + 0) * L::C + i]);
+    atomic_add_f(dbeta + i, gred[(0 * 2 + 1) * L::C + i] + gred[(1 * 2 + 1) * L::C + i] + gred[(2 * 2 + 1) * L::C + i] + gred[(3 * 2 + 1) * L::C + i]);
+  }
+}
+
+template <int NT, int MT, int CT>
+static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta,
+                      float eps, void* o0, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, hipStream_t st) {
+  using L = UpLds<NT, MT, CT>;
+  if (!bwd) {
+    const size_t smem = (size_t)L::fwd_bf16 * 2;
+    if (smem > 150 * 1024) return -100;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_fwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((upmix2_fwd_kernel<NT, MT, CT>), dim3(B < 2048 ? B : 2048), dim3(256), smem, st, (const bf16*)xc, W, bias, gamma, beta, eps,
+                       (bf16*)o0, mean, rstd, B);
+    return QAVIT_OK;
+  }
+  const size_t smem = (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2 + (size_t)(L::N + 8 * L::C) * 4;
+  if (smem > 150 * 1024) return -100;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_bwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((upmix2_bwd_kernel<NT, MT, CT>), dim3(B < 512 ? B : 512), dim3(256), smem, st, (const bf16*)a0, (const bf16*)xc, W, bias, gamma,
+                     mean, rstd, (bf16*)o0, dW, dbias, dgamma, dbeta, B);
+  return QAVIT_OK;
+}
+
+int upmix_bf16_try(bool bwd, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
+                   void* out, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(xc) & 7) || C != 192) return 0;
+  int rc = -100;
+  if (N == 64 && M == 16) rc = up2_launch<4, 1, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st);
+  else if (N == 256 && M == 64) rc = up2_launch<16, 4, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st);
+  if (rc == -100) return 0;
+  return rc == QAVIT_OK ? 1 : rc;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// TokenLearner mix: p = softmax_n(scores[b,:,m]);  xc[m,:] = sum_n p[n,m] x[n,:].   One workgroup per image; P and
+// the x tile are staged once in LDS as bf16 and every product is an MFMA on transposed-read fragments.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int MT, int CT>
+struct MixLds {
+  static constexpr int N = 16 * NT, M = 16 * MT, C = 16 * CT;
+  static constexpr int LDM = M + 4, LDC = C + 4;
+  static constexpr int p = 0;                                // bf16 [N][LDM]
+  static constexpr int x = p + N * LDM;                      // bf16 [N][LDC]
+  static constexpr int g = x + N * LDC;                      // bf16 [M][LDC]   (backward: dxc)
+  static constexpr int fwd_bf16 = g;
+  static constexpr int bwd_bf16 = g + M * LDC;
+};
+
+__device__ __forceinline__ float colred(float v, float* red, int M, int parts, bool is_max) {
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  const int m = threadIdx.x % M;
+  float r = is_max ? -INFINITY : 0.f;
+  for (int q = 0; q < parts; ++q) { const float o = red[q * M + m]; r = is_max ? fmaxf(r, o) : r + o; }
+  return r;
+}
+
+template <int NT, int MT, int CT>
+__device__ __forceinline__ void mix_stage_rows(bf16* dst, const bf16* src, int rows) {
+  using L = MixLds<NT, MT, CT>;
+  constexpr int CH = L::C / 4;
+  for (int i = threadIdx.x; i < rows * CH; i += 256) {
+    const int n = i / CH, ch = i - n * CH;
+    *reinterpret_cast<bf16x4*>(dst + n * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(src + (size_t)n * L::C + 4 * ch);
+  }
+}
+
+template <int NT, int MT, int CT>
+__global__ __launch_bounds__(256) void tokmix2_fwd_kernel(const bf16* scores, const bf16* x, bf16* p_out, bf16* xc, int B) {
+  using L = MixLds<NT, MT, CT>;
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  bf16* sm = reinterpret_cast<bf16*>(smraw);
+  float* red = reinterpret_cast<float*>(smraw + (size_t)((L::fwd_bf16 + 7) / 8 * 8) * 2);     // [256]
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, q4 = lane >> 4;
+  constexpr int parts = 256 / L::M, RP = L::N / parts;          // rows per thread of its column
+  const int m = t % L::M, part = t / L::M;
+  mix_stage_rows<NT, MT, CT>(sm + L::x, x + (size_t)b * L::N * L::C, L::N);
+  const bf16* sc = scores + (size_t)b * L::N * L::M;
+  float v[RP];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RP; ++i) { v[i] = (float)sc[(part + i * parts) * L::M + m]; mx = fmaxf(mx, v[i]); }
+  mx = colred(mx, red, L::M, parts, true);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < RP; ++i) { v[i] = __expf(v[i] - mx); s += v[i]; }
+  s = colred(s, red, L::M, parts, false);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    const int n = part + i * parts;
+    const bf16 pv = (bf16)(v[i] * inv);
+    sm[L::p + n * L::LDM + m] = pv;
+    p_out[(size_t)b * L::N * L::M + n * L::M + m] = pv;
+  }
+  __syncthreads();
+  for (int tile = wave; tile < MT * CT; tile += 4) {
+    const int mt = tile / CT, ct = tile - mt * CT;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) a = mma16(trfrag(sm + L::p, L::LDM, nt * 16, mt * 16), trfrag(sm + L::x, L::LDC, nt * 16, ct * 16), a);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)a[r];
+  }
+}
+
+// dx[n,:] = sum_m p[n,m] dxc[m,:];  dP[n,m] = x[n,:].dxc[m,:];  dscores = p * (dP - sum_n p*dP)
+template <int NT, int MT, int CT>
+__global__ __launch_bounds__(256) void tokmix2_bwd_kernel(const bf16* p_in, const bf16* x, const bf16* dxc, bf16* dx, bf16* dscores, int B) {
+  using L = MixLds<NT, MT, CT>;
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  bf16* sm = reinterpret_cast<bf16*>(smraw);
+  float* dP = reinterpret_cast<float*>(smraw + (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2);      // [N][M]
+  float* red = dP + L::N * L::M;                                                               // [256]
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, q4 = lane >> 4;
+  mix_stage_rows<NT, MT, CT>(sm + L::x, x + (size_t)b * L::N * L::C, L::N);
+  mix_stage_rows<NT, MT, CT>(sm + L::g, dxc + (size_t)b * L::M * L::C, L::M);
+  const bf16* pb = p_in + (size_t)b * L::N * L::M;
+  for (int i = t; i < L::N * L::M; i += 256) { const int n = i / L::M, m = i - n * L::M; sm[L::p + n * L::LDM + m] = pb[i]; }
+  __syncthreads();
+  for (int nt = wave; nt < NT; nt += 4) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a = mma16(rowfrag(sm + L::p, L::LDM, nt * 16, mt * 16), trfrag(sm + L::g, L::LDC, mt * 16, ct * 16), a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dx[((size_t)b * L::N + nt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)a[r];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) a = mma16(rowfrag(sm + L::x, L::LDC, nt * 16, ct * 16), rowfrag(sm + L::g, L::LDC, mt * 16, ct * 16), a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dP[(nt * 16 + 4 * q4 + r) * L::M + mt * 16 + col] = a[r];
+    }
+  }
+  __syncthreads();
+  constexpr int parts = 256 / L::M;
+  const int m = t % L::M, part = t / L::M;
+  float dot = 0.f;
+  for (int n = part; n < L::N; n += parts) dot += (float)sm[L::p + n * L::LDM + m] * dP[n * L::M + m];
+  dot = colred(dot, red, L::M, parts, false);
+  for (int n = part; n < L::N; n += parts)
+    dscores[(size_t)b * L::N * L::M + n * L::M + m] = (bf16)((float)sm[L::p + n * L::LDM + m] * (dP[n * L::M + m] - dot));
+}
+
+template <int NT, int MT, int CT>
+static int mix2_launch(bool bwd, const void* a0, const void* x, const void* dxc, void* o0, void* o1, int B, hipStream_t st) {
+  using L = MixLds<NT, MT, CT>;
+  if (!bwd) {
+    const size_t smem = (size_t)((L::fwd_bf16 + 7) / 8 * 8) * 2 + 256 * 4;
+    if (smem > 150 * 1024) return -100;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokmix2_fwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((tokmix2_fwd_kernel<NT, MT, CT>), dim3(B), dim3(256), smem, st, (const bf16*)a0, (const bf16*)x, (bf16*)o0, (bf16*)o1, B);
+    return QAVIT_OK;
+  }
+  const size_t smem = (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2 + (size_t)(L::N * L::M + 256) * 4;
+  if (smem > 150 * 1024) return -100;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tokmix2_bwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((tokmix2_bwd_kernel<NT, MT, CT>), dim3(B), dim3(256), smem, st, (const bf16*)a0, (const bf16*)x, (const bf16*)dxc, (bf16*)o0, (bf16*)o1, B);
+  return QAVIT_OK;
+}
+
+// forward: a0 = scores, o0 = p, o1 = xc.   backward: a0 = p, dxc, o0 = dx, o1 = dscores.
+int tokmix_bf16_try(bool bwd, const void* a0, const void* x, const void* dxc, void* o0, void* o1, int B, int N, int M, int C, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(x) & 7) || (bwd && (reinterpret_cast<uintptr_t>(dxc) & 7)) || C != 192) return 0;
+  int rc = -100;
+  if (N == 64 && M == 16) rc = mix2_launch<4, 1, 12>(bwd, a0, x, dxc, o0, o1, B, st);
+  else if (N == 256 && M == 64) rc = mix2_launch<16, 4, 12>(bwd, a0, x, dxc, o0, o1, B, st);
+  if (rc == -100) return 0;
+  return rc == QAVIT_OK ? 1 : rc;
+}
+
 }  // namespace qv
