@@ -56,11 +56,27 @@ template <int W> __device__ __forceinline__ float group_max(float v) {
 // ------------------------------------------------------------------------------------------------
 // exact-erf GELU (nn.GELU() default) and its derivative
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact (erf) GELU, HQAViT_CIFAR100.py nn.GELU().  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, the same size as
+// the fp32 round-off of 0.5*x*(1+erff(x/sqrt2))): one v_rcp + one v_exp + 6 fma instead of libm's ~50-instruction erff,
+// which made the GELU epilogue of the 1024-wide FFN GEMMs VALU-bound.  The negative tail is formed without the
+// 1 - (1 - t) cancellation, and exp(-x^2/2) is shared with the density term of the gradient.
+__device__ __forceinline__ float gelu_tail(float x, float& e) {      // returns 0.5 * erfc(|x|/sqrt2), e = exp(-x^2/2)
+  const float u = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * u);
+  e = __expf(-(u * u));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  return 0.5f * poly * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float e;
+  const float tail = gelu_tail(x, e);
+  return x * (x >= 0.f ? 1.0f - tail : tail);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e;
+  const float tail = gelu_tail(x, e);
+  const float cdf = x >= 0.f ? 1.0f - tail : tail;
+  return cdf + x * (0.39894228040143268f * e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -86,5 +102,12 @@ __device__ __forceinline__ float drop_factor(uint32_t key, uint32_t idx, float p
 }
 
 __device__ __forceinline__ void atomic_add_f(float* p, float v) { atomicAdd(p, v); }
+
+// Orders one wave's own LDS traffic (LDS operations of a wave execute in issue order; this stops the compiler
+// from reordering them).  NOT a workgroup barrier.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 }  // namespace qv

@@ -11,6 +11,7 @@
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
+#include "gemm_shared.h"
 #include <stdlib.h>
 
 namespace qv {
@@ -717,7 +718,12 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
     return set_error(QAVIT_EINVAL, "gemm_nt: drop-path needs rows-per-sample");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == QAVIT_F32) return dispatch_gemm_nt<float>(*a, st);
-  if (a->dtype == QAVIT_BF16) return dispatch_gemm_nt<bf16>(*a, st);
+  if (a->dtype == QAVIT_BF16) {
+    const int took = gemm_nt_big_try(*a, st);
+    if (took < 0) return took;
+    if (took == 1) return QAVIT_OK;
+    return dispatch_gemm_nt<bf16>(*a, st);
+  }
   return set_error(QAVIT_EINVAL, "gemm_nt: unknown dtype");
 }
 

@@ -1,0 +1,350 @@
+// bf16 gemm_nt for the "fat" problems of the path (N*K too large for a resident weight slice: the CCF-FFN
+// 256<->1024 linears, the patch / lateral projections, the fused qkv):  C[M,N] = epi( pro(A)[M,K] . B[N,K]^T + bias ).
+//
+// Classic K-loop tiling, sized for a CDNA4 CU: a workgroup owns a BM x BN output tile with BN = the whole N where
+// it fits (<= 256), so every A element is read from HBM ONCE (the resident-slice kernel in gemm.hip re-reads A once
+// per 32/64-column slice -- 8x for N = 256, and with a_mode 2 it also repeats the GELU'/dropout transform 8x).
+// A and B stream through LDS in 64-wide K chunks with a register prefetch of the next chunk issued before the
+// MFMAs of the current one.  4 waves form a 2 x 2 grid, each accumulating (BM/32) x (BN/32) 16x16 tiles of
+// v_mfma_f32_16x16x32_bf16.  Column blocks of one row tile are placed on the same XCD (workgroup ids are dealt
+// round-robin over the 8 XCDs) so their shared A rows hit that XCD's L2.
+#include "common.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+#include "gemm_shared.h"
+#include <stdlib.h>
+
+namespace qv {
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int LDT = BK + 8;   // 144-byte rows: 16-byte aligned, 8 consecutive rows cover all 32 banks
+
+struct EpiKeys {
+  uint32_t drop, dp;
+  float inv_keep, dp_inv;
+};
+
+// 16 consecutive output columns of row m starting at column n (v holds the fp32 accumulators)
+template <int EPI>
+__device__ __forceinline__ void epilogue16(const qavit_gemm_args& g, const EpiKeys& ek, int m, int n, float (&v)[16]) {
+  bf16* C = reinterpret_cast<bf16*>(g.C);
+  const bf16* Rr = reinterpret_cast<const bf16*>(g.R);
+  bf16* Zo = reinterpret_cast<bf16*>(g.Z);
+  const int nv = (g.N - n < 16) ? (g.N - n) : 16;
+  const bool full = (nv == 16) && (n % 8 == 0);
+  if (g.bias) {
+    if (nv == 16 && ((reinterpret_cast<uintptr_t>(g.bias + n) & 15) == 0)) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(g.bias + n + i);
+        v[i] += t[0]; v[i + 1] += t[1]; v[i + 2] += t[2]; v[i + 3] += t[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) if (i < nv) v[i] += g.bias[n + i];
+    }
+  }
+  float zv[16];
+  if (EPI == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zv[i] = v[i];
+    if (g.act == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = gelu_f(v[i]);
+    }
+    if (g.drop_p > 0.f) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] *= drop_factor(ek.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(n + i), g.drop_p, ek.inv_keep);
+    }
+    float rowf = g.scale;
+    if (g.dp_p > 0.f) rowf *= drop_factor(ek.dp, (uint32_t)(m / g.dp_rows), g.dp_p, ek.dp_inv);
+    if (rowf != 1.f) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] *= rowf;
+    }
+    if (Rr) {
+      if (full && (g.ldr % 8 == 0) && ((reinterpret_cast<uintptr_t>(Rr) & 15) == 0)) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 8) {
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(Rr + (size_t)m * g.ldr + n + i);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i + j] += (float)t[j];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (i < nv) v[i] += (float)Rr[(size_t)m * g.ldr + n + i];
+      }
+    }
+  }
+  bf16* crow = C + (size_t)m * g.ldc + n;
+  if (full && (g.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 8) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)v[i + j];
+      *reinterpret_cast<bf16x8*>(crow + i) = o;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (i < nv) crow[i] = (bf16)v[i];
+  }
+  if (EPI == 1 && Zo) {
+    bf16* zrow = Zo + (size_t)m * g.ldz + n;
+    if (full && (g.ldz % 8 == 0) && ((reinterpret_cast<uintptr_t>(Zo) & 15) == 0)) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 8) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)zv[i + j];
+        *reinterpret_cast<bf16x8*>(zrow + i) = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) if (i < nv) zrow[i] = (bf16)zv[i];
+    }
+  }
+}
+
+// Preconditions (checked by gemm_nt_big_try): K % 32 == 0; A / a_Z / a_out / B rows 16-byte aligned.
+template <int BM_, int BN_, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int n_tiles_m, int ncb) {
+  constexpr int TM = BM_ / 32, TN = BN_ / 32;       // 16x16 tiles per wave (rows, cols)
+  constexpr int WN = BN_ / 2;                       // columns per wave
+  constexpr int WLD = WN + 4;                       // epilogue scratch row stride (floats)
+  constexpr int AV = BM_ * (BK / 8) / 256;          // 16-byte vectors per thread per chunk
+  constexpr int BV = BN_ * (BK / 8) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* As = reinterpret_cast<bf16*>(smem);         // [BM][LDT]
+  bf16* Bs = As + BM_ * LDT;                        // [BN][LDT]
+  float* Gs = reinterpret_cast<float*>(Bs + BN_ * LDT);   // [2][K] LayerNorm gamma / beta (AMODE 1)
+
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+  const int cb = jj % ncb, tm = (jj / ncb) * 8 + xcd;
+  if (tm >= n_tiles_m) return;                      // uniform per workgroup, before any barrier
+  const int m0 = tm * BM_, n0 = cb * BN_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const bf16* A = reinterpret_cast<const bf16*>(g.A);
+  const bf16* B = reinterpret_cast<const bf16*>(g.B);
+  const bf16* Zin = reinterpret_cast<const bf16*>(g.a_Z);
+  bf16* Aout = reinterpret_cast<bf16*>(g.a_out);
+  constexpr bool bwd = AMODE == 2;
+  const bool use_z = bwd && Zin && g.a_act;
+  const bool write_aout = bwd && Aout && cb == 0;
+
+  uint32_t key_adrop = 0, key_adp = 0;
+  EpiKeys ek{0u, 0u, 1.f, 1.f};
+  if ((AMODE == 2 || EPI == 1) && g.rng) {
+    key_adrop = rng_key(g.rng, g.a_drop_site);
+    key_adp = rng_key(g.rng, g.a_dp_site);
+    ek.drop = rng_key(g.rng, g.drop_site);
+    ek.dp = rng_key(g.rng, g.dp_site);
+  }
+  const float a_inv_keep = g.a_drop_p > 0.f ? 1.f / (1.f - g.a_drop_p) : 1.f;
+  const float a_dp_inv = g.a_dp_p > 0.f ? 1.f / (1.f - g.a_dp_p) : 1.f;
+  ek.inv_keep = g.drop_p > 0.f ? 1.f / (1.f - g.drop_p) : 1.f;
+  ek.dp_inv = g.dp_p > 0.f ? 1.f / (1.f - g.dp_p) : 1.f;
+
+  // this thread's staging slots: vector idx = tid + i*256 -> row idx/8, 8-element column group idx%8
+  const int sv = tid & 7, sr = tid >> 3;            // rows advance by 32 per slot
+  float mu[AV], rs[AV], rowf[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int m = m0 + sr + 32 * i;
+    mu[i] = 0.f; rs[i] = 0.f; rowf[i] = 1.f;
+    if (m < g.M) {
+      if (AMODE == 1) { mu[i] = g.ln_mean[m]; rs[i] = g.ln_rstd[m]; }
+      if (bwd) {
+        rowf[i] = g.a_scale;
+        if (g.a_dp_p > 0.f) rowf[i] *= drop_factor(key_adp, (uint32_t)(m / g.a_dp_rows), g.a_dp_p, a_dp_inv);
+      }
+    }
+  }
+  if (AMODE == 1) {
+    for (int k = tid; k < g.K; k += 256) { Gs[k] = g.ln_gamma[k]; Gs[g.K + k] = g.ln_beta[k]; }
+  }
+
+  bf16x8 pa[AV], pz[AV], pb[BV];
+  auto prefetch = [&](int k0) {
+    const int k = k0 + sv * 8;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int m = m0 + sr + 32 * i;
+      bf16x8 x, z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { x[j] = (bf16)0.f; z[j] = (bf16)0.f; }
+      if (m < g.M && k < g.K) {
+        x = *reinterpret_cast<const bf16x8*>(A + (size_t)m * g.lda + k);
+        if (use_z) z = *reinterpret_cast<const bf16x8*>(Zin + (size_t)m * g.a_ldz + k);
+      }
+      pa[i] = x;
+      pz[i] = z;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int n = n0 + sr + 32 * i;
+      bf16x8 x;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = (bf16)0.f;
+      if (n < g.N && k < g.K) x = *reinterpret_cast<const bf16x8*>(B + (size_t)n * g.ldb + k);
+      pb[i] = x;
+    }
+  };
+  auto commit = [&](int k0) {
+    const int k = k0 + sv * 8;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int m = m0 + sr + 32 * i;
+      bf16x8 o = pa[i];
+      if (AMODE == 1 && m < g.M && k < g.K) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 4) {
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(Gs + k + j);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(Gs + g.K + k + j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[j + q] = (bf16)(((float)o[j + q] - mu[i]) * rs[i] * ga[q] + be[q]);
+        }
+      }
+      if (bwd && m < g.M && k < g.K) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)o[j] * rowf[i];
+        if (g.a_drop_p > 0.f) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] *= drop_factor(key_adrop, (uint32_t)m * (uint32_t)g.K + (uint32_t)(k + j), g.a_drop_p, a_inv_keep);
+        }
+        if (use_z) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] *= gelu_grad_f((float)pz[i][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)f[j];
+        if (write_aout) *reinterpret_cast<bf16x8*>(Aout + (size_t)m * g.a_ldo + k) = o;
+      }
+      *reinterpret_cast<bf16x8*>(As + (sr + 32 * i) * LDT + sv * 8) = o;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<bf16x8*>(Bs + (sr + 32 * i) * LDT + sv * 8) = pb[i];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  prefetch(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    __syncthreads();                                  // previous chunk's MFMAs are done with As/Bs (and Gs is staged)
+    commit(k0);
+    __syncthreads();
+    if (k0 + BK < g.K) prefetch(k0 + BK);
+    const int nf = (g.K - k0 < BK) ? (g.K - k0) / 32 : BK / 32;
+    for (int kf = 0; kf < nf; ++kf) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + ((wm * TM + i) * 16 + fr) * LDT + kf * 32 + fq * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * TN + j) * 16 + fr) * LDT + kf * 32 + fq * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                    // As/Bs are dead: reuse them as per-wave epilogue scratch
+  float* Ws = reinterpret_cast<float*>(smem) + wave * 16 * WLD;
+  constexpr int CG = WN / 16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ws[(fq * 4 + r) * WLD + j * 16 + fr] = acc[i][j][r];
+    wave_sync();
+    for (int idx = lane; idx < 16 * CG; idx += 64) {
+      const int r = idx / CG, cg = idx - r * CG;
+      const int m = m0 + (wm * TM + i) * 16 + r;
+      const int n = n0 + wn * WN + cg * 16;
+      if (m < g.M && n < g.N) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(Ws + r * WLD + cg * 16 + q);
+          v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+        }
+        epilogue16<EPI>(g, ek, m, n, v);
+      }
+    }
+    wave_sync();
+  }
+}
+
+template <int BM_, int BN_, int AMODE, int EPI>
+int big_launch(const qavit_gemm_args& g, hipStream_t st) {
+  const int n_tiles_m = (g.M + BM_ - 1) / BM_, ncb = (g.N + BN_ - 1) / BN_;
+  size_t smem = (size_t)(BM_ + BN_) * LDT * 2 + (AMODE == 1 ? (size_t)2 * g.K * 4 : 0);
+  const size_t scratch = (size_t)4 * 16 * (BN_ / 2 + 4) * 4;
+  if (smem < scratch) smem = scratch;
+  if (smem > 150 * 1024) return -100;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<BM_, BN_, AMODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int grid = (n_tiles_m + 7) / 8 * 8 * ncb;
+  hipLaunchKernelGGL((gemm_nt_big_kernel<BM_, BN_, AMODE, EPI>), dim3(grid), dim3(256), smem, st, g, n_tiles_m, ncb);
+  return QAVIT_OK;
+}
+
+template <int BM_, int BN_>
+int big_modes(const qavit_gemm_args& g, hipStream_t st) {
+  const bool full = g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f;
+  if (g.a_mode == 1) return full ? big_launch<BM_, BN_, 1, 1>(g, st) : big_launch<BM_, BN_, 1, 0>(g, st);
+  if (g.a_mode == 2) return full ? big_launch<BM_, BN_, 2, 1>(g, st) : big_launch<BM_, BN_, 2, 0>(g, st);
+  return full ? big_launch<BM_, BN_, 0, 1>(g, st) : big_launch<BM_, BN_, 0, 0>(g, st);
+}
+
+}  // namespace
+
+// returns 1 = launched, 0 = not applicable (caller falls back to the resident-slice kernel), < 0 error
+int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st) {
+  static long thresh = -1, force_bn = 0;
+  if (thresh < 0) {
+    const char* e = getenv("QAVIT_GEMM_BIG"); thresh = e ? atol(e) : 64L * 128L;
+    e = getenv("QAVIT_BIG_BN"); force_bn = e ? atol(e) : 0;
+  }
+  if (thresh == 0 || (long)g.N * g.K < thresh || g.N < 64 || g.K < 128 || g.M < 1024) return 0;
+  if (g.K % 32) return 0;
+  auto al = [](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
+  if (!al(g.A, g.lda) || !al(g.B, g.ldb)) return 0;
+  if (g.a_mode == 2) {
+    if (g.a_Z && g.a_act && !al(g.a_Z, g.a_ldz)) return 0;
+    if (g.a_out && !al(g.a_out, g.a_ldo)) return 0;
+  }
+  // column block: the whole N when the A-side transform is expensive (a_mode 2 would repeat it per block), otherwise
+  // 128-wide blocks (64 accumulator registers -> two workgroups per CU) unless N is a multiple of 192 only
+  int bn;
+  if (g.a_mode == 2 && g.N <= 256) bn = g.N > 192 ? 256 : (g.N > 128 ? 192 : 128);
+  else if (g.N % 128 == 0) bn = 128;
+  else if (g.N % 192 == 0) bn = 192;
+  else bn = g.N > 192 ? 256 : (g.N > 128 ? 192 : 128);
+  if (force_bn) bn = (int)force_bn;
+  const int ncb = (g.N + bn - 1) / bn;
+  const bool bm128 = (long)((g.M + 127) / 128) * ncb >= 448;
+  int rc;
+  if (bn == 256) rc = big_modes<128, 256>(g, st);                      // 64-row tiles would starve the MFMA pipe here
+  else if (bn == 192) rc = bm128 ? big_modes<128, 192>(g, st) : big_modes<64, 192>(g, st);
+  else rc = bm128 ? big_modes<128, 128>(g, st) : big_modes<64, 128>(g, st);
+  if (rc == -100) return 0;
+  if (rc != QAVIT_OK) return rc;
+  rc = check_launch("gemm_nt(big)");
+  return rc == QAVIT_OK ? 1 : rc;
+}
+
+}  // namespace qv

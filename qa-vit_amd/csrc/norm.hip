@@ -1,6 +1,7 @@
 // nn.LayerNorm over the channel axis, forward and backward.  HBM-bound streaming kernels: one wavefront
 // per row, 64 lanes stride the C <= 1024 channels, statistics by wave shuffles (no LDS in forward).
 #include "common.cuh"
+#include <stdlib.h>
 #include "../../include/qavit.h"
 #include "launch.h"
 
@@ -147,9 +148,11 @@ template <typename T> struct V4;
 template <> struct V4<float> { typedef f32x4 type; };
 template <> struct V4<bf16> { typedef bf16x4 type; };
 
-template <typename T, int NP>
-__global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+template <typename T, int NP, int RB, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                                const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C) {
+  // RB rows per wave per iteration: all their loads are issued before the first reduction, so a wave keeps
+  // 2*RB*NP vector loads in flight instead of 2 (the row loop is a pure load -> reduce -> store latency chain).
   typedef typename V4<T>::type v4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invC = 1.f / (float)C;
@@ -160,56 +163,78 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const T* dy, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; gm[i][j] = (c + j < C) ? gamma[c + j] : 0.f; }
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NP][4], g[NP][4];
-    float c1 = 0.f, c2 = 0.f;
+  for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
+    v4 xv[RB][NP], dv[RB][NP];
+    float mu[RB], rs[RB];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int c = 4 * lane + 256 * i;
-      if (c < C) {
-        const v4 xv = *reinterpret_cast<const v4*>(x + (size_t)row * C + c);
-        const v4 dv = *reinterpret_cast<const v4*>(dy + (size_t)row * C + c);
+    for (int r = 0; r < RB; ++r) {
+      const int row = row0 + r < rows ? row0 + r : rows - 1;       // clamp: tail rows are loaded twice, stored once
+      mu[r] = mean[row]; rs[r] = rstd[row];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = to_f<T>(dv[j]);
-          xh[i][j] = (to_f<T>(xv[j]) - mu) * rs;
-          g[i][j] = d * gm[i][j];
-          pg[i][j] += d * xh[i][j];
-          pb[i][j] += d;
-          c1 += g[i][j] * xh[i][j];
-          c2 += g[i][j];
+      for (int i = 0; i < NP; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < C) {
+          xv[r][i] = *reinterpret_cast<const v4*>(x + (size_t)row * C + c);
+          dv[r][i] = *reinterpret_cast<const v4*>(dy + (size_t)row * C + c);
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
       }
     }
-    c1 = wave_sum(c1) * invC;
-    c2 = wave_sum(c2) * invC;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int c = 4 * lane + 256 * i;
-      if (c < C) {
-        v4 o;
+    for (int r = 0; r < RB; ++r) {
+      const bool live = row0 + r < rows;
+      float xh[NP][4], g[NP][4];
+      float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = from_f<T>(rs * (g[i][j] - c2 - xh[i][j] * c1));
-        *reinterpret_cast<v4*>(dx + (size_t)row * C + c) = o;
+      for (int i = 0; i < NP; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < C) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = live ? to_f<T>(dv[r][i][j]) : 0.f;
+            xh[i][j] = (to_f<T>(xv[r][i][j]) - mu[r]) * rs[r];
+            g[i][j] = d * gm[i][j];
+            pg[i][j] += d * xh[i][j];
+            pb[i][j] += d;
+            c1 += g[i][j] * xh[i][j];
+            c2 += g[i][j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+        }
+      }
+      c1 = wave_sum(c1) * invC;
+      c2 = wave_sum(c2) * invC;
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int c = 4 * lane + 256 * i;
+          if (c < C) {
+            v4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = from_f<T>(rs[r] * (g[i][j] - c2 - xh[i][j] * c1));
+            *reinterpret_cast<v4*>(dx + (size_t)(row0 + r) * C + c) = o;
+          }
+        }
       }
     }
   }
-  __shared__ float red[2][4][256];
+  __shared__ float red[2][NW][256];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[0][wave][4 * lane + j] = pg[i][j]; red[1][wave][4 * lane + j] = pb[i][j]; }
     __syncthreads();
-    const int c = threadIdx.x + 256 * i;
-    if (c < C) {
-      const int t = threadIdx.x;
-      if (dgamma) atomic_add_f(dgamma + c, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
-      if (dbeta) atomic_add_f(dbeta + c, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+    for (int t = threadIdx.x; t < 512; t += 64 * NW) {          // 256 channels x {gamma, beta}
+      const int which = t >> 8, cc = t & 255, c = cc + 256 * i;
+      float* dst = which ? dbeta : dgamma;
+      if (c < C && dst) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sacc += red[which][w][cc];
+        atomic_add_f(dst + c, sacc);
+      }
     }
   }
 }
@@ -268,12 +293,16 @@ extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, con
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = (rows + 3) / 4;
   if (grid > 512) grid = 512;     // every workgroup ends with 2*C same-address atomics: keep the flush small
+  static const int v4_cap = getenv("QAVIT_LNB_GRID") ? atoi(getenv("QAVIT_LNB_GRID")) : 256;
   const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
   const bool v4ok = !dadd && (C % 4 == 0) && C <= 1024 &&
                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) % (4 * esz) == 0);
   if (v4ok) {
     const int np = (C + 255) / 256;
-#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_>), dim3(grid), dim3(256), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C)
+    constexpr int NW = 16;
+    grid = (rows + 4 * NW - 1) / (4 * NW);
+    if (grid > v4_cap) grid = v4_cap;
+#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_, (NP_ <= 2 ? 4 : 2), NW>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C)
     if (dtype == QAVIT_F32) { if (np == 1) LNV(float, 1); else if (np == 2) LNV(float, 2); else LNV(float, 4); }
     else if (dtype == QAVIT_BF16) { if (np == 1) LNV(bf16, 1); else if (np == 2) LNV(bf16, 2); else LNV(bf16, 4); }
     else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");

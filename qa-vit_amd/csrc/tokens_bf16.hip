@@ -10,11 +10,7 @@
 namespace qv {
 
 // Waves of a workgroup run different trip counts here, so no workgroup barrier may sit inside the image loops: each wave
-// owns its LDS tiles; LDS operations of one wave execute in issue order, this only stops the compiler reordering them.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
+// owns its LDS tiles and orders its own LDS traffic with wave_sync() (common.cuh).
 
 // ------------------------------------------------------------------------------------------------
 // bank statistics: U[s][c] += sum_b softmax_n(tn Wg^T + bg)^T tn,  tn = LN_write(LN_branch(tokens))
