@@ -731,6 +731,38 @@ extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* s
   using namespace qv;
   if (!a || n <= 0) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: empty group");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static int legacy = -1;
+  if (legacy < 0) { const char* e = getenv("QAVIT_TN_LEGACY"); legacy = e ? atoi(e) : 0; }
+  for (int i = 0; i < n; ++i) {
+    const qavit_gemm_tn_args& g = a[i];
+    if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: bad problem");
+    if (g.lda < g.N || g.ldb < g.K || g.ldc < g.K) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: leading dimension too small");
+    if (g.ln_mean && (!g.ln_rstd || !g.ln_gamma || !g.ln_beta)) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: incomplete LayerNorm-on-load arguments");
+    if (g.dtype != QAVIT_BF16 && g.dtype != QAVIT_F32) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: unknown dtype");
+  }
+  if (!legacy) {
+    // bf16 problems: wide-tile kernel, grouped by tile class.  fp32 problems: the single-problem path.
+    int done = 0;
+    while (done < n) {
+      if (a[done].dtype != QAVIT_BF16) {
+        const int rc = launch_gemm_tn<float>(a[done], st);
+        if (rc) return rc;
+        ++done;
+        continue;
+      }
+      int e = done;
+      while (e < n && a[e].dtype == QAVIT_BF16) ++e;
+      const int rc = gemm_tn_wide(a + done, e - done, st);
+      if (rc) return rc;
+      for (int i = done; i < e; ++i) {                 // odd strides / alignments: generic 64x64-tile kernel
+        if (gemm_tn_wide_ok(a[i])) continue;
+        const int rc2 = launch_gemm_tn<bf16>(a[i], st);
+        if (rc2) return rc2;
+      }
+      done = e;
+    }
+    return QAVIT_OK;
+  }
   int done = 0;
   while (done < n) {
     TnGroup G;
@@ -738,10 +770,8 @@ extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* s
     int wg = 0;
     while (done < n && G.n < TN_GROUP) {
       const qavit_gemm_tn_args& g = a[done];
-      if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: bad problem");
-      if (g.lda < g.N || g.ldb < g.K || g.ldc < g.K) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: leading dimension too small");
       if (g.dtype != QAVIT_BF16) {            // fp32 problems run through the single-problem path
-        int rc = qavit_gemm_tn(&g, stream);
+        int rc = launch_gemm_tn<float>(g, st);
         if (rc) return rc;
         ++done;
         continue;
@@ -770,6 +800,6 @@ extern "C" int qavit_gemm_tn(const qavit_gemm_tn_args* a, void* stream) {
   if (a->ln_mean && (!a->ln_rstd || !a->ln_gamma || !a->ln_beta)) return set_error(QAVIT_EINVAL, "gemm_tn: incomplete LayerNorm-on-load arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == QAVIT_F32) return launch_gemm_tn<float>(*a, st);
-  if (a->dtype == QAVIT_BF16) return launch_gemm_tn<bf16>(*a, st);
+  if (a->dtype == QAVIT_BF16) return qavit_gemm_tn_grouped(a, 1, stream);
   return set_error(QAVIT_EINVAL, "gemm_tn: unknown dtype");
 }

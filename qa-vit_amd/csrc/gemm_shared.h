@@ -7,4 +7,8 @@ namespace qv {
 // bf16 K-loop kernel for problems whose weight is too large for a resident LDS slice (gemm_big.hip).
 // 1 = launched, 0 = not applicable, < 0 = error code.
 int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st);
+// bf16 weight-gradient GEMMs with wide output tiles, grouped by tile class (gemm_tn_wide.hip).  Problems must be
+// validated bf16 problems; returns QAVIT_OK or an error code.
+int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st);   // launches the problems with gemm_tn_wide_ok()
+bool gemm_tn_wide_ok(const qavit_gemm_tn_args& g);
 }  // namespace qv

@@ -1,5 +1,6 @@
 """Raw (non-autograd) Python wrappers over the C-ABI: tensors in, kernels enqueued on torch's current
 stream.  PyTorch is plumbing here -- device memory, streams -- the arithmetic is in libqavit_hip.so."""
+import os
 import ctypes as C
 from typing import Optional
 
@@ -128,7 +129,7 @@ class DeferredTN:
     for the duration of a backward pass; queued problems keep their operand tensors alive until ``flush``."""
     enabled = False
     queue = []          # (GemmTnArgs, keepalive tuple)
-    MAX = 48
+    MAX = int(os.environ.get("QAVIT_DW_QUEUE", "96"))
 
     @classmethod
     def flush(cls):
