@@ -7,6 +7,7 @@
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
+#include <stdlib.h>
 
 namespace qv {
 
@@ -117,86 +118,138 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* dy, const T* x
 // ------------------------------------------------------------------------------------------------
 // 8x8 feature maps (the CIFAR lateral path): the whole map of one channel fits a lane's registers.  One lane =
 // one channel of one image; taps, rows and columns are compile-time loops, so every index is a register name and
-// the border tests fold away -- no LDS traffic inside the 49-tap loops.  4 waves of a workgroup take different
-// images of the same 64 channels; dw/dbias partials are reduced across them in LDS, one atomic per element per WG.
+// the border tests fold away -- no LDS traffic inside the tap loops.  4 waves of a workgroup take different
+// images of the same 64 channels.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KS>
-__global__ __launch_bounds__(256, 1) void dwconv_bwd8_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int C) {
+__global__ __launch_bounds__(256) void dwconv_fwd8_kernel(const T* x, const float* w, const float* bias, T* y, int B, int C) {
   constexpr int HW = 8, N = 64, R = KS / 2;
-  __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const bool cok = c < C;
-  float wt[KS * KS], aw[KS * KS];
+  const int cc = cok ? c : 0;                          // clamped: loads stay unconditional
+  float wt[KS * KS];
 #pragma unroll
-  for (int t = 0; t < KS * KS; ++t) { wt[t] = cok ? w[(size_t)c * KS * KS + t] : 0.f; aw[t] = 0.f; }
-  float ab = 0.f;
+  for (int t = 0; t < KS * KS; ++t) wt[t] = w[(size_t)cc * KS * KS + t];
+  const float bv = bias ? bias[cc] : 0.f;
   for (int b = blockIdx.y * 4 + wave; b < B; b += gridDim.y * 4) {
-    float g[N];
+    float xi[N];
 #pragma unroll
-    for (int n = 0; n < N; ++n) g[n] = cok ? to_f<T>(dy[((size_t)b * N + n) * C + c]) : 0.f;
-    // dx = full correlation of dy with the flipped taps
+    for (int n = 0; n < N; ++n) xi[n] = to_f<T>(x[((size_t)b * N + n) * C + cc]);
 #pragma unroll
     for (int yy = 0; yy < HW; ++yy) {
       float o[HW];
 #pragma unroll
       for (int xx = 0; xx < HW; ++xx) {
-        float s = 0.f;
+        float s_ = bv;
 #pragma unroll
         for (int dyy = 0; dyy < KS; ++dyy) {
-          const int yo = yy - dyy + R;
-          if (yo < 0 || yo >= HW) continue;
+          const int y2 = yy + dyy - R;
+          if (y2 < 0 || y2 >= HW) continue;
 #pragma unroll
           for (int dxx = 0; dxx < KS; ++dxx) {
-            const int xo = xx - dxx + R;
-            if (xo < 0 || xo >= HW) continue;
-            s += wt[dyy * KS + dxx] * g[yo * HW + xo];
+            const int x2 = xx + dxx - R;
+            if (x2 < 0 || x2 >= HW) continue;
+            s_ += wt[dyy * KS + dxx] * xi[y2 * HW + x2];
           }
         }
-        o[xx] = s;
+        o[xx] = s_;
       }
       if (cok) {
 #pragma unroll
-        for (int xx = 0; xx < HW; ++xx) dx[((size_t)b * N + yy * HW + xx) * C + c] = from_f<T>(o[xx]);
+        for (int xx = 0; xx < HW; ++xx) y[((size_t)b * N + yy * HW + xx) * C + c] = from_f<T>(o[xx]);
       }
     }
-    // dw[tap] += sum_n dy[n] * x[n + off(tap)]
-    float xi[N];
+  }
+}
+
+// Backward: dx first (needs dy + taps), then dw with x streamed one ROW at a time -- x row y2 meets dy row yy through
+// tap row dyy = y2 - yy + R -- so only 8 values of x are live next to dy[64] and the 49 tap sums: no scratch spills
+// at 7x7.  The tap sums of the 4 waves are folded through LDS in ONE pass and leave as contiguous fp32 atomics
+// (one [64 channels x taps] block per workgroup).
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_bwd8_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int C) {
+  constexpr int HW = 8, N = 64, R = KS / 2, KK = KS * KS;
+  __shared__ float red[4][64 * KK + 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64, c = c0 + lane;
+  const bool cok = c < C;
+  const int cc = cok ? c : 0;
+  float aw[KK];
 #pragma unroll
-    for (int n = 0; n < N; ++n) xi[n] = cok ? to_f<T>(x[((size_t)b * N + n) * C + c]) : 0.f;
+  for (int t = 0; t < KK; ++t) aw[t] = 0.f;
+  float ab = 0.f;
+  for (int b = blockIdx.y * 4 + wave; b < B; b += gridDim.y * 4) {
+    float g[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) g[n] = to_f<T>(dy[((size_t)b * N + n) * C + cc]);
+    {
+      float wt[KK];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) wt[t] = w[(size_t)cc * KK + t];      // L1/L2-resident; keeps 49 registers free in the dw phase
+      // dx = full correlation of dy with the flipped taps
+#pragma unroll
+      for (int yy = 0; yy < HW; ++yy) {
+        float o[HW];
+#pragma unroll
+        for (int xx = 0; xx < HW; ++xx) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int dyy = 0; dyy < KS; ++dyy) {
+            const int yo = yy - dyy + R;
+            if (yo < 0 || yo >= HW) continue;
+#pragma unroll
+            for (int dxx = 0; dxx < KS; ++dxx) {
+              const int xo = xx - dxx + R;
+              if (xo < 0 || xo >= HW) continue;
+              s_ += wt[dyy * KS + dxx] * g[yo * HW + xo];
+            }
+          }
+          o[xx] = s_;
+        }
+        if (cok) {
+#pragma unroll
+          for (int xx = 0; xx < HW; ++xx) dx[((size_t)b * N + yy * HW + xx) * C + c] = from_f<T>(o[xx]);
+        }
+      }
+    }
 #pragma unroll
     for (int n = 0; n < N; ++n) ab += g[n];
+    // dw[dyy][dxx] += sum_{yy,xx} dy[yy][xx] * x[yy+dyy-R][xx+dxx-R], one x row at a time
 #pragma unroll
-    for (int dyy = 0; dyy < KS; ++dyy)
+    for (int y2 = 0; y2 < HW; ++y2) {
+      float xr[HW];
 #pragma unroll
-      for (int dxx = 0; dxx < KS; ++dxx) {
-        float s = 0.f;
+      for (int xx = 0; xx < HW; ++xx) xr[xx] = to_f<T>(x[((size_t)b * N + y2 * HW + xx) * C + cc]);
 #pragma unroll
-        for (int yy = 0; yy < HW; ++yy) {
-          const int y2 = yy + dyy - R;
-          if (y2 < 0 || y2 >= HW) continue;
+      for (int yy = 0; yy < HW; ++yy) {
+        const int dyy = y2 - yy + R;
+        if (dyy < 0 || dyy >= KS) continue;
+#pragma unroll
+        for (int dxx = 0; dxx < KS; ++dxx) {
+          float s_ = 0.f;
 #pragma unroll
           for (int xx = 0; xx < HW; ++xx) {
             const int x2 = xx + dxx - R;
             if (x2 < 0 || x2 >= HW) continue;
-            s += g[yy * HW + xx] * xi[y2 * HW + x2];
+            s_ += g[yy * HW + xx] * xr[x2];
           }
+          aw[dyy * KS + dxx] += s_;
         }
-        aw[dyy * KS + dxx] += s;
       }
+    }
   }
+  // fold the 4 waves: red[wave][channel-in-chunk * KK + tap] mirrors dw's own layout for this 64-channel block
 #pragma unroll
-  for (int t = 0; t < KS * KS; ++t) {
-    __syncthreads();
-    red[wave][lane] = aw[t];
-    __syncthreads();
-    if (wave == 0 && cok) atomic_add_f(dw + (size_t)c * KS * KS + t, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
-  }
-  if (dbias) {
-    __syncthreads();
-    red[wave][lane] = ab;
-    __syncthreads();
-    if (wave == 0 && cok) atomic_add_f(dbias + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  for (int t = 0; t < KK; ++t) red[wave][lane * KK + t] = cok ? aw[t] : 0.f;
+  red[wave][64 * KK + lane] = cok ? ab : 0.f;
+  __syncthreads();
+  const int live = (C - c0 < 64 ? C - c0 : 64);
+  for (int i = threadIdx.x; i < live * KK; i += 256)
+    atomic_add_f(dw + (size_t)c0 * KK + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  if (dbias && threadIdx.x < live) {
+    const int i = 64 * KK + threadIdx.x;
+    atomic_add_f(dbias + c0 + threadIdx.x, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
   }
 }
 
@@ -205,6 +258,13 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
                      int B, int H, int W, int C, hipStream_t st) {
   const int N = H * W;
   const int chunks = (C + DW_CH - 1) / DW_CH;
+  if (!bwd && H == 8 && W == 8) {
+    int gy8 = (B + 3) / 4;
+    const int cap = 1024 / chunks > 0 ? 1024 / chunks : 1;
+    if (gy8 > cap) gy8 = cap;
+    hipLaunchKernelGGL((dwconv_fwd8_kernel<T, KS>), dim3(chunks, gy8), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, C);
+    return check_launch("dwconv_fwd8");
+  }
   if (!bwd) {
     const size_t smem = ((size_t)N * DW_CH + KS * KS * DW_CH) * sizeof(float);
     if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "dwconv_fwd: feature map too large for LDS");
@@ -216,7 +276,8 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
   }
   if (H == 8 && W == 8) {
     int gy8 = (B + 3) / 4;
-    const int cap = 512 / chunks > 0 ? 512 / chunks : 1;
+    static const int wgs8 = getenv("QAVIT_DW8_WGS") ? atoi(getenv("QAVIT_DW8_WGS")) : 256;
+    const int cap = wgs8 / chunks > 0 ? wgs8 / chunks : 1;
     if (gy8 > cap) gy8 = cap;
     hipLaunchKernelGGL((dwconv_bwd8_kernel<T, KS>), dim3(chunks, gy8), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, C);
     return check_launch("dwconv_bwd8");
