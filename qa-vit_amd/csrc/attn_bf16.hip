@@ -13,6 +13,7 @@
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
+#include <stdlib.h>
 #include "attn_shared.h"
 #include "frag16.cuh"
 
@@ -368,6 +369,12 @@ int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) 
   if (a.L > 0 && (!al(a.k_tok, 8) || !al(a.v_tok, 8))) return 0;
   if (a.mode == 0 && (!al(a.E_k, 16) || !al(a.E_v, 16))) return 0;
   if (bwd && (a.lddo % 4 || !al(a.d_o, 8))) return 0;
+  {
+    static int use3 = -1;
+    if (use3 < 0) { const char* e = getenv("QAVIT_ATTN3"); use3 = e ? atoi(e) : 1; }
+    const int t3 = use3 ? attn3_try(a, bwd, grid, st) : 0;
+    if (t3) return t3;
+  }
   int rc = -100;
   if (a.mode == 0 && nkt <= 3 && dt == 3) rc = a2_launch<0, 3, 3>(a, bwd, grid, st);
   else if (a.mode == 1 && nkt == 1 && dt == 3) rc = a2_launch<1, 1, 3>(a, bwd, grid, st);

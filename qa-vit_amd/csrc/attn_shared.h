@@ -18,5 +18,7 @@ __device__ __forceinline__ int64_t attn_krow(const qavit_attn_args& a, int g, in
 
 // bf16 fast path: 1 = launched, 0 = shape not covered (fall back to the generic kernel), < 0 = error
 int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st);
+// small-problem variant (<= 16 queries / token keys; attn3_bf16.hip), same return convention; called by attn_bf16_try
+int attn3_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st);
 
 }  // namespace qv
