@@ -324,9 +324,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
   for (int i = lane; i < n_acc; i += 64) ws[i] = sm[acc0 + i];
 }
 
-// fold the per-wave partials into the gradient buffers: thread = output element, blockIdx.y = slice of 32 waves
+// fold the per-wave partials into the gradient buffers: thread = output element, blockIdx.y = slice of 8*H waves
 // (coalesced reads across the element axis, one fp32 atomic per thread)
-constexpr int RED_WAVES = 32;
+constexpr int RED_WAVES = 8;
 __global__ __launch_bounds__(256) void attn_reduce_kernel(qavit_attn_args a, int nwaves) {
   const int nE = (a.mode == 0) ? a.L * a.KC : 0;
   const int nS = a.S * a.D;
@@ -339,7 +339,14 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(qavit_attn_args a, int
   if (w1 > nwaves) w1 = nwaves;
   float s = 0.f;
   if (i < 2 * nE) {
-    for (int w = w0; w < w1; ++w) s += a.ws[(size_t)w * per + i];
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;                   // independent chains: the loads of a slice are all in flight
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
+      s += a.ws[(size_t)w * per + i]; s1 += a.ws[(size_t)(w + 1) * per + i];
+      s2 += a.ws[(size_t)(w + 2) * per + i]; s3 += a.ws[(size_t)(w + 3) * per + i];
+    }
+    for (; w < w1; ++w) s += a.ws[(size_t)w * per + i];
+    s += s1 + s2 + s3;
     float* dst = (i < nE) ? a.dE_k : a.dE_v;
     if (dst) atomic_add_f(dst + (i < nE ? i : i - nE), s);
   } else {
@@ -347,7 +354,12 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(qavit_attn_args a, int
     const int which = r / (nS * a.H); r -= which * nS * a.H;
     const int h = r / nS; r -= h * nS;
     const int srow = r / a.D, dd = r - srow * a.D;
-    for (int w = w0 + h; w < w1; w += a.H) s += a.ws[(size_t)w * per + 2 * nE + which * nS + srow * a.D + dd];
+    const size_t off = (size_t)2 * nE + which * nS + srow * a.D + dd;
+    float s1 = 0.f;
+    int w = w0 + h;
+    for (; w + a.H < w1; w += 2 * a.H) { s += a.ws[(size_t)w * per + off]; s1 += a.ws[(size_t)(w + a.H) * per + off]; }
+    for (; w < w1; w += a.H) s += a.ws[(size_t)w * per + off];
+    s += s1;
     float* dst = which == 0 ? a.dsh_k : a.dsh_v;
     if (dst) atomic_add_f(dst + (size_t)srow * a.H * a.D + h * a.D + dd, s);
   }

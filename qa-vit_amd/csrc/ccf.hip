@@ -192,6 +192,167 @@ __global__ __launch_bounds__(256) void ccf_bwd_kernel(qavit_ccf_args p) {
   for (int i = threadIdx.x; i < 9 * C; i += 256) atomic_add_f(p.dw + i, pw[i]);
 }
 
+
+// Backward with NO LDS atomics.  Every phase uses one mapping -- wave w owns rows w, w+4, ...; lane l owns channels
+// l, l+64, ... (CP of them) -- so each parameter-gradient partial (LN gammas/betas, conv bias/scale, the 9 taps) is a
+// register of the thread that owns the channel, summed over the rows and images the thread visits, and folded across
+// the 4 waves through LDS once at the end.  (The first version issued 13 same-address LDS atomics per element.)
+template <typename T, int CP>
+__global__ __launch_bounds__(256) void ccf_bwd2_kernel(qavit_ccf_args p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = p.Hs * p.Ws, C = p.C;
+  float* hin = sm;                 // [N][C] raw input h (LN1 input)
+  float* a = hin + N * C;          // [N][C] LN1 output
+  float* raw = a + N * C;          // [N][C] conv (+bias) before scale; later d(LN1 output), then dh
+  float* t = raw + N * C;          // [N][C] LN2 input, then d(conv output)
+  const T* h = reinterpret_cast<const T*>(p.h);
+  const T* dout = reinterpret_cast<const T*>(p.d_out);
+  T* dh = reinterpret_cast<T*>(p.d_h);
+  const bool ln = p.flags & F_LN, hb = p.flags & F_BIAS, hs = p.flags & F_SCALE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  float rg1[CP], rb1[CP], rg2[CP], rb2[CP], rcb[CP], rcs[CP], rw[CP][9], wt[CP][9], g1v[CP], g2v[CP], csv[CP];
+#pragma unroll
+  for (int k = 0; k < CP; ++k) {
+    const int c = lane + 64 * k;
+    const bool ok = c < C;
+    rg1[k] = rb1[k] = rg2[k] = rb2[k] = rcb[k] = rcs[k] = 0.f;
+    g1v[k] = (ok && ln) ? p.g1[c] : 0.f;
+    g2v[k] = (ok && ln) ? p.g2[c] : 0.f;
+    csv[k] = (ok && hs) ? p.cscale[c] : 1.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { rw[k][q] = 0.f; wt[k][q] = ok ? p.w[c * 9 + q] : 0.f; }
+  }
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * C; i += 256) { const float v = to_f<T>(h[(size_t)b * N * C + i]); hin[i] = v; a[i] = v; }
+    __syncthreads();
+    if (ln) { ln_rows(a, N, C, p.g1, p.b1, p.eps, nullptr, nullptr); __syncthreads(); }
+    dwconv_rows(a, t, p.w, hb ? p.cbias : nullptr, hs ? p.cscale : nullptr, p.Hs, p.Ws, C, raw);
+    __syncthreads();
+    // LN2 backward, then d(conv output) = dt * scale, with dscale / dbias partials -- one pass over the owned elements
+    for (int r = wave; r < N; r += 4) {
+      const T* gr = dout + ((size_t)b * N + r) * C;
+      float* tr = t + r * C;
+      const float* rr = raw + r * C;
+      float d[CP], xh[CP];
+      float c1 = 0.f, c2 = 0.f;
+      float mu = 0.f, rs = 1.f;
+      if (ln) { mu = p.mean2[(size_t)b * N + r]; rs = p.rstd2[(size_t)b * N + r]; }
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        d[k] = 0.f; xh[k] = 0.f;
+        if (c < C) {
+          d[k] = to_f<T>(gr[c]);
+          xh[k] = (tr[c] - mu) * rs;
+          const float gg = d[k] * g2v[k];
+          c1 += gg * xh[k]; c2 += gg;
+        }
+      }
+      if (ln) { c1 = wave_sum(c1) * invC; c2 = wave_sum(c2) * invC; }
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+          float dt = d[k];
+          if (ln) {
+            rg2[k] += d[k] * xh[k];
+            rb2[k] += d[k];
+            dt = rs * (d[k] * g2v[k] - c2 - xh[k] * c1);
+          }
+          if (hs) { rcs[k] += dt * rr[c]; dt *= csv[k]; }
+          rcb[k] += dt;
+          tr[c] = dt;
+        }
+      }
+    }
+    __syncthreads();
+    // conv backward: tap partials in registers, d(LN1 output) into raw
+    for (int r = wave; r < N; r += 4) {
+      const int y = r / p.Ws, x = r - y * p.Ws;
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+          const float dc = t[r * C + c];
+          float da = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int yy = y + dy - 1, xx = x + dx - 1;           // forward tap read by output (y,x)
+              if (yy >= 0 && yy < p.Hs && xx >= 0 && xx < p.Ws) rw[k][dy * 3 + dx] += dc * a[(yy * p.Ws + xx) * C + c];
+              const int yo = y - dy + 1, xo = x - dx + 1;           // outputs that read input (y,x) through tap (dy,dx)
+              if (yo >= 0 && yo < p.Hs && xo >= 0 && xo < p.Ws) da += wt[k][dy * 3 + dx] * t[(yo * p.Ws + xo) * C + c];
+            }
+          raw[r * C + c] = da;
+        }
+      }
+    }
+    wave_sync();                                        // LN1 backward reads only the rows this wave just wrote
+    for (int r = wave; r < N; r += 4) {
+      const float* xr = hin + r * C;
+      const float* gr = raw + r * C;
+      float d[CP], xh[CP];
+      float c1 = 0.f, c2 = 0.f, mu = 0.f, rs = 1.f;
+      if (ln) { mu = p.mean1[(size_t)b * N + r]; rs = p.rstd1[(size_t)b * N + r]; }
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        d[k] = 0.f; xh[k] = 0.f;
+        if (c < C) {
+          d[k] = gr[c];
+          xh[k] = (xr[c] - mu) * rs;
+          const float gg = d[k] * g1v[k];
+          c1 += gg * xh[k]; c2 += gg;
+        }
+      }
+      if (ln) { c1 = wave_sum(c1) * invC; c2 = wave_sum(c2) * invC; }
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+          float dx = d[k];
+          if (ln) {
+            rg1[k] += d[k] * xh[k];
+            rb1[k] += d[k];
+            dx = rs * (d[k] * g1v[k] - c2 - xh[k] * c1);
+          }
+          dh[((size_t)b * N + r) * C + c] = from_f<T>(dx);
+        }
+      }
+    }
+  }
+  // fold the 4 waves: part[wave][15][C] over the (now dead) image buffers, then one atomic per parameter element
+  __syncthreads();
+  float* part = sm;
+#pragma unroll
+  for (int k = 0; k < CP; ++k) {
+    const int c = lane + 64 * k;
+    if (c < C) {
+      float* pw_ = part + (size_t)wave * 15 * C;
+      pw_[0 * C + c] = rg1[k]; pw_[1 * C + c] = rb1[k]; pw_[2 * C + c] = rg2[k]; pw_[3 * C + c] = rb2[k];
+      pw_[4 * C + c] = rcb[k]; pw_[5 * C + c] = rcs[k];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) pw_[6 * C + c * 9 + q] = rw[k][q];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 15 * C; i += 256) {
+    const float v = part[i] + part[15 * C + i] + part[30 * C + i] + part[45 * C + i];
+    const int which = i / C;
+    if (which >= 6) { atomic_add_f(p.dw + (i - 6 * C), v); continue; }
+    const int c = i - which * C;
+    if (which < 4) {
+      if (!ln) continue;
+      float* dst = which == 0 ? p.dg1 : which == 1 ? p.db1 : which == 2 ? p.dg2 : p.db2;
+      atomic_add_f(dst + c, v);
+    } else if (which == 4) { if (hb && p.dcbias) atomic_add_f(p.dcbias + c, v); }
+    else { if (hs && p.dcscale) atomic_add_f(p.dcscale + c, v); }
+  }
+}
+
 }  // namespace qv
 
 using namespace qv;
@@ -232,6 +393,16 @@ extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_bwd: image tile too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = a->B < 512 ? a->B : 512;
+  if (a->C <= 256 && a->Hs * a->Ws >= 15) {             // register-partial kernel (its wave fold needs 60*C floats of the image buffers)
+    const int cp = (a->C + 63) / 64;
+#define CCF2(T_, CP_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                        hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_>), dim3(grid), dim3(256), smem, st, *a); }
+    if (a->dtype == QAVIT_F32) { if (cp == 1) CCF2(float, 1) else if (cp == 2) CCF2(float, 2) else if (cp == 3) CCF2(float, 3) else CCF2(float, 4) }
+    else if (a->dtype == QAVIT_BF16) { if (cp == 1) CCF2(bf16, 1) else if (cp == 2) CCF2(bf16, 2) else if (cp == 3) CCF2(bf16, 3) else CCF2(bf16, 4) }
+    else return set_error(QAVIT_EINVAL, "ccf_mid_bwd: unknown dtype");
+#undef CCF2
+    return check_launch("ccf_mid_bwd");
+  }
   if (a->dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((ccf_bwd_kernel<float>), dim3(grid), dim3(256), smem, st, *a);
