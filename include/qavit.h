@@ -271,6 +271,19 @@ int qavit_scale_add_fwd(int dtype, const void* x, const void* u, const float* ga
                         float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
 int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, const float* gamma, void* du, float* dgamma,
                         int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
+/* nn.BatchNorm2d (+ optional exact GELU, act = 1) of the CNN stem on channel-last rows x[M = B*H*W, C]
+ * (HQAViT_CIFAR100.py:753,760,768,775).  training != 0: batch statistics (biased variance for the output, unbiased
+ * for running_var), running_mean / running_var updated in place with `momentum`, save_mean / save_rstd [C] written
+ * for backward; ws = float[3*C] scratch.  training == 0: normalises with the running statistics.
+ * bwd: dx, and dgamma / dbeta [C] ACCUMULATE (either may be NULL); ws = float[2*C] scratch; `training` as in forward
+ * (0: save_mean / save_rstd hold the running mean and rsqrt(running_var + eps), treated as constants).
+ * C must be a multiple of 8 (bf16) / 4 (fp32) with 256 % (C/vec) == 0; rows 16-byte aligned. */
+int qavit_bn_fwd(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float momentum, float eps, int act,
+                 float* save_mean, float* save_rstd, float* ws, int training, void* stream);
+int qavit_bn_bwd(int dtype, const void* dy, const void* x, int M, int C, const float* gamma, const float* beta,
+                 const float* save_mean, const float* save_rstd, int act, int training, void* dx, float* dgamma, float* dbeta,
+                 float* ws, void* stream);
 /* y = dropout(x) (pos_drop, HQAViT_CIFAR100.py:1251); bwd is the same call on dy */
 int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream);
 /* packed weights: dst = cast(src) and dstT = cast(src)^T for 2-D [rows, cols] fp32 params; descriptor table on device */

@@ -781,6 +781,41 @@ class DropoutFn(Function):
         return dx, None, None
 
 
+class BatchNormFn(Function):
+    """nn.BatchNorm2d (+ exact GELU when ``act``) on channel-last rows [M, C] -- csrc/bnorm.hip.  Running statistics
+    are updated in place by the forward kernel in training mode (the caller bumps ``num_batches_tracked``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, training):
+        K._require_cuda(x, weight)
+        x = x.contiguous()
+        M, Cc = x.shape
+        y = torch.empty_like(x)
+        dev = x.device
+        save_mean = torch.empty(Cc, dtype=torch.float32, device=dev) if training else None
+        save_rstd = torch.empty(Cc, dtype=torch.float32, device=dev) if training else None
+        ws = torch.empty(3 * Cc, dtype=torch.float32, device=dev) if training else None
+        K.bn_fwd(x, y, M, Cc, weight, bias, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training)
+        if not training:                                   # eval backward: the running statistics are constants
+            save_mean = running_mean.detach().clone()
+            save_rstd = torch.rsqrt(running_var.detach() + eps)
+        ctx.meta = (M, Cc, bool(act), bool(training))
+        ctx.save_for_backward(x, weight, bias, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, save_mean, save_rstd = ctx.saved_tensors
+        M, Cc, act, training = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        gbuf, gret = grad_sink(weight)
+        bbuf, bret = grad_sink(bias)
+        ws = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+        K.bn_bwd(dy, x, M, Cc, weight, bias, save_mean, save_rstd, act, training, dx, gbuf, bbuf, ws)
+        return dx, _ret(gret, weight), _ret(bret, bias), None, None, None, None, None, None
+
+
 def dropout(x, p, site, training):
     if not training or p <= 0.0:
         return x

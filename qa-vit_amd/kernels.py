@@ -320,6 +320,23 @@ def scale_add_bwd(dy, u, gamma, du, dgamma, rows, Cc, dp, rng):
     L.check(L.load().qavit_scale_add_bwd(dt_code(dy.dtype), dy.data_ptr(), u.data_ptr(), _p(gamma), du.data_ptr(), _p(dgamma), rows, Cc, dp[0], dp[1], dp[2], _p(rng), stream()), "scale_add_bwd")
 
 
+def bn_supported(dtype, Cc: int) -> bool:
+    vec = 8 if dtype == torch.bfloat16 else 4
+    return Cc % vec == 0 and Cc // vec <= 256 and 256 % (Cc // vec) == 0 and Cc <= 2048
+
+
+def bn_fwd(x, y, M, Cc, gamma, beta, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training):
+    L.check(L.load().qavit_bn_fwd(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(),
+                                  _p(running_mean), _p(running_var), float(momentum), float(eps), int(act),
+                                  _p(save_mean), _p(save_rstd), _p(ws), int(training), stream()), "bn_fwd")
+
+
+def bn_bwd(dy, x, M, Cc, gamma, beta, save_mean, save_rstd, act, training, dx, dgamma, dbeta, ws):
+    L.check(L.load().qavit_bn_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(),
+                                  save_mean.data_ptr(), save_rstd.data_ptr(), int(act), int(training), dx.data_ptr(), _p(dgamma), _p(dbeta),
+                                  ws.data_ptr(), stream()), "bn_bwd")
+
+
 def dropout(x, y, p, site, rng):
     L.check(L.load().qavit_dropout(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), x.numel(), p, site, rng.data_ptr(), stream()), "dropout")
 

@@ -91,6 +91,8 @@ _SIGS = {
     "qavit_hybrid_fuse_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "qavit_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "qavit_bn_fwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, i32, vp]),
+    "qavit_bn_bwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "qavit_dropout": (i32, [i32, vp, vp, i64, f32, i32, vp, vp]),
     "qavit_pack_weights": (i32, [i32, vp, i32, i32, vp]),
     "qavit_rng_advance": (i32, [vp, vp]),

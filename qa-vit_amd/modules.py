@@ -433,13 +433,18 @@ def _conv1x1_tokens(t, conv: nn.Conv2d):
     return F.linear(t, conv.weight, conv.bias)
 
 
-def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool):
-    """nn.BatchNorm2d on channel-last tokens == batch_norm over the rows of [B*H*W, C] (per-rank batch statistics)."""
+def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool, gelu: bool = False):
+    """nn.BatchNorm2d (+ nn.GELU when ``gelu``) on channel-last tokens == batch norm over the rows of [B*H*W, C]
+    (per-rank batch statistics) -- csrc/bnorm.hip; channel counts its 16-byte vectors do not tile take the stock op."""
     B, N, C = t.shape
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    if K.bn_supported(t.dtype, C) and bn.running_mean is not None and bn.momentum is not None and bn.affine:
+        y = F.BatchNormFn.apply(t.reshape(B * N, C), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, gelu, training)
+        return y.reshape(B, N, C)
     y = TF.batch_norm(t.reshape(B * N, C), bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
-    return y.reshape(B, N, C)
+    y = y.reshape(B, N, C)
+    return TF.gelu(y) if gelu else y
 
 
 class ConvNeXtBlock(nn.Module):
@@ -480,7 +485,7 @@ class CNNStemModel(nn.Module):
         B = dims[0]
         cols = F.Im2ColFn.apply(src, dims, cdt)
         t = F.linear(cols, conv.weight, conv.bias).reshape(B, -1, conv.out_channels)
-        return TF.gelu(_bn_tokens(t, bn, self.training))
+        return _bn_tokens(t, bn, self.training, gelu=True)
 
     def forward_tokens(self, x, cdt):
         """-> (F2, F3, F4) as channel-last tokens [B, h*w, c] in the compute dtype, and (h, w)."""

@@ -514,3 +514,34 @@ def test_adamw_and_l2norm_match_torch(Q):
         torch.nn.utils.clip_grad_norm_([pr], 0.5)
         opt.step()
     assert rel(p, pr) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cc,gelu", [(32, True), (256, False)])
+def test_batchnorm_matches_torch(F, dtype, Cc, gelu):
+    """csrc/bnorm.hip against nn.BatchNorm2d semantics (TF.batch_norm, + exact GELU): output, running statistics,
+    dx, dgamma, dbeta.  The pivoted sums must survive a mean far from zero."""
+    M = 4099
+    x = (leaf(M, Cc, seed=300).detach() * 1.7 + 3.0).to(dtype).requires_grad_(True)
+    w, b = leaf(Cc, scale=0.3, seed=301), leaf(Cc, scale=0.3, seed=302)
+    with torch.no_grad():
+        w.add_(1.0)
+    rm, rv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    y = F.BatchNormFn.apply(x, w, b, rm, rv, 0.1, 1e-5, gelu, True)
+    xr, wr, br = [t.detach().clone().float().requires_grad_(True) for t in (x, w, b)]
+    rmr, rvr = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    ref = TF.batch_norm(xr, rmr, rvr, wr, br, True, 0.1, 1e-5)
+    if gelu:
+        ref = TF.gelu(ref)
+    assert rel(y, ref) <= tol(dtype)
+    assert rel(rm, rmr) <= 1e-4 and rel(rv, rvr) <= 1e-4
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False) * 2
+    assert rel(w.grad, wr.grad) <= tol(dtype, False) * 2
+    assert rel(b.grad, br.grad) <= tol(dtype, False) * 2
+    # eval mode: running statistics
+    ye = F.BatchNormFn.apply(x.detach(), w, b, rm, rv, 0.1, 1e-5, gelu, False)
+    re_ = TF.batch_norm(xr.detach(), rmr, rvr, wr, br, False, 0.1, 1e-5)
+    assert rel(ye, TF.gelu(re_) if gelu else re_) <= tol(dtype)
