@@ -48,51 +48,106 @@ def parse():
 # per-launch kernel timing with HIP events (roofline)
 # ---------------------------------------------------------------------------------------------------
 class KernelTimer:
-    """Wraps the raw kernel wrappers of one eager step with torch.cuda.Event pairs recorded on the launch stream
-    (kernels are enqueued on torch's current stream, so the events bracket exactly one launch)."""
+    """Times every C-ABI entry point of libqavit_hip.so during one eager step of the benchmarked workload.
 
-    def __init__(self, K):
-        self.K, self.rec, self._orig = K, [], {}
+    Each call is bracketed by a torch.cuda.Event pair recorded on the launch stream (the kernels are enqueued on
+    torch's current stream).  An eager step is launch-bound on the host, so a short spin kernel is queued in front of
+    each bracket: the GPU is still busy with it while the host enqueues start-event, kernel(s), stop-event, which then
+    run back to back on the device -- the bracket measures device time, not host launch latency.
+    Algorithmic flops / bytes per call come from the call's own arguments (formulas below)."""
 
-    def _wrap(self, name, flops_fn):
-        orig = getattr(self.K, name)
+    ESZ = {0: 4, 1: 2}
+
+    def __init__(self, lib):
+        self.lib, self.rec, self._orig = lib, [], {}
+        # calibrate the spin kernel (wall-clock ticks on ROCm) to ~30 us
+        torch.cuda._sleep(1000); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(20000); e1.record(); torch.cuda.synchronize()
+        us_per_tick = max(e0.elapsed_time(e1) * 1e3 / 20000.0, 1e-6)
+        self.spin = max(int(30.0 / us_per_tick), 1)
+        # cost of an empty bracket (start-event, stop-event back to back behind the spin): subtracted from every call
+        pairs = []
+        for _ in range(64):
+            torch.cuda._sleep(self.spin)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in pairs)
+        self.empty_ms = ts[len(ts) // 2]
+
+    @staticmethod
+    def _obj(x):
+        return getattr(x, "_obj", x)
+
+    def _work(self, name, a):
+        """-> (flops, bytes) of one call; bytes = operands read once + results written once."""
+        esz = self.ESZ
+        if name == "qavit_gemm_nt":
+            g = self._obj(a[0]); e = esz[g.dtype]
+            by = (g.M * g.K + g.N * g.K + g.M * g.N) * e
+            if g.a_mode == 2:
+                by += g.M * g.K * e * ((1 if g.a_Z else 0) + (1 if g.a_out else 0))
+            if g.Z: by += g.M * g.N * e
+            if g.R: by += g.M * g.N * e
+            return 2.0 * g.M * g.N * g.K, float(by)
+        if name in ("qavit_gemm_tn", "qavit_gemm_tn_grouped"):
+            probs = [self._obj(a[0])] if name == "qavit_gemm_tn" else [a[0][i] for i in range(a[1])]
+            fl = sum(2.0 * g.M * g.N * g.K for g in probs)
+            by = sum((g.M * (g.N + g.K)) * esz[g.dtype] + g.N * g.K * 4 for g in probs)
+            return fl, float(by)
+        if name in ("qavit_attn_fwd", "qavit_attn_bwd"):
+            g = self._obj(a[0]); e = esz[g.dtype]
+            nk = (g.KC if g.mode == 0 else g.L) + g.S
+            fl = 4.0 * g.G * g.H * g.Nq * nk * g.D + (4.0 * g.G * g.H * g.KC * g.L * g.D if g.mode == 0 else 0.0)
+            by = (g.G * g.Nq + 2 * g.G * g.L) * g.H * g.D * e + g.G * g.Nq * g.H * g.D * e
+            return (fl, float(by)) if name == "qavit_attn_fwd" else (2.5 * fl, 2.5 * by)
+        if name in ("qavit_layernorm_fwd", "qavit_layernorm_bwd", "qavit_row_stats"):
+            e = esz[a[0]]
+            if name == "qavit_layernorm_fwd": rows, Cc, k = a[6], a[7], 2
+            elif name == "qavit_layernorm_bwd": rows, Cc, k = a[9], a[10], 3
+            else: rows, Cc, k = a[3], a[4], 1
+            return 8.0 * rows * Cc, float(k * rows * Cc * e)
+        return 0.0, 0.0
+
+    def _wrap(self, name):
+        orig = getattr(self.lib, name)
         self._orig[name] = orig
 
-        def f(*a, **kw):
+        def f(*a):
+            torch.cuda._sleep(self.spin)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = orig(*a, **kw)
+            r = orig(*a)
             e1.record()
-            self.rec.append((name, flops_fn(*a, **kw), e0, e1))
+            fl, by = self._work(name, a)
+            self.rec.append((name, fl, by, e0, e1))
             return r
-        setattr(self.K, name, f)
+        setattr(self.lib, name, f)
 
     def __enter__(self):
-        self._wrap("gemm_nt", lambda A, B, C, M, N, Kd, *r, **kw: 2.0 * M * N * Kd)
-        self._wrap("gemm_tn", lambda A, B, C, M, N, Kd, *r, **kw: 2.0 * M * N * Kd)
-
-        def attn_flops(a):
-            nk = (a.KC if a.mode == 0 else a.L) + a.S
-            f = 4.0 * a.G * a.H * a.Nq * nk * a.D
-            if a.mode == 0:
-                f += 4.0 * a.G * a.H * a.KC * a.L * a.D
-            return f
-        self._wrap("attn_fwd", attn_flops)
-        self._wrap("attn_bwd", lambda a: 2.5 * attn_flops(a))
+        import importlib
+        L = importlib.import_module("qa-vit_amd.lib")
+        for name in L.EXPORTS:
+            if name in ("qavit_version", "qavit_last_error", "qavit_attn_ws_floats", "qavit_bank_ws_floats"):
+                continue
+            self._wrap(name)
         return self
 
     def __exit__(self, *exc):
         for n, o in self._orig.items():
-            setattr(self.K, n, o)
+            setattr(self.lib, n, o)
 
     def summary(self):
         torch.cuda.synchronize()
         fam = {}
-        for name, fl, e0, e1 in self.rec:
-            d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        for name, fl, by, e0, e1 in self.rec:
+            d = fam.setdefault(name.replace("qavit_", ""), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
+            d["ms"] += max(e0.elapsed_time(e1) - self.empty_ms, 0.0)
             d["flops"] += fl
+            d["bytes"] += by
         return fam
 
 
@@ -238,17 +293,22 @@ def main():
     out["config"]["model_mfma_frac"] = round(step_tflops / (PEAK_BF16_TFLOPS * world), 5)
 
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        # one instrumented eager step of the same workload: per-launch HIP-event timing of the kernel families
+        # one instrumented eager step of the same workload: per-call HIP-event timing of every C-ABI entry point
+        import importlib
+        lib = importlib.import_module("qa-vit_amd.lib").load()
         for _ in range(2):
             tr.step(x, y) if with_optim else tr.fwd_bwd(x, y)
         torch.cuda.synchronize()
-        with KernelTimer(K) as kt:
+        with KernelTimer(lib) as kt:
             tr.step(x, y) if with_optim else tr.fwd_bwd(x, y)
             fam = kt.summary()
-        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
+        name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = d["ms"] / d["launches"]
-        ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+        tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        peak_fl = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        # which roof is nearer for this entry point's work mix
+        mfma_bound = (tfl / peak_fl) >= (gbs / PEAK_HBM_GBS)
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
@@ -256,12 +316,17 @@ def main():
                 traffic = json.load(open(tp)).get(name)
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 3), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
-                           "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 5),
-                           "traffic": traffic, "launches_per_step": d["launches"], "avg_launch_us": round(avg_ms * 1e3, 2),
-                           "flops_per_launch": round(d["flops"] / d["launches"]),
+        ach, peak, unit = (tfl, peak_fl, "TFLOP/s") if mfma_bound else (gbs, PEAK_HBM_GBS, "GB/s")
+        out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name, "achieved": round(ach, 3), "peak": peak,
+                           "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic,
+                           "launches_per_step": d["launches"], "avg_launch_us": round(avg_ms * 1e3, 2),
+                           "flops_per_launch": round(d["flops"] / d["launches"]), "bytes_per_launch": round(d["bytes"] / d["launches"]),
+                           "tflops": round(tfl, 2), "gbytes_per_s": round(gbs, 1), "event_bracket_overhead_us": round(kt.empty_ms * 1e3, 2),
+                           "device_ms_per_step_all_entry_points": round(sum(v["ms"] for v in fam.values()), 3),
                            "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                            "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in fam.items()}}
+                                            "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
+                                            "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
+                                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

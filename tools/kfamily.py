@@ -1,0 +1,23 @@
+"""Fold a rocprofv3 kernel_stats.csv into the C-ABI entry-point families bench.py's roofline reports.
+usage: kfamily.py <kernel_stats.csv> <steps-profiled>"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+n = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+FAM = [("gemm_nt", ("gemm_nt_kernel", "gemm_nt_big_kernel")), ("gemm_tn", ("gemm_tn_",)), ("attn_bwd", ("attn2_kernel<", "attn3_kernel<", "attn_bwd_kernel", "attn_reduce")),
+       ("layernorm_bwd", ("layernorm_bwd",)), ("layernorm_fwd", ("layernorm_fwd",)), ("row_stats", ("row_stats",)), ("dwconv", ("dwconv",)),
+       ("ccf", ("ccf_",)), ("bank", ("bank_",)), ("bn", ("bn_",)), ("tokmix/upmix", ("tokmix", "upmix")), ("torch/other", ("",))]
+agg = {}
+for r in rows:
+    nm = r["Name"]
+    fam = next(f for f, keys in FAM if any(k in nm for k in keys))
+    if fam == "attn_bwd" and ("false>" in nm or "attn_fwd_kernel" in nm):
+        fam = "attn_fwd"
+    if fam == "attn_bwd" and "true>" not in nm and "attn_reduce" not in nm and "attn_bwd_kernel" not in nm:
+        fam = "attn_fwd"
+    d = agg.setdefault(fam, [0, 0])
+    d[0] += int(r["Calls"]); d[1] += int(r["TotalDurationNs"])
+tot = sum(v[1] for v in agg.values())
+print(f"{'family':16s} {'kernels/step':>12s} {'ms/step':>9s} {'avg us':>8s} {'share':>6s}")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"{k:16s} {v[0]/n:12.1f} {v[1]/1e6/n:9.3f} {v[1]/1e3/max(v[0],1):8.2f} {100*v[1]/tot:5.1f}%")
+print(f"{'total':16s} {sum(v[0] for v in agg.values())/n:12.1f} {tot/1e6/n:9.3f}")
