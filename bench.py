@@ -314,6 +314,8 @@ def main():
         if os.path.exists(tp):
             try:
                 traffic = json.load(open(tp)).get(name)
+                if isinstance(traffic, dict):            # HBM bytes per launch from the rocprofv3 PMC passes (tools/pmc_traffic.py)
+                    traffic = traffic.get("hbm_bytes_per_kernel")
             except Exception:
                 traffic = None
         ach, peak, unit = (tfl, peak_fl, "TFLOP/s") if mfma_bound else (gbs, PEAK_HBM_GBS, "GB/s")
