@@ -64,7 +64,8 @@ __host__ __device__ inline int64_t attn_ws_per_wave(const qavit_attn_args& a) {
 static inline int attn_grid(const qavit_attn_args& a, bool bwd) {
   const int64_t problems = (int64_t)a.G * a.H;
   static const int bwd_cap = getenv("QAVIT_ATTN_BWD_CAP") ? atoi(getenv("QAVIT_ATTN_BWD_CAP")) : 2048;
-  int64_t cap = bwd ? bwd_cap : 4096;          // bwd: bounded so the partial-sum workspace stays small
+  static const int fwd_cap = getenv("QAVIT_ATTN_FWD_CAP") ? atoi(getenv("QAVIT_ATTN_FWD_CAP")) : 2048;
+  int64_t cap = bwd ? bwd_cap : fwd_cap;          // bwd: bounded so the partial-sum workspace stays small
   int64_t g = problems < cap ? problems : cap;
   g = g / a.H * a.H;                          // a multiple of H: the head of a wave is fixed
   if (g < a.H) g = a.H;

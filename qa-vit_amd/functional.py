@@ -733,6 +733,82 @@ class HybridFuseFn(Function):
         return dx, fret
 
 
+class CompressFuseFn(Function):
+    """QuadAttentionBlock's four  compress_i(norm_i(branch_i))  -> concat -> HybridFusion  (HQAViT_CIFAR100.py:904-925)
+    as one autograd node: each Linear(C -> C/4) with its LayerNorm prologue writes straight into its column slice of the
+    concatenated buffer (ldc = 4*C/4), and in backward reads its slice of the hybrid-fuse gradient in place (lda) --
+    no torch.cat, no .contiguous() copies of the four gradient slices.
+
+    apply(fw, eps, x_0, g_0, b_0, W_0, bias_0, ..., x_3, g_3, b_3, W_3, bias_3)"""
+
+    @staticmethod
+    def forward(ctx, fw, eps, *args):
+        nb = len(args) // 5
+        xs = [args[5 * i].reshape(-1, args[5 * i].shape[-1]) for i in range(nb)]
+        xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
+        K._require_cuda(xs[0], fw)
+        rt = _rt(xs[0])
+        M, Kd = xs[0].shape
+        dev, dt = xs[0].device, xs[0].dtype
+        Cb = args[3].shape[0]
+        cat = torch.empty(M, nb * Cb, dtype=dt, device=dev)
+        esz = cat.element_size()
+        stats = []
+        for i in range(nb):
+            g, b, W, bias = args[5 * i + 1: 5 * i + 5]
+            Wc, _ = pack_for(dev).get(W, dt)
+            mean, rstd = torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+            K.row_stats(xs[i], eps, M, Kd, mean, rstd)
+            K.gemm_nt(xs[i], Wc, cat, M, Cb, Kd, Kd, Kd, nb * Cb, None if bias is None else bias.detach(), a_mode=1,
+                      ln=(g, b, eps), ln_stats=(mean, rstd), rng=rt.rng, C_ptr=cat.data_ptr() + i * Cb * esz)
+            stats += [mean, rstd]
+        y = torch.empty_like(cat)
+        K.hybrid_fuse_fwd(cat, fw.detach(), y, M, nb, Cb)
+        ctx.meta = (nb, M, Kd, Cb, eps, args[0].shape)
+        ctx.save_for_backward(fw, cat, *xs, *[a for i in range(nb) for a in args[5 * i + 1: 5 * i + 5]], *stats)
+        return y.reshape(*args[0].shape[:-1], nb * Cb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        nb, M, Kd, Cb, eps, xshape = ctx.meta
+        sv = ctx.saved_tensors
+        fw, cat = sv[0], sv[1]
+        xs = sv[2:2 + nb]
+        prm = sv[2 + nb:2 + nb + 4 * nb]
+        stats = sv[2 + 5 * nb:]
+        dev, dt = cat.device, cat.dtype
+        rt = _rt(cat)
+        dy = dy.reshape(M, nb * Cb)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dcat = torch.empty_like(cat)
+        fbuf, fret = grad_sink(fw)
+        if fbuf is None:
+            fbuf = torch.zeros(nb, dtype=torch.float32, device=dev)
+        K.hybrid_fuse_bwd(dy, cat, fw.detach(), dcat, fbuf, M, nb, Cb)
+        esz = dcat.element_size()
+        grads = []
+        DeferDW.arm()
+        for i in range(nb):
+            g, b, W, bias = prm[4 * i: 4 * i + 4]
+            mean, rstd = stats[2 * i], stats[2 * i + 1]
+            _, Wt = pack_for(dev).get(W, dt)
+            a_ptr = dcat.data_ptr() + i * Cb * esz
+            dxn = torch.empty(M, Kd, dtype=dt, device=dev)
+            K.gemm_nt(dcat, Wt, dxn, M, Kd, Cb, nb * Cb, Wt.shape[1], Kd, None, rng=rt.rng, A_ptr=a_ptr)
+            gbuf, gret = grad_sink(g)
+            bbuf, bret = grad_sink(b)
+            dx = torch.empty_like(dxn)
+            K.layernorm_bwd(dxn, xs[i], g, mean, rstd, dx, gbuf, bbuf, M, Kd)
+            wbuf, wret = grad_sink(W)
+            bbuf2, b2ret = grad_sink(bias)
+            if wbuf is None:
+                wbuf = torch.zeros(W.shape, dtype=torch.float32, device=dev)
+            K.gemm_tn(dcat, xs[i], wbuf, M, Cb, Kd, nb * Cb, Kd, Kd, bbuf2, ln=(g, b, mean, rstd), A_ptr=a_ptr)
+            grads += [dx.reshape(xshape), _ret(gret, g), _ret(bret, b), _ret(wret, W), None if bias is None else _ret(b2ret, bias)]
+        return (fret, None, *grads)
+
+
 class ScaleAddFn(Function):
     """y = x + droppath(gamma * u)"""
 

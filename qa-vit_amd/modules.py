@@ -325,12 +325,12 @@ class QuadAttentionBlock(nn.Module):
         B, N, C = x.shape
         tr = self.training
         xn = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        outs = []
+        args = []
         for name, branch in (("swa", self.swa), ("msda", self.msda), ("cga", self.cga), ("cross", self.cross_attn)):
             bo = branch(xn)
             nrm, cmp_ = getattr(self, f"norm_{name}"), getattr(self, f"compress_{name}")
-            outs.append(F.linear(bo, cmp_.weight, cmp_.bias, ln=(nrm.weight, nrm.bias), eps=nrm.eps))
-        fused = F.HybridFuseFn.apply(torch.cat(outs, -1), self.fusion.fusion_weights)
+            args += [bo, nrm.weight, nrm.bias, cmp_.weight, cmp_.bias]
+        fused = F.CompressFuseFn.apply(self.fusion.fusion_weights, self.norm_swa.eps, *args)
         mlp = self.bottleneck_mlp
         p = mlp.dropout.p if tr else 0.0
         dp = (self._dp if tr else 0.0)
