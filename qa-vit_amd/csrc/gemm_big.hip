@@ -319,7 +319,7 @@ int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st) {
     const char* e = getenv("QAVIT_GEMM_BIG"); thresh = e ? atol(e) : 64L * 128L;
     e = getenv("QAVIT_BIG_BN"); force_bn = e ? atol(e) : 0;
   }
-  if (thresh == 0 || (long)g.N * g.K < thresh || g.N < 64 || g.K < 128 || g.M < 1024) return 0;
+  if (thresh == 0 || (long)g.N * g.K < thresh || g.N < 64 || g.K < 96 || g.M < 1024) return 0;
   if (g.K % 32) return 0;
   auto al = [](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
   if (!al(g.A, g.lda) || !al(g.B, g.ldb)) return 0;
