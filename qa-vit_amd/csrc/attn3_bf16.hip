@@ -45,6 +45,20 @@ __host__ __device__ inline A3Lds a3_lds(int mode, bool bwd, int NK16, int D16, i
   return L;
 }
 
+// 4 accumulator values = 4 consecutive elements of one output row: one 8-byte store
+__device__ __forceinline__ void row4_to_lds(bf16* dst, const f32x4& acc) {
+  bf16x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (bf16)acc[r];
+  *reinterpret_cast<bf16x4*>(dst) = v;
+}
+__device__ __forceinline__ void row4_to_global(bf16* dst, const f32x4& acc) {
+  bf16x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (bf16)acc[r];
+  *reinterpret_cast<bf16x4*>(dst) = v;
+}
+
 __device__ __forceinline__ bool any_nan4(bf16x4 v) {
   return ((float)v[0] != (float)v[0]) | ((float)v[1] != (float)v[1]) | ((float)v[2] != (float)v[2]) | ((float)v[3] != (float)v[3]);
 }
@@ -169,134 +183,137 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
       prefetch(np < total ? np : pid);                   // always issued: the last round re-reads its own rows
     }
     wave_sync();
+    // Every product below is formed TRANSPOSED (operands of the MFMA swapped): a lane's 4 accumulator values are then 4
+    // consecutive elements of ONE output row, so each accumulator tile leaves as one 8-byte store (LDS or global)
+    // instead of four 2-byte ones, and the softmax reductions run in-lane plus two cross-group shuffles.
+    // Accumulator element r of a tile: row = 4*q4 + r of the tile (the output's column index), col = lane & 15.
     if (MODE == 0) {
-      // Kf[j][d] = sum_l E_k[l][j] kt[l][d]   (both operands reduce along their rows -> transposed reads)
+      // Kf^T[d][j] = sum_l kt[l][d] E_k[l][j]
 #pragma unroll
       for (int jt = 0; jt < KT0; ++jt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
-          ak = mma16(trfrag(sm + L.ek, LDE, 0, jt * 16), trfrag(sm + L.kt, LDD, 0, dt * 16), ak);
-          av = mma16(trfrag(sm + L.ev, LDE, 0, jt * 16), trfrag(sm + L.vt, LDD, 0, dt * 16), av);
-          acc_to_lds(sm + L.kf, LDD, jt * 16, dt * 16, ak);
-          acc_to_lds(sm + L.vf, LDD, jt * 16, dt * 16, av);
+          ak = mma16(trfrag(sm + L.kt, LDD, 0, dt * 16), trfrag(sm + L.ek, LDE, 0, jt * 16), ak);
+          av = mma16(trfrag(sm + L.vt, LDD, 0, dt * 16), trfrag(sm + L.ev, LDE, 0, jt * 16), av);
+          row4_to_lds(sm + L.kf + (jt * 16 + col) * LDD + dt * 16 + 4 * q4, ak);
+          row4_to_lds(sm + L.vf + (jt * 16 + col) * LDD + dt * 16 + 4 * q4, av);
         }
       wave_sync();
     }
-    // ---------------- scores + softmax on registers ----------------
+    // ---------------- S^T[key][query], softmax over keys on registers ----------------
     f32x4 s[NKT];
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        acc = mma16(rowfrag(sm + L.q, LDD, 0, dt * 16), rowfrag(sm + L.kf, LDD, nt * 16, dt * 16), acc);
+        acc = mma16(rowfrag(sm + L.kf, LDD, nt * 16, dt * 16), rowfrag(sm + L.q, LDD, 0, dt * 16), acc);
       s[nt] = acc;
     }
-    float inv_sum[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    {
       float mx = -INFINITY;
 #pragma unroll
-      for (int nt = 0; nt < NKT; ++nt) {
-        const bool ok = nt * 16 + col < NK;
-        s[nt][r] = ok ? s[nt][r] * scale : -INFINITY;
-        mx = fmaxf(mx, s[nt][r]);
-      }
-      mx = grp_max<16>(mx);
+      for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = nt * 16 + 4 * q4 + r < NK;
+          s[nt][r] = ok ? s[nt][r] * scale : -INFINITY;
+          mx = fmaxf(mx, s[nt][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float sum = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < NKT; ++nt) { const float e = __expf(s[nt][r] - mx); s[nt][r] = e; sum += e; }
-      sum = grp_sum<16>(sum);
-      inv_sum[r] = 1.f / sum;
-    }
+      for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-    for (int nt = 0; nt < NKT; ++nt) {
+        for (int r = 0; r < 4; ++r) { const float e = __expf(s[nt][r] - mx); s[nt][r] = e; sum += e; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[nt][r] *= inv_sum[r];
-      acc_to_lds(sm + L.p, LDK, 0, nt * 16, s[nt]);
+      for (int nt = 0; nt < NKT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[nt][r] *= inv;
+        row4_to_lds(sm + L.p + col * LDK + nt * 16 + 4 * q4, s[nt]);
+      }
     }
     wave_sync();
+    const int64_t my_q = attn_qrow(a, g, col < a.Nq ? col : 0);     // this lane's query row (col) in the global matrices
     if (!BWD) {
+      // O^T[d][query] = sum_key Vf[key][d] P[query][key]
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt)
-          acc = mma16(rowfrag(sm + L.p, LDK, 0, nt * 16), trfrag(sm + L.vf, LDD, nt * 16, dt * 16), acc);
+          acc = mma16(trfrag(sm + L.vf, LDD, nt * 16, dt * 16), rowfrag(sm + L.p, LDK, 0, nt * 16), acc);
         bad |= (acc[0] != acc[0]) | (acc[1] != acc[1]) | (acc[2] != acc[2]) | (acc[3] != acc[3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * q4 + r;
-          if (row < a.Nq && dt * 16 + col < D)
-            og[attn_qrow(a, g, row) * a.ldo + h * D + dt * 16 + col] = (bf16)acc[r];
-        }
+        if (col < a.Nq && dt * 16 + 4 * q4 < D) row4_to_global(og + my_q * a.ldo + h * D + dt * 16 + 4 * q4, acc);
       }
     } else {
-      // dP = dO . Vf^T ; dS = P * (dP - rowdot) * scale
+      // dP^T[key][query] = sum_d Vf[key][d] dO[query][d] ; dS = P * (dP - rowdot) * scale
       f32x4 dp[NKT];
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-          acc = mma16(rowfrag(sm + L.d_o, LDD, 0, dt * 16), rowfrag(sm + L.vf, LDD, nt * 16, dt * 16), acc);
+          acc = mma16(rowfrag(sm + L.vf, LDD, nt * 16, dt * 16), rowfrag(sm + L.d_o, LDD, 0, dt * 16), acc);
         dp[nt] = acc;
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      {
         float dot = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NKT; ++nt) dot += s[nt][r] * dp[nt][r];
-        dot = grp_sum<16>(dot);
+        for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NKT; ++nt) dp[nt][r] = s[nt][r] * (dp[nt][r] - dot) * scale;
+          for (int r = 0; r < 4; ++r) dot += s[nt][r] * dp[nt][r];
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dp[nt][r] = s[nt][r] * (dp[nt][r] - dot) * scale;
+          row4_to_lds(sm + L.ds + col * LDK + nt * 16 + 4 * q4, dp[nt]);
+        }
       }
-#pragma unroll
-      for (int nt = 0; nt < NKT; ++nt) acc_to_lds(sm + L.ds, LDK, 0, nt * 16, dp[nt]);
       wave_sync();
       // per-problem key tiles start from zero; the shared-row tiles (nt >= KT0) keep accumulating
 #pragma unroll
       for (int nt = 0; nt < KT0; ++nt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { gK[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; gV[nt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      // dQ = dS . Kf ; dKf += dS^T . Q ; dVf += P^T . dO
+      // dQ^T[d][query] = sum_key Kf[key][d] dS[query][key] ; gK^T[d][key] += sum_query Q[query][d] dS[query][key] ;
+      // gV^T[d][key] += sum_query dO[query][d] P[query][key]
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt)
-          acc = mma16(rowfrag(sm + L.ds, LDK, 0, nt * 16), trfrag(sm + L.kf, LDD, nt * 16, dt * 16), acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 4 * q4 + r;
-          if (row < a.Nq && dt * 16 + col < D)
-            dqg[attn_qrow(a, g, row) * a.lddq + h * D + dt * 16 + col] = (bf16)acc[r];
-        }
-        const s16x4 bq = trfrag(sm + L.q, LDD, 0, dt * 16);
-        const s16x4 bo = trfrag(sm + L.d_o, LDD, 0, dt * 16);
+          acc = mma16(trfrag(sm + L.kf, LDD, nt * 16, dt * 16), rowfrag(sm + L.ds, LDK, 0, nt * 16), acc);
+        if (col < a.Nq && dt * 16 + 4 * q4 < D) row4_to_global(dqg + my_q * a.lddq + h * D + dt * 16 + 4 * q4, acc);
+        const s16x4 aq = trfrag(sm + L.q, LDD, 0, dt * 16);
+        const s16x4 ao = trfrag(sm + L.d_o, LDD, 0, dt * 16);
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt) {
-          gK[nt][dt] = mma16(trfrag(sm + L.ds, LDK, 0, nt * 16), bq, gK[nt][dt]);
-          gV[nt][dt] = mma16(trfrag(sm + L.p, LDK, 0, nt * 16), bo, gV[nt][dt]);
+          gK[nt][dt] = mma16(aq, trfrag(sm + L.ds, LDK, 0, nt * 16), gK[nt][dt]);
+          gV[nt][dt] = mma16(ao, trfrag(sm + L.p, LDK, 0, nt * 16), gV[nt][dt]);
         }
       }
       if (KT0 > 0) {
         if (MODE == 1) {
-          // token keys: their gradient rows leave directly
+          // token keys: lane = key row (col), 4 consecutive channels per tile
 #pragma unroll
-          for (int nt = 0; nt < KT0; ++nt)
+          for (int nt = 0; nt < KT0; ++nt) {
+            const int key = nt * 16 + col;
+            const int64_t kr = attn_krow(a, g, key < a.L ? key : 0);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int row = nt * 16 + 4 * q4 + r, cc = dt * 16 + col;
-                if (row < a.L && cc < D) {
-                  const int64_t kr = attn_krow(a, g, row);
-                  dktg[kr * a.lddk + h * D + cc] = (bf16)gK[nt][dt][r];
-                  dvtg[kr * a.lddv + h * D + cc] = (bf16)gV[nt][dt][r];
-                }
+              if (key < a.L && dt * 16 + 4 * q4 < D) {
+                row4_to_global(dktg + kr * a.lddk + h * D + dt * 16 + 4 * q4, gK[nt][dt]);
+                row4_to_global(dvtg + kr * a.lddv + h * D + dt * 16 + 4 * q4, gV[nt][dt]);
               }
+          }
         } else {
           // Linformer rows: dKf / dVf take over the (now dead) per-problem rows of the Kf / Vf tiles
           wave_sync();
@@ -304,27 +321,23 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
           for (int nt = 0; nt < KT0; ++nt)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-              acc_to_lds(sm + L.kf, LDD, nt * 16, dt * 16, gK[nt][dt]);
-              acc_to_lds(sm + L.vf, LDD, nt * 16, dt * 16, gV[nt][dt]);
+              row4_to_lds(sm + L.kf + (nt * 16 + col) * LDD + dt * 16 + 4 * q4, gK[nt][dt]);
+              row4_to_lds(sm + L.vf + (nt * 16 + col) * LDD + dt * 16 + 4 * q4, gV[nt][dt]);
             }
           wave_sync();
-          // dk_tok[l][d] = sum_j E_k[l][j] dKf[j][d]
+          // dk_tok^T[d][l] = sum_j dKf[j][d] E_k[l][j]
+          const int64_t kr = attn_krow(a, g, col < a.L ? col : 0);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jt = 0; jt < KT0; ++jt) {
-              ak = mma16(rowfrag(sm + L.ek, LDE, 0, jt * 16), trfrag(sm + L.kf, LDD, jt * 16, dt * 16), ak);
-              av = mma16(rowfrag(sm + L.ev, LDE, 0, jt * 16), trfrag(sm + L.vf, LDD, jt * 16, dt * 16), av);
+              ak = mma16(trfrag(sm + L.kf, LDD, jt * 16, dt * 16), rowfrag(sm + L.ek, LDE, 0, jt * 16), ak);
+              av = mma16(trfrag(sm + L.vf, LDD, jt * 16, dt * 16), rowfrag(sm + L.ev, LDE, 0, jt * 16), av);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int l = 4 * q4 + r, cc = dt * 16 + col;
-              if (l < a.L && cc < D) {
-                const int64_t kr = attn_krow(a, g, l);
-                dktg[kr * a.lddk + h * D + cc] = (bf16)ak[r];
-                dvtg[kr * a.lddv + h * D + cc] = (bf16)av[r];
-              }
+            if (col < a.L && dt * 16 + 4 * q4 < D) {
+              row4_to_global(dktg + kr * a.lddk + h * D + dt * 16 + 4 * q4, ak);
+              row4_to_global(dvtg + kr * a.lddv + h * D + dt * 16 + 4 * q4, av);
             }
           }
           // dE_k[l][j] += sum_d kt[l][d] dKf[j][d]
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int srow = (nt - KT0) * 16 + 4 * q4 + r, cc = dt * 16 + col;
+          const int srow = (nt - KT0) * 16 + col, cc = dt * 16 + 4 * q4 + r;      // transposed tiles: rows = channels, cols = keys
           if (srow < a.S && cc < D) {
             ws[2 * nE + srow * D + cc] = gK[nt][dt][r];
             ws[2 * nE + nS + srow * D + cc] = gV[nt][dt][r];
@@ -384,6 +397,10 @@ int a3_launch(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) {
 // 1 = launched, 0 = shape not covered.  The caller (attn_bf16_try) has already checked alignment and strides.
 int attn3_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) {
   if (a.Nq > 16 || a.L > 16 || a.S > 16 || a.S <= 0 || a.D % 4) return 0;
+  // 8-byte row-segment stores of the outputs
+  auto al8 = [](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 7) == 0 && ld % 4 == 0); };
+  if (!bwd && !al8(a.o, a.ldo)) return 0;
+  if (bwd && (!al8(a.dq, a.lddq) || (a.L > 0 && (!al8(a.dk_tok, a.lddk) || !al8(a.dv_tok, a.lddv))))) return 0;
   int rc = -100;
   if (a.mode == 0 && a.KC == 32 && a.L > 0 && a.D > 32 && a.D <= 48) rc = a3_launch<0, 3, 3, 2>(a, bwd, grid, st);
   else if (a.mode == 1 && a.L == 0 && a.D > 32 && a.D <= 48) rc = a3_launch<1, 1, 3, 0>(a, bwd, grid, st);

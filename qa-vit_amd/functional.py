@@ -166,6 +166,7 @@ class DeferDW:
             return False                                    # not inside a backward pass
         cls._armed = True
         K.DeferredTN.enabled = True
+        K.DeferredTN.home_stream = K.stream()                # backward starts on the caller's stream; only its dW GEMMs are queued
         return True
 
     @classmethod

@@ -128,6 +128,7 @@ class DeferredTN:
     """Queue of weight-gradient GEMMs (see qavit_gemm_tn_grouped).  ``enabled`` is switched on by the autograd layer
     for the duration of a backward pass; queued problems keep their operand tensors alive until ``flush``."""
     enabled = False
+    home_stream = None  # raw stream handle of the backward pass that armed the queue; other streams launch at once
     queue = []          # (GemmTnArgs, keepalive tuple)
     MAX = int(os.environ.get("QAVIT_DW_QUEUE", "96"))
 
@@ -153,7 +154,7 @@ def gemm_tn(A, Bm, Cgrad, M, N, K, lda, ldb, ldc, colsum=None, ln=None, A_ptr=No
         g, b_, mean, rstd = ln
         a.ln_gamma, a.ln_beta, a.ln_mean, a.ln_rstd = g.data_ptr(), b_.data_ptr(), mean.data_ptr(), rstd.data_ptr()
     a.splits = 0
-    if DeferredTN.enabled:
+    if DeferredTN.enabled and (DeferredTN.home_stream is None or DeferredTN.home_stream == stream()):
         DeferredTN.queue.append((a, (A, Bm, Cgrad, colsum, ln)))
         if len(DeferredTN.queue) >= DeferredTN.MAX:
             DeferredTN.flush()

@@ -8,6 +8,9 @@ Compute dtype: under ``torch.autocast(dtype=bf16)`` (what the reference's traini
 HQAViT_CIFAR100.py:1401-1403) activations are bf16 with fp32 accumulation; otherwise fp32 (exact-fp32 MFMA),
 which is the parity path.  ``model.compute_dtype = torch.bfloat16`` forces bf16 without autocast.
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 
@@ -61,6 +64,18 @@ class _Base(nn.Module):
         return F.linear(F.TokenMeanFn.apply(T), self.head.weight, self.head.bias)
 
 
+_LATERAL_STREAM = os.environ.get("QAVIT_LATERAL_STREAM", "0") != "0"
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class HQAViT(_Base):
     def __init__(self, config: HQAViTConfig, variant: str = "hqa"):
         super().__init__()
@@ -99,17 +114,29 @@ class HQAViT(_Base):
         self._check(x)
         cdt = self._dtype(x)
         self.patch_embed.proj.compute_dtype = cdt
-        # CNN lateral path: channel-last on the HIP kernels (no MIOpen convolution anywhere)
+        # CNN lateral path: channel-last on the HIP kernels (no MIOpen convolution anywhere).  It does not meet the token
+        # path before fuse2, so it runs on a second HIP stream beside patch-embed + stage 1 (autograd replays each node on
+        # its forward stream, so backward overlaps the same way; under hipGraph capture the fork/join become graph edges).
+        main = side = None
+        if _LATERAL_STREAM and x.is_cuda:
+            main = torch.cuda.current_stream(x.device)
+            side = _side_stream(x.device)
+            side.wait_stream(main)
         with torch.autocast("cuda", enabled=False):
-            feats, (fh, fw) = self.cnn_stem.forward_tokens(x, cdt)
-            R = {}
-            for i, f in zip((2, 3, 4), feats):
-                a = getattr(self, f"lmfa{i}").forward_tokens(f, fh, fw)
-                R[i] = getattr(self, f"rrcv{i}")(a, self.H, self.W)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                feats, (fh, fw) = self.cnn_stem.forward_tokens(x, cdt)
+                R = {}
+                for i, f in zip((2, 3, 4), feats):
+                    a = getattr(self, f"lmfa{i}").forward_tokens(f, fh, fw)
+                    R[i] = getattr(self, f"rrcv{i}")(a, self.H, self.W)
             T = self.patch_embed(x, self.pos_embed)
             T = F.dropout(T, self.pos_drop.p, self._pos_site, self.training)
             for si in (1, 2, 3, 4):
                 if si >= 2:
+                    if si == 2 and side is not None:
+                        main.wait_stream(side)
+                        for r_ in R.values():
+                            r_.record_stream(main)
                     T = self._sync(T, f"fuse{si}")
                     T = getattr(self, f"fuse{si}")(T, R[si])
                 T = self._sync(T, f"stage{si}_blocks")
