@@ -140,6 +140,104 @@ __global__ __launch_bounds__(256) void hybrid_bwd_kernel(const T* dy, const T* x
   }
 }
 
+// ---- 16-byte-vector forms (C and Cb multiples of the vector, aligned bases): 32-bit index math only -- the scalar
+// kernels above spend most of their time in the 64-bit `i % C` / `i / C` per element ----
+template <typename T>
+__global__ __launch_bounds__(256) void hybrid_fwd_vec_kernel(const T* x, const float* fw, T* y, uint32_t nvec, int nb, int Cb, int C) {
+  constexpr int VEC = Vec<T>::N;
+  typedef typename Vec<T>::type vec_t;
+  float w[8];
+  softmax_small(fw, nb, w);
+  const uint32_t vpr = C / VEC;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    const uint32_t cv = v % vpr;
+    const float wb = w[(cv * VEC) / Cb];
+    const vec_t xv = *reinterpret_cast<const vec_t*>(x + (size_t)v * VEC);
+    vec_t o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = from_f<T>(to_f<T>(xv[j]) * wb);
+    *reinterpret_cast<vec_t*>(y + (size_t)v * VEC) = o;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void hybrid_bwd_vec_kernel(const T* dy, const T* x, const float* fw, T* dx, float* dfw,
+                                                             uint32_t nvec, int nb, int Cb, int C) {
+  constexpr int VEC = Vec<T>::N;
+  typedef typename Vec<T>::type vec_t;
+  float w[8], part[8];
+  softmax_small(fw, nb, w);
+  for (int i = 0; i < 8; ++i) part[i] = 0.f;
+  const uint32_t vpr = C / VEC;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    const uint32_t cv = v % vpr;
+    const int b = (int)((cv * VEC) / Cb);
+    const vec_t gv = *reinterpret_cast<const vec_t*>(dy + (size_t)v * VEC);
+    const vec_t xv = *reinterpret_cast<const vec_t*>(x + (size_t)v * VEC);
+    const float wb = w[b];
+    vec_t o;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { const float g = to_f<T>(gv[j]); o[j] = from_f<T>(g * wb); t += g * to_f<T>(xv[j]); }
+    *reinterpret_cast<vec_t*>(dx + (size_t)v * VEC) = o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[j] += (j == b) ? t : 0.f;
+  }
+  __shared__ float red[8][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float s_ = wave_sum(part[j]);
+    if (lane == 0) red[j][wave] = s_;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ds[8];
+    for (int j = 0; j < nb; ++j) ds[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
+    float dot = 0.f;
+    for (int j = 0; j < nb; ++j) dot += ds[j] * w[j];
+    for (int j = 0; j < nb; ++j) atomic_add_f(dfw + j, w[j] * (ds[j] - dot));
+  }
+}
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void scale_add_vec_kernel(const T* a0, const T* u, const float* gamma, T* out, float* dgamma, uint32_t nvec, int C,
+                                                            float dp_p, int dp_site, int dp_rows, const int64_t* rng) {
+  // forward: a0 = x, out = y = x + f*gamma*u.   backward: a0 = dy, out = du = dy*f*gamma, dgamma += sum dy*f*u.
+  constexpr int VEC = Vec<T>::N;
+  typedef typename Vec<T>::type vec_t;
+  const float gm = gamma ? gamma[0] : 1.f;
+  const uint32_t key = dp_p > 0.f ? rng_key(rng, dp_site) : 0u;
+  const float inv = dp_p > 0.f ? 1.f / (1.f - dp_p) : 1.f;
+  const uint32_t vpr = C / VEC;
+  float part = 0.f;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    float f = 1.f;
+    if (dp_p > 0.f) f = drop_factor(key, (v / vpr) / (uint32_t)dp_rows, dp_p, inv);
+    const vec_t av = *reinterpret_cast<const vec_t*>(a0 + (size_t)v * VEC);
+    const vec_t uv = *reinterpret_cast<const vec_t*>(u + (size_t)v * VEC);
+    vec_t o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (!BWD) o[j] = from_f<T>(to_f<T>(av[j]) + f * gm * to_f<T>(uv[j]));
+      else { const float g = to_f<T>(av[j]) * f; o[j] = from_f<T>(g * gm); part += g * to_f<T>(uv[j]); }
+    }
+    *reinterpret_cast<vec_t*>(out + (size_t)v * VEC) = o;
+  }
+  if (BWD && dgamma) {
+    __shared__ float red[4];
+    const float s_ = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s_;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f(dgamma, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+template <typename T>
+static bool vec_ok(int C, int Cb, int64_t n, const void* p0, const void* p1, const void* p2) {
+  constexpr int VEC = Vec<T>::N;
+  return C % VEC == 0 && Cb % VEC == 0 && n / VEC < 0x7fffffffLL &&
+         ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+}
+
 // y = x + droppath(gamma * u)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_add_fwd_kernel(const T* x, const T* u, const float* gamma, T* y, int64_t n, int C,
@@ -298,6 +396,16 @@ extern "C" int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, 
   if (!x || !fw || !y || rows <= 0 || nb <= 0 || nb > 8 || Cb <= 0) return set_error(QAVIT_EINVAL, "hybrid_fuse_fwd: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)rows * nb * Cb;
+  if (dtype == QAVIT_BF16 && vec_ok<bf16>(nb * Cb, Cb, n, x, y, x)) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((hybrid_fwd_vec_kernel<bf16>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)x, fw, (bf16*)y, nvec, nb, Cb, nb * Cb);
+    return check_launch("hybrid_fuse_fwd");
+  }
+  if (dtype == QAVIT_F32 && vec_ok<float>(nb * Cb, Cb, n, x, y, x)) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((hybrid_fwd_vec_kernel<float>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)x, fw, (float*)y, nvec, nb, Cb, nb * Cb);
+    return check_launch("hybrid_fuse_fwd");
+  }
   const int g = blocks_for(n, 1024);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((hybrid_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, fw, (float*)y, n, nb, Cb),
@@ -309,6 +417,16 @@ extern "C" int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, c
   if (!dy || !x || !fw || !dx || !dfw || rows <= 0 || nb <= 0 || nb > 8 || Cb <= 0) return set_error(QAVIT_EINVAL, "hybrid_fuse_bwd: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)rows * nb * Cb;
+  if (dtype == QAVIT_BF16 && vec_ok<bf16>(nb * Cb, Cb, n, x, dy, dx)) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((hybrid_bwd_vec_kernel<bf16>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, nvec, nb, Cb, nb * Cb);
+    return check_launch("hybrid_fuse_bwd");
+  }
+  if (dtype == QAVIT_F32 && vec_ok<float>(nb * Cb, Cb, n, x, dy, dx)) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((hybrid_bwd_vec_kernel<float>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, nvec, nb, Cb, nb * Cb);
+    return check_launch("hybrid_fuse_bwd");
+  }
   const int g = blocks_for(n, 4096, 1024);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb),
@@ -322,6 +440,16 @@ extern "C" int qavit_scale_add_fwd(int dtype, const void* x, const void* u, cons
   if (dp_p > 0.f && (!rng || dp_rows <= 0)) return set_error(QAVIT_EINVAL, "scale_add_fwd: drop-path needs rng and rows-per-sample");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)rows * C;
+  if (dtype == QAVIT_BF16 && vec_ok<bf16>(C, C, n, x, u, y)) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((scale_add_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)x, (const bf16*)u, gamma, (bf16*)y, (float*)nullptr, nvec, C, dp_p, dp_site, dp_rows, rng);
+    return check_launch("scale_add_fwd");
+  }
+  if (dtype == QAVIT_F32 && vec_ok<float>(C, C, n, x, u, y)) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((scale_add_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)x, (const float*)u, gamma, (float*)y, (float*)nullptr, nvec, C, dp_p, dp_site, dp_rows, rng);
+    return check_launch("scale_add_fwd");
+  }
   const int g = blocks_for(n, 1024);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((scale_add_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)u, gamma, (float*)y, n, C, dp_p, dp_site, dp_rows, rng),
@@ -334,6 +462,16 @@ extern "C" int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, con
   if (dp_p > 0.f && (!rng || dp_rows <= 0)) return set_error(QAVIT_EINVAL, "scale_add_bwd: drop-path needs rng and rows-per-sample");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)rows * C;
+  if (dtype == QAVIT_BF16 && vec_ok<bf16>(C, C, n, dy, u, du)) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((scale_add_vec_kernel<bf16, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)u, gamma, (bf16*)du, dgamma, nvec, C, dp_p, dp_site, dp_rows, rng);
+    return check_launch("scale_add_bwd");
+  }
+  if (dtype == QAVIT_F32 && vec_ok<float>(C, C, n, dy, u, du)) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((scale_add_vec_kernel<float, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)dy, (const float*)u, gamma, (float*)du, dgamma, nvec, C, dp_p, dp_site, dp_rows, rng);
+    return check_launch("scale_add_bwd");
+  }
   const int g = blocks_for(n, 4096, 1024);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((scale_add_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)u, gamma, (float*)du, dgamma, n, C, dp_p, dp_site, dp_rows, rng),
