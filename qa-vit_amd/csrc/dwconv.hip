@@ -306,14 +306,14 @@ static int dispatch_dw(int ks, bool bwd, const void* a0, const void* a1, const f
 // im2col / col2im for the two strided 3x3 stem convolutions (HQAViT_CIFAR100.py:752, :759): the conv becomes a
 // GEMM over rows (b, oy, ox) with K = Cin*k*k in the nn.Conv2d weight's own (c, dy, dx) order.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool NCHW_F32>
+template <typename T, bool NCHW_F32, typename I>
 __global__ __launch_bounds__(256) void im2col_kernel(const void* src_, T* cols, int B, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
   const int Kc = Cin * k * k;
-  const int64_t total = (int64_t)B * Ho * Wo * Kc;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int col = (int)(i % Kc);
-    const int64_t row = i / Kc;
-    const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho), b = (int)(row / ((int64_t)Wo * Ho));
+  const I total = (I)B * Ho * Wo * Kc;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (I)Kc);
+    const I row = i / (I)Kc;
+    const int ox = (int)(row % (I)Wo), oy = (int)((row / (I)Wo) % (I)Ho), b = (int)(row / ((I)Wo * Ho));
     const int c = col / (k * k), r = col - c * k * k, dy = r / k, dx = r - dy * k;
     const int y = oy * stride + dy - pad, x = ox * stride + dx - pad;
     float v = 0.f;
@@ -326,14 +326,14 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* src_, T* cols, 
 }
 
 // dx[b, y*W+x, c] = sum over taps of dcols[(b,oy,ox), c*k*k + dy*k + dx]  (channel-last destination)
-template <typename T>
+template <typename T, typename I>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* dcols, T* dx, int B, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
   const int Kc = Cin * k * k;
-  const int64_t total = (int64_t)B * H * W * Cin;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Cin);
-    const int64_t pix = i / Cin;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+  const I total = (I)B * H * W * Cin;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (I)Cin);
+    const I pix = i / (I)Cin;
+    const int x = (int)(pix % (I)W), y = (int)((pix / (I)W) % (I)H), b = (int)(pix / ((I)W * H));
     float s = 0.f;
     for (int dy = 0; dy < k; ++dy) {
       const int ty = y + pad - dy;
@@ -362,13 +362,15 @@ extern "C" int qavit_im2col(int dtype, const void* src, int src_nchw_f32, void* 
   const int64_t total = (int64_t)B * Ho * Wo * Cin * k * k;
   int grid = (int)((total + 1023) / 1024); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool small = total < 0x7fffffffLL && (int64_t)B * Cin * H * W < 0x7fffffffLL;
+#define IM2COL(T_, N_) do { if (small) hipLaunchKernelGGL((im2col_kernel<T_, N_, uint32_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo); \
+                            else hipLaunchKernelGGL((im2col_kernel<T_, N_, int64_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo); } while (0)
   if (dtype == QAVIT_F32) {
-    if (src_nchw_f32) hipLaunchKernelGGL((im2col_kernel<float, true>), dim3(grid), dim3(256), 0, st, src, (float*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
-    else hipLaunchKernelGGL((im2col_kernel<float, false>), dim3(grid), dim3(256), 0, st, src, (float*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
+    if (src_nchw_f32) IM2COL(float, true); else IM2COL(float, false);
   } else if (dtype == QAVIT_BF16) {
-    if (src_nchw_f32) hipLaunchKernelGGL((im2col_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, src, (bf16*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
-    else hipLaunchKernelGGL((im2col_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, src, (bf16*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo);
+    if (src_nchw_f32) IM2COL(bf16, true); else IM2COL(bf16, false);
   } else return set_error(QAVIT_EINVAL, "im2col: unknown dtype");
+#undef IM2COL
   return check_launch("im2col");
 }
 
@@ -378,9 +380,14 @@ extern "C" int qavit_col2im(int dtype, const void* dcols, void* dx, int B, int C
   const int64_t total = (int64_t)B * H * W * Cin;
   int grid = (int)((total + 1023) / 1024); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == QAVIT_F32) hipLaunchKernelGGL((col2im_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)dcols, (float*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
-  else if (dtype == QAVIT_BF16) hipLaunchKernelGGL((col2im_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)dcols, (bf16*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
-  else return set_error(QAVIT_EINVAL, "col2im: unknown dtype");
+  const bool small = total < 0x7fffffffLL && (int64_t)B * Ho * Wo * Cin * k * k < 0x7fffffffLL;
+  if (dtype == QAVIT_F32) {
+    if (small) hipLaunchKernelGGL((col2im_kernel<float, uint32_t>), dim3(grid), dim3(256), 0, st, (const float*)dcols, (float*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
+    else hipLaunchKernelGGL((col2im_kernel<float, int64_t>), dim3(grid), dim3(256), 0, st, (const float*)dcols, (float*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
+  } else if (dtype == QAVIT_BF16) {
+    if (small) hipLaunchKernelGGL((col2im_kernel<bf16, uint32_t>), dim3(grid), dim3(256), 0, st, (const bf16*)dcols, (bf16*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
+    else hipLaunchKernelGGL((col2im_kernel<bf16, int64_t>), dim3(grid), dim3(256), 0, st, (const bf16*)dcols, (bf16*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
+  } else return set_error(QAVIT_EINVAL, "col2im: unknown dtype");
   return check_launch("col2im");
 }
 

@@ -249,27 +249,28 @@ __global__ __launch_bounds__(256) void upmix_bwd_kernel(const T* dy, const T* xc
 // ------------------------------------------------------------------------------------------------
 // MSDA landmark tokens: y[b,j,:] = mean_s x[b, idx[j*stride+s], :]
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// I = uint32_t whenever the element count allows: 64-bit div/mod per element costs more than the gather itself
+template <typename T, typename I>
 __global__ __launch_bounds__(256) void gather_pool_fwd_kernel(const T* x, const int32_t* idx, T* y, int B, int N, int NP, int stride, int C) {
-  const int64_t total = (int64_t)B * NP * C;
+  const I total = (I)B * NP * C;
   const float inv = 1.f / (float)stride;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int j = (int)((i / C) % NP);
-    const int b = (int)(i / ((int64_t)C * NP));
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (I)C);
+    const int j = (int)((i / (I)C) % (I)NP);
+    const int b = (int)(i / ((I)C * NP));
     float s = 0.f;
     for (int k = 0; k < stride; ++k) s += to_f<T>(x[((size_t)b * N + idx[j * stride + k]) * C + c]);
     y[i] = from_f<T>(s * inv);
   }
 }
-template <typename T>
+template <typename T, typename I>
 __global__ __launch_bounds__(256) void gather_pool_bwd_kernel(const T* dy, const int32_t* idx, T* dx, int B, int N, int NP, int stride, int C) {
-  const int64_t total = (int64_t)B * N * C;
+  const I total = (I)B * N * C;
   const float inv = 1.f / (float)stride;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int n = (int)((i / C) % N);
-    const int b = (int)(i / ((int64_t)C * N));
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (I)C);
+    const int n = (int)((i / (I)C) % (I)N);
+    const int b = (int)(i / ((I)C * N));
     float s = 0.f;
     for (int e = 0; e < NP * stride; ++e)
       if (idx[e] == n) s += to_f<T>(dy[((size_t)b * NP + e / stride) * C + c]);
@@ -374,8 +375,14 @@ extern "C" int qavit_gather_pool_fwd(int dtype, const void* x, const int32_t* id
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int64_t total = (int64_t)B * NP * C;
   int grid = (int)((total + 1023) / 1024); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
-  if (dtype == QAVIT_F32) hipLaunchKernelGGL((gather_pool_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, idx, (float*)y, B, N, NP, stride, C);
-  else if (dtype == QAVIT_BF16) hipLaunchKernelGGL((gather_pool_fwd_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)x, idx, (bf16*)y, B, N, NP, stride, C);
+  const bool small = (int64_t)B * (NP > N ? NP : N) * C < 0x7fffffffLL;
+  if (dtype == QAVIT_F32) {
+    if (small) hipLaunchKernelGGL((gather_pool_fwd_kernel<float, uint32_t>), dim3(grid), dim3(256), 0, st, (const float*)x, idx, (float*)y, B, N, NP, stride, C);
+    else hipLaunchKernelGGL((gather_pool_fwd_kernel<float, int64_t>), dim3(grid), dim3(256), 0, st, (const float*)x, idx, (float*)y, B, N, NP, stride, C);
+  } else if (dtype == QAVIT_BF16) {
+    if (small) hipLaunchKernelGGL((gather_pool_fwd_kernel<bf16, uint32_t>), dim3(grid), dim3(256), 0, st, (const bf16*)x, idx, (bf16*)y, B, N, NP, stride, C);
+    else hipLaunchKernelGGL((gather_pool_fwd_kernel<bf16, int64_t>), dim3(grid), dim3(256), 0, st, (const bf16*)x, idx, (bf16*)y, B, N, NP, stride, C);
+  }
   else return set_error(QAVIT_EINVAL, "gather_pool_fwd: unknown dtype");
   return check_launch("gather_pool_fwd");
 }
@@ -385,8 +392,14 @@ extern "C" int qavit_gather_pool_bwd(int dtype, const void* dy, const int32_t* i
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int64_t total = (int64_t)B * N * C;
   int grid = (int)((total + 1023) / 1024); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
-  if (dtype == QAVIT_F32) hipLaunchKernelGGL((gather_pool_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);
-  else if (dtype == QAVIT_BF16) hipLaunchKernelGGL((gather_pool_bwd_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, idx, (bf16*)dx, B, N, NP, stride, C);
+  const bool small = (int64_t)B * (NP > N ? NP : N) * C < 0x7fffffffLL;
+  if (dtype == QAVIT_F32) {
+    if (small) hipLaunchKernelGGL((gather_pool_bwd_kernel<float, uint32_t>), dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);
+    else hipLaunchKernelGGL((gather_pool_bwd_kernel<float, int64_t>), dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);
+  } else if (dtype == QAVIT_BF16) {
+    if (small) hipLaunchKernelGGL((gather_pool_bwd_kernel<bf16, uint32_t>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, idx, (bf16*)dx, B, N, NP, stride, C);
+    else hipLaunchKernelGGL((gather_pool_bwd_kernel<bf16, int64_t>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, idx, (bf16*)dx, B, N, NP, stride, C);
+  }
   else return set_error(QAVIT_EINVAL, "gather_pool_bwd: unknown dtype");
   return check_launch("gather_pool_bwd");
 }
