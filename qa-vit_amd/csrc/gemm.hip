@@ -437,6 +437,71 @@ static int dispatch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_nt, M <= 16 (the bank projections: Linear applied to the 16 global-token rows): one wave per 16 output
+// columns, operands straight from global memory into MFMA fragments -- every load of the tile is issued before the
+// first MFMA, so the whole GEMM is ONE memory round trip (the resident-slice kernel stages a 49 KB fp32 weight slice
+// through LDS first: 12 us for 1.2 MFLOP).  Plain epilogue (bias) only.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KB>   // KB = K / FK fragment blocks (compile-time so the loads unroll)
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(qavit_gemm_args g) {
+  using M_ = Mma<T>;
+  constexpr int FK = M_::FK, VN = Vec<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  if (n0 >= g.N) return;                                 // whole wave
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+  T* C = reinterpret_cast<T*>(g.C);
+  const int am = fr < g.M ? fr : g.M - 1;                // clamped rows: loads stay in bounds, extra rows/cols are not stored
+  const int bn = n0 + fr < g.N ? n0 + fr : g.N - 1;
+  typename M_::frag af[KB], bf_[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    af[kb] = *reinterpret_cast<const typename M_::frag*>(A + (size_t)am * g.lda + kb * FK + fq * VN);
+    bf_[kb] = *reinterpret_cast<const typename M_::frag*>(B + (size_t)bn * g.ldb + kb * FK + fq * VN);
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) M_::mma(af[kb], bf_[kb], acc);
+  const int n = n0 + fr;
+  if (n < g.N) {
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = fq * 4 + r;
+      if (m < g.M) C[(size_t)m * g.ldc + n] = from_f<T>(acc[r] + bv);
+    }
+  }
+}
+
+template <typename T>
+static int skinny_try(const qavit_gemm_args& g, hipStream_t st) {
+  constexpr int FK = Mma<T>::FK, VN = Vec<T>::N;
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("QAVIT_GEMM_SKINNY"); on = e ? atoi(e) : 1; }
+  if (!on) return 0;
+  if (g.M > 16 || g.a_mode != 0 || g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f) return 0;
+  if (g.K % FK || g.lda % VN || g.ldb % VN || ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15)) return 0;
+  const int kb = g.K / FK;
+  const int grid = (g.N + 63) / 64;
+#define SKINNY(KB_) hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, KB_>), dim3(grid), dim3(256), 0, st, g)
+  switch (kb) {
+    case 1: SKINNY(1); break;
+    case 2: SKINNY(2); break;
+    case 3: SKINNY(3); break;
+    case 4: SKINNY(4); break;
+    case 6: SKINNY(6); break;
+    case 8: SKINNY(8); break;
+    case 12: SKINNY(12); break;
+    default: return 0;
+  }
+#undef SKINNY
+  const int rc = check_launch("gemm_nt(skinny)");
+  return rc == QAVIT_OK ? 1 : rc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // gemm_tn : C[N,K] += A^T B over a slice of M, one 64x64 output tile per workgroup
 // ------------------------------------------------------------------------------------------------
 constexpr int TN_MC = 64;   // rows of M per staged chunk
@@ -717,6 +782,11 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   if ((a->dp_p > 0.f && a->dp_rows <= 0) || (a->a_dp_p > 0.f && a->a_dp_rows <= 0))
     return set_error(QAVIT_EINVAL, "gemm_nt: drop-path needs rows-per-sample");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->dtype == QAVIT_F32 || a->dtype == QAVIT_BF16) {
+    const int took = a->dtype == QAVIT_F32 ? skinny_try<float>(*a, st) : skinny_try<bf16>(*a, st);
+    if (took < 0) return took;
+    if (took == 1) return QAVIT_OK;
+  }
   if (a->dtype == QAVIT_F32) return dispatch_gemm_nt<float>(*a, st);
   if (a->dtype == QAVIT_BF16) {
     const int took = gemm_nt_big_try(*a, st);
