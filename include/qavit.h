@@ -266,6 +266,11 @@ int qavit_token_mean_bwd(int dtype, const void* dy, void* dx, int B, int N, int 
 int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, void* y, int rows, int nb, int Cb, void* stream);
 int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, const float* fw, void* dx, float* dfw,
                           int rows, int nb, int Cb, void* stream);
+/* SplitFusion blend (HQAViT_CIFAR100.py:959-963): y = s0*a + s1*b with s = softmax(fw[0..1]); n = element count (a multiple
+ * of the 16-byte vector, operands 16-byte aligned).  bwd: da = s0*dy, db = s1*dy, dfw[2] += (through the softmax; may be NULL) */
+int qavit_mix2_fwd(int dtype, const void* a, const void* b, const float* fw, void* y, int64_t n, void* stream);
+int qavit_mix2_bwd(int dtype, const void* dy, const void* a, const void* b, const float* fw, void* da, void* db, float* dfw,
+                   int64_t n, void* stream);
 /* y = x + droppath( gamma[0] * u )  (CCF-FFN gamma + residual, HQAViT_CIFAR100.py:712,1083); gamma may be NULL (=1) */
 int qavit_scale_add_fwd(int dtype, const void* x, const void* u, const float* gamma, void* y, int rows, int C,
                         float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);

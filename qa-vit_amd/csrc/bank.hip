@@ -155,7 +155,7 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
     const int took = bank_stats_bf16_try(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, grid, eps, st);
     if (took < 0) return took;
     if (took == 1) {
-      (void)hipMemsetAsync(acc, 0, (size_t)n_acc * sizeof(float), st);
+      zero_f32(acc, (size_t)n_acc, st);
       hipLaunchKernelGGL(bank_reduce_kernel, dim3((n_acc + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n_acc);
       return check_launch("bank_stats(bf16)");
     }
@@ -168,7 +168,7 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
     hipLaunchKernelGGL((bank_stats_kernel<bf16, true>), dim3(grid), dim3(256), smem, st, (const bf16*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);
   } else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
   const int n = S * C;
-  (void)hipMemsetAsync(acc, 0, (size_t)n * sizeof(float), st);
+  zero_f32(acc, (size_t)n, st);
   hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n);
   return check_launch("bank_stats");
 }

@@ -189,7 +189,7 @@ int bn_fwd_t(const void* x, void* y, int M, int C, const float* gamma, const flo
   constexpr int VEC = BV<T>::N;
   if (!bn_shape_ok<T>(x, y, x, C)) return set_error(QAVIT_EINVAL, "bn_fwd: C must be a multiple of the 16-byte vector with 256 % (C/vec) == 0, 16-byte aligned rows");
   if (training) {
-    (void)hipMemsetAsync(ws, 0, (size_t)3 * C * sizeof(float), st);
+    zero_f32(ws, (size_t)3 * C, st);
     int grid, rows;
     stats_grid(M, C, VEC, grid, rows);
     hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), st, (const T*)x, rm, ws, M, C, rows);
@@ -207,7 +207,7 @@ int bn_bwd_t(const void* dy, const void* x, int M, int C, const float* gamma, co
              int training, void* dx, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
   constexpr int VEC = BV<T>::N;
   if (!bn_shape_ok<T>(x, dy, dx, C)) return set_error(QAVIT_EINVAL, "bn_bwd: unsupported channel count / alignment");
-  (void)hipMemsetAsync(ws, 0, (size_t)2 * C * sizeof(float), st);
+  zero_f32(ws, (size_t)2 * C, st);
   int grid, rows;
   stats_grid(M, C, VEC, grid, rows);
   hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd,

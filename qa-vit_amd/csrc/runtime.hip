@@ -24,6 +24,15 @@ int check_launch(const char* what) {
   return QAVIT_OK;
 }
 
+__global__ void zero_f32_kernel(float* p, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+void zero_f32(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+}
+
 static inline int blocks_for(int64_t n, int per_block, int cap = 4096) {
   int64_t b = (n + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -231,6 +240,52 @@ __global__ __launch_bounds__(256) void scale_add_vec_kernel(const T* a0, const T
   }
 }
 
+// SplitFusion's learnable blend (HQAViT_CIFAR100.py:959-963): y = s0*a + s1*b, s = softmax(fw[2]).
+// bwd: da = s0*dy, db = s1*dy, dfw += softmax-jacobian of (sum dy*a, sum dy*b) -- per-workgroup partials are linear in the
+// sums, so each workgroup adds its own contribution.  (The stock mul/sum chain reduces with a memset-initialised
+// semaphore buffer; memset nodes of a replayed hipGraph were observed to race: garbage fusion-weight gradients.)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, const T* dy, const float* fw, T* o0, T* o1, float* dfw, uint32_t nvec) {
+  constexpr int VEC = Vec<T>::N;
+  typedef typename Vec<T>::type vec_t;
+  float w[8];
+  softmax_small(fw, 2, w);
+  float p0 = 0.f, p1 = 0.f;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    const vec_t av = *reinterpret_cast<const vec_t*>(a + (size_t)v * VEC);
+    const vec_t bv = *reinterpret_cast<const vec_t*>(b + (size_t)v * VEC);
+    vec_t x0, x1;
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) x0[j] = from_f<T>(w[0] * to_f<T>(av[j]) + w[1] * to_f<T>(bv[j]));
+      *reinterpret_cast<vec_t*>(o0 + (size_t)v * VEC) = x0;
+    } else {
+      const vec_t gv = *reinterpret_cast<const vec_t*>(dy + (size_t)v * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float g = to_f<T>(gv[j]);
+        x0[j] = from_f<T>(g * w[0]); x1[j] = from_f<T>(g * w[1]);
+        p0 += g * to_f<T>(av[j]); p1 += g * to_f<T>(bv[j]);
+      }
+      *reinterpret_cast<vec_t*>(o0 + (size_t)v * VEC) = x0;
+      *reinterpret_cast<vec_t*>(o1 + (size_t)v * VEC) = x1;
+    }
+  }
+  if (BWD && dfw) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float s0 = wave_sum(p0), s1 = wave_sum(p1);
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float d0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], d1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      const float dot = d0 * w[0] + d1 * w[1];
+      atomic_add_f(dfw + 0, w[0] * (d0 - dot));
+      atomic_add_f(dfw + 1, w[1] * (d1 - dot));
+    }
+  }
+}
+
 template <typename T>
 static bool vec_ok(int C, int Cb, int64_t n, const void* p0, const void* p1, const void* p2) {
   constexpr int VEC = Vec<T>::N;
@@ -432,6 +487,31 @@ extern "C" int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, c
              hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb),
              hipLaunchKernelGGL((hybrid_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, n, nb, Cb), "hybrid_fuse_bwd");
   return check_launch("hybrid_fuse_bwd");
+}
+
+extern "C" int qavit_mix2_fwd(int dtype, const void* a, const void* b, const float* fw, void* y, int64_t n, void* stream) {
+  if (!a || !b || !fw || !y || n <= 0) return set_error(QAVIT_EINVAL, "mix2_fwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_BF16 && vec_ok<bf16>(8, 8, n, a, b, y) && n % 8 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((mix2_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)nullptr, fw, (bf16*)y, (bf16*)nullptr, (float*)nullptr, nvec);
+  } else if (dtype == QAVIT_F32 && vec_ok<float>(4, 4, n, a, b, y) && n % 4 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((mix2_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)nullptr, fw, (float*)y, (float*)nullptr, (float*)nullptr, nvec);
+  } else return set_error(QAVIT_EINVAL, "mix2_fwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
+  return check_launch("mix2_fwd");
+}
+extern "C" int qavit_mix2_bwd(int dtype, const void* dy, const void* a, const void* b, const float* fw, void* da, void* db, float* dfw, int64_t n, void* stream) {
+  if (!dy || !a || !b || !fw || !da || !db || n <= 0) return set_error(QAVIT_EINVAL, "mix2_bwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_BF16 && vec_ok<bf16>(8, 8, n, a, b, dy) && vec_ok<bf16>(8, 8, n, da, db, dy) && n % 8 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((mix2_vec_kernel<bf16, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)dy, fw, (bf16*)da, (bf16*)db, dfw, nvec);
+  } else if (dtype == QAVIT_F32 && vec_ok<float>(4, 4, n, a, b, dy) && vec_ok<float>(4, 4, n, da, db, dy) && n % 4 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((mix2_vec_kernel<float, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)dy, fw, (float*)da, (float*)db, dfw, nvec);
+  } else return set_error(QAVIT_EINVAL, "mix2_bwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
+  return check_launch("mix2_bwd");
 }
 
 extern "C" int qavit_scale_add_fwd(int dtype, const void* x, const void* u, const float* gamma, void* y, int rows, int C,

@@ -810,6 +810,28 @@ class CompressFuseFn(Function):
         return (fret, None, *grads)
 
 
+class Mix2Fn(Function):
+    """y = s0*a + s1*b, s = softmax(fw) -- SplitFusion's learnable blend (csrc/runtime.hip: mix2)."""
+
+    @staticmethod
+    def forward(ctx, a, b, fw):
+        K._require_cuda(a, fw)
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        K.mix2_fwd(a, b, fw.detach(), y)
+        ctx.save_for_backward(a, b, fw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, fw = ctx.saved_tensors
+        dy = dy.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        fbuf, fret = grad_sink(fw)
+        K.mix2_bwd(dy, a, b, fw.detach(), da, db, fbuf)
+        return da, db, fret
+
+
 class ScaleAddFn(Function):
     """y = x + droppath(gamma * u)"""
 

@@ -313,6 +313,15 @@ def hybrid_fuse_bwd(dy, x, fw, dx, dfw, rows, nb, Cb):
     L.check(L.load().qavit_hybrid_fuse_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), fw.data_ptr(), dx.data_ptr(), dfw.data_ptr(), rows, nb, Cb, stream()), "hybrid_fuse_bwd")
 
 
+def mix2_fwd(a, b, fw, y):
+    L.check(L.load().qavit_mix2_fwd(dt_code(a.dtype), a.data_ptr(), b.data_ptr(), fw.data_ptr(), y.data_ptr(), a.numel(), stream()), "mix2_fwd")
+
+
+def mix2_bwd(dy, a, b, fw, da, db, dfw):
+    L.check(L.load().qavit_mix2_bwd(dt_code(a.dtype), dy.data_ptr(), a.data_ptr(), b.data_ptr(), fw.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                    _p(dfw), a.numel(), stream()), "mix2_bwd")
+
+
 def scale_add_fwd(x, u, gamma, y, rows, Cc, dp, rng):
     L.check(L.load().qavit_scale_add_fwd(dt_code(x.dtype), x.data_ptr(), u.data_ptr(), _p(gamma), y.data_ptr(), rows, Cc, dp[0], dp[1], dp[2], _p(rng), stream()), "scale_add_fwd")
 
@@ -322,6 +331,8 @@ def scale_add_bwd(dy, u, gamma, du, dgamma, rows, Cc, dp, rng):
 
 
 def bn_supported(dtype, Cc: int) -> bool:
+    if os.environ.get("QAVIT_BN", "1") == "0":
+        return False
     vec = 8 if dtype == torch.bfloat16 else 4
     return Cc % vec == 0 and Cc // vec <= 256 and 256 % (Cc // vec) == 0 and Cc <= 2048
 

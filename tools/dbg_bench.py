@@ -16,6 +16,16 @@ for i in range(80):
     tr.replay()
     if every and (i + 1) % every == 0:
         torch.cuda.synchronize()
-        print(i + 1, float(tr.loss), float(tr.gnorm), flush=True)
+        gn = float(tr.gnorm)
+        print(i + 1, float(tr.loss), gn, flush=True)
+        if gn != gn or gn > 1e3:
+            offenders = []
+            for n, p in model.named_parameters():
+                if p.grad is None: continue
+                m = p.grad.abs().max()
+                m = float(m)
+                if m != m or m > 1e2: offenders.append((n, m, tuple(p.shape)))
+            print("offenders:", offenders[:12], len(offenders), flush=True)
+            break
 torch.cuda.synchronize()
 print("final", float(tr.loss.item()), float(tr.gnorm))
