@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--mix", action="store_true", help="include device-side CutMix/MixUp + mixed loss in the step (off: the BASELINE metric)")
     ap.add_argument("--fwd-bwd-only", action="store_true", help="time forward+backward(+all-reduce) without the optimiser")
     return ap.parse_args()
 
@@ -234,7 +235,7 @@ def main():
     dp = None
     if world > 1 or force_ddp:
         dp = par.DataParallel(model)
-    tcfg = Q.TrainingConfig(batch_size=B * world, use_amp=(cdt == torch.bfloat16))
+    tcfg = Q.TrainingConfig(batch_size=B * world, use_amp=(cdt == torch.bfloat16), device_mix=args.mix)
     tr = Q.Trainer(model, tcfg, total_steps=100000, warmup_steps=1000, reducer=(dp.reducer if dp else None),
                    compute_dtype=cdt, order=par.bucket_order)
     if dp:
@@ -282,7 +283,7 @@ def main():
         "metric": "training images/sec (fwd+bwd) HQA-ViT CIFAR-100", "value": round(value, 1), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "HQAViT_CIFAR100 full training step (re-pack, fwd, CE loss, bwd, "
+        "config": {"workload": "HQAViT_CIFAR100 full training step (" + ("device CutMix/MixUp, " if args.mix else "") + "re-pack, fwd, CE loss, bwd, "
                                + ("grad all-reduce, " if world > 1 else "") + ("clip + fused AdamW)" if with_optim else "no optimiser)"),
                    "model": "HQAViT(HQAViTConfig()) 6,472,037 params, random-init (key-seeded filler)",
                    "global_batch": B * world, "per_gpu_batch": B, "image": "32x32x3", "parallelism": f"dp{world}",

@@ -266,6 +266,13 @@ int qavit_token_mean_bwd(int dtype, const void* dy, void* dx, int B, int N, int 
 int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, void* y, int rows, int nb, int Cb, void* stream);
 int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, const float* fw, void* dx, float* dfw,
                           int rows, int nb, int Cb, void* stream);
+/* perm[0..B) = a uniform random permutation drawn from the counter RNG (rng[0] seed, rng[1] step, site): the
+ * torch.randperm of train_epoch (HQAViT_CIFAR100.py:1383,1395) as one capturable kernel; B <= 16384. */
+int qavit_rand_perm(int64_t* perm, int B, const int64_t* rng, int site, void* stream);
+/* Device-side CutMix / MixUp of an fp32 NCHW batch (train_epoch, HQAViT_CIFAR100.py:1381-1399).  plan = device float[6]:
+ * mode (0 none, 1 cutmix, 2 mixup), lambda, x1, y1, x2, y2 (the box of rand_bbox :1339-1363); perm = device int64[B].
+ * out[b] = x[b] with the box pasted from x[perm[b]] (cutmix) or lambda*x[b] + (1-lambda)*x[perm[b]] (mixup).  out != x. */
+int qavit_mix_apply(const float* x, const int64_t* perm, const float* plan, float* out, int B, int C, int H, int W, void* stream);
 /* SplitFusion blend (HQAViT_CIFAR100.py:959-963): y = s0*a + s1*b with s = softmax(fw[0..1]); n = element count (a multiple
  * of the 16-byte vector, operands 16-byte aligned).  bwd: da = s0*dy, db = s1*dy, dfw[2] += (through the softmax; may be NULL) */
 int qavit_mix2_fwd(int dtype, const void* a, const void* b, const float* fw, void* y, int64_t n, void* stream);

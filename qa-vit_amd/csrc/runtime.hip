@@ -286,6 +286,63 @@ __global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, c
   }
 }
 
+// Device-side CutMix / MixUp of the input batch (train_epoch, HQAViT_CIFAR100.py:1381-1399).  plan[6] (device):
+// mode (0 none, 1 cutmix, 2 mixup), lambda, x1, y1, x2, y2.  out[b] = in[b] with the box pasted from in[perm[b]]
+// (cutmix) or lam*in[b] + (1-lam)*in[perm[b]] (mixup).  One thread per 4 pixels of a row (W % 4 == 0).
+__global__ __launch_bounds__(256) void mix_apply_kernel(const float* x, const int64_t* perm, const float* plan, float* out, int B, int C, int H, int W) {
+  const int mode = (int)plan[0];
+  const float lam = plan[1];
+  const int x1 = (int)plan[2], y1 = (int)plan[3], x2 = (int)plan[4], y2 = (int)plan[5];
+  const uint32_t w4 = W / 4, per_img = (uint32_t)C * H * w4, total = (uint32_t)B * per_img;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t b = i / per_img, r = i - b * per_img;
+    const uint32_t xx = (r % w4) * 4, yy = (r / w4) % H;
+    const size_t o = (size_t)b * per_img * 4 + (size_t)r * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + o);
+    f32x4 v = a;
+    if (mode != 0) {
+      const size_t o2 = (size_t)perm[b] * per_img * 4 + (size_t)r * 4;
+      const f32x4 c = *reinterpret_cast<const f32x4*>(x + o2);
+      if (mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = lam * a[j] + (1.f - lam) * c[j];
+      } else if ((int)yy >= y1 && (int)yy < y2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int px = (int)xx + j; v[j] = (px >= x1 && px < x2) ? c[j] : a[j]; }
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + o) = v;
+  }
+}
+
+// Uniform random permutation of 0..B-1 (the torch.randperm of train_epoch :1383,1395) without a library sort: random
+// 32-bit keys from the counter RNG (seed, step, site, index), bitonic sort of (key, index) pairs in LDS by one workgroup.
+// Ties (probability ~B^2 / 2^33) are broken by index, so the result is always a permutation.
+__global__ __launch_bounds__(256) void rand_perm_kernel(int64_t* perm, int B, int P, const int64_t* rng, int site) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sk[];     // keys [P], then indices [P]
+  uint32_t* si = sk + P;
+  const uint32_t key = rng_key(rng, site);
+  for (int i = threadIdx.x; i < P; i += 256) {
+    sk[i] = i < B ? (mix32((uint32_t)i * 0x9E3779B9U ^ key) >> 1) : 0xFFFFFFFFu;
+    si[i] = (uint32_t)i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const uint32_t ka = sk[i], kb = sk[l], ia = si[i], ib = si[l];
+          const bool gt = ka > kb || (ka == kb && ia > ib);
+          if (gt == up) { sk[i] = kb; sk[l] = ka; si[i] = ib; si[l] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < B; i += 256) perm[i] = (int64_t)si[i];
+}
+
 template <typename T>
 static bool vec_ok(int C, int Cb, int64_t n, const void* p0, const void* p1, const void* p2) {
   constexpr int VEC = Vec<T>::N;
@@ -487,6 +544,24 @@ extern "C" int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, c
              hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb),
              hipLaunchKernelGGL((hybrid_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, n, nb, Cb), "hybrid_fuse_bwd");
   return check_launch("hybrid_fuse_bwd");
+}
+
+extern "C" int qavit_rand_perm(int64_t* perm, int B, const int64_t* rng, int site, void* stream) {
+  if (!perm || !rng || B <= 0 || B > 16384) return set_error(QAVIT_EINVAL, "rand_perm: 1 <= B <= 16384");
+  int P = 1;
+  while (P < B) P <<= 1;
+  hipLaunchKernelGGL(rand_perm_kernel, dim3(1), dim3(256), (size_t)2 * P * sizeof(uint32_t), reinterpret_cast<hipStream_t>(stream), perm, B, P, rng, site);
+  return check_launch("rand_perm");
+}
+
+extern "C" int qavit_mix_apply(const float* x, const int64_t* perm, const float* plan, float* out, int B, int C, int H, int W, void* stream) {
+  if (!x || !perm || !plan || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return set_error(QAVIT_EINVAL, "mix_apply: bad arguments");
+  if (W % 4 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) || x == out || (int64_t)B * C * H * W >= 0x7fffffffLL)
+    return set_error(QAVIT_EINVAL, "mix_apply: W must be a multiple of 4, 16-byte aligned fp32 NCHW batches, out != x");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nv = (int64_t)B * C * H * W / 4;
+  hipLaunchKernelGGL(mix_apply_kernel, dim3(blocks_for(nv, 512, 2048)), dim3(256), 0, st, x, perm, plan, out, B, C, H, W);
+  return check_launch("mix_apply");
 }
 
 extern "C" int qavit_mix2_fwd(int dtype, const void* a, const void* b, const float* fw, void* y, int64_t n, void* stream) {

@@ -42,6 +42,35 @@ class TrainingConfig:
     beta1: float = 0.9
     beta2: float = 0.999
     eps: float = 1e-8
+    # batch mixing (:118-122); ``device_mix`` turns the device-side implementation on in Trainer
+    use_mixup: bool = True
+    mixup_alpha: float = 0.9
+    use_cutmix: bool = True
+    cutmix_alpha: float = 1.0
+    mix_prob: float = 0.6
+    device_mix: bool = False
+
+
+def mix_plan(u: torch.Tensor, lam_cut: torch.Tensor, lam_mix: torch.Tensor, cfg: "TrainingConfig", H: int, W: int) -> torch.Tensor:
+    """The per-step decisions of train_epoch's CutMix / MixUp branch (HQAViT_CIFAR100.py:1378-1399, rand_bbox :1339-1363)
+    as tensor arithmetic, so they can live on the device and inside a captured step.  ``u`` = 4 uniforms in [0,1)
+    (cutmix coin, mixup coin, box centre x, box centre y); ``lam_cut`` / ``lam_mix`` = the Beta(alpha, alpha) draws.
+    -> float[6]: mode (0 none / 1 cutmix / 2 mixup), lambda, x1, y1, x2, y2."""
+    cut = (u[0] < cfg.mix_prob) if cfg.use_cutmix else torch.zeros((), dtype=torch.bool, device=u.device)
+    mixu = (~cut) & ((u[1] < cfg.mix_prob) if cfg.use_mixup else torch.zeros((), dtype=torch.bool, device=u.device))
+    cut_rat = torch.sqrt(1.0 - lam_cut)
+    cut_w = torch.floor(W * cut_rat)
+    cut_h = torch.floor(H * cut_rat)
+    cx = torch.floor(u[2] * W)
+    cy = torch.floor(u[3] * H)
+    hw, hh = torch.floor(cut_w / 2), torch.floor(cut_h / 2)
+    x1, x2 = torch.clamp(cx - hw, 0, W), torch.clamp(cx + hw, 0, W)
+    y1, y2 = torch.clamp(cy - hh, 0, H), torch.clamp(cy + hh, 0, H)
+    lam_box = 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)           # "adjust lambda to exactly match pixel ratio" (:1390)
+    one = torch.ones((), dtype=torch.float32, device=u.device)
+    lam = torch.where(cut, lam_box, torch.where(mixu, lam_mix, one))
+    mode = cut.float() + 2.0 * mixu.float()
+    return torch.stack([mode, lam, x1, y1, x2, y2]).float()
 
 
 def never_trained(name: str) -> bool:
@@ -132,6 +161,52 @@ class GradientMonitor:
         return bad
 
 
+class BatchStager:
+    """Host -> device batch staging with pinned double buffers on a copy stream: while the step
+    consumes slot i, the loader thread fills slot i^1's pinned buffers and the copy engine moves them; the compute
+    stream only waits on the slot's event.  ``put`` returns the slot to pass to ``get``.
+
+        st = BatchStager((B, 3, 32, 32), B, device)
+        slot = st.put(x_cpu, y_cpu)                 # before the previous step has finished
+        x, y = st.get(slot); trainer.replay(x, y)
+    """
+
+    def __init__(self, x_shape, n_labels: int, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.hx = [torch.empty(x_shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.hy = [torch.empty(n_labels, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.dx = [torch.empty(x_shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.dy = [torch.empty(n_labels, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [torch.cuda.Event() for _ in range(2)]
+        self._i = 0
+        self._used = [False, False]
+
+    def put(self, x_cpu: torch.Tensor, y_cpu: torch.Tensor) -> int:
+        i = self._i
+        self._i ^= 1
+        if self._used[i]:
+            self.consumed[i].synchronize()                 # the step that read this slot's device buffers is done
+        self.hx[i].copy_(x_cpu)
+        self.hy[i].copy_(y_cpu)
+        with torch.cuda.stream(self.stream):
+            self.dx[i].copy_(self.hx[i], non_blocking=True)
+            self.dy[i].copy_(self.hy[i], non_blocking=True)
+            self.ready[i].record(self.stream)
+        return i
+
+    def get(self, slot: int):
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.ready[slot])
+        self._used[slot] = True
+        return self.dx[slot], self.dy[slot]
+
+    def done(self, slot: int):
+        """Call after enqueuing the step that consumed ``slot`` (records when its device buffers may be overwritten)."""
+        self.consumed[slot].record(torch.cuda.current_stream(self.device))
+
+
 class Trainer:
     """One object = model + flat optimiser state + (optional) data-parallel reducer + (optional) hipGraph."""
 
@@ -187,6 +262,7 @@ class Trainer:
         self.graph = None
         self._static_x = self._static_y = None
         self.rt = K.Runtime.get(dev) if dev.type == "cuda" else None
+        self._mix_site = K.new_site()
 
     # ------------------------------------------------------------------------------------------
     def _fwd_bwd(self, x, y):
@@ -195,13 +271,36 @@ class Trainer:
         self.flat_g.zero_()
         if self.reducer is not None:
             self.reducer.begin_step()
-        logits = self.model(x)
-        loss = TF.cross_entropy(logits.float(), y, label_smoothing=self.cfg.label_smoothing)
+        if self.cfg.device_mix:
+            x, y_b, lam = self._mix(x, y)
+            logits = self.model(x).float()
+            ls = self.cfg.label_smoothing
+            loss = lam * TF.cross_entropy(logits, y, label_smoothing=ls) + (1.0 - lam) * TF.cross_entropy(logits, y_b, label_smoothing=ls)
+        else:
+            logits = self.model(x)
+            loss = TF.cross_entropy(logits.float(), y, label_smoothing=self.cfg.label_smoothing)
         loss.backward()
         F.SideStream.join(self.device)                     # weight-gradient GEMMs ran on the side stream
         if self.reducer is not None:
             self.reducer.finish(self.flat_g)
         return loss.detach()
+
+    def _mix(self, x, y):
+        """Device-side CutMix / MixUp (no host RNG, no host sync: capturable).  -> mixed x, permuted labels, lambda."""
+        cfg = self.cfg
+        dev = x.device
+        B, _, H, W = x.shape
+        u = torch.rand(4, device=dev)
+
+        def beta(a):
+            g = torch._standard_gamma(torch.full((2,), float(a), device=dev))
+            return g[0] / (g[0] + g[1])
+        plan = mix_plan(u, beta(cfg.cutmix_alpha), beta(cfg.mixup_alpha), cfg, H, W)
+        perm = torch.empty(B, dtype=torch.int64, device=dev)
+        K.rand_perm(perm, B, self.rt.rng, self._mix_site)          # own kernel: a library sort brings memset nodes into the graph
+        out = torch.empty_like(x)
+        K.mix_apply(x.contiguous().float(), perm, plan, out)
+        return out, y[perm], plan[1]
 
     def _optim(self):
         cfg = self.cfg

@@ -313,6 +313,15 @@ def hybrid_fuse_bwd(dy, x, fw, dx, dfw, rows, nb, Cb):
     L.check(L.load().qavit_hybrid_fuse_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), fw.data_ptr(), dx.data_ptr(), dfw.data_ptr(), rows, nb, Cb, stream()), "hybrid_fuse_bwd")
 
 
+def rand_perm(perm, B, rng, site):
+    L.check(L.load().qavit_rand_perm(perm.data_ptr(), B, rng.data_ptr(), site, stream()), "rand_perm")
+
+
+def mix_apply(x, perm, plan, out):
+    B, Cc, H, W = x.shape
+    L.check(L.load().qavit_mix_apply(x.data_ptr(), perm.data_ptr(), plan.data_ptr(), out.data_ptr(), B, Cc, H, W, stream()), "mix_apply")
+
+
 def mix2_fwd(a, b, fw, y):
     L.check(L.load().qavit_mix2_fwd(dt_code(a.dtype), a.data_ptr(), b.data_ptr(), fw.data_ptr(), y.data_ptr(), a.numel(), stream()), "mix2_fwd")
 

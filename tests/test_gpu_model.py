@@ -213,3 +213,59 @@ def test_graph_replays_back_to_back_stay_finite(Q):
         assert gn == gn and ls == ls, (gn, ls)
         worst = max(worst, gn)
     assert worst < 1e3, worst
+
+
+def test_device_mix_apply_and_mixed_step(Q):
+    """qavit_mix_apply against the reference's tensor expressions for both modes, and a captured training step with
+    device-side CutMix/MixUp: replays stay finite and draw fresh plans."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    B, C, H, W = 16, 3, 32, 32
+    x = torch.randn(B, C, H, W, device="cuda")
+    perm = torch.randperm(B, device="cuda")
+    for plan_l in ([1.0, 0.7, 5, 9, 21, 27], [2.0, 0.35, 0, 0, 0, 0], [0.0, 1.0, 0, 0, 0, 0]):
+        plan = torch.tensor(plan_l, device="cuda", dtype=torch.float32)
+        out = torch.empty_like(x)
+        K.mix_apply(x, perm, plan, out)
+        ref = x.clone()
+        if plan_l[0] == 1.0:
+            x1, y1, x2, y2 = [int(v) for v in plan_l[2:]]
+            ref[:, :, y1:y2, x1:x2] = x[perm, :, y1:y2, x1:x2]
+        elif plan_l[0] == 2.0:
+            ref = plan_l[1] * x + (1 - plan_l[1]) * x[perm]
+        assert float((out - ref).abs().max()) <= 1e-6
+    rt = K.Runtime.get(torch.device("cuda:0"))
+    for n in (1, 16, 1000, 1024):
+        p1, p2 = torch.empty(n, dtype=torch.int64, device="cuda"), torch.empty(n, dtype=torch.int64, device="cuda")
+        K.rand_perm(p1, n, rt.rng, 77)
+        K.rand_perm(p2, n, rt.rng, 78)
+        assert sorted(p1.tolist()) == list(range(n)) and sorted(p2.tolist()) == list(range(n))
+        if n >= 16:
+            assert p1.tolist() != p2.tolist() and p1.tolist() != list(range(n))
+    model = Q.HQAViT(Q.HQAViTConfig())
+    Q.fill_module(model)
+    model = model.cuda().train()
+    y = torch.randint(0, 100, (B,), device="cuda")
+    tr = Q.Trainer(model, Q.TrainingConfig(batch_size=B, use_amp=True, device_mix=True), total_steps=1000, warmup_steps=10, compute_dtype=torch.bfloat16)
+    tr.capture(x, y, with_optim=True, warmup=2)
+    losses = []
+    for _ in range(6):
+        losses.append(float(tr.replay()))
+    assert all(l == l and 0.0 < l < 20.0 for l in losses), losses
+    assert len({round(l, 4) for l in losses}) > 1, losses
+
+
+def test_batch_stager_double_buffers(Q):
+    """Pinned double-buffered host->device staging: slots alternate, contents arrive intact, reuse waits for the consumer."""
+    st = Q.BatchStager((8, 3, 32, 32), 8, "cuda:0")
+    seen = []
+    for k in range(5):
+        xc = torch.full((8, 3, 32, 32), float(k))
+        yc = torch.full((8,), k, dtype=torch.int64)
+        slot = st.put(xc, yc)
+        x, y = st.get(slot)
+        seen.append((slot, float(x.sum()), int(y[0])))
+        st.done(slot)
+    torch.cuda.synchronize()
+    assert [s[0] for s in seen] == [0, 1, 0, 1, 0]
+    assert all(abs(v - k * 8 * 3 * 32 * 32) < 1e-3 and yy == k for k, (_, v, yy) in enumerate(seen))

@@ -134,3 +134,32 @@ def test_bucket_plan_covers_flat_buffer_in_backward_order(Q):
         while offs[i + 1] <= upto:
             assert pred(names[i]), (t, names[i])
             i += 1
+
+
+def test_mix_plan_follows_the_reference_decisions(Q):
+    """harness.mix_plan against a scalar restatement of train_epoch's CutMix/MixUp branch and rand_bbox
+    (HQAViT_CIFAR100.py:1339-1363, 1378-1399) for the same uniform / beta draws."""
+    import math
+    import numpy as np
+    cfg = Q.TrainingConfig()
+    H = W = 32
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        u = rng.random(4)
+        lam_c, lam_m = rng.beta(cfg.cutmix_alpha, cfg.cutmix_alpha), rng.beta(cfg.mixup_alpha, cfg.mixup_alpha)
+        # reference control flow with the draws substituted for np.random.*
+        mode, lam, box = 0, 1.0, (0, 0, 0, 0)
+        if cfg.use_cutmix and u[0] < cfg.mix_prob:
+            cut_rat = math.sqrt(1.0 - lam_c)
+            cut_w, cut_h = int(W * cut_rat), int(H * cut_rat)
+            cx, cy = int(u[2] * W), int(u[3] * H)                      # np.random.randint(W) from a uniform
+            x1, y1 = int(np.clip(cx - cut_w // 2, 0, W)), int(np.clip(cy - cut_h // 2, 0, H))
+            x2, y2 = int(np.clip(cx + cut_w // 2, 0, W)), int(np.clip(cy + cut_h // 2, 0, H))
+            mode, lam, box = 1, 1.0 - ((x2 - x1) * (y2 - y1) / float(W * H)), (x1, y1, x2, y2)
+        elif cfg.use_mixup and u[1] < cfg.mix_prob:
+            mode, lam = 2, lam_m
+        plan = Q.mix_plan(torch.tensor(u, dtype=torch.float64), torch.tensor(lam_c, dtype=torch.float64), torch.tensor(lam_m, dtype=torch.float64), cfg, H, W)
+        assert int(plan[0]) == mode
+        assert abs(float(plan[1]) - lam) <= 1e-6
+        if mode == 1:
+            assert tuple(int(v) for v in plan[2:]) == box
