@@ -106,15 +106,17 @@ int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* stream);
  * fwd: y = LN(x)*gamma+beta (+ add[row % add_rows] if add != NULL: the pos_embed add of :1250);
  *      mean/rstd [rows] saved for backward.
  * bwd: dx = LN'(dy); dgamma/dbeta += (fp32 atomics); dadd[row % add_rows] += dy when dadd != NULL.
+ * act = 1 fuses the exact GELU that follows the norm in LMFAdapter / SplitFusion.cat_mlp (HQAViT_CIFAR100.py:823,
+ * :927-931): fwd y = gelu(LN(x)), bwd takes dy through gelu' of the recomputed LN output (needs beta).
  * ------------------------------------------------------------------------------------------------- */
 int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                         float eps, int rows, int C, float* mean, float* rstd,
-                        const float* add, int add_rows, void* stream);
+                        const float* add, int add_rows, int act, void* stream);
 /* mean / rstd of each row only: the statistics half of a LayerNorm whose normalisation is fused into qavit_gemm_nt */
 int qavit_row_stats(int dtype, const void* x, float eps, int rows, int C, float* mean, float* rstd, void* stream);
 int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                         const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                        int rows, int C, float* dadd, int add_rows, void* stream);
+                        int rows, int C, float* dadd, int add_rows, const float* beta, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Attention core of the four branches: O = softmax(Q K_full^T / sqrt(D)) V_full per (group g, head h), with

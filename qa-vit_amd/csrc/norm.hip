@@ -12,7 +12,7 @@ constexpr int LN_MAX_C = 1024;
 template <typename T, int LN_MAX_PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, T* y, const float* gamma, const float* beta, float eps,
                                                             int rows, int C, float* mean_o, float* rstd_o,
-                                                            const float* add, int add_rows) {
+                                                            const float* add, int add_rows, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invC = 1.f / (float)C;
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, T* y, co
       const int c = lane + 64 * i;
       if (c < C) {
         float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (act) o = gelu_f(o);
         if (ar) o += ar[c];
         yr[c] = from_f<T>(o);
       }
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const T* x, float eps, i
 template <typename T, int LN_MAX_PER_LANE>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                             const float* rstd, T* dx, float* dgamma, float* dbeta,
-                                                            int rows, int C, float* dadd, int add_rows) {
+                                                            int rows, int C, float* dadd, int add_rows, const float* beta, int act) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invC = 1.f / (float)C;
   float pg[LN_MAX_PER_LANE], pb[LN_MAX_PER_LANE];
@@ -100,8 +101,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
       const int c = lane + 64 * i;
       if (c < C) {
-        const float d = to_f<T>(gr[c]);
+        float d = to_f<T>(gr[c]);
         xh[i] = (to_f<T>(xr[c]) - mu) * rs;
+        if (act) d *= gelu_grad_f(xh[i] * gamma[c] + beta[c]);      // y = gelu(LN(x)): gradient wrt the LN output
         g[i] = d * gamma[c];
         pg[i] += d * xh[i];
         pb[i] += d;
@@ -150,18 +152,18 @@ template <> struct V4<bf16> { typedef bf16x4 type; };
 
 template <typename T, int NP, int RB, int NW>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
-                                                               const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C) {
+                                                               const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act) {
   // RB rows per wave per iteration: all their loads are issued before the first reduction, so a wave keeps
   // 2*RB*NP vector loads in flight instead of 2 (the row loop is a pure load -> reduce -> store latency chain).
   typedef typename V4<T>::type v4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invC = 1.f / (float)C;
-  float pg[NP][4], pb[NP][4], gm[NP][4];
+  float pg[NP][4], pb[NP][4], gm[NP][4], bt[NP][4];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int c = 4 * lane + 256 * i;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; gm[i][j] = (c + j < C) ? gamma[c + j] : 0.f; }
+    for (int j = 0; j < 4; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; gm[i][j] = (c + j < C) ? gamma[c + j] : 0.f; bt[i][j] = (act && c + j < C) ? beta[c + j] : 0.f; }
   }
   for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
     v4 xv[RB][NP], dv[RB][NP];
@@ -190,8 +192,9 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, 
         if (c < C) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float d = live ? to_f<T>(dv[r][i][j]) : 0.f;
+            float d = live ? to_f<T>(dv[r][i][j]) : 0.f;
             xh[i][j] = (to_f<T>(xv[r][i][j]) - mu[r]) * rs[r];
+            if (act) d *= gelu_grad_f(xh[i][j] * gm[i][j] + bt[i][j]);
             g[i][j] = d * gm[i][j];
             pg[i][j] += d * xh[i][j];
             pb[i][j] += d;
@@ -253,7 +256,7 @@ static int ln_pl(int C) { const int p = (C + 63) / 64; return p <= 1 ? 1 : p <= 
 
 extern "C" int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, const float* beta,
                                    float eps, int rows, int C, float* mean, float* rstd,
-                                   const float* add, int add_rows, void* stream) {
+                                   const float* add, int add_rows, int act, void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_fwd: bad arguments");
   if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "layernorm_fwd: C > 1024 unsupported");
   if (add && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_fwd: add_rows must be positive");
@@ -262,9 +265,9 @@ extern "C" int qavit_layernorm_fwd(int dtype, const void* x, void* y, const floa
   if (grid > 4096) grid = 4096;
   const int pl = ln_pl(C);
   if (dtype == QAVIT_F32) {
-    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_fwd_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows))
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_fwd_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows, act))
   } else if (dtype == QAVIT_BF16) {
-    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows))
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows, act))
   } else return set_error(QAVIT_EINVAL, "layernorm_fwd: unknown dtype");
   return check_launch("layernorm_fwd");
 }
@@ -286,8 +289,9 @@ extern "C" int qavit_row_stats(int dtype, const void* x, float eps, int rows, in
 
 extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                                    const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                                   int rows, int C, float* dadd, int add_rows, void* stream) {
+                                   int rows, int C, float* dadd, int add_rows, const float* beta, int act, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: bad arguments");
+  if (act && !beta) return set_error(QAVIT_EINVAL, "layernorm_bwd: the fused-GELU gradient needs beta");
   if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "layernorm_bwd: C > 1024 unsupported");
   if (dadd && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: add_rows must be positive");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -302,7 +306,7 @@ extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, con
     constexpr int NW = 16;
     grid = (rows + 4 * NW - 1) / (4 * NW);
     if (grid > v4_cap) grid = v4_cap;
-#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_, (NP_ <= 2 ? 4 : 2), NW>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C)
+#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_, (NP_ <= 2 ? 4 : 2), NW>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C, beta, act)
     if (dtype == QAVIT_F32) { if (np == 1) LNV(float, 1); else if (np == 2) LNV(float, 2); else LNV(float, 4); }
     else if (dtype == QAVIT_BF16) { if (np == 1) LNV(bf16, 1); else if (np == 2) LNV(bf16, 2); else LNV(bf16, 4); }
     else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
@@ -311,9 +315,9 @@ extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, con
   }
   const int pl = ln_pl(C);
   if (dtype == QAVIT_F32) {
-    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, C, dadd, add_rows))
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<float, P>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, C, dadd, add_rows, beta, act))
   } else if (dtype == QAVIT_BF16) {
-    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, rows, C, dadd, add_rows))
+    LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, rows, C, dadd, add_rows, beta, act))
   } else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
   return check_launch("layernorm_bwd");
 }

@@ -383,7 +383,7 @@ class LinearStack3Fn(Function):
 # ---------------------------------------------------------------------------------------------------
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, g, b, add, eps):
+    def forward(ctx, x, g, b, add, eps, act=False):
         Cc = x.shape[-1]
         x2 = x.reshape(-1, Cc)
         if not x2.is_contiguous():
@@ -393,9 +393,10 @@ class LayerNormFn(Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         add_rows = 0 if add is None else add.numel() // Cc
-        K.layernorm_fwd(x2, y, g, b, eps, rows, Cc, mean, rstd, None if add is None else add.detach(), add_rows)
+        K.layernorm_fwd(x2, y, g, b, eps, rows, Cc, mean, rstd, None if add is None else add.detach(), add_rows, act=act)
         ctx.save_for_backward(x2, g, b, add, mean, rstd)
         ctx.xshape = x.shape
+        ctx.act = bool(act)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -409,12 +410,14 @@ class LayerNormFn(Function):
         bbuf, _ = grad_sink(b)
         abuf, _ = grad_sink(add)
         dx = torch.empty_like(x2)
-        K.layernorm_bwd(dy2, x2, g, mean, rstd, dx, gbuf, bbuf, rows, Cc, abuf, 0 if add is None else add.numel() // Cc)
-        return dx.reshape(ctx.xshape), None, None, None, None
+        K.layernorm_bwd(dy2, x2, g, mean, rstd, dx, gbuf, bbuf, rows, Cc, abuf, 0 if add is None else add.numel() // Cc,
+                        beta=b.detach() if ctx.act else None, act=ctx.act)
+        return dx.reshape(ctx.xshape), None, None, None, None, None
 
 
-def layer_norm(x, g, b, eps=1e-5, add=None):
-    return LayerNormFn.apply(x, g, b, add, eps)
+def layer_norm(x, g, b, eps=1e-5, add=None, act=None):
+    """LayerNorm (+ pos_embed-style broadcast add); ``act="gelu"`` fuses the exact GELU that follows it."""
+    return LayerNormFn.apply(x, g, b, add, eps, act == "gelu")
 
 
 # ---------------------------------------------------------------------------------------------------

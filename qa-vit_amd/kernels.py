@@ -165,19 +165,19 @@ def gemm_tn(A, Bm, Cgrad, M, N, K, lda, ldb, ldc, colsum=None, ln=None, A_ptr=No
 # ---------------------------------------------------------------------------------------------------
 # LayerNorm
 # ---------------------------------------------------------------------------------------------------
-def layernorm_fwd(x, y, gamma, beta, eps, rows, Cc, mean, rstd, add=None, add_rows=0):
+def layernorm_fwd(x, y, gamma, beta, eps, rows, Cc, mean, rstd, add=None, add_rows=0, act=0):
     L.check(L.load().qavit_layernorm_fwd(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                         eps, rows, Cc, _p(mean), _p(rstd), _p(add), add_rows, stream()), "layernorm_fwd")
+                                         eps, rows, Cc, _p(mean), _p(rstd), _p(add), add_rows, int(act), stream()), "layernorm_fwd")
 
 
 def row_stats(x, eps, rows, Cc, mean, rstd):
     L.check(L.load().qavit_row_stats(dt_code(x.dtype), x.data_ptr(), eps, rows, Cc, mean.data_ptr(), rstd.data_ptr(), stream()), "row_stats")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0, beta=None, act=0):
     L.check(L.load().qavit_layernorm_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, Cc, _p(dadd), add_rows,
-                                         stream()), "layernorm_bwd")
+                                         _p(beta), int(act), stream()), "layernorm_bwd")
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -527,7 +527,7 @@ class LMFAdapter(nn.Module):
             img = TF.interpolate(h.transpose(1, 2).reshape(B, -1, H, W).float(), size=(self.target_hw, self.target_hw),
                                  mode="bilinear", align_corners=False)
             h = _to_tokens(img).to(t.dtype)
-        return TF.gelu(F.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps))
+        return F.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act="gelu")
 
     def forward(self, feat):
         B, C, H, W = feat.shape
@@ -576,7 +576,7 @@ class SplitFusion(nn.Module):
         t_add = T + gate * R
         c0, c1 = self.cat_mlp[0], self.cat_mlp[1]
         h = F.linear(torch.cat([T, R], -1), c0.weight, c0.bias)
-        h = TF.gelu(F.layer_norm(h, c1.weight, c1.bias, c1.eps))
+        h = F.layer_norm(h, c1.weight, c1.bias, c1.eps, act="gelu")
         h = TF.dropout(h, self.cat_mlp[3].p, self.training)
         fn = self.final_norm
         if isinstance(self.fusion_weights, nn.Parameter) and self.fusion_weights.numel() == 2 and (t_add.numel() * t_add.element_size()) % 16 == 0:

@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu(Q):
     a = Q.lib.GemmArgs()
     assert lib.qavit_gemm_nt(ctypes.byref(a), None) == -1
     assert b"null operand" in lib.qavit_last_error()
-    assert lib.qavit_layernorm_fwd(0, None, None, None, None, 1e-5, 4, 8, None, None, None, 0, None) == -1
+    assert lib.qavit_layernorm_fwd(0, None, None, None, None, 1e-5, 4, 8, None, None, None, 0, 0, None) == -1
     assert lib.qavit_dropout(7, None, None, 0, 0.5, 0, None, None) == -1
 
 

@@ -156,6 +156,20 @@ def test_layernorm(F, dtype):
     assert rel(g_.grad, gr.grad) <= tol(dtype, False)
     assert rel(b.grad, br.grad) <= tol(dtype, False)
     assert rel(pos.grad, pr.grad) <= tol(dtype, False)
+    # fused exact GELU after the norm (LMFAdapter / SplitFusion.cat_mlp)
+    x2 = leaf(B * N, C, seed=54).detach().to(dtype).requires_grad_(True)
+    g2, b2 = leaf(C, scale=0.2, seed=55), leaf(C, scale=0.2, seed=56)
+    with torch.no_grad():
+        g2.add_(1.0)
+    y2 = F.layer_norm(x2, g2, b2, 1e-5, act="gelu")
+    r2 = [t.detach().clone().float().requires_grad_(True) for t in (x2, g2, b2)]
+    ref2 = TF.gelu(TF.layer_norm(r2[0], (C,), r2[1], r2[2]))
+    assert rel(y2, ref2) <= tol(dtype)
+    go2 = torch.randn_like(ref2)
+    y2.backward(go2.to(dtype))
+    ref2.backward(go2)
+    for a_, r_ in zip((x2, g2, b2), r2):
+        assert rel(a_.grad, r_.grad) <= tol(dtype, False) * 2
 
 
 # ---------------------------------------------------------------------------------------------------
