@@ -285,13 +285,13 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "HQAViT_CIFAR100 full training step (" + ("device CutMix/MixUp, " if args.mix else "") + "re-pack, fwd, CE loss, bwd, "
                                + ("grad all-reduce, " if world > 1 else "") + ("clip + fused AdamW)" if with_optim else "no optimiser)"),
-                   "model": "HQAViT(HQAViTConfig()) 6,472,037 params, random-init (key-seeded filler)",
+                   "weights": "HQAViTConfig() defaults, 6,472,037 parameters, random-init (key-seeded filler)",
                    "global_batch": B * world, "per_gpu_batch": B, "image": "32x32x3", "parallelism": f"dp{world}",
                    "launch": mode, "dropout": cfg.dropout, "drop_path": cfg.drop_path, "final_loss": round(loss_val, 4)},
     }
     step_tflops = value * MFLOP_PER_IMG_TRAIN * 1e6 / 1e12
-    out["config"]["model_tflops_per_s"] = round(step_tflops, 2)
-    out["config"]["model_mfma_frac"] = round(step_tflops / (PEAK_BF16_TFLOPS * world), 5)
+    out["config"]["algorithmic_tflops_per_s"] = round(step_tflops, 2)
+    out["config"]["algorithmic_mfma_frac"] = round(step_tflops / (PEAK_BF16_TFLOPS * world), 5)
 
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         # one instrumented eager step of the same workload: per-call HIP-event timing of every C-ABI entry point
