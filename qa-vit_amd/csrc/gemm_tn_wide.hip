@@ -213,9 +213,14 @@ int tile_class(int n, int which = 0) {           // 32-column units per workgrou
   if (n > 128 && force[which]) return force[which];
   if (n <= 32) return 1;
   if (n <= 64) return 2;
+  if (which == 1) {                // K side: <= 128-wide tiles keep the accumulators at <= 96 registers (two workgroups per CU)
+    static int k96 = -1;
+    if (k96 < 0) { const char* e = getenv("QAVIT_TN_K96"); k96 = e ? atoi(e) : 0; }   // measured: no gain (more classes = more launches)
+    if (k96 && n % 96 == 0 && n % 128 != 0) return 3;     // 96, 192, 576: exact 96-wide tiles instead of padded 128-wide ones
+    return 4;
+  }
   if (n <= 128) return 4;
-  if (n <= 192) return which == 1 ? 4 : 6;
-  if (which == 1) return 4;        // K side: 128-wide tiles keep the accumulators at <= 96 registers (two workgroups per CU)
+  if (n <= 192) return 6;
   const int p128 = (n + 127) / 128 * 128, p192 = (n + 191) / 192 * 192;
   return p128 < p192 ? 4 : 6;
 }
@@ -263,8 +268,8 @@ template <int IN> class_fn pick_j(int jc) {
   switch (jc) {
     case 1: return launch_class<IN, 1>;
     case 2: return launch_class<IN, 2>;
-    case 4: return launch_class<IN, 4>;
-    default: return launch_class<IN, 6>;
+    case 3: return launch_class<IN, 3>;
+    default: return launch_class<IN, 4>;
   }
 }
 class_fn pick(int ic, int jc) {
@@ -285,18 +290,18 @@ bool gemm_tn_wide_ok(const qavit_gemm_tn_args& g) {
 }
 
 int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st) {
-  static const int classes[4] = {1, 2, 4, 6};
+  static const int ncls[4] = {1, 2, 4, 6}, kcls[4] = {1, 2, 3, 4};
   const qavit_gemm_tn_args* sel[256];
   for (int ci = 0; ci < 4; ++ci)
     for (int cj = 0; cj < 4; ++cj) {
       int cnt = 0;
       for (int i = 0; i < n; ++i) {
-        if (gemm_tn_wide_ok(a[i]) && tile_class(a[i].N, 0) == classes[ci] && tile_class(a[i].K, 1) == classes[cj]) {
+        if (gemm_tn_wide_ok(a[i]) && tile_class(a[i].N, 0) == ncls[ci] && tile_class(a[i].K, 1) == kcls[cj]) {
           sel[cnt++] = a + i;
-          if (cnt == 256) { pick(classes[ci], classes[cj])(sel, cnt, st); cnt = 0; }
+          if (cnt == 256) { pick(ncls[ci], kcls[cj])(sel, cnt, st); cnt = 0; }
         }
       }
-      if (cnt) pick(classes[ci], classes[cj])(sel, cnt, st);
+      if (cnt) pick(ncls[ci], kcls[cj])(sel, cnt, st);
     }
   return check_launch("gemm_tn(wide)");
 }
