@@ -79,6 +79,9 @@ typedef struct qavit_gemm_args {
 } qavit_gemm_args;
 
 int qavit_gemm_nt(const qavit_gemm_args* a, void* stream);
+/* n independent problems (host array); up to 4 of one shape / dtype / prologue / epilogue kind that take the resident-slice
+ * kernel share a grid (the four compress_* Linears of a block and their input gradients), others are launched one by one */
+int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * C[N,K] += A[M,N]^T . B[M,K]   (fp32 atomics, split over M);   colsum[N] += sum_m A[m,n]
@@ -117,6 +120,14 @@ int qavit_row_stats(int dtype, const void* x, float eps, int rows, int C, float*
 int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                         const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                         int rows, int C, float* dadd, int add_rows, const float* beta, int act, void* stream);
+
+/* The four branch norms of a QuadAttentionBlock (norm_{swa,msda,cga,cross}, HQAViT_CIFAR100.py:1046-1049,1075-1078) act on
+ * four same-shape tensors that are independent of each other: n <= 4 inputs per grid.  Host arrays of device pointers. */
+int qavit_row_stats_multi(int dtype, int n, const void* const* x, float eps, int rows, int C, float* const* mean,
+                          float* const* rstd, void* stream);
+int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy, const void* const* x, const float* const* gamma,
+                              const float* const* mean, const float* const* rstd, void* const* dx,
+                              float* const* dgamma, float* const* dbeta, int rows, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Attention core of the four branches: O = softmax(Q K_full^T / sqrt(D)) V_full per (group g, head h), with

@@ -69,7 +69,7 @@ template <typename T> __host__ __device__ constexpr int kca_elems() { return siz
 
 // AMODE: 0 plain rows, 1 fused LayerNorm, 2 backward transform.  EPI: 0 = bias only, 1 = full epilogue.
 template <typename T, int BNT, int AMODE, int EPI, int KC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g, int n_tiles_m) {
+__device__ __forceinline__ void gemm_nt_body(const qavit_gemm_args& g, int n_tiles_m) {
   using M_ = Mma<T>;
   constexpr int VN = Vec<T>::N;
   constexpr int FK = M_::FK;
@@ -375,7 +375,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g
 }
 
 template <typename T, int BNT, int AMODE, int EPI, int KC>
-static int launch_gemm_nt3(const qavit_gemm_args& g, hipStream_t st) {
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(qavit_gemm_args g, int n_tiles_m) {
+  gemm_nt_body<T, BNT, AMODE, EPI, KC>(g, n_tiles_m);
+}
+
+// up to 4 problems of ONE shape and mode in a grid (blockIdx.z = problem): the four compress GEMMs of a block and their
+// input-gradient GEMMs are independent and each fills the chip for only a few microseconds
+constexpr int NT_GROUP = 4;
+struct GemmGroup { qavit_gemm_args p[NT_GROUP]; };
+template <typename T, int BNT, int AMODE, int EPI, int KC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_group_kernel(GemmGroup G, int n_tiles_m) {
+  gemm_nt_body<T, BNT, AMODE, EPI, KC>(G.p[blockIdx.z], n_tiles_m);
+}
+
+template <typename T, int BNT, int AMODE, int EPI, int KC>
+static int launch_gemm_nt3(const qavit_gemm_args& g, hipStream_t st, const qavit_gemm_args* grp = nullptr, int ng = 1) {
   constexpr int VN = Vec<T>::N;
   constexpr int FK = Mma<T>::FK;
   const int Kp = round_up(g.K, FK);
@@ -396,27 +410,41 @@ static int launch_gemm_nt3(const qavit_gemm_args& g, hipStream_t st) {
   int gy = (wg_target + n_slices - 1) / n_slices;    // ~3 workgroups per CU across the chip
   if (gy > n_tiles_m) gy = n_tiles_m;
   if (gy < 1) gy = 1;
+  if (grp) {
+    static bool attr_g = false;
+    if (!attr_g) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_group_kernel<T, BNT, AMODE, EPI, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_g = true;
+    }
+    GemmGroup G;
+    for (int i = 0; i < ng; ++i) G.p[i] = grp[i];
+    int gyg = (wg_target + n_slices * ng - 1) / (n_slices * ng);
+    if (gyg > n_tiles_m) gyg = n_tiles_m;
+    if (gyg < 1) gyg = 1;
+    hipLaunchKernelGGL((gemm_nt_group_kernel<T, BNT, AMODE, EPI, KC>), dim3(n_slices, gyg, ng), dim3(GEMM_THREADS), smem, st, G, n_tiles_m);
+    return check_launch("gemm_nt(grouped)");
+  }
   hipLaunchKernelGGL((gemm_nt_kernel<T, BNT, AMODE, EPI, KC>), dim3(n_slices, gy), dim3(GEMM_THREADS), smem, st, g, n_tiles_m);
   return check_launch("gemm_nt");
 }
 
 // fp32 with a long K: the resident fp32 weight slice is large, so the row tile streams in 64-wide chunks
 template <typename T, int BNT, int AMODE, int EPI>
-static int launch_gemm_nt2(const qavit_gemm_args& g, hipStream_t st) {
-  if (sizeof(T) == 4 && g.K > 256) return launch_gemm_nt3<T, BNT, AMODE, EPI, 64>(g, st);
-  return launch_gemm_nt3<T, BNT, AMODE, EPI, 256>(g, st);
+static int launch_gemm_nt2(const qavit_gemm_args& g, hipStream_t st, const qavit_gemm_args* grp = nullptr, int ng = 1) {
+  if (sizeof(T) == 4 && g.K > 256) return launch_gemm_nt3<T, BNT, AMODE, EPI, 64>(g, st, grp, ng);
+  return launch_gemm_nt3<T, BNT, AMODE, EPI, 256>(g, st, grp, ng);
 }
 
 template <typename T, int BNT>
-static int launch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
+static int launch_gemm_nt(const qavit_gemm_args& g, hipStream_t st, const qavit_gemm_args* grp = nullptr, int ng = 1) {
   const bool full = g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f;
-  if (g.a_mode == 1) return full ? launch_gemm_nt2<T, BNT, 1, 1>(g, st) : launch_gemm_nt2<T, BNT, 1, 0>(g, st);
-  if (g.a_mode == 2) return full ? launch_gemm_nt2<T, BNT, 2, 1>(g, st) : launch_gemm_nt2<T, BNT, 2, 0>(g, st);
-  return full ? launch_gemm_nt2<T, BNT, 0, 1>(g, st) : launch_gemm_nt2<T, BNT, 0, 0>(g, st);
+  if (g.a_mode == 1) return full ? launch_gemm_nt2<T, BNT, 1, 1>(g, st, grp, ng) : launch_gemm_nt2<T, BNT, 1, 0>(g, st, grp, ng);
+  if (g.a_mode == 2) return full ? launch_gemm_nt2<T, BNT, 2, 1>(g, st, grp, ng) : launch_gemm_nt2<T, BNT, 2, 0>(g, st, grp, ng);
+  return full ? launch_gemm_nt2<T, BNT, 0, 1>(g, st, grp, ng) : launch_gemm_nt2<T, BNT, 0, 0>(g, st, grp, ng);
 }
 
 template <typename T>
-static int dispatch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
+static int dispatch_gemm_nt(const qavit_gemm_args& g, hipStream_t st, const qavit_gemm_args* grp = nullptr, int ng = 1) {
   constexpr int VN = Vec<T>::N;
   constexpr int FK = Mma<T>::FK;
   const int Kp = round_up(g.K, FK);
@@ -430,9 +458,9 @@ static int dispatch_gemm_nt(const qavit_gemm_args& g, hipStream_t st) {
   if (bn > 32 && g.N <= bn / 2) bn = (g.N <= 32) ? 32 : 64;
   if ((size_t)bn * row_bytes > 132 * 1024) return set_error(QAVIT_EINVAL, "gemm_nt: K too large");
   switch (bn) {
-    case 128: return launch_gemm_nt<T, 128>(g, st);
-    case 64: return launch_gemm_nt<T, 64>(g, st);
-    default: return launch_gemm_nt<T, 32>(g, st);
+    case 128: return launch_gemm_nt<T, 128>(g, st, grp, ng);
+    case 64: return launch_gemm_nt<T, 64>(g, st, grp, ng);
+    default: return launch_gemm_nt<T, 32>(g, st, grp, ng);
   }
 }
 
@@ -795,6 +823,33 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
     return dispatch_gemm_nt<bf16>(*a, st);
   }
   return set_error(QAVIT_EINVAL, "gemm_nt: unknown dtype");
+}
+
+extern "C" int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stream) {
+  using namespace qv;
+  if (!a || n <= 0) return set_error(QAVIT_EINVAL, "gemm_nt_grouped: empty group");
+  // one grid when the problems share shape, dtype, prologue and epilogue kind and take the resident-slice kernel;
+  // otherwise one launch each
+  auto kind = [](const qavit_gemm_args& g) { return (g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f) ? 1 : 0; };
+  bool same = n <= NT_GROUP;
+  for (int i = 1; i < n && same; ++i)
+    same = a[i].dtype == a[0].dtype && a[i].M == a[0].M && a[i].N == a[0].N && a[i].K == a[0].K && a[i].a_mode == a[0].a_mode && kind(a[i]) == kind(a[0]);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool big = a[0].dtype == QAVIT_BF16 && a[0].N >= 64 && a[0].K >= 96 && a[0].M >= 1024;     // K-loop kernel territory
+  if (!same || n == 1 || big || a[0].M <= 16) {
+    for (int i = 0; i < n; ++i) { const int rc = qavit_gemm_nt(a + i, stream); if (rc) return rc; }
+    return QAVIT_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const qavit_gemm_args& g = a[i];
+    if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(QAVIT_EINVAL, "gemm_nt_grouped: bad problem");
+    if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return set_error(QAVIT_EINVAL, "gemm_nt_grouped: leading dimension too small");
+    if (g.a_mode == 1 && (!g.ln_gamma || !g.ln_beta || !g.ln_mean || !g.ln_rstd)) return set_error(QAVIT_EINVAL, "gemm_nt_grouped: LayerNorm prologue needs gamma/beta and row statistics");
+    if ((g.drop_p > 0.f || g.dp_p > 0.f || g.a_drop_p > 0.f || g.a_dp_p > 0.f) && !g.rng) return set_error(QAVIT_EINVAL, "gemm_nt_grouped: dropout requested without rng state");
+  }
+  if (a[0].dtype == QAVIT_F32) return dispatch_gemm_nt<float>(a[0], st, a, n);
+  if (a[0].dtype == QAVIT_BF16) return dispatch_gemm_nt<bf16>(a[0], st, a, n);
+  return set_error(QAVIT_EINVAL, "gemm_nt_grouped: unknown dtype");
 }
 
 extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* stream) {

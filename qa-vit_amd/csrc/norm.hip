@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, T* y, co
 
 // mean / rstd only (the statistics half of a LayerNorm whose normalisation is fused into the consumer GEMM)
 template <typename T, int LN_MAX_PER_LANE>
-__global__ __launch_bounds__(256) void row_stats_kernel(const T* x, float eps, int rows, int C, float* mean_o, float* rstd_o) {
+__device__ __forceinline__ void row_stats_body(const T* x, float eps, int rows, int C, float* mean_o, float* rstd_o) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invC = 1.f / (float)C;
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -79,6 +79,17 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const T* x, float eps, i
     const float rstd = rsqrtf(wave_sum(s2) * invC + eps);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
   }
+}
+
+template <typename T, int LN_MAX_PER_LANE>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* x, float eps, int rows, int C, float* mean_o, float* rstd_o) {
+  row_stats_body<T, LN_MAX_PER_LANE>(x, eps, rows, C, mean_o, rstd_o);
+}
+// up to 4 same-shape inputs in one grid (blockIdx.y = input): the four branch norms of a QuadAttentionBlock
+struct Ptr4 { const void* x[4]; float* mean[4]; float* rstd[4]; };
+template <typename T, int LN_MAX_PER_LANE>
+__global__ __launch_bounds__(256) void row_stats_multi_kernel(Ptr4 P, float eps, int rows, int C) {
+  row_stats_body<T, LN_MAX_PER_LANE>(reinterpret_cast<const T*>(P.x[blockIdx.y]), eps, rows, C, P.mean[blockIdx.y], P.rstd[blockIdx.y]);
 }
 
 template <typename T, int LN_MAX_PER_LANE>
@@ -151,8 +162,8 @@ template <> struct V4<float> { typedef f32x4 type; };
 template <> struct V4<bf16> { typedef bf16x4 type; };
 
 template <typename T, int NP, int RB, int NW>
-__global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
-                                                               const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act) {
+__device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                      const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act) {
   // RB rows per wave per iteration: all their loads are issued before the first reduction, so a wave keeps
   // 2*RB*NP vector loads in flight instead of 2 (the row loop is a pure load -> reduce -> store latency chain).
   typedef typename V4<T>::type v4;
@@ -242,6 +253,19 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, 
   }
 }
 
+template <typename T, int NP, int RB, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                               const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act) {
+  layernorm_bwd_v4_body<T, NP, RB, NW>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, beta, act);
+}
+struct LnBwd4 { const void* dy[4]; const void* x[4]; const float* gamma[4]; const float* mean[4]; const float* rstd[4]; void* dx[4]; float* dgamma[4]; float* dbeta[4]; };
+template <typename T, int NP, int RB, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_multi_kernel(LnBwd4 P, int rows, int C) {
+  const int i = blockIdx.y;
+  layernorm_bwd_v4_body<T, NP, RB, NW>(reinterpret_cast<const T*>(P.dy[i]), reinterpret_cast<const T*>(P.x[i]), P.gamma[i], P.mean[i], P.rstd[i],
+                                       reinterpret_cast<T*>(P.dx[i]), P.dgamma[i], P.dbeta[i], rows, C, nullptr, 0);
+}
+
 static int ln_pl(int C) { const int p = (C + 63) / 64; return p <= 1 ? 1 : p <= 2 ? 2 : p <= 3 ? 3 : p <= 4 ? 4 : p <= 8 ? 8 : 16; }
 
 #define LN_DISPATCH(PL, CALL)            \
@@ -320,4 +344,55 @@ extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, con
     LN_DISPATCH(pl, hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, P>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, rows, C, dadd, add_rows, beta, act))
   } else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
   return check_launch("layernorm_bwd");
+}
+
+
+extern "C" int qavit_row_stats_multi(int dtype, int n, const void* const* x, float eps, int rows, int C, float* const* mean, float* const* rstd, void* stream) {
+  if (!x || !mean || !rstd || n <= 0 || n > 4 || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "row_stats_multi: bad arguments (1 <= n <= 4)");
+  if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "row_stats_multi: C > 1024 unsupported");
+  Ptr4 ptrs;
+  for (int i = 0; i < n; ++i) {
+    if (!x[i] || !mean[i] || !rstd[i]) return set_error(QAVIT_EINVAL, "row_stats_multi: null operand");
+    ptrs.x[i] = x[i]; ptrs.mean[i] = mean[i]; ptrs.rstd[i] = rstd[i];
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int grid = (rows + 3) / 4;
+  if (grid > 4096 / n) grid = 4096 / n;
+  const int pl = ln_pl(C);
+  if (dtype == QAVIT_F32) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((row_stats_multi_kernel<float, P>), dim3(grid, n), dim3(256), 0, st, ptrs, eps, rows, C))
+  } else if (dtype == QAVIT_BF16) {
+    LN_DISPATCH(pl, hipLaunchKernelGGL((row_stats_multi_kernel<bf16, P>), dim3(grid, n), dim3(256), 0, st, ptrs, eps, rows, C))
+  } else return set_error(QAVIT_EINVAL, "row_stats_multi: unknown dtype");
+  return check_launch("row_stats_multi");
+}
+
+extern "C" int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy, const void* const* x, const float* const* gamma,
+                                         const float* const* mean, const float* const* rstd, void* const* dx,
+                                         float* const* dgamma, float* const* dbeta, int rows, int C, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || n <= 0 || n > 4 || rows <= 0 || C <= 0)
+    return set_error(QAVIT_EINVAL, "layernorm_bwd_multi: bad arguments (1 <= n <= 4)");
+  const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
+  bool v4ok = (C % 4 == 0) && C <= 512;
+  for (int i = 0; i < n && v4ok; ++i)
+    v4ok = ((reinterpret_cast<uintptr_t>(x[i]) | reinterpret_cast<uintptr_t>(dy[i]) | reinterpret_cast<uintptr_t>(dx[i])) % (4 * esz)) == 0;
+  if (!v4ok || (dtype != QAVIT_F32 && dtype != QAVIT_BF16)) {          // odd shapes: one launch each through the general entry point
+    for (int i = 0; i < n; ++i) {
+      const int rc = qavit_layernorm_bwd(dtype, dy[i], x[i], gamma[i], mean[i], rstd[i], dx[i], dgamma[i], dbeta[i], rows, C, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
+    return QAVIT_OK;
+  }
+  LnBwd4 P;
+  for (int i = 0; i < n; ++i) { P.dy[i] = dy[i]; P.x[i] = x[i]; P.gamma[i] = gamma[i]; P.mean[i] = mean[i]; P.rstd[i] = rstd[i]; P.dx[i] = dx[i]; P.dgamma[i] = dgamma[i]; P.dbeta[i] = dbeta[i]; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  constexpr int NW = 16;
+  int grid = (rows + 4 * NW - 1) / (4 * NW);
+  if (grid > 256) grid = 256;
+  const int np = (C + 255) / 256;
+#define LNVM(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_multi_kernel<T_, NP_, 4, NW>), dim3(grid, n), dim3(64 * NW), 0, st, P, rows, C)
+  if (dtype == QAVIT_F32) { if (np == 1) LNVM(float, 1); else LNVM(float, 2); }
+  else { if (np == 1) LNVM(bf16, 1); else LNVM(bf16, 2); }
+#undef LNVM
+  return check_launch("layernorm_bwd_multi");
 }

@@ -757,15 +757,18 @@ class CompressFuseFn(Function):
         Cb = args[3].shape[0]
         cat = torch.empty(M, nb * Cb, dtype=dt, device=dev)
         esz = cat.element_size()
-        stats = []
+        means = [torch.empty(M, dtype=torch.float32, device=dev) for _ in range(nb)]
+        rstds = [torch.empty(M, dtype=torch.float32, device=dev) for _ in range(nb)]
+        K.row_stats_multi(xs, eps, M, Kd, means, rstds)                      # the four branch norms: one grid
+        probs, stats = [], []
         for i in range(nb):
             g, b, W, bias = args[5 * i + 1: 5 * i + 5]
             Wc, _ = pack_for(dev).get(W, dt)
-            mean, rstd = torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
-            K.row_stats(xs[i], eps, M, Kd, mean, rstd)
-            K.gemm_nt(xs[i], Wc, cat, M, Cb, Kd, Kd, Kd, nb * Cb, None if bias is None else bias.detach(), a_mode=1,
-                      ln=(g, b, eps), ln_stats=(mean, rstd), rng=rt.rng, C_ptr=cat.data_ptr() + i * Cb * esz)
-            stats += [mean, rstd]
+            probs.append(K.gemm_nt(xs[i], Wc, cat, M, Cb, Kd, Kd, Kd, nb * Cb, None if bias is None else bias.detach(), a_mode=1,
+                                   ln=(g, b, eps), ln_stats=(means[i], rstds[i]), rng=rt.rng, C_ptr=cat.data_ptr() + i * Cb * esz,
+                                   build_only=True))
+            stats += [means[i], rstds[i]]
+        K.gemm_nt_grouped(probs)                                             # the four compress Linears: one grid
         y = torch.empty_like(cat)
         K.hybrid_fuse_fwd(cat, fw.detach(), y, M, nb, Cb)
         ctx.meta = (nb, M, Kd, Cb, eps, args[0].shape)
@@ -791,25 +794,34 @@ class CompressFuseFn(Function):
             fbuf = torch.zeros(nb, dtype=torch.float32, device=dev)
         K.hybrid_fuse_bwd(dy, cat, fw.detach(), dcat, fbuf, M, nb, Cb)
         esz = dcat.element_size()
-        grads = []
         DeferDW.arm()
+        dxns = [torch.empty(M, Kd, dtype=dt, device=dev) for _ in range(nb)]
+        probs = []
+        for i in range(nb):
+            _, Wt = pack_for(dev).get(prm[4 * i + 2], dt)
+            probs.append(K.gemm_nt(dcat, Wt, dxns[i], M, Kd, Cb, nb * Cb, Wt.shape[1], Kd, None, rng=rt.rng,
+                                   A_ptr=dcat.data_ptr() + i * Cb * esz, build_only=True))
+        K.gemm_nt_grouped(probs)                                             # four input-gradient GEMMs: one grid
+        gsinks = [grad_sink(prm[4 * i]) for i in range(nb)]
+        bsinks = [grad_sink(prm[4 * i + 1]) for i in range(nb)]
+        dxs = [torch.empty_like(dxns[i]) for i in range(nb)]
+        if all(gs[0] is not None for gs in gsinks) and all(bs[0] is not None for bs in bsinks):
+            K.layernorm_bwd_multi(dxns, xs, [prm[4 * i] for i in range(nb)], [stats[2 * i] for i in range(nb)], [stats[2 * i + 1] for i in range(nb)],
+                                  dxs, [gs[0] for gs in gsinks], [bs[0] for bs in bsinks], M, Kd)    # four LayerNorm backwards: one grid
+        else:
+            for i in range(nb):
+                K.layernorm_bwd(dxns[i], xs[i], prm[4 * i], stats[2 * i], stats[2 * i + 1], dxs[i], gsinks[i][0], bsinks[i][0], M, Kd)
+        grads = []
         for i in range(nb):
             g, b, W, bias = prm[4 * i: 4 * i + 4]
             mean, rstd = stats[2 * i], stats[2 * i + 1]
-            _, Wt = pack_for(dev).get(W, dt)
             a_ptr = dcat.data_ptr() + i * Cb * esz
-            dxn = torch.empty(M, Kd, dtype=dt, device=dev)
-            K.gemm_nt(dcat, Wt, dxn, M, Kd, Cb, nb * Cb, Wt.shape[1], Kd, None, rng=rt.rng, A_ptr=a_ptr)
-            gbuf, gret = grad_sink(g)
-            bbuf, bret = grad_sink(b)
-            dx = torch.empty_like(dxn)
-            K.layernorm_bwd(dxn, xs[i], g, mean, rstd, dx, gbuf, bbuf, M, Kd)
             wbuf, wret = grad_sink(W)
             bbuf2, b2ret = grad_sink(bias)
             if wbuf is None:
                 wbuf = torch.zeros(W.shape, dtype=torch.float32, device=dev)
             K.gemm_tn(dcat, xs[i], wbuf, M, Cb, Kd, nb * Cb, Kd, Kd, bbuf2, ln=(g, b, mean, rstd), A_ptr=a_ptr)
-            grads += [dx.reshape(xshape), _ret(gret, g), _ret(bret, b), _ret(wret, W), None if bias is None else _ret(b2ret, bias)]
+            grads += [dxs[i].reshape(xshape), _ret(gsinks[i][1], g), _ret(bsinks[i][1], b), _ret(wret, W), None if bias is None else _ret(b2ret, bias)]
         return (fret, None, *grads)
 
 

@@ -86,9 +86,9 @@ def new_site() -> int:
 # ---------------------------------------------------------------------------------------------------
 def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None, ln_stats=None,
             bwd=None, Z=None, act=0, drop=(0.0, 0), scale=1.0, dp=(0.0, 0, 1), R=None, ldr=0, rng=None,
-            A_ptr=None, B_ptr=None, C_ptr=None):
+            A_ptr=None, B_ptr=None, C_ptr=None, build_only=False):
     """C[M,N] = epi(pro(A)[M,K] @ B[N,K]^T + bias).  A/B/Cout are tensors used for dtype/liveness; *_ptr
-    override the base address (column-offset views)."""
+    override the base address (column-offset views).  ``build_only`` returns the argument struct for gemm_nt_grouped."""
     a = L.GemmArgs()
     a.dtype = dt_code(A.dtype)
     a.M, a.N, a.K = M, N, K
@@ -121,7 +121,15 @@ def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None,
     if R is not None:
         a.R, a.ldr = R.data_ptr(), (ldr or N)
     a.rng = _p(rng)
+    if build_only:
+        return a
     L.check(L.load().qavit_gemm_nt(C.byref(a), stream()), "gemm_nt")
+
+
+def gemm_nt_grouped(args):
+    """Independent gemm_nt problems (structs from ``gemm_nt(..., build_only=True)``); same-shape ones share a grid."""
+    arr = (L.GemmArgs * len(args))(*args)
+    L.check(L.load().qavit_gemm_nt_grouped(arr, len(args), stream()), "gemm_nt_grouped")
 
 
 class DeferredTN:
@@ -172,6 +180,21 @@ def layernorm_fwd(x, y, gamma, beta, eps, rows, Cc, mean, rstd, add=None, add_ro
 
 def row_stats(x, eps, rows, Cc, mean, rstd):
     L.check(L.load().qavit_row_stats(dt_code(x.dtype), x.data_ptr(), eps, rows, Cc, mean.data_ptr(), rstd.data_ptr(), stream()), "row_stats")
+
+
+def _ptr_arr(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def row_stats_multi(xs, eps, rows, Cc, means, rstds):
+    L.check(L.load().qavit_row_stats_multi(dt_code(xs[0].dtype), len(xs), _ptr_arr(xs), eps, rows, Cc, _ptr_arr(means), _ptr_arr(rstds), stream()),
+            "row_stats_multi")
+
+
+def layernorm_bwd_multi(dys, xs, gammas, means, rstds, dxs, dgammas, dbetas, rows, Cc):
+    L.check(L.load().qavit_layernorm_bwd_multi(dt_code(xs[0].dtype), len(xs), _ptr_arr(dys), _ptr_arr(xs), _ptr_arr(gammas), _ptr_arr(means),
+                                               _ptr_arr(rstds), _ptr_arr(dxs), _ptr_arr(dgammas), _ptr_arr(dbetas), rows, Cc, stream()),
+            "layernorm_bwd_multi")
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0, beta=None, act=0):

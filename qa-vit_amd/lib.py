@@ -60,10 +60,13 @@ _SIGS = {
     "qavit_version": (i32, []),
     "qavit_last_error": (C.c_char_p, []),
     "qavit_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
+    "qavit_gemm_nt_grouped": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "qavit_gemm_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "qavit_gemm_tn_grouped": (i32, [C.POINTER(GemmTnArgs), i32, vp]),
     "qavit_layernorm_fwd": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, i32, i32, vp]),
     "qavit_row_stats": (i32, [i32, vp, f32, i32, i32, vp, vp, vp]),
+    "qavit_row_stats_multi": (i32, [i32, i32, vp, f32, i32, i32, vp, vp, vp]),
+    "qavit_layernorm_bwd_multi": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp]),
     "qavit_attn_fwd": (i32, [C.POINTER(AttnArgs), vp]),
     "qavit_attn_bwd": (i32, [C.POINTER(AttnArgs), vp]),
