@@ -178,6 +178,7 @@ int qavit_attn_fwd(const qavit_attn_args* a, void* stream);
 int qavit_attn_bwd(const qavit_attn_args* a, void* stream);      /* includes the partial-sum reduction */
 int64_t qavit_attn_ws_floats(const qavit_attn_args* a);
 /* zero `n` elements of x if *flag != 0, then clear the flag (efficient_attention's NaN -> zeros rule) */
+/* x := 0 if flag[0] != 0, then flag[0] := 0 (flag = device int[2]: the flag and the guard's arrival ticket, both zero at rest) */
 int qavit_nan_guard(int dtype, void* x, int64_t n, int* flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -257,6 +258,8 @@ int qavit_col2im(int dtype, const void* dcols, void* dx, int B, int Cin, int H, 
  * apply: U = acc / B_total; upd_v = clamp(U); upd_k = clamp(U Wc^T + bc)  (exact: softmax columns sum to 1);
  *        bank += rate*upd; clamp; update_count += 1; acc := 0.   mode 0 = HQA rule (rate by count, clamps
  *        0.05/0.5), mode 1 = QAViT.py rule (rate 0.01, clamps 0.1/1.0, no counter).
+ * Contract on `acc`: float[S*C + 1], ZERO before the first stats call; apply consumes it and leaves it zero again (the
+ * extra word is apply's arrival ticket for the once-per-write counter increment), so a write is stats -> apply, no memset.
  * ------------------------------------------------------------------------------------------------- */
 int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const float* b_branch,
                      const float* g_write, const float* b_write, const float* Wg, const float* bg,

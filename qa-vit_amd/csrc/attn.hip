@@ -366,12 +366,20 @@ __global__ __launch_bounds__(256) void attn_reduce_kernel(qavit_attn_args a, int
   }
 }
 
+// x := 0 if flag[0] != 0; the LAST workgroup to have read the flag resets it (flag[1] is the arrival ticket), so the flag is
+// clear for the next attention call without a second launch
 template <typename T>
 __global__ __launch_bounds__(256) void nan_guard_kernel(T* x, int64_t n, int* flag) {
-  if (*flag == 0) return;
+  __shared__ int f_s;
+  if (threadIdx.x == 0) {
+    f_s = *reinterpret_cast<volatile int*>(flag);
+    __threadfence();
+    if (atomicAdd(flag + 1, 1) == (int)gridDim.x - 1) { flag[0] = 0; flag[1] = 0; }
+  }
+  __syncthreads();
+  if (f_s == 0) return;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = from_f<T>(0.f);
 }
-__global__ void nan_flag_clear_kernel(int* flag) { *flag = 0; }
 
 static int attn_validate(const qavit_attn_args* a, bool bwd) {
   if (!a) return set_error(QAVIT_EINVAL, "attn: null args");
@@ -457,10 +465,9 @@ extern "C" int qavit_nan_guard(int dtype, void* x, int64_t n, int* flag, void* s
   if (!x || !flag || n <= 0) return set_error(QAVIT_EINVAL, "nan_guard: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int nb = (int)((n + 2047) / 2048);
-  if (nb > 2048) nb = 2048;
+  if (nb > 64) nb = 64;          // the common case reads the flag and leaves; every workgroup also takes a ticket on one address
   if (dtype == QAVIT_F32) hipLaunchKernelGGL((nan_guard_kernel<float>), dim3(nb), dim3(256), 0, st, (float*)x, n, flag);
   else if (dtype == QAVIT_BF16) hipLaunchKernelGGL((nan_guard_kernel<bf16>), dim3(nb), dim3(256), 0, st, (bf16*)x, n, flag);
   else return set_error(QAVIT_EINVAL, "nan_guard: unknown dtype");
-  hipLaunchKernelGGL(nan_flag_clear_kernel, dim3(1), dim3(1), 0, st, flag);
   return check_launch("nan_guard");
 }

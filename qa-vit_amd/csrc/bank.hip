@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
   for (int i = t; i < S * C; i += 256) out[i] = U[i];
 }
 
-// acc (zeroed by the launcher) += partials; blockIdx.y = slice of 16 partials
+// acc (zero on entry: bank_apply re-zeroes what it consumes) += partials; blockIdx.y = slice of 16 partials
 __global__ __launch_bounds__(256) void bank_reduce_kernel(const float* ws, float* acc, int nparts, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -106,15 +106,20 @@ __global__ __launch_bounds__(256) void bank_reduce_kernel(const float* ws, float
 }
 
 // one workgroup per slot s
-__global__ __launch_bounds__(256) void bank_apply_kernel(const float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
-                                                         const int64_t* update_count, int S, int C, float inv_batch, int mode) {
+__global__ __launch_bounds__(256) void bank_apply_kernel(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
+                                                         int64_t* update_count, int S, int C, float inv_batch, int mode) {
   extern __shared__ __attribute__((aligned(16))) float u[];   // [C]
   const int s = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) u[c] = acc[s * C + c] * inv_batch;
-  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { u[c] = acc[s * C + c] * inv_batch; acc[s * C + c] = 0.f; }   // consumed: zero for the next write
   float rate, cu, cb;
   if (mode == 1) { rate = 0.01f; cu = 0.1f; cb = 1.0f; }
   else { rate = (update_count && update_count[0] >= 1000) ? 0.01f : 0.005f; cu = 0.05f; cb = 0.5f; }
+  __syncthreads();
+  // update_count += 1 once per write, by the LAST workgroup to get here: every workgroup has read the counter by then
+  if (mode == 0 && threadIdx.x == 0) {
+    int* ticket = reinterpret_cast<int*>(acc + (size_t)S * C);
+    if (atomicAdd(ticket, 1) == S - 1) { update_count[0] += 1; *ticket = 0; }
+  }
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float dotk = bc[c];
     const float* wr = Wc + (size_t)c * C;
@@ -127,7 +132,6 @@ __global__ __launch_bounds__(256) void bank_apply_kernel(const float* acc, const
     bank_v[s * C + c] = fminf(fmaxf(nv, -cb), cb);
   }
 }
-__global__ void bank_count_kernel(int64_t* update_count) { update_count[0] += 1; }
 
 static int bank_grid(int B) { return B < BANK_MAX_WG ? B : BANK_MAX_WG; }
 
@@ -155,7 +159,6 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
     const int took = bank_stats_bf16_try(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, grid, eps, st);
     if (took < 0) return took;
     if (took == 1) {
-      zero_f32(acc, (size_t)n_acc, st);
       hipLaunchKernelGGL(bank_reduce_kernel, dim3((n_acc + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n_acc);
       return check_launch("bank_stats(bf16)");
     }
@@ -168,7 +171,6 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
     hipLaunchKernelGGL((bank_stats_kernel<bf16, true>), dim3(grid), dim3(256), smem, st, (const bf16*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);
   } else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
   const int n = S * C;
-  zero_f32(acc, (size_t)n, st);
   hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n);
   return check_launch("bank_stats");
 }
@@ -179,6 +181,5 @@ extern "C" int qavit_bank_apply(float* acc, const float* Wc, const float* bc, fl
   if (mode == 0 && !update_count) return set_error(QAVIT_EINVAL, "bank_apply: mode 0 needs update_count");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(256), (size_t)C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode);
-  if (mode == 0) hipLaunchKernelGGL(bank_count_kernel, dim3(1), dim3(1), 0, st, update_count);
   return check_launch("bank_apply");
 }

@@ -955,7 +955,7 @@ def bank_write(tokens, norm_g, norm_b, bank, mode, sync=None):
     rt = _rt(tokens)
     S = bank.bank_size
     tokens = tokens.contiguous()
-    acc = rt.workspace("bank_acc", S * Cc)
+    acc = rt.workspace("bank_acc", S * Cc + 1, zero=True)     # zero on entry; bank_apply leaves it zero again (+1: its ticket word)
     ws = rt.workspace("bank_ws", K.bank_ws_floats(B, N, Cc, S))
     K.bank_stats(tokens, norm_g, norm_b, bank.write_norm.weight, bank.write_norm.bias, bank.write_gate.weight, bank.write_gate.bias,
                  acc, ws, B, N, Cc, S, 1e-5)

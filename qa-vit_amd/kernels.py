@@ -32,13 +32,13 @@ def _require_cuda(*ts):
 
 
 class Runtime:
-    """Per-device state: RNG words, NaN flag, dropout-site ids, scratch workspaces."""
+    """Per-device state: RNG words, NaN flags, dropout-site ids, scratch workspaces."""
     _inst = {}
 
     def __init__(self, device):
         self.device = device
         self.rng = torch.tensor([0x5EED, 0], dtype=torch.int64, device=device)
-        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.nan_flag = torch.zeros(2, dtype=torch.int32, device=device)       # [flag, guard arrival ticket]
         self._ws = {}
         self._tbl = {}
         self.nan_guard = True
@@ -57,10 +57,12 @@ class Runtime:
     def advance(self):
         L.check(L.load().qavit_rng_advance(self.rng.data_ptr(), stream()), "rng_advance")
 
-    def workspace(self, name: str, n_floats: int) -> torch.Tensor:
+    def workspace(self, name: str, n_floats: int, zero: bool = False) -> torch.Tensor:
+        """Named scratch buffer; ``zero`` = zero-filled at creation (for buffers whose users leave them zero again)."""
         w = self._ws.get(name)
         if w is None or w.numel() < n_floats:
-            w = torch.empty(max(int(n_floats), 1), dtype=torch.float32, device=self.device)
+            alloc = torch.zeros if zero else torch.empty
+            w = alloc(max(int(n_floats), 1), dtype=torch.float32, device=self.device)
             self._ws[name] = w
         return w
 
