@@ -282,6 +282,9 @@ int qavit_token_mean_bwd(int dtype, const void* dy, void* dx, int B, int N, int 
 int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, void* y, int rows, int nb, int Cb, void* stream);
 int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, const float* fw, void* dx, float* dfw,
                           int rows, int nb, int Cb, void* stream);
+/* out = xs[0] + ... + xs[k-1] (k <= 8 same-shape tensors, host array of device pointers): the gradient of norm1's output,
+ * which feeds five consumers in QuadAttentionBlock (HQAViT_CIFAR100.py:1072-1078), summed in one pass. */
+int qavit_sum_k(int dtype, const void* const* xs, int k, void* out, int64_t n, void* stream);
 /* perm[0..B) = a uniform random permutation drawn from the counter RNG (rng[0] seed, rng[1] step, site): the
  * torch.randperm of train_epoch (HQAViT_CIFAR100.py:1383,1395) as one capturable kernel; B <= 16384. */
 int qavit_rand_perm(int64_t* perm, int B, const int64_t* rng, int site, void* stream);

@@ -343,6 +343,29 @@ __global__ __launch_bounds__(256) void rand_perm_kernel(int64_t* perm, int B, in
   for (int i = threadIdx.x; i < B; i += 256) perm[i] = (int64_t)si[i];
 }
 
+// out = sum of k same-shape tensors (k <= 8): the gradient fan-in of a tensor with k consumers as ONE pass
+// (autograd would issue k-1 pairwise adds, each reading two tensors and writing one)
+struct SumPtrs { const void* p[8]; };
+template <typename T>
+__global__ __launch_bounds__(256) void sum_k_kernel(SumPtrs P, int k, T* out, uint32_t nvec) {
+  constexpr int VEC = Vec<T>::N;
+  typedef typename Vec<T>::type vec_t;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int i = 0; i < k; ++i) {
+      const vec_t x = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(P.p[i]) + (size_t)v * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += to_f<T>(x[j]);
+    }
+    vec_t o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = from_f<T>(acc[j]);
+    *reinterpret_cast<vec_t*>(out + (size_t)v * VEC) = o;
+  }
+}
+
 template <typename T>
 static bool vec_ok(int C, int Cb, int64_t n, const void* p0, const void* p1, const void* p2) {
   constexpr int VEC = Vec<T>::N;
@@ -544,6 +567,21 @@ extern "C" int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, c
              hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb),
              hipLaunchKernelGGL((hybrid_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, n, nb, Cb), "hybrid_fuse_bwd");
   return check_launch("hybrid_fuse_bwd");
+}
+
+extern "C" int qavit_sum_k(int dtype, const void* const* xs, int k, void* out, int64_t n, void* stream) {
+  if (!xs || !out || k <= 0 || k > 8 || n <= 0) return set_error(QAVIT_EINVAL, "sum_k: bad arguments (1 <= k <= 8)");
+  const int vec = dtype == QAVIT_BF16 ? 8 : 4;
+  SumPtrs P;
+  uintptr_t al = reinterpret_cast<uintptr_t>(out);
+  for (int i = 0; i < k; ++i) { if (!xs[i]) return set_error(QAVIT_EINVAL, "sum_k: null operand"); P.p[i] = xs[i]; al |= reinterpret_cast<uintptr_t>(xs[i]); }
+  if ((al & 15) || n % vec || n / vec >= 0x7fffffffLL) return set_error(QAVIT_EINVAL, "sum_k: 16-byte aligned operands, element count a multiple of the 16-byte vector");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint32_t nvec = (uint32_t)(n / vec);
+  if (dtype == QAVIT_BF16) hipLaunchKernelGGL((sum_k_kernel<bf16>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, P, k, (bf16*)out, nvec);
+  else if (dtype == QAVIT_F32) hipLaunchKernelGGL((sum_k_kernel<float>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, P, k, (float*)out, nvec);
+  else return set_error(QAVIT_EINVAL, "sum_k: unknown dtype");
+  return check_launch("sum_k");
 }
 
 extern "C" int qavit_rand_perm(int64_t* perm, int B, const int64_t* rng, int site, void* stream) {

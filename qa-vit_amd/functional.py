@@ -825,6 +825,36 @@ class CompressFuseFn(Function):
         return (fret, None, *grads)
 
 
+class FanOutFn(Function):
+    """k aliases of x; backward sums the k incoming gradients in ONE kernel (autograd's own fan-in is k-1 pairwise adds).
+    Use where a tensor feeds several consumers: ``a, b, c = FanOutFn.apply(x, 3)``."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        gs = [g if g.is_contiguous() else g.contiguous() for g in gs]
+        vec = 8 if gs[0].dtype == torch.bfloat16 else 4
+        ok = gs[0].is_cuda and gs[0].dtype in (torch.bfloat16, torch.float32) and gs[0].numel() % vec == 0 and len(gs) <= 8 \
+            and all(g.dtype == gs[0].dtype and g.shape == gs[0].shape and g.data_ptr() % 16 == 0 for g in gs)
+        if not ok:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(gs[0])
+        K.sum_k(gs, out)
+        return out, None
+
+
 class Mix2Fn(Function):
     """y = s0*a + s1*b, s = softmax(fw) -- SplitFusion's learnable blend (csrc/runtime.hip: mix2)."""
 

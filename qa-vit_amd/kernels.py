@@ -338,6 +338,10 @@ def hybrid_fuse_bwd(dy, x, fw, dx, dfw, rows, nb, Cb):
     L.check(L.load().qavit_hybrid_fuse_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), fw.data_ptr(), dx.data_ptr(), dfw.data_ptr(), rows, nb, Cb, stream()), "hybrid_fuse_bwd")
 
 
+def sum_k(xs, out):
+    L.check(L.load().qavit_sum_k(dt_code(out.dtype), _ptr_arr(xs), len(xs), out.data_ptr(), out.numel(), stream()), "sum_k")
+
+
 def rand_perm(perm, B, rng, site):
     L.check(L.load().qavit_rand_perm(perm.data_ptr(), B, rng.data_ptr(), site, stream()), "rand_perm")
 

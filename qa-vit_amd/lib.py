@@ -92,6 +92,7 @@ _SIGS = {
     "qavit_token_mean_bwd": (i32, [i32, vp, vp, i32, i32, i32, vp]),
     "qavit_hybrid_fuse_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
     "qavit_hybrid_fuse_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "qavit_sum_k": (i32, [i32, vp, i32, vp, i64, vp]),
     "qavit_rand_perm": (i32, [vp, i32, vp, i32, vp]),
     "qavit_mix_apply": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_mix2_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),

@@ -134,7 +134,10 @@ class EfficientMultiScaleDilatedAttention(_Branch):
         self.norm = nn.LayerNorm(d)
         self._site = K.new_site()
 
-    def forward(self, x):
+    def forward(self, x, x_q=None):
+        """``x_q``: optional second alias of the same tensor for the Q projection (lets the caller's fan-out node sum both
+        gradient contributions in its one pass)."""
+        x_q = x if x_q is None else x_q
         B, N, C = x.shape
         Hs = _hw(N)
         stride = self.config.landmark_pooling_stride
@@ -150,7 +153,7 @@ class EfficientMultiScaleDilatedAttention(_Branch):
         NP = idx.numel() // stride
         pooled = F.GatherPoolFn.apply(x, idx, stride)
         kv = F.linear(pooled, self.qkv.weight, self.qkv.bias, rows=(C, 2 * C)).reshape(B * NP, 2 * C)
-        q = F.linear(x, self.qkv.weight, self.qkv.bias, rows=(0, C)).reshape(B * N, C)
+        q = F.linear(x_q, self.qkv.weight, self.qkv.bias, rows=(0, C)).reshape(B * N, C)
         Lk = min(NP, self.linformer.seq_len)
         spec = dict(mode=0, G=B, Nq=N, L=Lk, H=self.num_heads, D=self.head_dim, KC=self.linformer.compressed_len,
                     S=self.global_bank.bank_size, groups_per_b=1, q_rows_per_b=N, k_rows_per_b=NP,
@@ -325,9 +328,11 @@ class QuadAttentionBlock(nn.Module):
         B, N, C = x.shape
         tr = self.training
         xn = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # norm1's output feeds four branches (MSDA twice): one k-way gradient sum instead of autograd's pairwise adds
+        xns = F.FanOutFn.apply(xn, 5) if (torch.is_grad_enabled() and xn.requires_grad) else (xn,) * 5
         args = []
-        for name, branch in (("swa", self.swa), ("msda", self.msda), ("cga", self.cga), ("cross", self.cross_attn)):
-            bo = branch(xn)
+        for (name, branch), xb in zip((("swa", self.swa), ("msda", self.msda), ("cga", self.cga), ("cross", self.cross_attn)), xns):
+            bo = branch(xb, xns[4]) if name == "msda" else branch(xb)
             nrm, cmp_ = getattr(self, f"norm_{name}"), getattr(self, f"compress_{name}")
             args += [bo, nrm.weight, nrm.bias, cmp_.weight, cmp_.bias]
         fused = F.CompressFuseFn.apply(self.fusion.fusion_weights, self.norm_swa.eps, *args)
@@ -572,16 +577,20 @@ class SplitFusion(nn.Module):
 
     def forward(self, T, R):
         gn, gf = self.gate_norm, self.gate_fc
-        gate = torch.sigmoid(F.linear(T + R, gf.weight, gf.bias, ln=(gn.weight, gn.bias), eps=gn.eps))
-        t_add = T + gate * R
+        grad = torch.is_grad_enabled()
+        # T feeds four expressions and R three: one k-way gradient sum each instead of autograd's pairwise adds
+        T0, T1, T2, T3 = F.FanOutFn.apply(T, 4) if (grad and T.requires_grad) else (T,) * 4
+        R0, R1, R2 = F.FanOutFn.apply(R, 3) if (grad and R.requires_grad) else (R,) * 3
+        gate = torch.sigmoid(F.linear(T0 + R0, gf.weight, gf.bias, ln=(gn.weight, gn.bias), eps=gn.eps))
+        t_add = T1 + gate * R1
         c0, c1 = self.cat_mlp[0], self.cat_mlp[1]
-        h = F.linear(torch.cat([T, R], -1), c0.weight, c0.bias)
+        h = F.linear(torch.cat([T2, R2], -1), c0.weight, c0.bias)
         h = F.layer_norm(h, c1.weight, c1.bias, c1.eps, act="gelu")
         h = TF.dropout(h, self.cat_mlp[3].p, self.training)
         fn = self.final_norm
         if isinstance(self.fusion_weights, nn.Parameter) and self.fusion_weights.numel() == 2 and (t_add.numel() * t_add.element_size()) % 16 == 0:
-            mixed = F.Mix2Fn.apply(t_add, T + h, self.fusion_weights)
+            mixed = F.Mix2Fn.apply(t_add, T3 + h, self.fusion_weights)
         else:
             w = torch.softmax(self.fusion_weights, 0).to(T.dtype)
-            mixed = w[0] * t_add + w[1] * (T + h)
+            mixed = w[0] * t_add + w[1] * (T3 + h)
         return F.layer_norm(mixed, fn.weight, fn.bias, fn.eps)
