@@ -292,6 +292,10 @@ int qavit_rand_perm(int64_t* perm, int B, const int64_t* rng, int site, void* st
  * mode (0 none, 1 cutmix, 2 mixup), lambda, x1, y1, x2, y2 (the box of rand_bbox :1339-1363); perm = device int64[B].
  * out[b] = x[b] with the box pasted from x[perm[b]] (cutmix) or lambda*x[b] + (1-lambda)*x[perm[b]] (mixup).  out != x. */
 int qavit_mix_apply(const float* x, const int64_t* perm, const float* plan, float* out, int B, int C, int H, int W, void* stream);
+/* SplitFusion gate (HQAViT_CIFAR100.py:945-949): y = t + sigmoid(g) * r (n elements, same dtype, 16-byte aligned).
+ * bwd: dt = dy (the caller passes it through), dr = dy * sigmoid(g), dg = dy * r * sigmoid(g) * (1 - sigmoid(g)). */
+int qavit_gate_mix_fwd(int dtype, const void* t, const void* r, const void* g, void* y, int64_t n, void* stream);
+int qavit_gate_mix_bwd(int dtype, const void* dy, const void* r, const void* g, void* dr, void* dg, int64_t n, void* stream);
 /* SplitFusion blend (HQAViT_CIFAR100.py:959-963): y = s0*a + s1*b with s = softmax(fw[0..1]); n = element count (a multiple
  * of the 16-byte vector, operands 16-byte aligned).  bwd: da = s0*dy, db = s1*dy, dfw[2] += (through the softmax; may be NULL) */
 int qavit_mix2_fwd(int dtype, const void* a, const void* b, const float* fw, void* y, int64_t n, void* stream);

@@ -343,6 +343,37 @@ __global__ __launch_bounds__(256) void rand_perm_kernel(int64_t* perm, int B, in
   for (int i = threadIdx.x; i < B; i += 256) perm[i] = (int64_t)si[i];
 }
 
+// SplitFusion gate (HQAViT_CIFAR100.py:945-949): y = t + sigmoid(g) * r.   bwd: dt = dy, dr = dy*s, dg = dy*r*s*(1-s).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gate_mix_kernel(const T* t, const T* r, const T* g, const T* dy, T* o0, T* o1, uint32_t nvec) {
+  constexpr int VEC = Vec<T>::N;
+  typedef typename Vec<T>::type vec_t;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    const vec_t rv = *reinterpret_cast<const vec_t*>(r + (size_t)v * VEC);
+    const vec_t gv = *reinterpret_cast<const vec_t*>(g + (size_t)v * VEC);
+    vec_t a, b;
+    if (!BWD) {
+      const vec_t tv = *reinterpret_cast<const vec_t*>(t + (size_t)v * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float sg = 1.f / (1.f + __expf(-to_f<T>(gv[j])));
+        a[j] = from_f<T>(to_f<T>(tv[j]) + sg * to_f<T>(rv[j]));
+      }
+      *reinterpret_cast<vec_t*>(o0 + (size_t)v * VEC) = a;
+    } else {
+      const vec_t dv = *reinterpret_cast<const vec_t*>(dy + (size_t)v * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float sg = 1.f / (1.f + __expf(-to_f<T>(gv[j]))), d = to_f<T>(dv[j]);
+        a[j] = from_f<T>(d * sg);
+        b[j] = from_f<T>(d * to_f<T>(rv[j]) * sg * (1.f - sg));
+      }
+      *reinterpret_cast<vec_t*>(o0 + (size_t)v * VEC) = a;
+      *reinterpret_cast<vec_t*>(o1 + (size_t)v * VEC) = b;
+    }
+  }
+}
+
 // out = sum of k same-shape tensors (k <= 8): the gradient fan-in of a tensor with k consumers as ONE pass
 // (autograd would issue k-1 pairwise adds, each reading two tensors and writing one)
 struct SumPtrs { const void* p[8]; };
@@ -567,6 +598,31 @@ extern "C" int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, c
              hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb),
              hipLaunchKernelGGL((hybrid_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, n, nb, Cb), "hybrid_fuse_bwd");
   return check_launch("hybrid_fuse_bwd");
+}
+
+extern "C" int qavit_gate_mix_fwd(int dtype, const void* t, const void* r, const void* g, void* y, int64_t n, void* stream) {
+  if (!t || !r || !g || !y || n <= 0) return set_error(QAVIT_EINVAL, "gate_mix_fwd: bad arguments");
+  const int vec = dtype == QAVIT_BF16 ? 8 : 4;
+  if (((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y)) & 15) || n % vec || n / vec >= 0x7fffffffLL)
+    return set_error(QAVIT_EINVAL, "gate_mix_fwd: 16-byte aligned operands, element count a multiple of the 16-byte vector");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint32_t nvec = (uint32_t)(n / vec);
+  if (dtype == QAVIT_BF16) hipLaunchKernelGGL((gate_mix_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)t, (const bf16*)r, (const bf16*)g, (const bf16*)nullptr, (bf16*)y, (bf16*)nullptr, nvec);
+  else if (dtype == QAVIT_F32) hipLaunchKernelGGL((gate_mix_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)t, (const float*)r, (const float*)g, (const float*)nullptr, (float*)y, (float*)nullptr, nvec);
+  else return set_error(QAVIT_EINVAL, "gate_mix_fwd: unknown dtype");
+  return check_launch("gate_mix_fwd");
+}
+extern "C" int qavit_gate_mix_bwd(int dtype, const void* dy, const void* r, const void* g, void* dr, void* dg, int64_t n, void* stream) {
+  if (!dy || !r || !g || !dr || !dg || n <= 0) return set_error(QAVIT_EINVAL, "gate_mix_bwd: bad arguments");
+  const int vec = dtype == QAVIT_BF16 ? 8 : 4;
+  if (((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dr) | reinterpret_cast<uintptr_t>(dg)) & 15) || n % vec || n / vec >= 0x7fffffffLL)
+    return set_error(QAVIT_EINVAL, "gate_mix_bwd: 16-byte aligned operands, element count a multiple of the 16-byte vector");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const uint32_t nvec = (uint32_t)(n / vec);
+  if (dtype == QAVIT_BF16) hipLaunchKernelGGL((gate_mix_kernel<bf16, true>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)nullptr, (const bf16*)r, (const bf16*)g, (const bf16*)dy, (bf16*)dr, (bf16*)dg, nvec);
+  else if (dtype == QAVIT_F32) hipLaunchKernelGGL((gate_mix_kernel<float, true>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)nullptr, (const float*)r, (const float*)g, (const float*)dy, (float*)dr, (float*)dg, nvec);
+  else return set_error(QAVIT_EINVAL, "gate_mix_bwd: unknown dtype");
+  return check_launch("gate_mix_bwd");
 }
 
 extern "C" int qavit_sum_k(int dtype, const void* const* xs, int k, void* out, int64_t n, void* stream) {

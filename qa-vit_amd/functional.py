@@ -855,6 +855,27 @@ class FanOutFn(Function):
         return out, None
 
 
+class GateMixFn(Function):
+    """y = t + sigmoid(g) * r -- SplitFusion's gated add (csrc/runtime.hip: gate_mix), one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, t, r, g):
+        K._require_cuda(t, r)
+        t, r, g = t.contiguous(), r.contiguous(), g.contiguous()
+        y = torch.empty_like(t)
+        K.gate_mix_fwd(t, r, g, y)
+        ctx.save_for_backward(r, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        r, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        dr, dg = torch.empty_like(r), torch.empty_like(g)
+        K.gate_mix_bwd(dy, r, g, dr, dg)
+        return dy, dr, dg
+
+
 class Mix2Fn(Function):
     """y = s0*a + s1*b, s = softmax(fw) -- SplitFusion's learnable blend (csrc/runtime.hip: mix2)."""
 

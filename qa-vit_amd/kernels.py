@@ -351,6 +351,14 @@ def mix_apply(x, perm, plan, out):
     L.check(L.load().qavit_mix_apply(x.data_ptr(), perm.data_ptr(), plan.data_ptr(), out.data_ptr(), B, Cc, H, W, stream()), "mix_apply")
 
 
+def gate_mix_fwd(t, r, g, y):
+    L.check(L.load().qavit_gate_mix_fwd(dt_code(t.dtype), t.data_ptr(), r.data_ptr(), g.data_ptr(), y.data_ptr(), t.numel(), stream()), "gate_mix_fwd")
+
+
+def gate_mix_bwd(dy, r, g, dr, dg):
+    L.check(L.load().qavit_gate_mix_bwd(dt_code(r.dtype), dy.data_ptr(), r.data_ptr(), g.data_ptr(), dr.data_ptr(), dg.data_ptr(), r.numel(), stream()), "gate_mix_bwd")
+
+
 def mix2_fwd(a, b, fw, y):
     L.check(L.load().qavit_mix2_fwd(dt_code(a.dtype), a.data_ptr(), b.data_ptr(), fw.data_ptr(), y.data_ptr(), a.numel(), stream()), "mix2_fwd")
 

@@ -95,6 +95,8 @@ _SIGS = {
     "qavit_sum_k": (i32, [i32, vp, i32, vp, i64, vp]),
     "qavit_rand_perm": (i32, [vp, i32, vp, i32, vp]),
     "qavit_mix_apply": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "qavit_gate_mix_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
+    "qavit_gate_mix_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
     "qavit_mix2_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
     "qavit_mix2_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "qavit_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),

@@ -581,8 +581,11 @@ class SplitFusion(nn.Module):
         # T feeds four expressions and R three: one k-way gradient sum each instead of autograd's pairwise adds
         T0, T1, T2, T3 = F.FanOutFn.apply(T, 4) if (grad and T.requires_grad) else (T,) * 4
         R0, R1, R2 = F.FanOutFn.apply(R, 3) if (grad and R.requires_grad) else (R,) * 3
-        gate = torch.sigmoid(F.linear(T0 + R0, gf.weight, gf.bias, ln=(gn.weight, gn.bias), eps=gn.eps))
-        t_add = T1 + gate * R1
+        gl = F.linear(T0 + R0, gf.weight, gf.bias, ln=(gn.weight, gn.bias), eps=gn.eps)
+        if (T1.numel() * T1.element_size()) % 16 == 0 and T1.dtype == R1.dtype == gl.dtype:
+            t_add = F.GateMixFn.apply(T1, R1, gl)            # T + sigmoid(gate) * R in one kernel
+        else:
+            t_add = T1 + torch.sigmoid(gl) * R1
         c0, c1 = self.cat_mlp[0], self.cat_mlp[1]
         h = F.linear(torch.cat([T2, R2], -1), c0.weight, c0.bias)
         h = F.layer_norm(h, c1.weight, c1.bias, c1.eps, act="gelu")

@@ -559,3 +559,24 @@ def test_batchnorm_matches_torch(F, dtype, Cc, gelu):
     ye = F.BatchNormFn.apply(x.detach(), w, b, rm, rv, 0.1, 1e-5, gelu, False)
     re_ = TF.batch_norm(xr.detach(), rmr, rvr, wr, br, False, 0.1, 1e-5)
     assert rel(ye, TF.gelu(re_) if gelu else re_) <= tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_splitfusion_helpers_match_torch(F, dtype):
+    """GateMixFn (t + sigmoid(g)*r), Mix2Fn (softmax-weighted blend, scalar-weight gradients through own reduction) and
+    FanOutFn (k-way gradient fan-in) against their torch expressions."""
+    n, Cc = 4096, 192
+    t, r, g_ = [leaf(n, Cc, seed=400 + i).detach().to(dtype).requires_grad_(True) for i in range(3)]
+    fw = torch.tensor([0.75, 0.25], device=DEV, requires_grad=True)
+    tr_, rr, gr, fr = [v.detach().clone().float().requires_grad_(True) for v in (t, r, g_, fw)]
+    t1, t2 = F.FanOutFn.apply(t, 2)
+    r1, r2, r3 = F.FanOutFn.apply(r, 3)
+    y = F.Mix2Fn.apply(F.GateMixFn.apply(t1, r1, g_), t2 + r2 * 0.5 + r3, fw)
+    w = torch.softmax(fr, 0)
+    ref = w[0] * (tr_ + torch.sigmoid(gr) * rr) + w[1] * (tr_ + rr * 0.5 + rr)
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    for a_, b_, nm in ((t, tr_, "t"), (r, rr, "r"), (g_, gr, "g"), (fw, fr, "fw")):
+        assert rel(a_.grad, b_.grad) <= tol(dtype, False) * 2, nm
