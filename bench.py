@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--config", default="c100", choices=["c100", "tin"], help="c100 = the BASELINE metric's model (default); tin = HQAViT_IN_Tiny defaults (64x64, 200 classes)")
     ap.add_argument("--mix", action="store_true", help="include device-side CutMix/MixUp + mixed loss in the step (off: the BASELINE metric)")
     ap.add_argument("--fwd-bwd-only", action="store_true", help="time forward+backward(+all-reduce) without the optimiser")
     return ap.parse_args()
@@ -152,8 +153,8 @@ class KernelTimer:
         return fam
 
 
-def cpu_baseline(batch=32, budget_s=20.0):
-    """CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host: HQA-ViT C100 train step."""
+def cpu_baseline(batch=32, budget_s=20.0, tin=False):
+    """CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host: one HQA-ViT train step of the benched configuration."""
     import qavit_amd as Q
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import qavit_oracle as O
@@ -166,7 +167,9 @@ def cpu_baseline(batch=32, budget_s=20.0):
     cores = max(1, min(cores, int(os.environ.get("QAVIT_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
-    cfg = Q.HQAViTConfig()
+    cfg = Q.HQAViTTinyINConfig() if tin else Q.HQAViTConfig()
+    if tin:
+        batch = 8
     model = Q.HQAViT(cfg)
     Q.fill_module(model)
     P = {k: v.clone() for k, v in model.state_dict().items()}
@@ -176,8 +179,8 @@ def cpu_baseline(batch=32, budget_s=20.0):
     for n, _ in model.named_parameters():
         P[n].requires_grad_(True)
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn(batch, 3, 32, 32, generator=g)
-    y = torch.randint(0, 100, (batch,), generator=g)
+    x = torch.randn(batch, 3, cfg.img_size, cfg.img_size, generator=g)
+    y = torch.randint(0, cfg.num_classes, (batch,), generator=g)
     times = []
     t_start = time.time()
     it = 0
@@ -196,7 +199,7 @@ def cpu_baseline(batch=32, budget_s=20.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"HQA-ViT CIFAR-100 train fwd+bwd, B={batch}, fp32, {len(times)} timed steps after 2 warm-up, median {med * 1e3:.0f} ms/step"}
+            "sample": f"HQA-ViT {'Tiny-ImageNet' if tin else 'CIFAR-100'} train fwd+bwd, B={batch}, fp32, {len(times)} timed steps after 2 warm-up, median {med * 1e3:.0f} ms/step"}
 
 
 def main():
@@ -223,13 +226,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    cfg = Q.HQAViTConfig()
+    cfg = Q.HQAViTConfig() if args.config == "c100" else Q.HQAViTTinyINConfig()
     model = Q.HQAViT(cfg)
     Q.fill_module(model)
     model = model.to(dev).train()
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+    x = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=g).to(dev)
     y = torch.randint(0, cfg.num_classes, (B,), generator=g).to(dev)
 
     dp = None
@@ -280,16 +283,16 @@ def main():
     value = B * world * args.steps / dt
 
     out = {
-        "metric": "training images/sec (fwd+bwd) HQA-ViT CIFAR-100", "value": round(value, 1), "unit": "images/sec",
+        "metric": "training images/sec (fwd+bwd) HQA-ViT CIFAR-100" if args.config == "c100" else "training images/sec (fwd+bwd) HQA-ViT Tiny-ImageNet", "value": round(value, 1), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "HQAViT_CIFAR100 full training step (" + ("device CutMix/MixUp, " if args.mix else "") + "re-pack, fwd, CE loss, bwd, "
+        "config": {"workload": ("HQAViT_CIFAR100" if args.config == "c100" else "HQAViT_IN_Tiny") + " full training step (" + ("device CutMix/MixUp, " if args.mix else "") + "re-pack, fwd, CE loss, bwd, "
                                + ("grad all-reduce, " if world > 1 else "") + ("clip + fused AdamW)" if with_optim else "no optimiser)"),
-                   "weights": "HQAViTConfig() defaults, 6,472,037 parameters, random-init (key-seeded filler)",
-                   "global_batch": B * world, "per_gpu_batch": B, "image": "32x32x3", "parallelism": f"dp{world}",
+                   "weights": f"{type(cfg).__name__}() defaults, {sum(p.numel() for p in model.parameters()):,} parameters, random-init (key-seeded filler)",
+                   "global_batch": B * world, "per_gpu_batch": B, "image": f"{cfg.img_size}x{cfg.img_size}x3", "parallelism": f"dp{world}",
                    "launch": mode, "dropout": cfg.dropout, "drop_path": cfg.drop_path, "final_loss": round(loss_val, 4)},
     }
-    step_tflops = value * MFLOP_PER_IMG_TRAIN * 1e6 / 1e12
+    step_tflops = value * (MFLOP_PER_IMG_TRAIN if args.config == "c100" else 6490.0) * 1e6 / 1e12     # 1,293 / 6,490 MFLOP per image
     out["config"]["algorithmic_tflops_per_s"] = round(step_tflops, 2)
     out["config"]["algorithmic_mfma_frac"] = round(step_tflops / (PEAK_BF16_TFLOPS * world), 5)
 
@@ -331,7 +334,7 @@ def main():
                                             "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                                         for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(tin=args.config == "tin")
     if rank == 0:
         print(json.dumps(out))
     if dist:

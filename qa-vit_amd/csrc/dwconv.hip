@@ -253,6 +253,154 @@ __global__ __launch_bounds__(256) void dwconv_bwd8_kernel(const T* dy, const T* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Maps whose sides are multiples of 8 (Tiny-ImageNet: 16x16): the same lane-per-channel scheme on 8x8 OUTPUT tiles.
+// A wave takes one (image, tile); the (8+2R)-wide halo rows are streamed one at a time -- input row r meets output row
+// yy through tap row r - yy -- so 64 outputs, the taps and one halo row are all that is live.  Halo cells outside the
+// map are clamped loads zeroed by a wave-uniform select.  FLIP correlates with the flipped taps (dx of the forward).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int HR>
+__device__ __forceinline__ void dw_halo_row(const T* src, float (&xr)[HR], int b, int gy, int x0, int H, int W, int C, int cc) {
+  const bool rok = gy >= 0 && gy < H;
+  const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+#pragma unroll
+  for (int ci = 0; ci < HR; ++ci) {
+    const int gx = x0 + ci;
+    const bool ok = rok && gx >= 0 && gx < W;
+    const int gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+    const float v = to_f<T>(src[(((size_t)b * H + gyc) * W + gxc) * C + cc]);
+    xr[ci] = ok ? v : 0.f;
+  }
+}
+
+template <typename T, int KS, bool FLIP>
+__device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS * KS], float (&o)[8][8], int b, int y0, int x0, int H, int W, int C, int cc) {
+  constexpr int TS = 8, R = KS / 2, HR = TS + 2 * R;
+  float xr[HR], xn[HR];
+  dw_halo_row<T, HR>(src, xr, b, y0, x0, H, W, C, cc);
+#pragma unroll
+  for (int r = 0; r < HR; ++r) {
+    if (r + 1 < HR) dw_halo_row<T, HR>(src, xn, b, y0 + r + 1, x0, H, W, C, cc);     // one row ahead, no further
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int yy = 0; yy < TS; ++yy) {
+      const int dyy = r - yy;
+      if (dyy < 0 || dyy >= KS) continue;
+#pragma unroll
+      for (int xx = 0; xx < TS; ++xx)
+#pragma unroll
+        for (int dxx = 0; dxx < KS; ++dxx) {
+          const int tap = FLIP ? (KS - 1 - dyy) * KS + (KS - 1 - dxx) : dyy * KS + dxx;
+          o[yy][xx] += wt[tap] * xr[xx + dxx];
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < HR; ++ci) xr[ci] = xn[ci];
+  }
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H, int W, int C) {
+  constexpr int TS = 8, R = KS / 2, KK = KS * KS;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = blockIdx.x * 64 + lane;
+  const bool cok = c < C;
+  const int cc = cok ? c : 0;
+  float wt[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) wt[t] = w[(size_t)cc * KK + t];
+  const float bv = bias ? bias[cc] : 0.f;
+  const int TX = W / TS, TPI = (H / TS) * TX, units = B * TPI;
+  for (int u = blockIdx.y * 4 + wave; u < units; u += gridDim.y * 4) {
+    const int b = u / TPI, t = u - b * TPI, ty = t / TX, tx = t - ty * TX;
+    float o[TS][TS];
+#pragma unroll
+    for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < TS; ++xx) o[yy][xx] = bv;
+    dw_tile_rows<T, KS, false>(x, wt, o, b, ty * TS - R, tx * TS - R, H, W, C, cc);
+    if (cok) {
+#pragma unroll
+      for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < TS; ++xx) y[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx]);
+    }
+  }
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int H, int W, int C) {
+  constexpr int TS = 8, R = KS / 2, KK = KS * KS, HR = TS + 2 * R;
+  __shared__ float red[4][64 * KK + 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = blockIdx.x * 64, c = c0 + lane;
+  const bool cok = c < C;
+  const int cc = cok ? c : 0;
+  float aw[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) aw[t] = 0.f;
+  float ab = 0.f;
+  const int TX = W / TS, TPI = (H / TS) * TX, units = B * TPI;
+  for (int u = blockIdx.y * 4 + wave; u < units; u += gridDim.y * 4) {
+    const int b = u / TPI, t = u - b * TPI, ty = t / TX, tx = t - ty * TX;
+    {
+      float wt[KK];
+#pragma unroll
+      for (int i = 0; i < KK; ++i) wt[i] = w[(size_t)cc * KK + i];
+      float o[TS][TS];
+#pragma unroll
+      for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < TS; ++xx) o[yy][xx] = 0.f;
+      dw_tile_rows<T, KS, true>(dy, wt, o, b, ty * TS - R, tx * TS - R, H, W, C, cc);
+      if (cok) {
+#pragma unroll
+        for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+          for (int xx = 0; xx < TS; ++xx) dx[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx]);
+      }
+    }
+    float g[TS][TS];
+#pragma unroll
+    for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < TS; ++xx) { g[yy][xx] = to_f<T>(dy[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + cc]); ab += g[yy][xx]; }
+    // dw[dyy][dxx] += sum_{yy,xx} dy[yy][xx] * x[yy+dyy-R][xx+dxx-R]: halo rows of x streamed against the dy tile
+    float xr[HR], xn[HR];
+    dw_halo_row<T, HR>(x, xr, b, ty * TS - R, tx * TS - R, H, W, C, cc);
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+      if (r + 1 < HR) dw_halo_row<T, HR>(x, xn, b, ty * TS - R + r + 1, tx * TS - R, H, W, C, cc);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int yy = 0; yy < TS; ++yy) {
+        const int dyy = r - yy;
+        if (dyy < 0 || dyy >= KS) continue;
+#pragma unroll
+        for (int dxx = 0; dxx < KS; ++dxx) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int xx = 0; xx < TS; ++xx) s_ += g[yy][xx] * xr[xx + dxx];
+          aw[dyy * KS + dxx] += s_;
+        }
+      }
+#pragma unroll
+      for (int ci = 0; ci < HR; ++ci) xr[ci] = xn[ci];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KK; ++t) red[wave][lane * KK + t] = cok ? aw[t] : 0.f;
+  red[wave][64 * KK + lane] = cok ? ab : 0.f;
+  __syncthreads();
+  const int live = (C - c0 < 64 ? C - c0 : 64);
+  for (int i = threadIdx.x; i < live * KK; i += 256)
+    atomic_add_f(dw + (size_t)c0 * KK + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  if (dbias && threadIdx.x < live) {
+    const int i = 64 * KK + threadIdx.x;
+    atomic_add_f(dbias + c0 + threadIdx.x, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+  }
+}
+
 template <typename T, int KS>
 static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, const float* bias, void* o0, float* dw, float* dbias,
                      int B, int H, int W, int C, hipStream_t st) {
@@ -264,6 +412,19 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
     if (gy8 > cap) gy8 = cap;
     hipLaunchKernelGGL((dwconv_fwd8_kernel<T, KS>), dim3(chunks, gy8), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, C);
     return check_launch("dwconv_fwd8");
+  }
+  static const bool tiled = !(getenv("QAVIT_DW_TILED") && atoi(getenv("QAVIT_DW_TILED")) == 0);
+  if (tiled && H % 8 == 0 && W % 8 == 0 && H * W > 64) {
+    const int units = B * (H / 8) * (W / 8);
+    int gy = (units + 3) / 4;
+    const int cap = (bwd ? 512 : 2048) / chunks > 0 ? (bwd ? 512 : 2048) / chunks : 1;
+    if (gy > cap) gy = cap;
+    if (!bwd) {
+      hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
+      return check_launch("dwconv_fwdt");
+    }
+    hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
+    return check_launch("dwconv_bwdt");
   }
   if (!bwd) {
     const size_t smem = ((size_t)N * DW_CH + KS * KS * DW_CH) * sizeof(float);

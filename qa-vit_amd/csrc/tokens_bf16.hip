@@ -166,9 +166,9 @@ struct UpLds {
   static constexpr int LDM = M + 4, LDC = C + 4;
   static constexpr int wt = 0;                               // bf16 [N][LDM]
   static constexpr int xc = wt + N * LDM;                    // bf16 [M][LDC]
-  static constexpr int dup = xc + M * LDC;                   // bf16 [N][LDC]   (backward only)
+  static constexpr int dup = xc + M * LDC;                   // bf16 [min(N,64)][LDC]   (backward only: one 4-tile chunk)
   static constexpr int fwd_bf16 = dup;
-  static constexpr int bwd_bf16 = dup + N * LDC;
+  static constexpr int bwd_bf16 = dup + (N < 64 ? N : 64) * LDC;
 };
 
 template <int NT, int MT, int CT>
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
                                                          float* dgamma, float* dbeta, int B) {
   using L = UpLds<NT, MT, CT>;
   constexpr int NTW = (NT + 3) / 4;                           // row tiles per wave
+  constexpr int DXT = (MT * CT + 3) / 4;                      // dxc tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   bf16* sm = reinterpret_cast<bf16*>(smraw);
   float* fl = reinterpret_cast<float*>(smraw + (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2);   // [N] dbias + [4][2][C] gamma/beta partials
@@ -266,9 +267,13 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
-    __syncthreads();
+    f32x4 dxa[DXT];
+#pragma unroll
+    for (int i = 0; i < DXT; ++i) dxa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the row tiles go through LDS four at a time (one per wave); dxc accumulates over the chunks in registers
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
+      __syncthreads();                                           // xc staged / previous chunk consumed
       const int nt = wave + 4 * tw;
       if (nt < NT) {
         f32x4 acc[CT];
@@ -297,29 +302,38 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
           if (col == 0) dba[nt * 16 + 4 * q4 + r] += rsum;       // this row belongs to this wave only
         }
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc_to_lds(sm + L::dup, L::LDC, nt * 16, ct * 16, acc[ct]);
+        for (int ct = 0; ct < CT; ++ct) acc_to_lds(sm + L::dup, L::LDC, wave * 16, ct * 16, acc[ct]);
       }
-    }
-    __syncthreads();
-    // dxc[m][c] = sum_n W[n][m] dup[n][c]
-    for (int tile = wave; tile < MT * CT; tile += 4) {
-      const int mt = tile / CT, ct = tile - mt * CT;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      __syncthreads();
+      // dxc[m][c] += sum_{n in chunk} W[n][m] dup[n][c]
+      constexpr int KT = NT < 4 ? NT : 4;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) a = mma16(trfrag(sm + L::wt, L::LDM, nt * 16, mt * 16), trfrag(sm + L::dup, L::LDC, nt * 16, ct * 16), a);
+      for (int i = 0; i < DXT; ++i) {
+        const int tile = wave + 4 * i;
+        if (tile < MT * CT) {
+          const int mt = tile / CT, ct = tile - mt * CT;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dxc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)a[r];
-    }
-    // dW[n][m] += sum_c dup[n][c] xc[m][c]
-#pragma unroll
-    for (int tw = 0; tw < NTW; ++tw) {
-      const int nt = wave + 4 * tw;
+          for (int k = 0; k < KT; ++k)
+            if (4 * tw + k < NT)
+              dxa[i] = mma16(trfrag(sm + L::wt, L::LDM, (4 * tw + k) * 16, mt * 16), trfrag(sm + L::dup, L::LDC, k * 16, ct * 16), dxa[i]);
+        }
+      }
+      // dW[n][m] += sum_c dup[n][c] xc[m][c]   (own row tile)
       if (nt < NT) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
-            dwacc[tw][mt] = mma16(rowfrag(sm + L::dup, L::LDC, nt * 16, ct * 16), rowfrag(sm + L::xc, L::LDC, mt * 16, ct * 16), dwacc[tw][mt]);
+            dwacc[tw][mt] = mma16(rowfrag(sm + L::dup, L::LDC, wave * 16, ct * 16), rowfrag(sm + L::xc, L::LDC, mt * 16, ct * 16), dwacc[tw][mt]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DXT; ++i) {
+      const int tile = wave + 4 * i;
+      if (tile < MT * CT) {
+        const int mt = tile / CT, ct = tile - mt * CT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dxc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)dxa[i][r];
       }
     }
   }
@@ -391,9 +405,12 @@ struct MixLds {
   static constexpr int LDM = M + 4, LDC = C + 4;
   static constexpr int p = 0;                                // bf16 [N][LDM]
   static constexpr int x = p + N * LDM;                      // bf16 [N][LDC]
-  static constexpr int g = x + N * LDC;                      // bf16 [M][LDC]   (backward: dxc)
+  static constexpr int g = x + N * LDC;                      // (forward ends here)
   static constexpr int fwd_bf16 = g;
-  static constexpr int bwd_bf16 = g + M * LDC;
+  // backward: x is staged one 16-row tile per wave, so its region is [4][16][LDC]; dxc follows
+  static constexpr int bx = p + N * LDM;                     // bf16 [4][16][LDC]
+  static constexpr int bg = bx + 64 * LDC;                   // bf16 [M][LDC]
+  static constexpr int bwd_bf16 = bg + M * LDC;
 };
 
 __device__ __forceinline__ float colred(float v, float* red, int M, int parts, bool is_max) {
@@ -464,17 +481,25 @@ __global__ __launch_bounds__(256) void tokmix2_bwd_kernel(const bf16* p_in, cons
   float* dP = reinterpret_cast<float*>(smraw + (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2);      // [N][M]
   float* red = dP + L::N * L::M;                                                               // [256]
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, q4 = lane >> 4;
-  mix_stage_rows<NT, MT, CT>(sm + L::x, x + (size_t)b * L::N * L::C, L::N);
-  mix_stage_rows<NT, MT, CT>(sm + L::g, dxc + (size_t)b * L::M * L::C, L::M);
+  mix_stage_rows<NT, MT, CT>(sm + L::bg, dxc + (size_t)b * L::M * L::C, L::M);
   const bf16* pb = p_in + (size_t)b * L::N * L::M;
   for (int i = t; i < L::N * L::M; i += 256) { const int n = i / L::M, m = i - n * L::M; sm[L::p + n * L::LDM + m] = pb[i]; }
   __syncthreads();
+  bf16* xw = sm + L::bx + wave * 16 * L::LDC;                  // this wave's x tile
+  constexpr int CH = L::C / 4;
   for (int nt = wave; nt < NT; nt += 4) {
+    wave_sync();
+    const bf16* xs = x + ((size_t)b * L::N + nt * 16) * L::C;
+    for (int i = lane; i < 16 * CH; i += 64) {
+      const int n = i / CH, ch = i - n * CH;
+      *reinterpret_cast<bf16x4*>(xw + n * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(xs + (size_t)n * L::C + 4 * ch);
+    }
+    wave_sync();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a = mma16(rowfrag(sm + L::p, L::LDM, nt * 16, mt * 16), trfrag(sm + L::g, L::LDC, mt * 16, ct * 16), a);
+      for (int mt = 0; mt < MT; ++mt) a = mma16(rowfrag(sm + L::p, L::LDM, nt * 16, mt * 16), trfrag(sm + L::bg, L::LDC, mt * 16, ct * 16), a);
 #pragma unroll
       for (int r = 0; r < 4; ++r) dx[((size_t)b * L::N + nt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)a[r];
     }
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(256) void tokmix2_bwd_kernel(const bf16* p_in, cons
     for (int mt = 0; mt < MT; ++mt) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) a = mma16(rowfrag(sm + L::x, L::LDC, nt * 16, ct * 16), rowfrag(sm + L::g, L::LDC, mt * 16, ct * 16), a);
+      for (int ct = 0; ct < CT; ++ct) a = mma16(rowfrag(xw, L::LDC, 0, ct * 16), rowfrag(sm + L::bg, L::LDC, mt * 16, ct * 16), a);
 #pragma unroll
       for (int r = 0; r < 4; ++r) dP[(nt * 16 + 4 * q4 + r) * L::M + mt * 16 + col] = a[r];
     }

@@ -382,7 +382,7 @@ def test_ccf_mid(F, dtype, Hs, flags):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("ks,C,H", [(7, 64, 8), (7, 256, 8), (3, 128, 8), (5, 100, 8), (7, 64, 16)])
+@pytest.mark.parametrize("ks,C,H", [(7, 64, 8), (7, 256, 8), (3, 128, 8), (5, 100, 8), (7, 64, 16), (3, 100, 16), (5, 192, 16), (3, 128, 24), (7, 64, 12)])
 def test_dwconv_tokens(F, dtype, ks, C, H):
     B = 21
     x = leaf(B, H * H, C, seed=130).detach().to(dtype).requires_grad_(True)
