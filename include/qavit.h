@@ -335,6 +335,9 @@ int qavit_rng_advance(int64_t* rng, void* stream);
 int qavit_adamw(float* p, const float* g, float* m, float* v, const uint8_t* skip, int64_t n,
                 const float* lr_dev, float beta1, float beta2, float eps, float wd,
                 const float* step_dev, const float* gnorm_dev, float max_norm, void* stream);
+/* per-tensor clip of nseg segments of the flat gradient buffer, seg = device int64 [nseg][2] = (offset, length):
+ * g[seg] *= min(1, clip / (||g[seg]||_2 + 1e-6))   (clip_grad_norm_ per parameter, HQAViT_CIFAR100.py:1416-1418) */
+int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, void* stream);
 /* out[0] = sqrt(sum g^2) over a flat buffer (two-pass, deterministic order within a block) */
 int qavit_l2norm(const float* g, int64_t n, float* partial, float* out, void* stream);
 

@@ -748,6 +748,36 @@ extern "C" int qavit_l2norm(const float* g, int64_t n, float* partial, float* ou
   return check_launch("l2norm");
 }
 
+// Per-tensor gradient clip of selected segments of the flat gradient buffer: g *= min(1, clip / (||g|| + 1e-6)).
+// One workgroup per segment (they are small: stem / depthwise-conv weights); norm and rescale in the same launch.
+__global__ __launch_bounds__(512) void local_clip_kernel(float* g, const int64_t* seg, float clip) {
+  __shared__ float red[8];
+  __shared__ float scale_s;
+  float* p = g + seg[2 * blockIdx.x];
+  const int64_t n = seg[2 * blockIdx.x + 1];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 512) { const float v = p[i]; s += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 8; ++w) t += red[w];
+    scale_s = fminf(clip / (sqrtf(t) + 1e-6f), 1.f);
+  }
+  __syncthreads();
+  const float sc = scale_s;
+  if (sc < 1.f)
+    for (int64_t i = threadIdx.x; i < n; i += 512) p[i] *= sc;
+}
+
+extern "C" int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, void* stream) {
+  if (!g || !seg || nseg <= 0 || !(clip > 0.f)) return set_error(QAVIT_EINVAL, "local_clip: bad arguments");
+  hipLaunchKernelGGL(local_clip_kernel, dim3(nseg), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), g, seg, clip);
+  return check_launch("local_clip");
+}
+
 extern "C" int qavit_adamw(float* p, const float* g, float* m, float* v, const uint8_t* skip, int64_t n,
                            const float* lr_dev, float beta1, float beta2, float eps, float wd,
                            const float* step_dev, const float* gnorm_dev, float max_norm, void* stream) {

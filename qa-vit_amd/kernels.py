@@ -408,5 +408,10 @@ def adamw(p, g, m, v, skip, lr_dev, b1, b2, eps, wd, step_dev, gnorm_dev, max_no
                                  step_dev.data_ptr(), _p(gnorm_dev), max_norm, stream()), "adamw")
 
 
+def local_clip(flat_g, seg, clip):
+    """seg: int64 device tensor [n, 2] of (offset, length) into flat_g; each segment is clipped to L2 norm ``clip``."""
+    L.check(L.load().qavit_local_clip(flat_g.data_ptr(), seg.data_ptr(), seg.shape[0], float(clip), stream()), "local_clip")
+
+
 def l2norm(g, partial, out):
     L.check(L.load().qavit_l2norm(g.data_ptr(), g.numel(), partial.data_ptr(), out.data_ptr(), stream()), "l2norm")

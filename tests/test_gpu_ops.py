@@ -530,6 +530,25 @@ def test_adamw_and_l2norm_match_torch(Q):
     assert rel(p, pr) <= 1e-6
 
 
+def test_local_clip_matches_clip_grad_norm(Q):
+    """Per-parameter clip of the stem / depthwise-conv gradients (reference :1416-1418) on segments of the flat buffer."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    gen = torch.Generator().manual_seed(5)
+    flat = (torch.randn(40_000, generator=gen) * 0.02).to(DEV)
+    segs = [(0, 27), (64, 4704), (4800, 1), (8192, 20_000), (30_016, 3)]        # some above, some below the threshold
+    flat[30_016:30_019] = torch.tensor([0.01, 0.0, -0.01], device=DEV)
+    ref = flat.clone()
+    for o, n in segs:
+        t = ref[o:o + n].clone().requires_grad_(True)
+        t.grad = ref[o:o + n].clone()
+        torch.nn.utils.clip_grad_norm_([t], 0.1)
+        ref[o:o + n] = t.grad
+    K.local_clip(flat, torch.tensor(segs, dtype=torch.int64, device=DEV), 0.1)
+    assert rel(flat, ref) <= 1e-6
+    assert torch.equal(flat[30_016:30_019], ref[30_016:30_019])                  # below the threshold: untouched
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Cc,gelu", [(32, True), (256, False)])
 def test_batchnorm_matches_torch(F, dtype, Cc, gelu):
