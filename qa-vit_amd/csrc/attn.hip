@@ -27,10 +27,12 @@ struct AttnLds {
   int q, s, kf, vf, kt, vt, ek, ev;            // fwd
   int d_o, dp, dkf, dvf, acc_ek, acc_ev, acc_shk, acc_shv;   // bwd only
   int total;
+  int spill;                                   // bwd, mode 0: E read from global, dE accumulated in the wave's workspace
 };
-__host__ __device__ inline AttnLds attn_lds(const qavit_attn_args& a, bool bwd) {
+__host__ __device__ inline AttnLds attn_lds_impl(const qavit_attn_args& a, bool bwd, bool spill) {
   const AttnDims d = attn_dims(a);
   AttnLds L; int o = 0;
+  L.spill = spill ? 1 : 0;
   L.q = o; o += 16 * a.D;
   L.s = o; o += 16 * d.NKp;
   L.kf = o; o += d.NK * a.D;
@@ -39,8 +41,7 @@ __host__ __device__ inline AttnLds attn_lds(const qavit_attn_args& a, bool bwd) 
   if (a.mode == 0) {
     L.kt = o; o += a.L * a.D;
     L.vt = o; o += a.L * a.D;
-    L.ek = o; o += a.L * a.KC;
-    L.ev = o; o += a.L * a.KC;
+    if (!spill) { L.ek = o; o += a.L * a.KC; L.ev = o; o += a.L * a.KC; }
   }
   L.d_o = L.dp = L.dkf = L.dvf = L.acc_ek = L.acc_ev = L.acc_shk = L.acc_shv = 0;
   if (bwd) {
@@ -48,11 +49,18 @@ __host__ __device__ inline AttnLds attn_lds(const qavit_attn_args& a, bool bwd) 
     L.dp = o; o += 16 * d.NKp;
     L.dkf = o; o += d.NK * a.D;
     L.dvf = o; o += d.NK * a.D;
-    if (a.mode == 0) { L.acc_ek = o; o += a.L * a.KC; L.acc_ev = o; o += a.L * a.KC; }
+    if (a.mode == 0 && !spill) { L.acc_ek = o; o += a.L * a.KC; L.acc_ev = o; o += a.L * a.KC; }
     L.acc_shk = o; o += a.S * a.D;
     L.acc_shv = o; o += a.S * a.D;
   }
   L.total = (o + 3) / 4 * 4;
+  return L;
+}
+// Backward problems whose Linformer matrices do not fit next to everything else (MSDA at 224 px: L=128, KC=64)
+// keep E in global memory (L2-resident, shared by every wave) and accumulate dE in place in the wave's workspace.
+__host__ __device__ inline AttnLds attn_lds(const qavit_attn_args& a, bool bwd) {
+  AttnLds L = attn_lds_impl(a, bwd, false);
+  if (bwd && a.mode == 0 && (size_t)L.total * 4 > 160 * 1024) L = attn_lds_impl(a, bwd, true);
   return L;
 }
 
@@ -84,7 +92,7 @@ __device__ __forceinline__ int64_t krow(const qavit_attn_args& a, int g, int l) 
 }
 
 // ---- shared staging: builds Kf / Vf (and keeps kt/vt/ek/ev for bwd) for problem (g,h) ----
-template <typename T, bool BF>
+template <typename T, bool BF, bool SPILL = false>
 __device__ __forceinline__ bool stage_keys(const qavit_attn_args& a, const AttnDims& d, const AttnLds& L, float* sm, int g, int h) {
   const int lane = threadIdx.x;
   const int D = a.D;
@@ -110,14 +118,19 @@ __device__ __forceinline__ bool stage_keys(const qavit_attn_args& a, const AttnD
       sm[L.kt + i] = k;
       sm[L.vt + i] = v;
     }
-    for (int i = lane; i < a.L * a.KC; i += 64) { sm[L.ek + i] = a.E_k[i]; sm[L.ev + i] = a.E_v[i]; }
+    if (!SPILL) for (int i = lane; i < a.L * a.KC; i += 64) { sm[L.ek + i] = a.E_k[i]; sm[L.ev + i] = a.E_v[i]; }
     __syncthreads();
     // Kf[j][d] = sum_l E_k[l][j] * kt[l][d]
     for (int jt = 0; jt * 16 < a.KC; ++jt)
       for (int dt = 0; dt * 16 < D; ++dt) {
         f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
-        ak = mma_tile<BF>(sm + L.ek + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.kt + dt * 16, D, 1, D - dt * 16, a.L, ak);
-        av = mma_tile<BF>(sm + L.ev + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.vt + dt * 16, D, 1, D - dt * 16, a.L, av);
+        if (SPILL) {
+          ak = mma_tile<BF>(a.E_k + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.kt + dt * 16, D, 1, D - dt * 16, a.L, ak);
+          av = mma_tile<BF>(a.E_v + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.vt + dt * 16, D, 1, D - dt * 16, a.L, av);
+        } else {
+          ak = mma_tile<BF>(sm + L.ek + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.kt + dt * 16, D, 1, D - dt * 16, a.L, ak);
+          av = mma_tile<BF>(sm + L.ev + jt * 16, 1, a.KC, a.KC - jt * 16, sm + L.vt + dt * 16, D, 1, D - dt * 16, a.L, av);
+        }
         tile_to_f32<false>(sm + L.kf + jt * 16 * D + dt * 16, D, 1, a.KC - jt * 16, D - dt * 16, ak);
         tile_to_f32<false>(sm + L.vf + jt * 16 * D + dt * 16, D, 1, a.KC - jt * 16, D - dt * 16, av);
       }
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(qavit_attn_args a) {
   if (a.nan_flag && __any(bad) && threadIdx.x == 0) atomicOr(a.nan_flag, 1);
 }
 
-template <typename T, bool BF>
+template <typename T, bool BF, bool SPILL>
 __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const AttnDims d = attn_dims(a);
@@ -237,14 +250,20 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
   T* dq = reinterpret_cast<T*>(a.dq);
   T* dkt = reinterpret_cast<T*>(a.dk_tok);
   T* dvt = reinterpret_cast<T*>(a.dv_tok);
-  const int n_acc = (a.mode == 0 ? 2 * a.L * a.KC : 0) + 2 * a.S * D;
-  const int acc0 = (a.mode == 0) ? L.acc_ek : L.acc_shk;        // accumulators are contiguous in LDS
+  const int n_e = (a.mode == 0) ? 2 * a.L * a.KC : 0;
+  const int n_acc = (SPILL ? 0 : n_e) + 2 * a.S * D;             // accumulators held in LDS (contiguous)
+  const int acc0 = (a.mode == 0 && !SPILL) ? L.acc_ek : L.acc_shk;
   for (int i = lane; i < n_acc; i += 64) sm[acc0 + i] = 0.f;
+  float* ws = a.ws + (size_t)blockIdx.x * attn_ws_per_wave(a);
+  if (SPILL) {                                                   // dE_k | dE_v live in the workspace itself
+    for (int i = lane; i < n_e; i += 64) ws[i] = 0.f;
+    __threadfence();
+  }
 
   for (int pid = blockIdx.x; pid < a.G * a.H; pid += gridDim.x) {
     const int g = pid / a.H, h = pid - g * a.H;
     __syncthreads();
-    stage_keys<T, BF>(a, d, L, sm, g, h);
+    stage_keys<T, BF, SPILL>(a, d, L, sm, g, h);
     for (int i = lane; i < 2 * d.NK * D; i += 64) sm[L.dkf + i] = 0.f;     // dkf and dvf are adjacent
     for (int q0 = 0; q0 < a.Nq; q0 += 16) {
       const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
@@ -298,8 +317,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
       for (int lt = 0; lt * 16 < a.L; ++lt) {
         for (int dt = 0; dt * 16 < D; ++dt) {
           f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
-          ak = mma_tile<BF>(sm + L.ek + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dkf + dt * 16, D, 1, D - dt * 16, a.KC, ak);
-          av = mma_tile<BF>(sm + L.ev + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dvf + dt * 16, D, 1, D - dt * 16, a.KC, av);
+          if (SPILL) {
+            ak = mma_tile<BF>(a.E_k + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dkf + dt * 16, D, 1, D - dt * 16, a.KC, ak);
+            av = mma_tile<BF>(a.E_v + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dvf + dt * 16, D, 1, D - dt * 16, a.KC, av);
+          } else {
+            ak = mma_tile<BF>(sm + L.ek + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dkf + dt * 16, D, 1, D - dt * 16, a.KC, ak);
+            av = mma_tile<BF>(sm + L.ev + lt * 16 * a.KC, a.KC, 1, a.L - lt * 16, sm + L.dvf + dt * 16, D, 1, D - dt * 16, a.KC, av);
+          }
           store_krows<T>(a, g, lt * 16, dkt, a.lddk, h * D + dt * 16, a.L - lt * 16, D - dt * 16, ak);
           store_krows<T>(a, g, lt * 16, dvt, a.lddv, h * D + dt * 16, a.L - lt * 16, D - dt * 16, av);
         }
@@ -307,8 +331,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
           f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
           ak = mma_tile<BF>(sm + L.kt + lt * 16 * D, D, 1, a.L - lt * 16, sm + L.dkf + jt * 16 * D, 1, D, a.KC - jt * 16, D, ak);
           av = mma_tile<BF>(sm + L.vt + lt * 16 * D, D, 1, a.L - lt * 16, sm + L.dvf + jt * 16 * D, 1, D, a.KC - jt * 16, D, av);
-          tile_to_f32<true>(sm + L.acc_ek + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, ak);
-          tile_to_f32<true>(sm + L.acc_ev + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, av);
+          if (SPILL) {     // the same lane owns the same element in every problem: plain read-modify-write
+            tile_to_f32<true>(ws + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, ak);
+            tile_to_f32<true>(ws + a.L * a.KC + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, av);
+          } else {
+            tile_to_f32<true>(sm + L.acc_ek + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, ak);
+            tile_to_f32<true>(sm + L.acc_ev + lt * 16 * a.KC + jt * 16, a.KC, 1, a.L - lt * 16, a.KC - jt * 16, av);
+          }
         }
       }
     } else {
@@ -321,8 +350,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
     }
   }
   __syncthreads();
-  float* ws = a.ws + (size_t)blockIdx.x * attn_ws_per_wave(a);
-  for (int i = lane; i < n_acc; i += 64) ws[i] = sm[acc0 + i];
+  float* wo = SPILL ? ws + n_e : ws;
+  for (int i = lane; i < n_acc; i += 64) wo[i] = sm[acc0 + i];
 }
 
 // fold the per-wave partials into the gradient buffers: thread = output element, blockIdx.y = slice of 8*H waves
@@ -436,9 +465,14 @@ static int attn_launch(const qavit_attn_args& a, bool bwd, hipStream_t st) {
     hipLaunchKernelGGL((attn_fwd_kernel<T, BF>), dim3(grid), dim3(64), smem, st, a);
     return check_launch("attn_fwd");
   }
-  static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-  hipLaunchKernelGGL((attn_bwd_kernel<T, BF>), dim3(grid), dim3(64), smem, st, a);
+  if (L.spill) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, BF, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, BF, true>), dim3(grid), dim3(64), smem, st, a);
+  } else {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<T, BF, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    hipLaunchKernelGGL((attn_bwd_kernel<T, BF, false>), dim3(grid), dim3(64), smem, st, a);
+  }
   launch_reduce(a, grid, st);
   return check_launch("attn_bwd");
 }

@@ -13,23 +13,26 @@ namespace qv {
 
 constexpr int BANK_MAX_WG = 256;
 
+// NCH = token rows resident in LDS at a time.  NCH >= N: one pass.  Otherwise (N = 196 at 224 px) two passes over the
+// chunks: logits of every chunk first (the softmax runs over ALL tokens of the image), then the chunks are staged and
+// normalised again for U += w^T tn -- the re-read comes from L2.
 template <typename T, bool BF>
 __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr,
-                                                         const float* Wg, const float* bg, float* ws, int B, int N, int C, int S, float eps) {
+                                                         const float* Wg, const float* bg, float* ws, int B, int N, int C, int S, int NCH, float eps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* tn = sm;                    // [N][C]
-  float* lg = tn + N * C;            // [N][S] logits -> weights
+  float* tn = sm;                    // [NCH][C]
+  float* lg = tn + NCH * C;          // [N][S] logits -> weights
   float* U = lg + N * S;             // [S][C] accumulator over this workgroup's images
   float* red = U + S * C;            // [256]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float invC = 1.f / (float)C;
   for (int i = t; i < S * C; i += 256) U[i] = 0.f;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  // rows [n0, n0 + rows) of image b -> tn, through the two chained LayerNorms
+  auto stage_ln = [&](int b, int n0, int rows) {
     __syncthreads();
-    for (int i = t; i < N * C; i += 256) tn[i] = to_f<T>(tokens[(size_t)b * N * C + i]);
+    for (int i = t; i < rows * C; i += 256) tn[i] = to_f<T>(tokens[((size_t)b * N + n0) * C + i]);
     __syncthreads();
-    // two chained LayerNorms per row
-    for (int r = wave; r < N; r += 4) {
+    for (int r = wave; r < rows; r += 4) {
       float* row = tn + r * C;
       for (int pass = 0; pass < 2; ++pass) {
         const float* g = pass == 0 ? gbr : gwr;
@@ -44,20 +47,38 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
       }
     }
     __syncthreads();
-    // logits[n][s] = tn[n,:] . Wg[s,:] + bg[s]
-    {
-      const int nt_n = (N + 15) / 16, st_n = (S + 15) / 16;
-      for (int tile = wave; tile < nt_n * st_n; tile += 4) {
-        const int nt = tile / st_n, stt = tile - nt * st_n;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma_tile<BF>(tn + nt * 16 * C, C, 1, N - nt * 16, Wg + (size_t)stt * 16 * C, 1, C, S - stt * 16, C, acc);
-        const int col = tile_col();
+  };
+  // logits[n0 + n][s] = tn[n,:] . Wg[s,:] + bg[s]
+  auto logits = [&](int n0, int rows) {
+    const int nt_n = (rows + 15) / 16, st_n = (S + 15) / 16;
+    for (int tile = wave; tile < nt_n * st_n; tile += 4) {
+      const int nt = tile / st_n, stt = tile - nt * st_n;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mma_tile<BF>(tn + nt * 16 * C, C, 1, rows - nt * 16, Wg + (size_t)stt * 16 * C, 1, C, S - stt * 16, C, acc);
+      const int col = tile_col();
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = nt * 16 + tile_row(reg);
-          if (row < N && stt * 16 + col < S) lg[row * S + stt * 16 + col] = acc[reg] + bg[stt * 16 + col];
-        }
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = nt * 16 + tile_row(reg);
+        if (row < rows && stt * 16 + col < S) lg[(n0 + row) * S + stt * 16 + col] = acc[reg] + bg[stt * 16 + col];
       }
+    }
+  };
+  // U[s][c] += sum_n w[n0 + n][s] tn[n][c]
+  auto accum = [&](int n0, int rows) {
+    const int st_n = (S + 15) / 16, ct_n = (C + 15) / 16;
+    for (int tile = wave; tile < st_n * ct_n; tile += 4) {
+      const int stt = tile / ct_n, ct = tile - stt * ct_n;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mma_tile<BF>(lg + n0 * S + stt * 16, 1, S, S - stt * 16, tn + ct * 16, C, 1, C - ct * 16, rows, acc);
+      tile_to_f32<true>(U + stt * 16 * C + ct * 16, C, 1, S - stt * 16, C - ct * 16, acc);
+    }
+  };
+  const bool one_pass = NCH >= N;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int n0 = 0; n0 < N; n0 += NCH) {
+      const int rows = N - n0 < NCH ? N - n0 : NCH;
+      stage_ln(b, n0, rows);
+      logits(n0, rows);
     }
     __syncthreads();
     // softmax over tokens per slot: S columns, 256/S threads per column (S divides 256)
@@ -78,16 +99,13 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
       for (int n = part; n < N; n += parts) lg[n * S + s_] *= inv;
     }
     __syncthreads();
-    // U[s][c] += sum_n w[n][s] tn[n][c]
-    {
-      const int st_n = (S + 15) / 16, ct_n = (C + 15) / 16;
-      for (int tile = wave; tile < st_n * ct_n; tile += 4) {
-        const int stt = tile / ct_n, ct = tile - stt * ct_n;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma_tile<BF>(lg + stt * 16, 1, S, S - stt * 16, tn + ct * 16, C, 1, C - ct * 16, N, acc);
-        tile_to_f32<true>(U + stt * 16 * C + ct * 16, C, 1, S - stt * 16, C - ct * 16, acc);
+    if (one_pass) accum(0, N);
+    else
+      for (int n0 = 0; n0 < N; n0 += NCH) {
+        const int rows = N - n0 < NCH ? N - n0 : NCH;
+        stage_ln(b, n0, rows);
+        accum(n0, rows);
       }
-    }
   }
   __syncthreads();
   float* out = ws + (size_t)blockIdx.x * S * C;
@@ -151,8 +169,15 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
   if (B <= 0 || N <= 0 || C <= 0 || S <= 0 || S > 256 || (256 % S) != 0) return set_error(QAVIT_EINVAL, "bank_stats: bad dimensions (S must divide 256)");
   const int grid = bank_grid(B);
   if (ws_floats < (int64_t)grid * S * C) return set_error(QAVIT_EINVAL, "bank_stats: workspace too small");
-  const size_t smem = ((size_t)N * C + (size_t)N * S + (size_t)S * C + 256) * sizeof(float);
-  if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "bank_stats: token tile too large for LDS");
+  const size_t fixed = ((size_t)N * S + (size_t)S * C + 256) * sizeof(float);
+  int NCH = N;
+  if (fixed + (size_t)NCH * C * sizeof(float) > 160 * 1024) {
+    if (fixed + (size_t)16 * C * sizeof(float) > 160 * 1024) return set_error(QAVIT_EINVAL, "bank_stats: token tile too large for LDS");
+    NCH = (int)((160 * 1024 - fixed) / ((size_t)C * sizeof(float))) / 16 * 16;
+    const int chunks = (N + NCH - 1) / NCH;                // balance the chunks
+    NCH = ((N + chunks - 1) / chunks + 15) / 16 * 16;
+  }
+  const size_t smem = fixed + (size_t)NCH * C * sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n_acc = S * C;
   if (dtype == QAVIT_BF16) {
@@ -165,10 +190,10 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
   }
   if (dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((bank_stats_kernel<float, false>), dim3(grid), dim3(256), smem, st, (const float*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);
+    hipLaunchKernelGGL((bank_stats_kernel<float, false>), dim3(grid), dim3(256), smem, st, (const float*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, NCH, eps);
   } else if (dtype == QAVIT_BF16) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((bank_stats_kernel<bf16, true>), dim3(grid), dim3(256), smem, st, (const bf16*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, eps);
+    hipLaunchKernelGGL((bank_stats_kernel<bf16, true>), dim3(grid), dim3(256), smem, st, (const bf16*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, NCH, eps);
   } else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
   const int n = S * C;
   hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n);

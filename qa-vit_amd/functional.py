@@ -491,7 +491,9 @@ class AttnFn(Function):
             if kv_t is None:
                 dst = dq_t
             else:
-                dkv_t = torch.empty_like(kv_t) if 2 * HD == kv_t.shape[1] else torch.zeros_like(kv_t)
+                # every row and column written by the kernel?  (MSDA at 224 px keeps only the first 128 landmarks: the rest get 0)
+                covered_kv = 2 * HD == kv_t.shape[1] and s["G"] * s["L"] == kv_t.shape[0]
+                dkv_t = torch.empty_like(kv_t) if covered_kv else torch.zeros_like(kv_t)
                 dst = dkv_t
             a.dk_tok, a.lddk = dst.data_ptr() + s["k_off"] * esz, dst.shape[1]
             a.dv_tok, a.lddv = dst.data_ptr() + s["v_off"] * esz, dst.shape[1]
@@ -679,6 +681,22 @@ class Im2ColFn(Function):
         return dx, None, None
 
 
+def ccf_mid(h, g1, b1, g2, b2, w, cbias, cscale, Hs, Ws, eps=1e-5):
+    """LN -> depthwise 3x3 (+bias) * scale -> LN on [B, Hs*Ws, C] tokens.  One kernel each way while the image tile
+    fits LDS (32 px and 64 px models); larger maps (14x14x96 at 224 px) compose the same math from the LayerNorm and
+    depthwise-conv kernels, with the per-channel scale folded into the taps: (conv(a; w) + b) * s = conv(a; w*s) + b*s."""
+    B, N, Cc = h.shape
+    if (4 * N * Cc + 15 * Cc) * 4 <= 160 * 1024:
+        return CcfMidFn.apply(h, g1, b1, g2, b2, w, cbias, cscale, Hs, Ws, eps)
+    a = layer_norm(h, g1, b1, eps) if g1 is not None else h
+    if cscale is not None:
+        sc = cscale.reshape(-1)
+        w = w * sc.reshape(-1, 1, 1, 1)
+        cbias = cbias * sc if cbias is not None else None
+    t = DwConvFn.apply(a, w, cbias, Hs, Ws)
+    return layer_norm(t, g2, b2, eps) if g2 is not None else t
+
+
 class DwConvFn(Function):
     """Depthwise k x k conv on channel-last tokens [B, H*W, C] (csrc/dwconv.hip)."""
 
@@ -699,12 +717,12 @@ class DwConvFn(Function):
         B, H, W, Cc, ks = ctx.dims
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        wbuf, _ = grad_sink(w)
-        bbuf, _ = grad_sink(bias)
+        wbuf, wret = grad_sink(w)
+        bbuf, bret = grad_sink(bias)
         if wbuf is None:
             wbuf = torch.zeros_like(w, dtype=torch.float32)
         K.dwconv_bwd(dy, x, w.detach(), dx, wbuf, bbuf, B, H, W, Cc, ks)
-        return dx, None, None, None, None
+        return dx, _ret(wret, w), _ret(bret, bias), None, None
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -47,7 +47,7 @@ class _Base(nn.Module):
         if self.compute_dtype is not None:
             return self.compute_dtype
         if torch.is_autocast_enabled():
-            return torch.get_autocast_gpu_dtype()
+            return torch.get_autocast_dtype("cuda")
         return torch.float32
 
     def _check(self, x):

@@ -286,7 +286,7 @@ class CCFFFN(nn.Module):
         h = F.linear(x, self.fc1.weight, self.fc1.bias, ln=(pre_norm.weight, pre_norm.bias), eps=pre_norm.eps, act="gelu")
         n1 = (self.dwconv_norm.weight, self.dwconv_norm.bias) if rt.ccf_norm else (None, None)
         n2 = (self.post_dwconv_norm.weight, self.post_dwconv_norm.bias) if rt.ccf_norm else (None, None)
-        mid = F.CcfMidFn.apply(h, n1[0], n1[1], n2[0], n2[1], self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
+        mid = F.ccf_mid(h, n1[0], n1[1], n2[0], n2[1], self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
                                self.dwconv.scale if rt.dw_scale else None, Hs, Hs, 1e-5)
         p = self.dropout.p if self.training else 0.0
         return F.linear(mid, self.fc2.weight, self.fc2.bias, drop=(p, self._site))

@@ -110,6 +110,40 @@ def test_fresh_batch_vs_oracle_and_bf16(Q, oracle):
     assert r32 <= LOGIT_TOL
     assert r16 <= 0.15            # torch's own bf16 autocast deviates 2.6e-2 on these logits
 
+@pytest.mark.parametrize("variant", ["v1", "v2"])
+def test_qavit_224_vs_oracle(Q, oracle, variant):
+    """QA-ViT at its own default size (224 px, patch 16: N=196, 7x7 windows, 135 MSDA landmarks of which 128 are keys):
+    train-mode logits, loss and every parameter gradient against the CPU oracle.  Exercises the chunked bank statistics,
+    the attention backward's spill layout and the composed CCF middle."""
+    cfg = Q.QAViTConfig(dropout=0.0, drop_path=0.0)
+    model = Q.QAViT(cfg, variant)
+    Q.fill_module(model)
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters()]
+    for n in names:
+        P[n].requires_grad_(True)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (3,), generator=g)
+    ref = oracle.qavit_forward(P, x, cfg, train=True, variant=variant)
+    ref_loss = oracle.loss_fn(ref, y, 0.1)
+    ref_loss.backward()
+    model = model.cuda().train()
+    out = model(x.cuda())
+    assert max_rel(out.detach().cpu().numpy(), ref.detach().numpy()) <= LOGIT_TOL
+    loss = torch.nn.functional.cross_entropy(out.float(), y.cuda(), label_smoothing=0.1)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= LOGIT_TOL * abs(float(ref_loss.detach()))
+    loss.backward()
+    scale = max(float(P[n].grad.abs().max()) for n in names if P[n].grad is not None)
+    for n, p in model.named_parameters():
+        if P[n].grad is None:
+            continue
+        r = P[n].grad.numpy()
+        if np.abs(r).max() < 1e-6 * scale:        # zero by construction (e.g. a key bias under softmax): round-off only
+            assert float(p.grad.abs().max()) <= 1e-5 * scale, n
+            continue
+        assert max_rel(p.grad.cpu().numpy(), r) <= GRAD_TOL, n
+
 
 def test_harness_three_steps_vs_reference_recipe(golden, Q):
     """Trainer (flat AdamW + OneCycle + clipping, fp32) against the 3-step trace recorded with torch.optim on

@@ -218,23 +218,26 @@ def test_attn_swa_like(F, Q, dtype, B, Hs, ws):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,NP", [(16, 10), (64, 40)])
-def test_attn_msda_like(F, dtype, N, NP):
-    """mode 0, separate q and kv matrices, ragged L (10 / 40 of a 128-row Linformer)."""
-    B, C, H, KC, S = 21, 192, 4, 32, 16
+@pytest.mark.parametrize("N,NP,KC", [(16, 10, 32), (64, 40, 32), (196, 135, 64)])
+def test_attn_msda_like(F, dtype, N, NP, KC):
+    """mode 0, separate q and kv matrices, ragged L (10 / 40 of a 128-row Linformer).  (196, 135, 64) are the 224-px
+    dimensions: only the first 128 landmarks are keys (the rest get zero gradient) and the backward keeps E in global
+    memory (attn.hip spill layout)."""
+    B, C, H, S = 21, 192, 4, 16
     D = C // H
+    Lk = min(NP, 128)
     q_t = leaf(B * N, C, seed=70).detach().to(dtype).requires_grad_(True)
     kv_t = leaf(B * NP, 2 * C, seed=71).detach().to(dtype).requires_grad_(True)
     Ek, Ev = leaf(128, KC, scale=0.3, seed=72), leaf(128, KC, scale=0.3, seed=73)
     bk, bv = leaf(1, S, C, scale=0.5, seed=74), leaf(1, S, C, scale=0.5, seed=75)
-    spec = dict(mode=0, G=B, Nq=N, L=NP, H=H, D=D, KC=KC, S=S, groups_per_b=1, q_rows_per_b=N, k_rows_per_b=NP,
+    spec = dict(mode=0, G=B, Nq=N, L=Lk, H=H, D=D, KC=KC, S=S, groups_per_b=1, q_rows_per_b=N, k_rows_per_b=NP,
                 q_off=0, k_off=0, v_off=C, q_rows=B * N)
     o = F.AttnFn.apply(q_t, kv_t, Ek, Ev, bk, bv, spec)
     qr, kvr, Ekr, Evr, bkr, bvr = [t.detach().clone().float().requires_grad_(True) for t in (q_t, kv_t, Ek, Ev, bk, bv)]
     q = qr.view(B, N, H, D).transpose(1, 2)
     kv = kvr.view(B, NP, 2, H, D).permute(2, 0, 3, 1, 4)
-    k = TF.pad(kv[0], (0, 0, 0, 128 - NP))
-    v = TF.pad(kv[1], (0, 0, 0, 128 - NP))
+    k = TF.pad(kv[0][:, :, :Lk], (0, 0, 0, 128 - Lk))
+    v = TF.pad(kv[1][:, :, :Lk], (0, 0, 0, 128 - Lk))
     kc = torch.matmul(Ekr.T, k.reshape(B * H, 128, D)).reshape(B, H, KC, D)
     vc = torch.matmul(Evr.T, v.reshape(B * H, 128, D)).reshape(B, H, KC, D)
     kb = bkr.expand(B, -1, -1).reshape(B, S, H, D).transpose(1, 2)
@@ -248,7 +251,10 @@ def test_attn_msda_like(F, dtype, N, NP):
     assert rel(kv_t.grad, kvr.grad) <= tol(dtype, False)
     assert rel(Ek.grad, Ekr.grad) <= tol(dtype, False)
     assert rel(Ev.grad, Evr.grad) <= tol(dtype, False)
-    assert float(Ek.grad[NP:].abs().max()) == 0.0          # zero-padded rows get no gradient
+    if Lk < 128:
+        assert float(Ek.grad[Lk:].abs().max()) == 0.0      # zero-padded rows get no gradient
+    if NP > Lk:
+        assert float(kv_t.grad.view(B, NP, -1)[:, Lk:].abs().max()) == 0.0      # landmarks past the Linformer length are not keys
     assert rel(bk.grad, bkr.grad) <= tol(dtype, False)
     assert rel(bv.grad, bvr.grad) <= tol(dtype, False)
 
@@ -352,8 +358,9 @@ def test_tokmix_upmix(F, dtype, N, M):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Hs,flags", [(4, "hqa"), (8, "hqa"), (8, "v1"), (4, "v2")])
+@pytest.mark.parametrize("Hs,flags", [(4, "hqa"), (8, "hqa"), (8, "v1"), (4, "v2"), (14, "v1"), (14, "v2")])
 def test_ccf_mid(F, dtype, Hs, flags):
+    """Hs=14 (224 px) exceeds the fused kernel's LDS tile: functional.ccf_mid composes LN / dwconv / LN instead."""
     B, C = 29, 96
     N = Hs * Hs
     h = leaf(B, N, C, seed=110).detach().to(dtype).requires_grad_(True)
@@ -362,7 +369,7 @@ def test_ccf_mid(F, dtype, Hs, flags):
     bias = leaf(C, scale=0.2, seed=112) if flags in ("v1", "v2") else None
     scale = (leaf(1, C, 1, 1, scale=0.05, seed=113).detach() + 0.1).requires_grad_(True) if flags != "v1" else None
     g1, b1, g2, b2 = [leaf(C, scale=0.2, seed=114 + i) if ln else None for i in range(4)]
-    out = F.CcfMidFn.apply(h, g1, b1, g2, b2, w, bias, scale, Hs, Hs, 1e-5)
+    out = F.ccf_mid(h, g1, b1, g2, b2, w, bias, scale, Hs, Hs, 1e-5)
     params = [t for t in (h, w, bias, scale, g1, b1, g2, b2)]
     r = [None if t is None else t.detach().clone().float().requires_grad_(True) for t in params]
     hr, wr, br, sr, g1r, b1r, g2r, b2r = r
@@ -468,13 +475,14 @@ def test_small_ops(F):
     assert rel(cols, refc) <= 1e-7
 
 
-def test_bank_write_matches_oracle(F, Q, oracle):
+@pytest.mark.parametrize("N", [16, 196])           # 196 = the 224-px token count: chunked two-pass statistics
+def test_bank_write_matches_oracle(F, Q, oracle, N):
     cfg = Q.HQAViTConfig()
     bank = Q.HQAViT(cfg).global_bank
     Q.fill_module(bank)
     P = {("global_bank." + k): v.clone() for k, v in bank.state_dict().items()}
     bank = bank.cuda()
-    tokens = torch.randn(37, 16, 192)
+    tokens = torch.randn(37, N, 192)
     ng, nb = torch.randn(192) * 0.1 + 1, torch.randn(192) * 0.1
     for step in range(3):
         pre = torch.nn.functional.layer_norm(tokens + step, (192,), ng, nb)
@@ -485,7 +493,7 @@ def test_bank_write_matches_oracle(F, Q, oracle):
     assert int(bank.update_count) == 3 == int(P["global_bank.update_count"])
 
 
-@pytest.mark.parametrize("N", [16, 64])
+@pytest.mark.parametrize("N", [16, 64, 196])
 def test_bank_write_bf16_path_close_to_fp32(F, Q, N):
     """The bf16 fast path of the bank statistics (tokens_bf16.hip) against the fp32 kernel on the same tokens."""
     banks = []
