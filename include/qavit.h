@@ -319,6 +319,20 @@ int qavit_bn_fwd(int dtype, const void* x, void* y, int M, int C, const float* g
 int qavit_bn_bwd(int dtype, const void* dy, const void* x, int M, int C, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_rstd, int act, int training, void* dx, float* dgamma, float* dbeta,
                  float* ws, void* stream);
+/* nn.LayerNorm([C,H,W]) of the ConvNeXt-Tiny style stem (HQAViTv2_CIFAR100.py:766, :777, :791) on channel-last tokens
+ * x [B, N=H*W, C]: each SAMPLE is normalised over its N*C elements; w / b keep the reference's [C][N] layout.  N*C must be
+ * 4096, 8192 or 16384, C % 4 == 0, rows 16-byte aligned.  mean / rstd [B] are written by fwd and read by bwd; bwd writes
+ * dx and ACCUMULATES dw / db ([C][N] fp32). */
+int qavit_spatial_ln_fwd(int dtype, const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                         int B, int N, int C, float eps, void* stream);
+int qavit_spatial_ln_bwd(int dtype, const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                         void* dx, float* dw, float* db, int B, int N, int C, void* stream);
+/* ConvNeXt layer scale + drop path + residual on rows [rows, C]: y = x + droppath(gamma[c] * u)
+ * (HQAViTv2_CIFAR100.py:744-748).  bwd: du = dy * mask * gamma[c]; dgamma [C] ACCUMULATES; dx = dy is the caller's. */
+int qavit_chan_scale_add_fwd(int dtype, const void* x, const void* u, const float* gamma, void* y, int rows, int C,
+                             float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
+int qavit_chan_scale_add_bwd(int dtype, const void* dy, const void* u, const float* gamma, void* du, float* dgamma,
+                             int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
 /* y = dropout(x) (pos_drop, HQAViT_CIFAR100.py:1251); bwd is the same call on dy */
 int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream);
 /* packed weights: dst = cast(src) and dstT = cast(src)^T for 2-D [rows, cols] fp32 params; descriptor table on device */

@@ -318,13 +318,16 @@ def _bn(P, pre: str, x: Tensor, train: bool) -> Tensor:
                         P[pre + ".bias"], train, 0.1, 1e-5)
 
 
-def _convnext(P, pre: str, x: Tensor) -> Tensor:
-    """ConvNeXtBlock.forward, HQAViT_CIFAR100.py:729-739 (drop_path is Identity: default 0)."""
+def _convnext(P, pre: str, x: Tensor, dp: float = 0.0, train: bool = False) -> Tensor:
+    """ConvNeXtBlock.forward, HQAViT_CIFAR100.py:729-739 (drop_path is Identity: default 0) and its layer-scaled
+    form HQAViTv2_CIFAR100.py:736-750 (``gamma`` present in the state dict; drop path ``dp``)."""
     h = F.conv2d(x, P[pre + ".dwconv.weight"], P[pre + ".dwconv.bias"], padding=3, groups=x.shape[1])
     h = h.permute(0, 2, 3, 1)
     h = _ln(P, pre + ".norm", h, 1e-6)
     h = _lin(P, pre + ".pwconv2", F.gelu(_lin(P, pre + ".pwconv1", h)))
-    return x + h.permute(0, 3, 1, 2)
+    if pre + ".gamma" in P:
+        h = P[pre + ".gamma"] * h
+    return x + _drop_path(h.permute(0, 3, 1, 2), dp, train)
 
 
 def cnn_stem(P, x: Tensor, train: bool):
@@ -336,6 +339,32 @@ def cnn_stem(P, x: Tensor, train: bool):
     f3 = _convnext(P, p + "stage2.2", _bn(P, p + "stage2.1", F.conv2d(f2, P[p + "stage2.0.weight"], P[p + "stage2.0.bias"]), train))
     f4 = _convnext(P, p + "stage3.2", _bn(P, p + "stage3.1", F.conv2d(f3, P[p + "stage3.0.weight"], P[p + "stage3.0.bias"]), train))
     return f2, f3, f4
+
+
+STEM_V2_DROP_PATH = ((0.0, 0.0), (0.0, 0.1, 0.1), (0.1, 0.1))     # HQAViTv2_CIFAR100.py:772-773, :783-785, :797-798
+
+
+def _spatial_ln(P, pre: str, x: Tensor) -> Tensor:
+    """nn.LayerNorm([C, H, W], eps=1e-6) on an NCHW map, HQAViTv2_CIFAR100.py:766."""
+    return F.layer_norm(x, tuple(x.shape[1:]), P[pre + ".weight"], P[pre + ".bias"], 1e-6)
+
+
+def cnn_stem_v2(P, x: Tensor, train: bool, stem_drop: bool = True):
+    """CNNStemModel.forward of the ConvNeXt-Tiny style stem, HQAViTv2_CIFAR100.py:809-829."""
+    p = "cnn_stem."
+    dps = STEM_V2_DROP_PATH if stem_drop else ((0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0))
+    h = _spatial_ln(P, p + "stem.1", F.conv2d(x, P[p + "stem.0.weight"], P[p + "stem.0.bias"], stride=4))
+    for i, dp in enumerate(dps[0]):
+        h = _convnext(P, f"{p}stage2.{i}", h, dp, train)
+    f2 = h
+    h = F.conv2d(_spatial_ln(P, p + "downsample2.0", f2), P[p + "downsample2.1.weight"], P[p + "downsample2.1.bias"])
+    for i, dp in enumerate(dps[1]):
+        h = _convnext(P, f"{p}stage3.{i}", h, dp, train)
+    f3 = h
+    h = F.conv2d(_spatial_ln(P, p + "downsample3.0", f3), P[p + "downsample3.1.weight"], P[p + "downsample3.1.bias"])
+    for i, dp in enumerate(dps[2]):
+        h = _convnext(P, f"{p}stage4.{i}", h, dp, train)
+    return f2, f3, h
 
 
 def lmfa(P, pre: str, feat: Tensor, target_hw: int) -> Tensor:
@@ -380,12 +409,17 @@ def hqavit_stage_sizes(cfg):
 
 
 def hqavit_forward(P, x: Tensor, cfg, train: bool = False, variant: str = "hqa", taps=None,
-                   cat_dropout: Optional[bool] = None, sync=None) -> Tensor:
+                   cat_dropout: Optional[bool] = None, sync=None, stem_drop: bool = True) -> Tensor:
     """HQAViT.forward, HQAViT_CIFAR100.py:1226-1277.  ``P`` is the model's state_dict (fp32 tensors);
-    bank tensors are mutated in place in train mode, as the reference does."""
+    bank tensors are mutated in place in train mode, as the reference does.  A state dict with the ConvNeXt-Tiny
+    style stem (``cnn_stem.downsample2.*``) takes HQAViTv2_CIFAR100.py's stem; the rest of that file's forward
+    (:1262-1310) is the same code."""
     var = VARIANTS[variant]
     Hh = cfg.img_size // cfg.patch_size
-    f2, f3, f4 = cnn_stem(P, x, train)
+    if "cnn_stem.downsample2.0.weight" in P:
+        f2, f3, f4 = cnn_stem_v2(P, x, train, stem_drop)
+    else:
+        f2, f3, f4 = cnn_stem(P, x, train)
     R = {}
     for i, f in ((2, f2), (3, f3), (4, f4)):
         R[i] = rrcv(P, f"rrcv{i}", lmfa(P, f"lmfa{i}", f, Hh), Hh, Hh)

@@ -681,6 +681,37 @@ class Im2ColFn(Function):
         return dx, None, None
 
 
+class SpatialLayerNormFn(Function):
+    """nn.LayerNorm([C,H,W]) on channel-last tokens [B, H*W, C]; weight / bias are the module's own [C,H,W] parameters
+    (csrc/spatial_ln.hip; HQAViTv2_CIFAR100.py:766)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        B, N, Cc = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(B, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(B, dtype=torch.float32, device=x.device)
+        K.spatial_ln_fwd(x, w.detach(), b.detach(), y, mean, rstd, B, N, Cc, eps)
+        ctx.save_for_backward(x, w, b, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, mean, rstd = ctx.saved_tensors
+        B, N, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        wbuf, wret = grad_sink(w)
+        bbuf, bret = grad_sink(b)
+        if wbuf is None:
+            wbuf = torch.zeros_like(w, dtype=torch.float32)
+        if bbuf is None:
+            bbuf = torch.zeros_like(b, dtype=torch.float32)
+        K.spatial_ln_bwd(dy, x, w.detach(), mean, rstd, dx, wbuf, bbuf, B, N, Cc)
+        return dx, _ret(wret, w), _ret(bret, b), None
+
+
 def ccf_mid(h, g1, b1, g2, b2, w, cbias, cscale, Hs, Ws, eps=1e-5):
     """LN -> depthwise 3x3 (+bias) * scale -> LN on [B, Hs*Ws, C] tokens.  One kernel each way while the image tile
     fits LDS (32 px and 64 px models); larger maps (14x14x96 at 224 px) compose the same math from the LayerNorm and
@@ -943,6 +974,37 @@ class ScaleAddFn(Function):
         gbuf, gret = grad_sink(gamma)
         K.scale_add_bwd(dy, u, None if gamma is None else gamma.detach(), du, gbuf, rows, Cc, ctx.dp, rt.rng)
         return dy, du, gret, None
+
+
+class ChanScaleAddFn(Function):
+    """y = x + droppath(gamma[c] * u): ConvNeXt layer scale (HQAViTv2_CIFAR100.py:744-748)."""
+
+    @staticmethod
+    def forward(ctx, x, u, gamma, dp):
+        rt = _rt(x)
+        Cc = x.shape[-1]
+        x = x.contiguous()
+        u = u.contiguous()
+        rows = x.numel() // Cc
+        y = torch.empty_like(x)
+        K.chan_scale_add_fwd(x, u, gamma.detach(), y, rows, Cc, dp, rt.rng)
+        ctx.save_for_backward(u, gamma)
+        ctx.dp = dp
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, gamma = ctx.saved_tensors
+        rt = _rt(u)
+        Cc = u.shape[-1]
+        rows = u.numel() // Cc
+        dy = dy.contiguous()
+        du = torch.empty_like(u)
+        gbuf, gret = grad_sink(gamma)
+        if gbuf is None:
+            gbuf = torch.zeros_like(gamma, dtype=torch.float32)
+        K.chan_scale_add_bwd(dy, u, gamma.detach(), du, gbuf, rows, Cc, ctx.dp, rt.rng)
+        return dy, du, _ret(gret, gamma), None
 
 
 class DropoutFn(Function):

@@ -376,6 +376,16 @@ def scale_add_bwd(dy, u, gamma, du, dgamma, rows, Cc, dp, rng):
     L.check(L.load().qavit_scale_add_bwd(dt_code(dy.dtype), dy.data_ptr(), u.data_ptr(), _p(gamma), du.data_ptr(), _p(dgamma), rows, Cc, dp[0], dp[1], dp[2], _p(rng), stream()), "scale_add_bwd")
 
 
+def chan_scale_add_fwd(x, u, gamma, y, rows, Cc, dp, rng):
+    L.check(L.load().qavit_chan_scale_add_fwd(dt_code(x.dtype), x.data_ptr(), u.data_ptr(), gamma.data_ptr(), y.data_ptr(), rows, Cc,
+                                              dp[0], dp[1], dp[2], _p(rng), stream()), "chan_scale_add_fwd")
+
+
+def chan_scale_add_bwd(dy, u, gamma, du, dgamma, rows, Cc, dp, rng):
+    L.check(L.load().qavit_chan_scale_add_bwd(dt_code(dy.dtype), dy.data_ptr(), u.data_ptr(), gamma.data_ptr(), du.data_ptr(), dgamma.data_ptr(),
+                                              rows, Cc, dp[0], dp[1], dp[2], _p(rng), stream()), "chan_scale_add_bwd")
+
+
 def bn_supported(dtype, Cc: int) -> bool:
     if os.environ.get("QAVIT_BN", "1") == "0":
         return False
@@ -393,6 +403,20 @@ def bn_bwd(dy, x, M, Cc, gamma, beta, save_mean, save_rstd, act, training, dx, d
     L.check(L.load().qavit_bn_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(),
                                   save_mean.data_ptr(), save_rstd.data_ptr(), int(act), int(training), dx.data_ptr(), _p(dgamma), _p(dbeta),
                                   ws.data_ptr(), stream()), "bn_bwd")
+
+
+def spatial_ln_supported(N, Cc):
+    return Cc % 4 == 0 and N * Cc in (4096, 8192, 16384)
+
+
+def spatial_ln_fwd(x, w, b, y, mean, rstd, B, N, Cc, eps):
+    L.check(L.load().qavit_spatial_ln_fwd(dt_code(x.dtype), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), B, N, Cc, float(eps), stream()), "spatial_ln_fwd")
+
+
+def spatial_ln_bwd(dy, x, w, mean, rstd, dx, dw, db, B, N, Cc):
+    L.check(L.load().qavit_spatial_ln_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          dx.data_ptr(), dw.data_ptr(), db.data_ptr(), B, N, Cc, stream()), "spatial_ln_bwd")
 
 
 def dropout(x, y, p, site, rng):

@@ -101,8 +101,12 @@ _SIGS = {
     "qavit_mix2_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     "qavit_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "qavit_chan_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "qavit_chan_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_bn_fwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, i32, vp]),
     "qavit_bn_bwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "qavit_spatial_ln_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "qavit_spatial_ln_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "qavit_dropout": (i32, [i32, vp, vp, i64, f32, i32, vp, vp]),
     "qavit_pack_weights": (i32, [i32, vp, i32, i32, vp]),
     "qavit_rng_advance": (i32, [vp, vp]),

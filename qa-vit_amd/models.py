@@ -77,8 +77,13 @@ def _side_stream(device):
 
 
 class HQAViT(_Base):
-    def __init__(self, config: HQAViTConfig, variant: str = "hqa"):
+    """``stem="v1"``: HQAViT_CIFAR100.py / HQAViT_IN_Tiny.py (BatchNorm stem).  ``stem="v2"``: HQAViTv2_CIFAR100.py -- the
+    ConvNeXt-Tiny style stem and layer-scaled ConvNeXt blocks (also inside RRCV); everything else is identical."""
+
+    def __init__(self, config: HQAViTConfig, variant: str = "hqa", stem: str = "v1"):
         super().__init__()
+        if stem not in ("v1", "v2"):
+            raise ValueError("stem must be 'v1' or 'v2'")
         self.config = config
         self._rt = M._Ctx(variant)
         self.num_patches = (config.img_size // config.patch_size) ** 2
@@ -88,11 +93,14 @@ class HQAViT(_Base):
         self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, d))
         self.pos_drop = nn.Dropout(config.dropout)
         self.global_bank = M.GlobalTokenBank(config.global_bank_size, d)
-        self.cnn_stem = M.CNNStemModel(config.in_channels, config.cnn_c2, config.cnn_c3, config.cnn_c4)
+        if stem == "v2":
+            self.cnn_stem = M.CNNStemModelV2(config.in_channels, config.cnn_c2, config.cnn_c3, config.cnn_c4, hw=config.img_size // 4)
+        else:
+            self.cnn_stem = M.CNNStemModel(config.in_channels, config.cnn_c2, config.cnn_c3, config.cnn_c4)
         for i, c in ((2, config.cnn_c2), (3, config.cnn_c3), (4, config.cnn_c4)):
             setattr(self, f"lmfa{i}", M.LMFAdapter(c, d, target_hw=self.H))
         for i in (2, 3, 4):
-            setattr(self, f"rrcv{i}", M.RRCV(d, config.rrcv_channels, config.rrcv_num_blocks))
+            setattr(self, f"rrcv{i}", M.RRCV(d, config.rrcv_channels, config.rrcv_num_blocks, 1e-6 if stem == "v2" else None))
         for i in (2, 3, 4):
             setattr(self, f"fuse{i}", M.SplitFusion(d))
         dpr = [v.item() for v in torch.linspace(0, config.drop_path, config.depth)]

@@ -453,21 +453,31 @@ def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool, gelu: bool = False):
 
 
 class ConvNeXtBlock(nn.Module):
-    """HQAViT_CIFAR100.py:718-739 on channel-last tokens: dw7x7 (csrc/dwconv.hip) -> LN+Linear+GELU -> Linear+residual."""
+    """HQAViT_CIFAR100.py:718-739 on channel-last tokens: dw7x7 (csrc/dwconv.hip) -> LN+Linear+GELU -> Linear+residual.
+    ``layer_scale_init_value`` adds the v2 file's per-channel layer scale ``gamma`` and its drop path
+    (HQAViTv2_CIFAR100.py:718-750); ``None`` keeps the v1 class (no ``gamma`` key in the state_dict)."""
 
-    def __init__(self, dim, drop_path=0.0):
+    def __init__(self, dim, drop_path=0.0, layer_scale_init_value=None):
         super().__init__()
         self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         self.pwconv1 = nn.Linear(dim, 4 * dim)
         self.act = nn.GELU()
         self.pwconv2 = nn.Linear(4 * dim, dim)
-        self.drop_path = nn.Identity()
+        self.layer_scale = layer_scale_init_value is not None
+        if self.layer_scale:
+            self.gamma = nn.Parameter(layer_scale_init_value * torch.ones(dim)) if layer_scale_init_value > 0 else None
+        self.drop_path = DropPath(drop_path) if (self.layer_scale and drop_path > 0.0) else nn.Identity()
+        self._site = K.new_site()
 
     def forward_tokens(self, t, H, W):
         h = F.DwConvFn.apply(t, self.dwconv.weight, self.dwconv.bias, H, W)
         h = F.linear(h, self.pwconv1.weight, self.pwconv1.bias, ln=(self.norm.weight, self.norm.bias), eps=self.norm.eps, act="gelu")
-        return F.linear(h, self.pwconv2.weight, self.pwconv2.bias, resid=t)
+        p = self.drop_path.drop_prob if (self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob) else 0.0
+        if self.layer_scale and self.gamma is not None:
+            u = F.linear(h, self.pwconv2.weight, self.pwconv2.bias)
+            return F.ChanScaleAddFn.apply(t, u, self.gamma, (p, self._site, H * W))
+        return F.linear(h, self.pwconv2.weight, self.pwconv2.bias, resid=t, dp=(p, self._site, H * W) if p > 0.0 else None)
 
     def forward(self, x):                                   # NCHW surface of the reference class
         B, C, H, W = x.shape
@@ -511,6 +521,63 @@ class CNNStemModel(nn.Module):
         return tuple(f.transpose(1, 2).reshape(B, -1, h, w) for f in (f2, f3, f4))
 
 
+def _spatial_ln_tokens(t, ln: nn.LayerNorm):
+    """nn.LayerNorm([C,H,W]) on channel-last tokens (csrc/spatial_ln.hip): a sample is one row of N*C elements."""
+    B, N, C = t.shape
+    if not K.spatial_ln_supported(N, C):
+        raise RuntimeError(f"spatial LayerNorm over [{C},{N}] has no HIP kernel (N*C must be 4096, 8192 or 16384)")
+    return F.SpatialLayerNormFn.apply(t, ln.weight, ln.bias, ln.eps)
+
+
+class CNNStemModelV2(nn.Module):
+    """HQAViTv2_CIFAR100.py:753-829 (ConvNeXt-Tiny style): 4x4/s4 patchify conv + LayerNorm([c2,8,8]); [2,3,2] ConvNeXt
+    blocks with layer scale; LayerNorm([c,8,8]) + 1x1 conv between the stages.  Channel-last throughout: the patchify
+    conv is patch gather + MFMA GEMM, the 1x1 convolutions are GEMMs."""
+
+    def __init__(self, in_ch=3, c2=64, c3=128, c4=256, norm_layer=nn.LayerNorm, hw=8):
+        super().__init__()
+        ls = 1e-6
+        self.stem = nn.Sequential(nn.Conv2d(in_ch, c2, kernel_size=4, stride=4), nn.LayerNorm([c2, hw, hw], eps=1e-6))
+        self.stage2 = nn.Sequential(ConvNeXtBlock(c2, 0.0, ls), ConvNeXtBlock(c2, 0.0, ls))
+        self.downsample2 = nn.Sequential(nn.LayerNorm([c2, hw, hw], eps=1e-6), nn.Conv2d(c2, c3, kernel_size=1))
+        self.stage3 = nn.Sequential(ConvNeXtBlock(c3, 0.0, ls), ConvNeXtBlock(c3, 0.1, ls), ConvNeXtBlock(c3, 0.1, ls))
+        self.downsample3 = nn.Sequential(nn.LayerNorm([c3, hw, hw], eps=1e-6), nn.Conv2d(c3, c4, kernel_size=1))
+        self.stage4 = nn.Sequential(ConvNeXtBlock(c4, 0.1, ls), ConvNeXtBlock(c4, 0.1, ls))
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def forward_tokens(self, x, cdt):
+        B, Cin, H, W = x.shape
+        with torch.autocast("cuda", enabled=False):
+            conv = self.stem[0]
+            p = conv.kernel_size[0]
+            h, w = H // p, W // p
+            t = F.linear(F.patchify(x, p, cdt), conv.weight, conv.bias).reshape(B, h * w, conv.out_channels)
+            t = _spatial_ln_tokens(t, self.stem[1])
+            for blk in self.stage2:
+                t = blk.forward_tokens(t, h, w)
+            f2 = t
+            t = _conv1x1_tokens(_spatial_ln_tokens(f2, self.downsample2[0]), self.downsample2[1])
+            for blk in self.stage3:
+                t = blk.forward_tokens(t, h, w)
+            f3 = t
+            t = _conv1x1_tokens(_spatial_ln_tokens(f3, self.downsample3[0]), self.downsample3[1])
+            for blk in self.stage4:
+                t = blk.forward_tokens(t, h, w)
+        return (f2, f3, t), (h, w)
+
+    def forward(self, x):                                   # NCHW surface of the reference class
+        (f2, f3, f4), (h, w) = self.forward_tokens(x, x.dtype)
+        B = x.shape[0]
+        return tuple(f.transpose(1, 2).reshape(B, -1, h, w) for f in (f2, f3, f4))
+
+
 class LMFAdapter(nn.Module):
     """HQAViT_CIFAR100.py:799-849 on channel-last tokens."""
 
@@ -542,11 +609,11 @@ class LMFAdapter(nn.Module):
 class RRCV(nn.Module):
     """HQAViT_CIFAR100.py:855-907 on channel-last tokens (the reverse / re-embed 1x1 convolutions are GEMMs)."""
 
-    def __init__(self, embed_dim: int, rec_channels: int = 64, num_blocks: int = 1):
+    def __init__(self, embed_dim: int, rec_channels: int = 64, num_blocks: int = 1, layer_scale_init_value=None):
         super().__init__()
         self.embed_dim, self.rec_channels = embed_dim, rec_channels
         self.reverse_proj = nn.Conv2d(embed_dim, rec_channels, 1)
-        self.blocks = nn.ModuleList([ConvNeXtBlock(rec_channels) for _ in range(num_blocks)])
+        self.blocks = nn.ModuleList([ConvNeXtBlock(rec_channels, 0.0, layer_scale_init_value) for _ in range(num_blocks)])
         self.reembed_proj = nn.Conv2d(rec_channels, embed_dim, 1)
         self.norm = nn.LayerNorm(embed_dim)
         self.beta = nn.Parameter(torch.tensor(0.1))

@@ -25,9 +25,24 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+class _Golden:
+    """golden_v1.npz (make_golden.py) + golden_v2.npz (make_golden_v2.py) behind one mapping; tags do not collide."""
+
+    def __init__(self, *paths):
+        self._z = [np.load(p) for p in paths]
+        self.files = [k for z in self._z for k in z.files]
+
+    def __getitem__(self, key):
+        for z in self._z:
+            if key in z.files:
+                return z[key]
+        raise KeyError(key)
+
+
 @pytest.fixture(scope="session")
 def golden():
-    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    gd = os.path.join(ROOT, "tests", "golden")
+    return _Golden(os.path.join(gd, "golden_v1.npz"), os.path.join(gd, "golden_v2.npz"))
 
 
 @pytest.fixture(scope="session")
@@ -48,7 +63,12 @@ MODELS = {
     "tin": (lambda Q, **kw: Q.HQAViT(Q.HQAViTTinyINConfig(**kw)), "hqavit_forward", "hqa", 0.12),
     "q32": (lambda Q, **kw: Q.QAViT(Q.qavit32_config(**kw), "v1"), "qavit_forward", "v1", 0.1),
     "v2_32": (lambda Q, **kw: Q.QAViT(Q.qavit32_config(**kw), "v2"), "qavit_forward", "v2", 0.1),
+    # golden_v2.npz: the ConvNeXt-Tiny style stem (HQAViTv2_CIFAR100.py) and QA-ViT v1 / v2 at 224 px (N = 196)
+    "c100v2": (lambda Q, **kw: Q.HQAViT(Q.HQAViTConfig(**kw), stem="v2"), "hqavit_forward", "hqa", 0.12),
+    "q224": (lambda Q, **kw: Q.QAViT(Q.QAViTConfig(**kw), "v1"), "qavit_forward", "v1", 0.1),
+    "v2_224": (lambda Q, **kw: Q.QAViT(Q.QAViTConfig(**kw), "v2"), "qavit_forward", "v2", 0.1),
 }
+HQA_TAGS = ("c100", "tin", "c100v2")
 
 
 def sig(t: torch.Tensor) -> np.ndarray:

@@ -24,6 +24,8 @@ def zero_dropout(model):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
+        if type(m).__name__ == "DropPath":          # the v2 stem hard-wires DropPath(0.1) into four blocks
+            m.drop_prob = 0.0
 
 
 @pytest.mark.parametrize("tag", list(MODELS))

@@ -538,6 +538,55 @@ def test_adamw_and_l2norm_match_torch(Q):
     assert rel(p, pr) <= 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_spatial_layernorm_and_layer_scale(F, dtype, C):
+    """nn.LayerNorm([C,8,8]) on channel-last tokens and the ConvNeXt layer scale (HQAViTv2_CIFAR100.py:766, :744-748)."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    B, Hs = 19, 8
+    N = Hs * Hs
+    x = leaf(B, N, C, seed=300).detach().to(dtype).requires_grad_(True)
+    w, b = leaf(C, Hs, Hs, scale=0.2, seed=301), leaf(C, Hs, Hs, scale=0.2, seed=302)
+    with torch.no_grad():
+        w.add_(1.0)
+    y = F.SpatialLayerNormFn.apply(x, w, b, 1e-6)
+    xr, wr, br = [t.detach().clone().float().requires_grad_(True) for t in (x, w, b)]
+    img = xr.transpose(1, 2).reshape(B, C, Hs, Hs)
+    ref = TF.layer_norm(img, (C, Hs, Hs), wr, br, 1e-6).flatten(2).transpose(1, 2)
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+    assert rel(w.grad, wr.grad) <= tol(dtype, False)
+    assert rel(b.grad, br.grad) <= tol(dtype, False)
+    # layer scale + drop path + residual
+    t = leaf(B, N, C, seed=303).detach().to(dtype).requires_grad_(True)
+    u = leaf(B, N, C, seed=304).detach().to(dtype).requires_grad_(True)
+    gam = leaf(C, scale=0.5, seed=305)
+    out = F.ChanScaleAddFn.apply(t, u, gam, (0.0, 0, N))
+    tr, ur, gr = [v.detach().clone().float().requires_grad_(True) for v in (t, u, gam)]
+    ref2 = tr + gr * ur
+    assert rel(out, ref2) <= tol(dtype)
+    go2 = torch.randn_like(ref2)
+    out.backward(go2.to(dtype))
+    ref2.backward(go2)
+    assert rel(t.grad, tr.grad) <= tol(dtype, False)
+    assert rel(u.grad, ur.grad) <= tol(dtype, False)
+    assert rel(gam.grad, gr.grad) <= tol(dtype, False)
+    # drop path: whole samples share one factor in {0, 1/keep}; backward regenerates the same mask
+    site = K.new_site()
+    t2 = t.detach().clone().requires_grad_(True)
+    u2 = u.detach().clone().requires_grad_(True)
+    o2 = F.ChanScaleAddFn.apply(t2, u2, gam.detach(), (0.5, site, N))
+    fac = ((o2.detach().float() - t2.detach().float()) / (gam.detach() * u2.detach().float())).reshape(B, -1).median(1).values
+    assert set(torch.round(fac).tolist()) <= {0.0, 2.0}
+    o2.backward(torch.ones_like(o2))
+    per = (u2.grad.float() / gam.detach()).reshape(B, -1).median(1).values
+    assert torch.equal(torch.round(per), torch.round(fac))
+
+
 def test_local_clip_matches_clip_grad_norm(Q):
     """Per-parameter clip of the stem / depthwise-conv gradients (reference :1416-1418) on segments of the flat buffer."""
     import importlib

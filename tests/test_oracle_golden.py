@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import MODELS, max_rel, sig, zero_by_construction
+from conftest import HQA_TAGS, MODELS, max_rel, sig, zero_by_construction
 
 TOL = 1e-5
 
@@ -41,7 +41,7 @@ def test_eval_forward_matches_reference(tag, golden, Q, oracle):
     assert max_rel(logits.numpy(), golden[f"{tag}/eval_logits"]) <= TOL
     loss = oracle.loss_fn(logits, y, MODELS[tag][3]).item()
     assert abs(loss - float(golden[f"{tag}/eval_loss"])) <= 1e-5 * abs(float(golden[f"{tag}/eval_loss"]))
-    tmap = TAP_MAP_HQA if tag in ("c100", "tin") else TAP_MAP_Q
+    tmap = TAP_MAP_HQA if tag in HQA_TAGS else TAP_MAP_Q
     checked = 0
     for ref_name, key in tmap.items():
         gk = f"{tag}/tap/{ref_name}"
@@ -66,7 +66,7 @@ def test_train_forward_backward_matches_reference(tag, golden, Q, oracle):
     fwd = getattr(oracle, MODELS[tag][1])
     x = torch.from_numpy(golden[f"{tag}/x"])
     y = torch.from_numpy(golden[f"{tag}/y"])
-    kw = dict(cat_dropout=False) if tag in ("c100", "tin") else {}
+    kw = dict(cat_dropout=False, stem_drop=False) if tag in HQA_TAGS else {}
     logits = fwd(P, x, model.config, train=True, variant=MODELS[tag][2], **kw)
     loss = oracle.loss_fn(logits, y, MODELS[tag][3])
     loss.backward()
