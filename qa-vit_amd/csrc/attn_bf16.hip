@@ -22,6 +22,7 @@ namespace qv {
 struct A2Lds {   // offsets in bf16 elements unless noted
   int ldd, ldk, lde;
   int q, d_o, p, ds, kt, vt, ek, ev, kf, vf, dkf, dvf;
+  int end16;                // bf16 elements in use (zeroed once)
   int accf;                 // float offset (from the float view of the base) of the fp32 accumulators
   int bytes;
 };
@@ -47,13 +48,17 @@ __host__ __device__ inline A2Lds a2_lds(const qavit_attn_args& a, bool bwd, int 
   if (bwd) {
     L.d_o = o; o += 16 * L.ldd;
     L.ds = o; o += 16 * L.ldk;
-    L.dkf = o; o += NK16 * L.ldd;
-    L.dvf = o; o += NK16 * L.ldd;
+    // dKf / dVf (bf16 operands of the Linformer products) are written after the last query tile, when Kf / Vf are dead:
+    // same tiles.  Their padded rows / columns come out 0 (P = dS = 0 there), which is what the next problem expects.
+    L.dkf = L.kf;
+    L.dvf = L.vf;
   }
+  L.end16 = o;
   o = (o + 7) / 8 * 8;                         // 16-byte boundary
   L.accf = o / 2;
-  int fl = 0;
-  if (bwd) fl = (a.mode == 0 ? 2 * a.L * a.KC : 0) + 2 * a.S * a.D;
+  // fp32 accumulators in LDS: the shared-row (bank) gradients only.  dE_k / dE_v accumulate in the wave's own slice of
+  // the workspace (attn.hip: attn_ws_per_wave) -- 10 KB less LDS per wave, 4 instead of 2 waves per CU for MSDA at N=64.
+  const int fl = bwd ? 2 * a.S * a.D : 0;
   L.bytes = o * 2 + fl * 4;
   return L;
 }
@@ -82,16 +87,14 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
 
   const int nE = (MODE == 0) ? a.L * a.KC : 0;
   const int nS = a.S * D;
-  float* accEk = smf + L.accf;
-  float* accEv = accEk + nE;
-  float* accSk = accEv + nE;
+  float* accSk = smf + L.accf;
   float* accSv = accSk + nS;
-  if (BWD) for (int i = lane; i < 2 * nE + 2 * nS; i += 64) accEk[i] = 0.f;
+  float* wsE = BWD ? a.ws + (size_t)blockIdx.x * (2 * nE + 2 * nS) : nullptr;    // [dE_k | dE_v | dsh_k | dsh_v]
+  if (BWD) for (int i = lane; i < 2 * nS; i += 64) accSk[i] = 0.f;
 
   // zero the padded tiles once: rows / columns beyond the valid extents must read as 0 in every product
   {
-    const int total = (BWD ? L.dvf + NK16 * L.ldd : (MODE == 0 ? L.ev + L16 * L.lde : L.vf + NK16 * L.ldd));
-    for (int i = lane; i < total; i += 64) sm[i] = (bf16)0.f;
+    for (int i = lane; i < L.end16; i += 64) sm[i] = (bf16)0.f;
   }
 
   for (int pid = blockIdx.x; pid < a.G * a.H; pid += gridDim.x) {
@@ -328,7 +331,13 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int l = lt * 16 + 4 * q4 + r, j = jt * 16 + col;
-              if (l < a.L && j < a.KC) { accEk[l * a.KC + j] += ak[r]; accEv[l * a.KC + j] += av[r]; }
+              if (l < a.L && j < a.KC) {
+                // the same lane owns the same element in every problem of this wave: plain store, then read-modify-write
+                float* ek_ = wsE + l * a.KC + j;
+                float* ev_ = wsE + nE + l * a.KC + j;
+                if (pid == (int)blockIdx.x) { *ek_ = ak[r]; *ev_ = av[r]; }
+                else { *ek_ += ak[r]; *ev_ += av[r]; }
+              }
             }
           }
         }
@@ -337,8 +346,7 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
   }
   if (BWD) {
     __syncthreads();
-    float* ws = a.ws + (size_t)blockIdx.x * (2 * nE + 2 * nS);
-    for (int i = lane; i < 2 * nE + 2 * nS; i += 64) ws[i] = accEk[i];
+    for (int i = lane; i < 2 * nS; i += 64) wsE[2 * nE + i] = accSk[i];
   } else {
     if (a.nan_flag && __any(bad) && lane == 0) atomicOr(a.nan_flag, 1);
   }
