@@ -13,7 +13,7 @@ constexpr int F_LN = 1, F_BIAS = 2, F_SCALE = 4;
 __device__ __forceinline__ void ln_rows(float* buf, int N, int C, const float* g, const float* b, float eps, float* mean_o, float* rstd_o) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invC = 1.f / (float)C;
-  for (int r = wave; r < N; r += 4) {
+  for (int r = wave; r < N; r += (int)(blockDim.x >> 6)) {
     float* row = buf + r * C;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += row[c];
@@ -30,7 +30,7 @@ __device__ __forceinline__ void ln_rows(float* buf, int N, int C, const float* g
 __device__ __forceinline__ void dwconv_rows(const float* a, float* t, const float* w, const float* cbias, const float* cscale,
                                             int Hs, int Ws, int C, float* raw) {
   const int N = Hs * Ws;
-  for (int i = threadIdx.x; i < N * C; i += 256) {
+  for (int i = threadIdx.x; i < N * C; i += (int)blockDim.x) {
     const int n = i / C, c = i - n * C;
     const int y = n / Ws, x = n - y * Ws;
     float s = 0.f;
@@ -49,7 +49,7 @@ __device__ __forceinline__ void dwconv_rows(const float* a, float* t, const floa
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void ccf_fwd_kernel(qavit_ccf_args p) {
+__global__ __launch_bounds__(512) void ccf_fwd_kernel(qavit_ccf_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = p.Hs * p.Ws, C = p.C;
   float* a = sm;               // [N][C]
@@ -58,13 +58,13 @@ __global__ __launch_bounds__(256) void ccf_fwd_kernel(qavit_ccf_args p) {
   T* out = reinterpret_cast<T*>(p.out);
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     __syncthreads();
-    for (int i = threadIdx.x; i < N * C; i += 256) a[i] = to_f<T>(h[(size_t)b * N * C + i]);
+    for (int i = threadIdx.x; i < N * C; i += (int)blockDim.x) a[i] = to_f<T>(h[(size_t)b * N * C + i]);
     __syncthreads();
     if (p.flags & F_LN) { ln_rows(a, N, C, p.g1, p.b1, p.eps, p.mean1 + (size_t)b * N, p.rstd1 + (size_t)b * N); __syncthreads(); }
     dwconv_rows(a, t, p.w, (p.flags & F_BIAS) ? p.cbias : nullptr, (p.flags & F_SCALE) ? p.cscale : nullptr, p.Hs, p.Ws, C, nullptr);
     __syncthreads();
     if (p.flags & F_LN) { ln_rows(t, N, C, p.g2, p.b2, p.eps, p.mean2 + (size_t)b * N, p.rstd2 + (size_t)b * N); __syncthreads(); }
-    for (int i = threadIdx.x; i < N * C; i += 256) out[(size_t)b * N * C + i] = from_f<T>(t[i]);
+    for (int i = threadIdx.x; i < N * C; i += (int)blockDim.x) out[(size_t)b * N * C + i] = from_f<T>(t[i]);
   }
 }
 
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void ccf_bwd_kernel(qavit_ccf_args p) {
 // l, l+64, ... (CP of them) -- so each parameter-gradient partial (LN gammas/betas, conv bias/scale, the 9 taps) is a
 // register of the thread that owns the channel, summed over the rows and images the thread visits, and folded across
 // the 4 waves through LDS once at the end.  (The first version issued 13 same-address LDS atomics per element.)
-template <typename T, int CP>
-__global__ __launch_bounds__(256) void ccf_bwd2_kernel(qavit_ccf_args p) {
+template <typename T, int CP, int NW>
+__global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int N = p.Hs * p.Ws, C = p.C;
   float* hin = sm;                 // [N][C] raw input h (LN1 input)
@@ -225,13 +225,13 @@ __global__ __launch_bounds__(256) void ccf_bwd2_kernel(qavit_ccf_args p) {
   }
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     __syncthreads();
-    for (int i = threadIdx.x; i < N * C; i += 256) { const float v = to_f<T>(h[(size_t)b * N * C + i]); hin[i] = v; a[i] = v; }
+    for (int i = threadIdx.x; i < N * C; i += 64 * NW) { const float v = to_f<T>(h[(size_t)b * N * C + i]); hin[i] = v; a[i] = v; }
     __syncthreads();
     if (ln) { ln_rows(a, N, C, p.g1, p.b1, p.eps, nullptr, nullptr); __syncthreads(); }
     dwconv_rows(a, t, p.w, hb ? p.cbias : nullptr, hs ? p.cscale : nullptr, p.Hs, p.Ws, C, raw);
     __syncthreads();
     // LN2 backward, then d(conv output) = dt * scale, with dscale / dbias partials -- one pass over the owned elements
-    for (int r = wave; r < N; r += 4) {
+    for (int r = wave; r < N; r += NW) {
       const T* gr = dout + ((size_t)b * N + r) * C;
       float* tr = t + r * C;
       const float* rr = raw + r * C;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void ccf_bwd2_kernel(qavit_ccf_args p) {
     }
     __syncthreads();
     // conv backward: tap partials in registers, d(LN1 output) into raw
-    for (int r = wave; r < N; r += 4) {
+    for (int r = wave; r < N; r += NW) {
       const int y = r / p.Ws, x = r - y * p.Ws;
 #pragma unroll
       for (int k = 0; k < CP; ++k) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void ccf_bwd2_kernel(qavit_ccf_args p) {
       }
     }
     wave_sync();                                        // LN1 backward reads only the rows this wave just wrote
-    for (int r = wave; r < N; r += 4) {
+    for (int r = wave; r < N; r += NW) {
       const float* xr = hin + r * C;
       const float* gr = raw + r * C;
       float d[CP], xh[CP];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void ccf_bwd2_kernel(qavit_ccf_args p) {
       }
     }
   }
-  // fold the 4 waves: part[wave][15][C] over the (now dead) image buffers, then one atomic per parameter element
+  // fold the NW waves: part[wave][15][C] over the (now dead) image buffers, then one atomic per parameter element
   __syncthreads();
   float* part = sm;
 #pragma unroll
@@ -339,8 +339,10 @@ __global__ __launch_bounds__(256) void ccf_bwd2_kernel(qavit_ccf_args p) {
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 15 * C; i += 256) {
-    const float v = part[i] + part[15 * C + i] + part[30 * C + i] + part[45 * C + i];
+  for (int i = threadIdx.x; i < 15 * C; i += 64 * NW) {
+    float v = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < NW; ++w_) v += part[w_ * 15 * C + i];
     const int which = i / C;
     if (which >= 6) { atomic_add_f(p.dw + (i - 6 * C), v); continue; }
     const int c = i - which * C;
@@ -376,12 +378,13 @@ extern "C" int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream) {
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_fwd: image tile too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = a->B < 2048 ? a->B : 2048;
+  const int threads = a->Hs * a->Ws >= 64 ? 512 : 256;    // 64-token maps fill one CU per image: 8 waves share the rows
   if (a->dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((ccf_fwd_kernel<float>), dim3(grid), dim3(256), smem, st, *a);
+    hipLaunchKernelGGL((ccf_fwd_kernel<float>), dim3(grid), dim3(threads), smem, st, *a);
   } else if (a->dtype == QAVIT_BF16) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((ccf_fwd_kernel<bf16>), dim3(grid), dim3(256), smem, st, *a);
+    hipLaunchKernelGGL((ccf_fwd_kernel<bf16>), dim3(grid), dim3(threads), smem, st, *a);
   } else return set_error(QAVIT_EINVAL, "ccf_mid_fwd: unknown dtype");
   return check_launch("ccf_mid_fwd");
 }
@@ -395,8 +398,12 @@ extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
   const int grid = a->B < 512 ? a->B : 512;
   if (a->C <= 256 && a->Hs * a->Ws >= 15) {             // register-partial kernel (its wave fold needs 60*C floats of the image buffers)
     const int cp = (a->C + 63) / 64;
-#define CCF2(T_, CP_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                        hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_>), dim3(grid), dim3(256), smem, st, *a); }
+#define CCF2(T_, CP_) { if (a->Hs * a->Ws >= 64) { \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                          hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_, 8>), dim3(grid), dim3(512), smem, st, *a); \
+                        } else { \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                          hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_, 4>), dim3(grid), dim3(256), smem, st, *a); } }
     if (a->dtype == QAVIT_F32) { if (cp == 1) CCF2(float, 1) else if (cp == 2) CCF2(float, 2) else if (cp == 3) CCF2(float, 3) else CCF2(float, 4) }
     else if (a->dtype == QAVIT_BF16) { if (cp == 1) CCF2(bf16, 1) else if (cp == 2) CCF2(bf16, 2) else if (cp == 3) CCF2(bf16, 3) else CCF2(bf16, 4) }
     else return set_error(QAVIT_EINVAL, "ccf_mid_bwd: unknown dtype");
