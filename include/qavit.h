@@ -350,8 +350,12 @@ int qavit_adamw(float* p, const float* g, float* m, float* v, const uint8_t* ski
                 const float* lr_dev, float beta1, float beta2, float eps, float wd,
                 const float* step_dev, const float* gnorm_dev, float max_norm, void* stream);
 /* per-tensor clip of nseg segments of the flat gradient buffer, seg = device int64 [nseg][2] = (offset, length):
- * g[seg] *= min(1, clip / (||g[seg]||_2 + 1e-6))   (clip_grad_norm_ per parameter, HQAViT_CIFAR100.py:1416-1418) */
-int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, void* stream);
+ * g[seg] *= min(1, clip / (||g[seg]||_2 + 1e-6))   (clip_grad_norm_ per parameter, HQAViT_CIFAR100.py:1416-1418).
+ * ws = float[2*nseg], zero on first use; the call leaves it zero again. */
+int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, float* ws, void* stream);
+/* dst_a = src_a, dst_b = src_b (n fp32 each, n % 4 == 0, 16-byte aligned): forward-time snapshot of the bank's K / V rows
+ * (the reference's torch.cat / Linear-on-expand copies, HQAViT_CIFAR100.py:398-399, :576-577) in one launch */
+int qavit_copy2(const float* src_a, const float* src_b, float* dst_a, float* dst_b, int64_t n, void* stream);
 /* out[0] = sqrt(sum g^2) over a flat buffer (two-pass, deterministic order within a block) */
 int qavit_l2norm(const float* g, int64_t n, float* partial, float* out, void* stream);
 

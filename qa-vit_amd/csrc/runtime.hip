@@ -749,33 +749,58 @@ extern "C" int qavit_l2norm(const float* g, int64_t n, float* partial, float* ou
 }
 
 // Per-tensor gradient clip of selected segments of the flat gradient buffer: g *= min(1, clip / (||g|| + 1e-6)).
-// One workgroup per segment (they are small: stem / depthwise-conv weights); norm and rescale in the same launch.
-__global__ __launch_bounds__(512) void local_clip_kernel(float* g, const int64_t* seg, float clip) {
-  __shared__ float red[8];
-  __shared__ float scale_s;
-  float* p = g + seg[2 * blockIdx.x];
+// blockIdx.x = segment, blockIdx.y = chunk of it (the 4x-MLP weights of the stem are 262 k elements: one workgroup per
+// segment took 210 us).  Pass 1 leaves sum g^2 per segment in ws[seg]; pass 2 rescales and the last chunk of a segment
+// to finish (ticket in ws[nseg + seg]) zeroes both words, so the workspace is clean for the next step without a memset.
+__global__ __launch_bounds__(256) void local_clip_norm_kernel(const float* g, const int64_t* seg, float* ws) {
+  __shared__ float red[4];
+  const float* p = g + seg[2 * blockIdx.x];
   const int64_t n = seg[2 * blockIdx.x + 1];
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 512) { const float v = p[i]; s += v * v; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) { const float v = p[i]; s += v * v; }
+  s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < 8; ++w) t += red[w];
-    scale_s = fminf(clip / (sqrtf(t) + 1e-6f), 1.f);
-  }
-  __syncthreads();
-  const float sc = scale_s;
+  if (threadIdx.x == 0) { const float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomic_add_f(ws + blockIdx.x, t); }
+}
+__global__ __launch_bounds__(256) void local_clip_scale_kernel(float* g, const int64_t* seg, float* ws, int nseg, float clip) {
+  float* p = g + seg[2 * blockIdx.x];
+  const int64_t n = seg[2 * blockIdx.x + 1];
+  const float sc = fminf(clip / (sqrtf(ws[blockIdx.x]) + 1e-6f), 1.f);
   if (sc < 1.f)
-    for (int64_t i = threadIdx.x; i < n; i += 512) p[i] *= sc;
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) p[i] *= sc;
+  __syncthreads();                                         // every thread of this chunk has read ws[seg]
+  if (threadIdx.x == 0) {
+    int* ticket = reinterpret_cast<int*>(ws + nseg) + blockIdx.x;
+    if (atomicAdd(ticket, 1) == (int)gridDim.y - 1) { ws[blockIdx.x] = 0.f; *ticket = 0; }
+  }
 }
 
-extern "C" int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, void* stream) {
-  if (!g || !seg || nseg <= 0 || !(clip > 0.f)) return set_error(QAVIT_EINVAL, "local_clip: bad arguments");
-  hipLaunchKernelGGL(local_clip_kernel, dim3(nseg), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), g, seg, clip);
+extern "C" int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, float* ws, void* stream) {
+  if (!g || !seg || !ws || nseg <= 0 || !(clip > 0.f)) return set_error(QAVIT_EINVAL, "local_clip: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(nseg, 16);
+  hipLaunchKernelGGL(local_clip_norm_kernel, grid, dim3(256), 0, st, g, seg, ws);
+  hipLaunchKernelGGL(local_clip_scale_kernel, grid, dim3(256), 0, st, g, seg, ws, nseg, clip);
   return check_launch("local_clip");
+}
+
+// dst_a = src_a, dst_b = src_b (same length): the forward-time snapshot of the bank's K and V rows in one launch
+// (two clone() calls were two memcpy nodes of the step graph each time a branch reads the bank).
+__global__ __launch_bounds__(256) void copy2_kernel(const float* a, const float* b, float* da, float* db, int n4) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n4; i += gridDim.x * 256) {
+    const bool second = i >= n4;
+    const int j = second ? i - n4 : i;
+    reinterpret_cast<f32x4*>(second ? db : da)[j] = reinterpret_cast<const f32x4*>(second ? b : a)[j];
+  }
+}
+extern "C" int qavit_copy2(const float* src_a, const float* src_b, float* dst_a, float* dst_b, int64_t n, void* stream) {
+  if (!src_a || !src_b || !dst_a || !dst_b || n <= 0 || n % 4 || n / 4 >= 0x3fffffffLL) return set_error(QAVIT_EINVAL, "copy2: bad arguments");
+  if ((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(src_b) | reinterpret_cast<uintptr_t>(dst_a) | reinterpret_cast<uintptr_t>(dst_b)) & 15)
+    return set_error(QAVIT_EINVAL, "copy2: 16-byte aligned fp32 buffers");
+  const int n4 = (int)(n / 4);
+  hipLaunchKernelGGL(copy2_kernel, dim3(blocks_for(2 * (int64_t)n4, 256, 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src_a, src_b, dst_a, dst_b, n4);
+  return check_launch("copy2");
 }
 
 extern "C" int qavit_adamw(float* p, const float* g, float* m, float* v, const uint8_t* skip, int64_t n,

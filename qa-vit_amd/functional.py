@@ -457,8 +457,12 @@ class AttnFn(Function):
         # a parameter.
         ctx.sh_alias = (sh_k, sh_v)
         need = any(ctx.needs_input_grad)
-        sk_s = sh_k.detach().clone() if (need and sh_k.is_leaf) else sh_k
-        sv_s = sh_v.detach().clone() if (need and sh_v.is_leaf) else sh_v
+        sk_s, sv_s = sh_k, sh_v
+        if need and sh_k.is_leaf and sh_v.is_leaf:
+            sk_s, sv_s = K.copy2(sh_k, sh_v)
+        elif need and (sh_k.is_leaf or sh_v.is_leaf):
+            sk_s = sh_k.detach().clone() if sh_k.is_leaf else sh_k
+            sv_s = sh_v.detach().clone() if sh_v.is_leaf else sh_v
         ctx.save_for_backward(q_t, kv_t, E_k, E_v, sk_s, sv_s)
         return o
 
@@ -1075,6 +1079,25 @@ def patchify(img, patch, dtype):
     cols = torch.empty(B * (H // patch) * (W // patch), Cin * patch * patch, dtype=dtype, device=img.device)
     K.patchify(img, cols, B, Cin, H, W, patch)
     return cols
+
+
+class _Snapshot2Fn(Function):
+    """(k, v) -> (k.clone(), v.clone()) as one kernel; gradients pass straight through (what ``clone`` does)."""
+
+    @staticmethod
+    def forward(ctx, k, v):
+        return K.copy2(k, v)
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        return dk, dv
+
+
+def bank_snapshot(bank):
+    """The bank rows as the reference's ``Linear`` on the EXPANDED bank sees them: a copy taken now, so the weight gradient
+    is computed against the forward-time bank although ``GlobalTokenBank.write`` mutates the parameter in place later in
+    the same forward (HQAViT_CIFAR100.py:576-577)."""
+    return _Snapshot2Fn.apply(bank.global_k, bank.global_v)
 
 
 @torch.no_grad()

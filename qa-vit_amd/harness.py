@@ -248,6 +248,7 @@ class Trainer:
         self.local_clip_params = [p for p, nme in zip(self.params, self.names) if ("cnn_stem" in nme or "dwconv" in nme)]
         segs = [(o, s) for nme, o, s in zip(self.names, self.offsets, sizes) if ("cnn_stem" in nme or "dwconv" in nme)]
         self.local_clip_seg = torch.tensor(segs, dtype=torch.int64, device=dev).reshape(-1, 2) if segs else None
+        self.local_clip_ws = torch.zeros(2 * max(len(segs), 1), dtype=torch.float32, device=dev)
         self.total_steps = total_steps
         warm = warmup_steps if warmup_steps is not None else max(1, int(total_steps * cfg.warmup_epochs / max(cfg.epochs, 1)))
         table = [onecycle_lr(i, total_steps, cfg.base_lr, warm / total_steps) for i in range(total_steps)]
@@ -307,7 +308,7 @@ class Trainer:
     def _optim(self):
         cfg = self.cfg
         if cfg.local_clip > 0 and self.local_clip_seg is not None:
-            K.local_clip(self.flat_g, self.local_clip_seg, cfg.local_clip)
+            K.local_clip(self.flat_g, self.local_clip_seg, cfg.local_clip, self.local_clip_ws)
         K.l2norm(self.flat_g, self.partial, self.gnorm)
         torch.index_select(self.lr_table, 0, torch.clamp(self.step_idx, max=self.total_steps - 1), out=self.lr_dev)
         self.step_f += 1.0

@@ -432,9 +432,22 @@ def adamw(p, g, m, v, skip, lr_dev, b1, b2, eps, wd, step_dev, gnorm_dev, max_no
                                  step_dev.data_ptr(), _p(gnorm_dev), max_norm, stream()), "adamw")
 
 
-def local_clip(flat_g, seg, clip):
-    """seg: int64 device tensor [n, 2] of (offset, length) into flat_g; each segment is clipped to L2 norm ``clip``."""
-    L.check(L.load().qavit_local_clip(flat_g.data_ptr(), seg.data_ptr(), seg.shape[0], float(clip), stream()), "local_clip")
+def local_clip(flat_g, seg, clip, ws):
+    """seg: int64 device tensor [n, 2] of (offset, length) into flat_g; each segment is clipped to L2 norm ``clip``.
+    ws: zero-initialised fp32 [2*n] scratch (left zero by the call)."""
+    L.check(L.load().qavit_local_clip(flat_g.data_ptr(), seg.data_ptr(), seg.shape[0], float(clip), ws.data_ptr(), stream()), "local_clip")
+
+
+def copy2(a, b):
+    """-> (a.clone(), b.clone()) for two same-size fp32 tensors in ONE kernel (no memcpy nodes in the step graph)."""
+    a, b = a.detach(), b.detach()
+    n = a.numel()
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or b.numel() != n or n % 4 or not (a.is_contiguous() and b.is_contiguous()) \
+            or (a.data_ptr() | b.data_ptr()) & 15:
+        return a.clone(), b.clone()
+    out = torch.empty(2, n, dtype=torch.float32, device=a.device)
+    L.check(L.load().qavit_copy2(a.data_ptr(), b.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), n, stream()), "copy2")
+    return out[0].view(a.shape), out[1].view(b.shape)
 
 
 def l2norm(g, partial, out):

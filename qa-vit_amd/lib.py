@@ -112,7 +112,8 @@ _SIGS = {
     "qavit_rng_advance": (i32, [vp, vp]),
     "qavit_adamw": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, f32, vp]),
     "qavit_l2norm": (i32, [vp, i64, vp, vp, vp]),
-    "qavit_local_clip": (i32, [vp, vp, i32, f32, vp]),
+    "qavit_local_clip": (i32, [vp, vp, i32, f32, vp, vp]),
+    "qavit_copy2": (i32, [vp, vp, vp, vp, i64, vp]),
 }
 
 # every symbol include/qavit.h declares (checked by tests/test_abi.py against the header text)

@@ -194,8 +194,9 @@ class EfficientChannelGroupAttention(_Branch):
         bank = self.global_bank
         # .clone(): the reference's Linear flattens the EXPANDED bank, which copies -- its weight gradient sees the
         # forward-time bank, not the in-place writes that follow (HQAViT_CIFAR100.py:576-577)
-        sh_k = F.linear(bank.global_k.clone(), self.bank_k_proj.weight, self.bank_k_proj.bias).reshape(bank.bank_size, ccg)
-        sh_v = F.linear(bank.global_v.clone(), self.bank_v_proj.weight, self.bank_v_proj.bias).reshape(bank.bank_size, ccg)
+        gk, gv = F.bank_snapshot(bank)
+        sh_k = F.linear(gk, self.bank_k_proj.weight, self.bank_k_proj.bias).reshape(bank.bank_size, ccg)
+        sh_v = F.linear(gv, self.bank_v_proj.weight, self.bank_v_proj.bias).reshape(bank.bank_size, ccg)
         tbl = K.Runtime.get(x.device).table(("cga", N, G), lambda: [n * G + g for g in range(G) for n in range(N)])
         spec = dict(mode=1, G=B * G, Nq=N, L=N, H=H, D=ccg // H, S=bank.bank_size, groups_per_b=G,
                     q_rows_per_b=N * G, k_rows_per_b=N * G, q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=ccg, v_off=2 * ccg,
@@ -223,8 +224,9 @@ class CrossAttentionBranch(_Branch):
         B, N, C = x.shape
         bank = self.global_bank
         q = F.linear(x, self.q_proj.weight, self.q_proj.bias).reshape(B * N, C)
-        sh_k = F.linear(bank.global_k.clone(), self.k_proj.weight, self.k_proj.bias).reshape(bank.bank_size, C)   # clone: see CGA
-        sh_v = F.linear(bank.global_v.clone(), self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
+        gk, gv = F.bank_snapshot(bank)                                                                         # see CGA
+        sh_k = F.linear(gk, self.k_proj.weight, self.k_proj.bias).reshape(bank.bank_size, C)
+        sh_v = F.linear(gv, self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
         spec = dict(mode=1, G=B, Nq=N, L=0, H=self.num_heads, D=self.head_dim, S=bank.bank_size, q_off=0, k_off=0, v_off=0,
                     q_rows=B * N)
         o = F.AttnFn.apply(q, None, None, None, sh_k, sh_v, spec)

@@ -601,8 +601,10 @@ def test_local_clip_matches_clip_grad_norm(Q):
         t.grad = ref[o:o + n].clone()
         torch.nn.utils.clip_grad_norm_([t], 0.1)
         ref[o:o + n] = t.grad
-    K.local_clip(flat, torch.tensor(segs, dtype=torch.int64, device=DEV), 0.1)
+    ws = torch.zeros(2 * len(segs), device=DEV)
+    K.local_clip(flat, torch.tensor(segs, dtype=torch.int64, device=DEV), 0.1, ws)
     assert rel(flat, ref) <= 1e-6
+    assert float(ws.abs().max()) == 0.0                                          # scratch left clean for the next step
     assert torch.equal(flat[30_016:30_019], ref[30_016:30_019])                  # below the threshold: untouched
 
 
