@@ -338,9 +338,13 @@ int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st) {
   const int ncb = (g.N + bn - 1) / bn;
   const bool bm128 = (long)((g.M + 127) / 128) * ncb >= 448;
   int rc;
+  // fewer than ~1.75 workgroups per CU at 64-row tiles (rows = B*16 learned tokens): 32-row tiles put two workgroups on a
+  // CU so one's global-load latency hides behind the other's MFMAs
+  static const int bm32_below = getenv("QAVIT_BIG_BM32") ? atoi(getenv("QAVIT_BIG_BM32")) : 448;
+  const bool bm32 = !bm128 && (long)((g.M + 63) / 64) * ncb < bm32_below;
   if (bn == 256) rc = big_modes<128, 256>(g, st);                      // 64-row tiles would starve the MFMA pipe here
-  else if (bn == 192) rc = bm128 ? big_modes<128, 192>(g, st) : big_modes<64, 192>(g, st);
-  else rc = bm128 ? big_modes<128, 128>(g, st) : big_modes<64, 128>(g, st);
+  else if (bn == 192) rc = bm128 ? big_modes<128, 192>(g, st) : (bm32 ? big_modes<32, 192>(g, st) : big_modes<64, 192>(g, st));
+  else rc = bm128 ? big_modes<128, 128>(g, st) : (bm32 ? big_modes<32, 128>(g, st) : big_modes<64, 128>(g, st));
   if (rc == -100) return 0;
   if (rc != QAVIT_OK) return rc;
   rc = check_launch("gemm_nt(big)");
