@@ -163,3 +163,21 @@ def test_mix_plan_follows_the_reference_decisions(Q):
         assert abs(float(plan[1]) - lam) <= 1e-6
         if mode == 1:
             assert tuple(int(v) for v in plan[2:]) == box
+
+
+def test_reference_named_shims_resolve(golden, Q):
+    """qa-vit_amd/shims/<reference module name>.py: the classes the reference's scripts import by name, with the
+    reference's one-argument constructors and state_dict layouts."""
+    import importlib.util
+    import os
+    sdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qa-vit_amd", "shims")
+    want = {"HQAViT_CIFAR100": ("HQAViT", "HQAViTConfig", "c100"), "HQAViT_IN_Tiny": ("HQAViT", "HQAViTConfig", "tin"),
+            "HQAViTv2_CIFAR100": ("HQAViT", "HQAViTConfig", "c100v2"), "QAViT": ("QAViT", "QAViTConfig", "q224"),
+            "QAViTv2": ("QAViT", "QAViTConfig", "v2_224"), "QAViTV2_EXTREME": ("QAViT", "QAViTConfig", None)}
+    for name, (cls, cfg, tag) in want.items():
+        spec = importlib.util.spec_from_file_location("shim_" + name, os.path.join(sdir, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        model = getattr(mod, cls)(getattr(mod, cfg)())
+        if tag is not None:
+            assert sorted(model.state_dict().keys()) == golden[f"{tag}/state_keys"].tolist(), name
