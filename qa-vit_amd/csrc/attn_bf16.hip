@@ -388,6 +388,9 @@ int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) 
   else if (a.mode == 1 && nkt == 1 && dt == 3) rc = a2_launch<1, 1, 3>(a, bwd, grid, st);
   else if (a.mode == 1 && nkt <= 2 && dt == 1) rc = a2_launch<1, 2, 1>(a, bwd, grid, st);
   else if (a.mode == 1 && nkt <= 5 && dt == 1) rc = a2_launch<1, 5, 1>(a, bwd, grid, st);
+  // 224-px shapes (N = 196): 64 Linformer rows + 16 bank rows = 80 keys for SWA / MSDA; 196 tokens + 16 for CGA (D = 4)
+  else if (a.mode == 0 && nkt <= 5 && dt == 3) rc = a2_launch<0, 5, 3>(a, bwd, grid, st);
+  else if (a.mode == 1 && nkt <= 14 && dt == 1) rc = a2_launch<1, 14, 1>(a, bwd, grid, st);
   if (rc == -100) return 0;
   return rc == QAVIT_OK ? 1 : rc;
 }

@@ -178,12 +178,13 @@ def _ref_attn(q, k, v):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,Hs,ws", [(37, 4, 4), (9, 8, 4)])
-def test_attn_swa_like(F, Q, dtype, B, Hs, ws):
-    """mode 0 with the window table: qkv [B*N,3C] -> windows -> Linformer(16->32) + 16 bank rows."""
+@pytest.mark.parametrize("B,Hs,ws,KC", [(37, 4, 4, 32), (9, 8, 4, 32), (5, 14, 7, 64)])
+def test_attn_swa_like(F, Q, dtype, B, Hs, ws, KC):
+    """mode 0 with the window table: qkv [B*N,3C] -> windows -> Linformer(16->32) + 16 bank rows.
+    (5, 14, 7, 64): the 224-px windows -- 49 tokens, 64 Linformer rows (80 keys with the bank)."""
     import importlib
     K = importlib.import_module("qa-vit_amd.kernels")
-    N, C, H, KC, S = Hs * Hs, 192, 4, 32, 16
+    N, C, H, S = Hs * Hs, 192, 4, 16
     D = C // H
     nw = Hs // ws
     qkv = leaf(B * N, 3 * C, seed=60).detach().to(dtype).requires_grad_(True)
@@ -260,7 +261,7 @@ def test_attn_msda_like(F, dtype, N, NP, KC):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N", [16, 64])
+@pytest.mark.parametrize("N", [16, 64, 196])
 def test_attn_cga_like(F, dtype, N):
     """mode 1, D=4, keys = own tokens + 16 shared rows, channel-group row table."""
     B, G, H, S, ccg = 13, 6, 4, 16, 16
