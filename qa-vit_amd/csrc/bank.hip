@@ -16,23 +16,24 @@ constexpr int BANK_MAX_WG = 256;
 // NCH = token rows resident in LDS at a time.  NCH >= N: one pass.  Otherwise (N = 196 at 224 px) two passes over the
 // chunks: logits of every chunk first (the softmax runs over ALL tokens of the image), then the chunks are staged and
 // normalised again for U += w^T tn -- the re-read comes from L2.
-template <typename T, bool BF>
-__global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr,
+template <typename T, bool BF, int NTH>
+__global__ __launch_bounds__(NTH) void bank_stats_kernel(const T* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr,
                                                          const float* Wg, const float* bg, float* ws, int B, int N, int C, int S, int NCH, float eps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* tn = sm;                    // [NCH][C]
   float* lg = tn + NCH * C;          // [N][S] logits -> weights
   float* U = lg + N * S;             // [S][C] accumulator over this workgroup's images
-  float* red = U + S * C;            // [256]
+  float* red = U + S * C;            // [NTH]
+  constexpr int NW = NTH / 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float invC = 1.f / (float)C;
-  for (int i = t; i < S * C; i += 256) U[i] = 0.f;
+  for (int i = t; i < S * C; i += NTH) U[i] = 0.f;
   // rows [n0, n0 + rows) of image b -> tn, through the two chained LayerNorms
   auto stage_ln = [&](int b, int n0, int rows) {
     __syncthreads();
-    for (int i = t; i < rows * C; i += 256) tn[i] = to_f<T>(tokens[((size_t)b * N + n0) * C + i]);
+    for (int i = t; i < rows * C; i += NTH) tn[i] = to_f<T>(tokens[((size_t)b * N + n0) * C + i]);
     __syncthreads();
-    for (int r = wave; r < rows; r += 4) {
+    for (int r = wave; r < rows; r += NW) {
       float* row = tn + r * C;
       for (int pass = 0; pass < 2; ++pass) {
         const float* g = pass == 0 ? gbr : gwr;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
   // logits[n0 + n][s] = tn[n,:] . Wg[s,:] + bg[s]
   auto logits = [&](int n0, int rows) {
     const int nt_n = (rows + 15) / 16, st_n = (S + 15) / 16;
-    for (int tile = wave; tile < nt_n * st_n; tile += 4) {
+    for (int tile = wave; tile < nt_n * st_n; tile += NW) {
       const int nt = tile / st_n, stt = tile - nt * st_n;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = mma_tile<BF>(tn + nt * 16 * C, C, 1, rows - nt * 16, Wg + (size_t)stt * 16 * C, 1, C, S - stt * 16, C, acc);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
   // U[s][c] += sum_n w[n0 + n][s] tn[n][c]
   auto accum = [&](int n0, int rows) {
     const int st_n = (S + 15) / 16, ct_n = (C + 15) / 16;
-    for (int tile = wave; tile < st_n * ct_n; tile += 4) {
+    for (int tile = wave; tile < st_n * ct_n; tile += NW) {
       const int stt = tile / ct_n, ct = tile - stt * ct_n;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = mma_tile<BF>(lg + n0 * S + stt * 16, 1, S, S - stt * 16, tn + ct * 16, C, 1, C - ct * 16, rows, acc);
@@ -81,9 +82,9 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
       logits(n0, rows);
     }
     __syncthreads();
-    // softmax over tokens per slot: S columns, 256/S threads per column (S divides 256)
+    // softmax over tokens per slot: S columns, NTH/S threads per column (S divides 256)
     {
-      const int parts = 256 / S, s_ = t % S, part = t / S;
+      const int parts = NTH / S, s_ = t % S, part = t / S;
       float mx = -INFINITY;
       for (int n = part; n < N; n += parts) mx = fmaxf(mx, lg[n * S + s_]);
       red[t] = mx; __syncthreads();
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void bank_stats_kernel(const T* tokens, const 
   }
   __syncthreads();
   float* out = ws + (size_t)blockIdx.x * S * C;
-  for (int i = t; i < S * C; i += 256) out[i] = U[i];
+  for (int i = t; i < S * C; i += NTH) out[i] = U[i];
 }
 
 // acc (zero on entry: bank_apply re-zeroes what it consumes) += partials; blockIdx.y = slice of 16 partials
@@ -169,7 +170,7 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
   if (B <= 0 || N <= 0 || C <= 0 || S <= 0 || S > 256 || (256 % S) != 0) return set_error(QAVIT_EINVAL, "bank_stats: bad dimensions (S must divide 256)");
   const int grid = bank_grid(B);
   if (ws_floats < (int64_t)grid * S * C) return set_error(QAVIT_EINVAL, "bank_stats: workspace too small");
-  const size_t fixed = ((size_t)N * S + (size_t)S * C + 256) * sizeof(float);
+  const size_t fixed = ((size_t)N * S + (size_t)S * C + 1024) * sizeof(float);
   int NCH = N;
   if (fixed + (size_t)NCH * C * sizeof(float) > 160 * 1024) {
     if (fixed + (size_t)16 * C * sizeof(float) > 160 * 1024) return set_error(QAVIT_EINVAL, "bank_stats: token tile too large for LDS");
@@ -188,13 +189,14 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
       return check_launch("bank_stats(bf16)");
     }
   }
-  if (dtype == QAVIT_F32) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((bank_stats_kernel<float, false>), dim3(grid), dim3(256), smem, st, (const float*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, NCH, eps);
-  } else if (dtype == QAVIT_BF16) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((bank_stats_kernel<bf16, true>), dim3(grid), dim3(256), smem, st, (const bf16*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, NCH, eps);
-  } else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
+  // one image per workgroup: a 196-token image (two chunks) gets 16 waves to share its rows and MFMA tiles
+#define BANK_LAUNCH(T_, BF_, NTH_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<T_, BF_, NTH_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((bank_stats_kernel<T_, BF_, NTH_>), dim3(grid), dim3(NTH_), smem, st, (const T_*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, NCH, eps); }
+  const bool wide = N > 64;
+  if (dtype == QAVIT_F32) { if (wide) BANK_LAUNCH(float, false, 1024) else BANK_LAUNCH(float, false, 256) }
+  else if (dtype == QAVIT_BF16) { if (wide) BANK_LAUNCH(bf16, true, 1024) else BANK_LAUNCH(bf16, true, 256) }
+  else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
+#undef BANK_LAUNCH
   const int n = S * C;
   hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n);
   return check_launch("bank_stats");
