@@ -2,6 +2,7 @@
 // One 256-thread workgroup per image; matrices are tiny (N,M <= 256), so operands sit in LDS / L2 and the
 // products run as 16x16 MFMA tiles (mma_lds.cuh) distributed over the 4 waves.
 #include "common.cuh"
+#include <type_traits>
 #include "mma_lds.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
@@ -278,6 +279,67 @@ __global__ __launch_bounds__(256) void gather_pool_bwd_kernel(const T* dy, const
   }
 }
 
+// Same result with the scatter turned into a gather once per workgroup: thread n scans the index list (staged in LDS) in
+// order and keeps the (at most 4) pooled rows that read token n -- a token appears once per dilation -- so each output
+// vector is the sum of <= 4 rows instead of a scan of all NP*stride entries per element.  Deterministic (list order =
+// index order).  A token with more than 4 readers makes its workgroup take the scan for every element.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pool_bwd2_kernel(const T* dy, const int32_t* idx, T* dx, int B, int N, int NP, int stride, int C) {
+  constexpr int VEC = 16 / sizeof(T);
+  typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) int ism[];
+  int* sidx = ism;                 // [E]
+  int* src = ism + NP * stride;    // [N][4]
+  __shared__ int over;
+  const int E = NP * stride;
+  if (threadIdx.x == 0) over = 0;
+  for (int e = threadIdx.x; e < E; e += 256) sidx[e] = idx[e];
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) {
+    int k = 0, loc[4] = {-1, -1, -1, -1};
+    for (int e = 0; e < E; ++e)
+      if (sidx[e] == n) { if (k < 4) loc[k] = e / stride; ++k; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) src[n * 4 + q] = loc[q];
+    if (k > 4) over = 1;
+  }
+  __syncthreads();
+  const bool slow = over != 0;
+  const float inv = 1.f / (float)stride;
+  const int CV = C / VEC;
+  const uint32_t total = (uint32_t)B * N * CV;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const int cv = (int)(i % (uint32_t)CV);
+    const int n = (int)((i / (uint32_t)CV) % (uint32_t)N);
+    const int b = (int)(i / ((uint32_t)CV * N));
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if (!slow) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = src[n * 4 + q];
+        if (r >= 0) {
+          const vec_t v = *reinterpret_cast<const vec_t*>(dy + ((size_t)b * NP + r) * C + cv * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] += to_f<T>(v[j]);
+        }
+      }
+    } else {
+      for (int e = 0; e < E; ++e)
+        if (sidx[e] == n) {
+          const vec_t v = *reinterpret_cast<const vec_t*>(dy + ((size_t)b * NP + e / stride) * C + cv * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] += to_f<T>(v[j]);
+        }
+    }
+    vec_t o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = from_f<T>(acc[j] * inv);
+    *reinterpret_cast<vec_t*>(dx + ((size_t)b * N + n) * C + cv * VEC) = o;
+  }
+}
+
 }  // namespace qv
 
 using namespace qv;
@@ -393,6 +455,18 @@ extern "C" int qavit_gather_pool_bwd(int dtype, const void* dy, const int32_t* i
   int64_t total = (int64_t)B * N * C;
   int grid = (int)((total + 1023) / 1024); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
   const bool small = (int64_t)B * (NP > N ? NP : N) * C < 0x7fffffffLL;
+  {
+    const int vec = dtype == QAVIT_BF16 ? 8 : 4;
+    const size_t lds = ((size_t)NP * stride + (size_t)N * 4) * sizeof(int);
+    const bool al = !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15);
+    if (small && al && C % vec == 0 && lds <= 96 * 1024 && (dtype == QAVIT_BF16 || dtype == QAVIT_F32)) {
+      int64_t nv = (int64_t)B * N * (C / vec);
+      int g2 = (int)((nv + 1023) / 1024); if (g2 > 512) g2 = 512; if (g2 < 1) g2 = 1;
+      if (dtype == QAVIT_BF16) hipLaunchKernelGGL((gather_pool_bwd2_kernel<bf16>), dim3(g2), dim3(256), lds, st, (const bf16*)dy, idx, (bf16*)dx, B, N, NP, stride, C);
+      else hipLaunchKernelGGL((gather_pool_bwd2_kernel<float>), dim3(g2), dim3(256), lds, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);
+      return check_launch("gather_pool_bwd");
+    }
+  }
   if (dtype == QAVIT_F32) {
     if (small) hipLaunchKernelGGL((gather_pool_bwd_kernel<float, uint32_t>), dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);
     else hipLaunchKernelGGL((gather_pool_bwd_kernel<float, int64_t>), dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);

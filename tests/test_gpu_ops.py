@@ -359,6 +359,31 @@ def test_tokmix_upmix(F, dtype, N, M):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Hs,dil", [(4, (1, 2)), (8, (1, 2)), (14, (1, 2, 3)), (4, (1, 1, 1, 1, 1, 2))])
+def test_gather_pool(F, dtype, Hs, dil):
+    """MSDA landmarks: dilated grid gather + AvgPool1d(2,2) over the gathered sequence (HQAViT_CIFAR100.py:493-503).
+    The last case repeats dilation 1 five times so every token has more than 4 readers (the backward's scan path)."""
+    B, C, stride = 7, 192, 2
+    N = Hs * Hs
+    t = []
+    for d in dil:
+        for y in range(0, Hs, d):
+            for x_ in range(0, Hs, d):
+                t.append(y * Hs + x_)
+    t = t[: (len(t) // stride) * stride]
+    idx = torch.tensor(t, dtype=torch.int32, device=DEV)
+    x = leaf(B, N, C, seed=400).detach().to(dtype).requires_grad_(True)
+    y = F.GatherPoolFn.apply(x, idx, stride)
+    xr = x.detach().clone().float().requires_grad_(True)
+    ref = TF.avg_pool1d(xr[:, idx.long()].transpose(1, 2), stride, stride).transpose(1, 2)
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Hs,flags", [(4, "hqa"), (8, "hqa"), (8, "v1"), (4, "v2"), (14, "v1"), (14, "v2")])
 def test_ccf_mid(F, dtype, Hs, flags):
     """Hs=14 (224 px) exceeds the fused kernel's LDS tile: functional.ccf_mid composes LN / dwconv / LN instead."""
