@@ -161,25 +161,47 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
         for (int j = 0; j < DT; ++j) { gK[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; gV[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
 
+    // query side: the next tile's q / dO rows are fetched into registers while this tile computes (unconditional loads
+    // of clamped rows, zeroed at commit: a load under a lane-dependent branch would be waited for at the join)
+    bf16x4 pq[DT], pg[DT];
+    auto fetch = [&](int q0) {
+      const int rows_n = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
+#pragma unroll
+      for (int c = 0; c < DT; ++c) {
+        const int i = lane + 64 * c;
+        const int r = i / DC, ch = i - r * DC;
+        const int rc = r < rows_n ? r : rows_n - 1;
+        const int64_t qr = attn_qrow(a, g, q0 + (rc < 0 ? 0 : rc));
+        const int chc = (i < 16 * DC) ? ch : 0;
+        pq[c] = *reinterpret_cast<const bf16x4*>(qg + qr * a.ldq + h * D + 4 * chc);
+        if (BWD) pg[c] = *reinterpret_cast<const bf16x4*>(dog + qr * a.lddo + h * D + 4 * chc);
+      }
+    };
+    fetch(0);
     for (int q0 = 0; q0 < a.Nq; q0 += 16) {
       const int rows = (a.Nq - q0 < 16) ? a.Nq - q0 : 16;
       __syncthreads();
-      for (int i = lane; i < 16 * DC; i += 64) {
-        const int r = i / DC, ch = i - r * DC;
-        bf16x4 v, gvv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = (bf16)0.f; gvv[j] = (bf16)0.f; }
-        if (r < rows) {
-          const int64_t qr = attn_qrow(a, g, q0 + r);
-          v = *reinterpret_cast<const bf16x4*>(qg + qr * a.ldq + h * D + 4 * ch);
-          if (BWD) gvv = *reinterpret_cast<const bf16x4*>(dog + qr * a.lddo + h * D + 4 * ch);
+      for (int c = 0; c < DT; ++c) {
+        const int i = lane + 64 * c;
+        if (i < 16 * DC) {
+          const int r = i / DC, ch = i - r * DC;
+          bf16x4 v = pq[c], gvv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gvv[j] = (bf16)0.f;
+          if (BWD) gvv = pg[c];
+          if (r >= rows) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = (bf16)0.f; gvv[j] = (bf16)0.f; }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bad |= ((float)v[j] != (float)v[j]);
+          *reinterpret_cast<bf16x4*>(sm + L.q + r * L.ldd + 4 * ch) = v;
+          if (BWD) *reinterpret_cast<bf16x4*>(sm + L.d_o + r * L.ldd + 4 * ch) = gvv;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bad |= ((float)v[j] != (float)v[j]);
-        *reinterpret_cast<bf16x4*>(sm + L.q + r * L.ldd + 4 * ch) = v;
-        if (BWD) *reinterpret_cast<bf16x4*>(sm + L.d_o + r * L.ldd + 4 * ch) = gvv;
       }
       __syncthreads();
+      if (q0 + 16 < a.Nq) fetch(q0 + 16);
       // ---------------- scores + softmax on registers ----------------
       f32x4 s[NKT];
 #pragma unroll
