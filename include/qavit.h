@@ -265,8 +265,12 @@ int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const
                      const float* g_write, const float* b_write, const float* Wg, const float* bg,
                      float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps, void* stream);
 int64_t qavit_bank_ws_floats(int B, int N, int C, int S);
+/* acc == NULL in bank_stats: the per-workgroup partials stay in ws ([nparts = ws_floats / (S*C)][S][C]) and bank_apply folds
+ * them itself when given `parts` (single-GPU write = stats -> apply, fixed summation order).  With acc, stats also reduces
+ * into it (the data-parallel path all-reduces acc between the two calls) and apply is called with parts = NULL. */
 int qavit_bank_apply(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
-                     int64_t* update_count, int S, int C, float inv_batch, int mode, void* stream);
+                     int64_t* update_count, int S, int C, float inv_batch, int mode,
+                     const float* parts, int nparts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * small helpers

@@ -124,12 +124,36 @@ __global__ __launch_bounds__(256) void bank_reduce_kernel(const float* ws, float
   atomic_add_f(acc + i, s);
 }
 
-// one workgroup per slot s
-__global__ __launch_bounds__(256) void bank_apply_kernel(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
-                                                         int64_t* update_count, int S, int C, float inv_batch, int mode) {
-  extern __shared__ __attribute__((aligned(16))) float u[];   // [C]
+// one workgroup per slot s.  ``parts`` (optional): the per-workgroup partial sums of bank_stats, [nparts][S][C]; the
+// slot's row is folded here in a fixed order (threads = (group, 4-column vector), groups stride over the partials, then
+// an LDS fold over the groups) -- the single-GPU write is stats -> apply, deterministic, no reduce launch.  Without
+// ``parts`` the row comes from ``acc`` (already summed, and all-reduced across ranks when data-parallel).
+__global__ __launch_bounds__(1024) void bank_apply_kernel(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
+                                                          int64_t* update_count, int S, int C, float inv_batch, int mode,
+                                                          const float* parts, int nparts) {
+  extern __shared__ __attribute__((aligned(16))) float u[];   // [C] + fold scratch [groups][C]
   const int s = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) { u[c] = acc[s * C + c] * inv_batch; acc[s * C + c] = 0.f; }   // consumed: zero for the next write
+  if (parts) {
+    float* fold = u + C;
+    const int C4 = C >> 2, groups = (int)blockDim.x / C4;
+    const int g = threadIdx.x / C4, c4 = threadIdx.x - g * C4;
+    if (g < groups) {
+      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+      for (int p_ = g; p_ < nparts; p_ += groups) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(parts + ((size_t)p_ * S + s) * C + 4 * c4);
+        a4[0] += v[0]; a4[1] += v[1]; a4[2] += v[2]; a4[3] += v[3];
+      }
+      *reinterpret_cast<f32x4*>(fold + g * C + 4 * c4) = a4;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float t = 0.f;
+      for (int q = 0; q < groups; ++q) t += fold[q * C + c];
+      u[c] = t * inv_batch;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { u[c] = acc[s * C + c] * inv_batch; acc[s * C + c] = 0.f; }   // consumed: zero for the next write
+  }
   float rate, cu, cb;
   if (mode == 1) { rate = 0.01f; cu = 0.1f; cb = 1.0f; }
   else { rate = (update_count && update_count[0] >= 1000) ? 0.01f : 0.005f; cu = 0.05f; cb = 0.5f; }
@@ -166,7 +190,7 @@ extern "C" int64_t qavit_bank_ws_floats(int B, int N, int C, int S) {
 extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const float* b_branch,
                                 const float* g_write, const float* b_write, const float* Wg, const float* bg,
                                 float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps, void* stream) {
-  if (!tokens || !g_branch || !b_branch || !g_write || !b_write || !Wg || !bg || !acc || !ws) return set_error(QAVIT_EINVAL, "bank_stats: null operand");
+  if (!tokens || !g_branch || !b_branch || !g_write || !b_write || !Wg || !bg || !ws) return set_error(QAVIT_EINVAL, "bank_stats: null operand");
   if (B <= 0 || N <= 0 || C <= 0 || S <= 0 || S > 256 || (256 % S) != 0) return set_error(QAVIT_EINVAL, "bank_stats: bad dimensions (S must divide 256)");
   const int grid = bank_grid(B);
   if (ws_floats < (int64_t)grid * S * C) return set_error(QAVIT_EINVAL, "bank_stats: workspace too small");
@@ -185,7 +209,7 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
     const int took = bank_stats_bf16_try(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, grid, eps, st);
     if (took < 0) return took;
     if (took == 1) {
-      hipLaunchKernelGGL(bank_reduce_kernel, dim3((n_acc + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n_acc);
+      if (acc) hipLaunchKernelGGL(bank_reduce_kernel, dim3((n_acc + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n_acc);
       return check_launch("bank_stats(bf16)");
     }
   }
@@ -198,15 +222,22 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
   else return set_error(QAVIT_EINVAL, "bank_stats: unknown dtype");
 #undef BANK_LAUNCH
   const int n = S * C;
-  hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n);
+  if (acc) hipLaunchKernelGGL(bank_reduce_kernel, dim3((n + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n);
   return check_launch("bank_stats");
 }
 
 extern "C" int qavit_bank_apply(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
-                                int64_t* update_count, int S, int C, float inv_batch, int mode, void* stream) {
+                                int64_t* update_count, int S, int C, float inv_batch, int mode,
+                                const float* parts, int nparts, void* stream) {
   if (!acc || !Wc || !bc || !bank_k || !bank_v || S <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "bank_apply: bad arguments");
   if (mode == 0 && !update_count) return set_error(QAVIT_EINVAL, "bank_apply: mode 0 needs update_count");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(256), (size_t)C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode);
+  if (parts) {
+    if (nparts <= 0 || C % 4 || C / 4 > 1024 || (reinterpret_cast<uintptr_t>(parts) & 15)) return set_error(QAVIT_EINVAL, "bank_apply: partials need C % 4 == 0, 16-byte alignment");
+    const int groups = 1024 / (C / 4);
+    hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(1024), (size_t)(1 + groups) * C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode, parts, nparts);
+  } else {
+    hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(256), (size_t)C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode, (const float*)nullptr, 0);
+  }
   return check_launch("bank_apply");
 }

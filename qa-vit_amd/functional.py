@@ -1110,11 +1110,14 @@ def bank_write(tokens, norm_g, norm_b, bank, mode, sync=None):
     S = bank.bank_size
     tokens = tokens.contiguous()
     acc = rt.workspace("bank_acc", S * Cc + 1, zero=True)     # zero on entry; bank_apply leaves it zero again (+1: its ticket word)
-    ws = rt.workspace("bank_ws", K.bank_ws_floats(B, N, Cc, S))
+    n_ws = K.bank_ws_floats(B, N, Cc, S)                      # = workgroups of the statistics kernel * S * C
+    ws = rt.workspace("bank_ws", n_ws)
+    fold_in_apply = sync is None and Cc % 4 == 0          # single GPU: apply folds the partials itself (no reduce launch)
     K.bank_stats(tokens, norm_g, norm_b, bank.write_norm.weight, bank.write_norm.bias, bank.write_gate.weight, bank.write_gate.bias,
-                 acc, ws, B, N, Cc, S, 1e-5)
+                 None if fold_in_apply else acc, ws, B, N, Cc, S, 1e-5)
     total = B
     if sync is not None:
         total = sync(acc[: S * Cc], B)
     K.bank_apply(acc, bank.write_compression.weight, bank.write_compression.bias, bank.global_k.data, bank.global_v.data,
-                 getattr(bank, "update_count", None), S, Cc, 1.0 / float(total), mode)
+                 getattr(bank, "update_count", None), S, Cc, 1.0 / float(total), mode,
+                 ws if fold_in_apply else None, n_ws // (S * Cc) if fold_in_apply else 0)

@@ -310,7 +310,7 @@ def dwconv_bwd(dy, x, w, dx, dw, dbias, B, H, W, Cc, ks):
 # ---------------------------------------------------------------------------------------------------
 def bank_stats(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, acc, ws, B, N, Cc, S, eps):
     L.check(L.load().qavit_bank_stats(dt_code(tokens.dtype), tokens.data_ptr(), g_branch.data_ptr(), b_branch.data_ptr(), g_write.data_ptr(),
-                                      b_write.data_ptr(), Wg.data_ptr(), bg.data_ptr(), acc.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      b_write.data_ptr(), Wg.data_ptr(), bg.data_ptr(), _p(acc), ws.data_ptr(), ws.numel(),
                                       B, N, Cc, S, eps, stream()), "bank_stats")
 
 
@@ -318,9 +318,9 @@ def bank_ws_floats(B, N, Cc, S) -> int:
     return int(L.load().qavit_bank_ws_floats(B, N, Cc, S))
 
 
-def bank_apply(acc, Wc, bc, bank_k, bank_v, update_count, S, Cc, inv_batch, mode):
+def bank_apply(acc, Wc, bc, bank_k, bank_v, update_count, S, Cc, inv_batch, mode, parts=None, nparts=0):
     L.check(L.load().qavit_bank_apply(acc.data_ptr(), Wc.data_ptr(), bc.data_ptr(), bank_k.data_ptr(), bank_v.data_ptr(), _p(update_count),
-                                      S, Cc, inv_batch, mode, stream()), "bank_apply")
+                                      S, Cc, inv_batch, mode, _p(parts), int(nparts), stream()), "bank_apply")
 
 
 # ---------------------------------------------------------------------------------------------------
