@@ -404,6 +404,8 @@ int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) 
     if (use3 < 0) { const char* e = getenv("QAVIT_ATTN3"); use3 = e ? atoi(e) : 1; }
     const int t3 = use3 ? attn3_try(a, bwd, grid, st) : 0;
     if (t3) return t3;
+    const int t4 = attn4_try(a, bwd, grid, st);
+    if (t4) return t4;
   }
   int rc = -100;
   if (a.mode == 0 && nkt <= 3 && dt == 3) rc = a2_launch<0, 3, 3>(a, bwd, grid, st);

@@ -20,5 +20,7 @@ __device__ __forceinline__ int64_t attn_krow(const qavit_attn_args& a, int g, in
 int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st);
 // small-problem variant (<= 16 queries / token keys; attn3_bf16.hip), same return convention; called by attn_bf16_try
 int attn3_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st);
+// four-waves-per-problem variant for Nq >= 32 (attn4_bf16.hip), same return convention; called by attn_bf16_try
+int attn4_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st);
 
 }  // namespace qv
