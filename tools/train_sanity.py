@@ -1,17 +1,18 @@
 """End-to-end sanity of the captured bf16 training step: memorise a small fixed synthetic set (random labels).
-Loss must fall and every parameter stay finite.  usage: python tools/train_sanity.py [steps] [stem]"""
+Loss must fall and every parameter stay finite.  usage: python tools/train_sanity.py [steps] [v1|v2|tin]"""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qavit_amd as Q
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 stem = sys.argv[2] if len(sys.argv) > 2 else "v1"
 torch.manual_seed(0)
-cfg = Q.HQAViTConfig()
-model = Q.HQAViT(cfg, stem=stem).cuda().train()
-B, NSET = 1024, 4096
+tin = stem == "tin"
+cfg = Q.HQAViTTinyINConfig() if tin else Q.HQAViTConfig()
+model = Q.HQAViT(cfg, stem="v1" if tin else stem).cuda().train()
+B, NSET = (256, 1024) if tin else (1024, 4096)
 g = torch.Generator().manual_seed(1)
-X = torch.randn(NSET, 3, 32, 32, generator=g).cuda()
-Y = torch.randint(0, 100, (NSET,), generator=g).cuda()
+X = torch.randn(NSET, 3, cfg.img_size, cfg.img_size, generator=g).cuda()
+Y = torch.randint(0, cfg.num_classes, (NSET,), generator=g).cuda()
 tcfg = Q.TrainingConfig(batch_size=B, use_amp=True)
 tr = Q.Trainer(model, tcfg, total_steps=steps, warmup_steps=max(steps // 10, 1), compute_dtype=torch.bfloat16)
 tr.capture(X[:B], Y[:B], with_optim=True, warmup=2)
