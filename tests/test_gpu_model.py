@@ -112,6 +112,78 @@ def test_fresh_batch_vs_oracle_and_bf16(Q, oracle):
     assert r32 <= LOGIT_TOL
     assert r16 <= 0.15            # torch's own bf16 autocast deviates 2.6e-2 on these logits
 
+def test_large_batch_step_vs_oracle_and_bf16(Q, oracle):
+    """B = 640: past every kernel's workgroup cap (attention 2048 problems, up-mix / CCF 512 images, bank 256, LayerNorm
+    backward 16384 rows), so workgroups loop over several images / problems and their parameter-gradient partials
+    accumulate -- the benchmark's regime, which the B = 2..4 golden fixtures never reach.  fp32 step against the CPU
+    oracle (logits, loss, every parameter gradient), then the bf16 kernels against the fp32 ones on the same step."""
+    cfg = Q.HQAViTConfig(dropout=0.0, drop_path=0.0)
+    model = Q.HQAViT(cfg)
+    Q.fill_module(model)
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in list(P):                                  # the bank must be ONE tensor under all its aliased keys
+        if k.endswith(("global_bank.global_k", "global_bank.global_v", "global_bank.update_count")):
+            P[k] = P["global_bank." + k.rsplit(".", 1)[-1]]
+    names = [n for n, _ in model.named_parameters()]
+    for n in names:
+        P[n].requires_grad_(True)
+    g = torch.Generator().manual_seed(11)
+    B = 640
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, 100, (B,), generator=g)
+    torch.set_num_threads(16)
+    ref = oracle.hqavit_forward(P, x, cfg, train=True, cat_dropout=False)
+    ref_loss = oracle.loss_fn(ref, y, 0.12)
+    ref_loss.backward()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(dtype):
+        m = Q.HQAViT(cfg)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        zero_dropout(m)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            out = m(x.cuda())
+        loss = torch.nn.functional.cross_entropy(out.float(), y.cuda(), label_smoothing=0.12)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().float().cpu(), float(loss.detach()), {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}
+
+    out32, loss32, g32 = run(torch.float32)
+    assert max_rel(out32.numpy(), ref.detach().numpy()) <= LOGIT_TOL
+    assert abs(loss32 - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
+    scale = max(float(P[n].grad.norm()) for n in names if P[n].grad is not None)
+    worst = []
+    for n in names:
+        if P[n].grad is None or zero_by_construction(n):
+            continue
+        r = P[n].grad
+        if float(r.norm()) < 1e-6 * scale:
+            continue
+        worst.append((float((g32[n] - r).norm() / r.norm()), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= GRAD_TOL * 2, worst[:5]
+    # bf16 kernels (the fast paths the benchmark runs) against the fp32 ones: same step, bf16 rounding only
+    out16, loss16, g16 = run(torch.bfloat16)
+    assert abs(loss16 - loss32) <= 2e-2 * abs(loss32)
+    bad = []
+    for n in names:
+        if n not in g32 or n not in g16 or zero_by_construction(n) or float(g32[n].norm()) < 1e-4 * scale:
+            continue
+        a, b = g16[n].reshape(-1), g32[n].reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm() / b.norm())
+        if a.numel() <= 2:
+            # scalar parameters (RRCV.beta, CCF gamma, fusion weights): one sum of ~3 M signed bf16 products with heavy
+            # cancellation, so only sign and order of magnitude are meaningful between the two precisions
+            if cos < 0.98 or not (0.4 <= ratio <= 2.5):
+                bad.append((n, round(cos, 4), round(ratio, 4)))
+            continue
+        if cos < 0.98 or not (0.9 <= ratio <= 1.1):
+            bad.append((n, round(cos, 4), round(ratio, 4)))
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("variant", ["v1", "v2"])
 def test_qavit_224_vs_oracle(Q, oracle, variant):
     """QA-ViT at its own default size (224 px, patch 16: N=196, 7x7 windows, 135 MSDA landmarks of which 128 are keys):
