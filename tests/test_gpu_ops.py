@@ -325,9 +325,10 @@ def test_attn_cross_like_and_nan_guard(F, dtype):
 
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,M", [(64, 16), (256, 64)])
-def test_tokmix_upmix(F, dtype, N, M):
-    B, C = 11, 192
+@pytest.mark.parametrize("N,M,B", [(64, 16, 11), (256, 64, 11), (64, 16, 700), (256, 64, 530)])
+def test_tokmix_upmix(F, dtype, N, M, B):
+    """B = 700 / 530: more images than the up-mix backward's 512 workgroups, so its dW / dgamma partials span images."""
+    C = 192
     scores = leaf(B, N, M, seed=100).detach().to(dtype).requires_grad_(True)
     x = leaf(B, N, C, seed=101).detach().to(dtype).requires_grad_(True)
     xc = F.TokMixFn.apply(scores, x)
@@ -417,9 +418,11 @@ def test_ccf_mid(F, dtype, Hs, flags):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("ks,C,H", [(7, 64, 8), (7, 256, 8), (3, 128, 8), (5, 100, 8), (7, 64, 16), (3, 100, 16), (5, 192, 16), (3, 128, 24), (7, 64, 12)])
-def test_dwconv_tokens(F, dtype, ks, C, H):
-    B = 21
+@pytest.mark.parametrize("case", [(7, 64, 8), (7, 256, 8), (3, 128, 8), (5, 100, 8), (7, 64, 16), (3, 100, 16), (5, 192, 16), (3, 128, 24), (7, 64, 12), (3, 64, 16, 700), (7, 64, 8, 1200)])
+def test_dwconv_tokens(F, dtype, case):
+    """4-tuples carry a batch large enough that a wave visits several (image, tile) units and its tap sums span them."""
+    ks, C, H = case[:3]
+    B = case[3] if len(case) > 3 else 21
     x = leaf(B, H * H, C, seed=130).detach().to(dtype).requires_grad_(True)
     w = leaf(C, 1, ks, ks, scale=0.2, seed=131)
     b = leaf(C, scale=0.2, seed=132)
