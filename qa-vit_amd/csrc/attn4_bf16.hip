@@ -21,6 +21,14 @@ namespace qv {
 
 namespace {
 
+// 4 accumulator values of a TRANSPOSED product = 4 consecutive elements of one output row: one 8-byte store
+__device__ __forceinline__ bf16x4 row4(const f32x4& acc) {
+  bf16x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (bf16)acc[r];
+  return v;
+}
+
 struct A4Lds {   // offsets in bf16 elements unless noted
   int ldd, ldk, lde;
   int kf, vf, kt, vt, ek, ev;          // shared by the workgroup
@@ -228,20 +236,17 @@ __global__ __launch_bounds__(256) void attn4_kernel(qavit_attn_args a) {
         acc_to_lds(Wp, L.ldk, 0, nt * 16, s[nt]);
       }
       wave_sync();
+      const int64_t my_q = attn_qrow(a, g, q0 + (col < rows ? col : 0));      // this lane's query row in the global matrices
       if (!BWD) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int nt = 0; nt < NKT; ++nt)
-            acc = mma16(rowfrag(Wp, L.ldk, 0, nt * 16), trfrag(sm + L.vf, L.ldd, nt * 16, dt * 16), acc);
+          for (int nt = 0; nt < NKT; ++nt)       // O^T[d][query]: this lane = query row `col`, 4 consecutive d
+            acc = mma16(trfrag(sm + L.vf, L.ldd, nt * 16, dt * 16), rowfrag(Wp, L.ldk, 0, nt * 16), acc);
           bad |= (acc[0] != acc[0]) | (acc[1] != acc[1]) | (acc[2] != acc[2]) | (acc[3] != acc[3]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 4 * q4 + r;
-            if (row < rows && dt * 16 + col < D)
-              og[attn_qrow(a, g, q0 + row) * a.ldo + h * D + dt * 16 + col] = (bf16)acc[r];
-          }
+          if (col < rows && dt * 16 + 4 * q4 < D)
+            *reinterpret_cast<bf16x4*>(og + my_q * a.ldo + h * D + dt * 16 + 4 * q4) = row4(acc);
         }
       } else {
         f32x4 dp[NKT];
@@ -269,20 +274,16 @@ __global__ __launch_bounds__(256) void attn4_kernel(qavit_attn_args a) {
         for (int dt = 0; dt < DT; ++dt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int nt = 0; nt < NKT; ++nt)
-            acc = mma16(rowfrag(Wds, L.ldk, 0, nt * 16), trfrag(sm + L.kf, L.ldd, nt * 16, dt * 16), acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 4 * q4 + r;
-            if (row < rows && dt * 16 + col < D)
-              dqg[attn_qrow(a, g, q0 + row) * a.lddq + h * D + dt * 16 + col] = (bf16)acc[r];
-          }
+          for (int nt = 0; nt < NKT; ++nt)       // dQ^T[d][query]
+            acc = mma16(trfrag(sm + L.kf, L.ldd, nt * 16, dt * 16), rowfrag(Wds, L.ldk, 0, nt * 16), acc);
+          if (col < rows && dt * 16 + 4 * q4 < D)
+            *reinterpret_cast<bf16x4*>(dqg + my_q * a.lddq + h * D + dt * 16 + 4 * q4) = row4(acc);
           const s16x4 bq = trfrag(Wq, L.ldd, 0, dt * 16);
           const s16x4 bo = trfrag(Wdo, L.ldd, 0, dt * 16);
 #pragma unroll
-          for (int nt = 0; nt < NKT; ++nt) {
-            gK[nt][dt] = mma16(trfrag(Wds, L.ldk, 0, nt * 16), bq, gK[nt][dt]);
-            gV[nt][dt] = mma16(trfrag(Wp, L.ldk, 0, nt * 16), bo, gV[nt][dt]);
+          for (int nt = 0; nt < NKT; ++nt) {     // dKf^T[d][key], dVf^T[d][key]: lane = key `nt*16 + col`, 4 consecutive d
+            gK[nt][dt] = mma16(bq, trfrag(Wds, L.ldk, 0, nt * 16), gK[nt][dt]);
+            gV[nt][dt] = mma16(bo, trfrag(Wp, L.ldk, 0, nt * 16), gV[nt][dt]);
           }
         }
       }
@@ -297,13 +298,17 @@ __global__ __launch_bounds__(256) void attn4_kernel(qavit_attn_args a) {
 #pragma unroll
           for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt) {
+              f32x4* rk = reinterpret_cast<f32x4*>(Rk + (nt * 16 + col) * RS + dt * 16 + 4 * q4);   // key row, 4 consecutive d
+              f32x4* rv = reinterpret_cast<f32x4*>(Rv + (nt * 16 + col) * RS + dt * 16 + 4 * q4);
+              if (w == 0) { *rk = gK[nt][dt]; *rv = gV[nt][dt]; }
+              else {
+                f32x4 tk = *rk, tv = *rv;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int o = (nt * 16 + 4 * q4 + r) * RS + dt * 16 + col;
-                if (w == 0) { Rk[o] = gK[nt][dt][r]; Rv[o] = gV[nt][dt][r]; }
-                else { Rk[o] += gK[nt][dt][r]; Rv[o] += gV[nt][dt][r]; }
+                for (int r = 0; r < 4; ++r) { tk[r] += gK[nt][dt][r]; tv[r] += gV[nt][dt][r]; }
+                *rk = tk; *rv = tv;
               }
+            }
         }
         __syncthreads();                     // after the last turn every wave is out of its tile loop: Kf / Vf are dead
       }

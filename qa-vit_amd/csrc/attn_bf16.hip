@@ -19,6 +19,14 @@
 
 namespace qv {
 
+// 4 accumulator values of a TRANSPOSED product = 4 consecutive elements of one output row: one 8-byte store
+__device__ __forceinline__ bf16x4 row4(const f32x4& acc) {
+  bf16x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (bf16)acc[r];
+  return v;
+}
+
 struct A2Lds {   // offsets in bf16 elements unless noted
   int ldd, ldk, lde;
   int q, d_o, p, ds, kt, vt, ek, ev, kf, vf, dkf, dvf;
@@ -236,20 +244,17 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
         acc_to_lds(sm + L.p, L.ldk, 0, nt * 16, s[nt]);
       }
       __syncthreads();
+      const int64_t my_q = attn_qrow(a, g, q0 + (col < rows ? col : 0));      // this lane's query row in the global matrices
       if (!BWD) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int nt = 0; nt < NKT; ++nt)
-            acc = mma16(rowfrag(sm + L.p, L.ldk, 0, nt * 16), trfrag(sm + L.vf, L.ldd, nt * 16, dt * 16), acc);
+          for (int nt = 0; nt < NKT; ++nt)       // O^T[d][query]: this lane = query row `col`, 4 consecutive d
+            acc = mma16(trfrag(sm + L.vf, L.ldd, nt * 16, dt * 16), rowfrag(sm + L.p, L.ldk, 0, nt * 16), acc);
           bad |= (acc[0] != acc[0]) | (acc[1] != acc[1]) | (acc[2] != acc[2]) | (acc[3] != acc[3]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 4 * q4 + r;
-            if (row < rows && dt * 16 + col < D)
-              og[attn_qrow(a, g, q0 + row) * a.ldo + h * D + dt * 16 + col] = (bf16)acc[r];
-          }
+          if (col < rows && dt * 16 + 4 * q4 < D)
+            *reinterpret_cast<bf16x4*>(og + my_q * a.ldo + h * D + dt * 16 + 4 * q4) = row4(acc);
         }
       } else {
         // dP = dO . Vf^T ; dS = P * (dP - rowdot) * scale
@@ -279,20 +284,16 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
         for (int dt = 0; dt < DT; ++dt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int nt = 0; nt < NKT; ++nt)
-            acc = mma16(rowfrag(sm + L.ds, L.ldk, 0, nt * 16), trfrag(sm + L.kf, L.ldd, nt * 16, dt * 16), acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 4 * q4 + r;
-            if (row < rows && dt * 16 + col < D)
-              dqg[attn_qrow(a, g, q0 + row) * a.lddq + h * D + dt * 16 + col] = (bf16)acc[r];
-          }
+          for (int nt = 0; nt < NKT; ++nt)       // dQ^T[d][query]
+            acc = mma16(trfrag(sm + L.kf, L.ldd, nt * 16, dt * 16), rowfrag(sm + L.ds, L.ldk, 0, nt * 16), acc);
+          if (col < rows && dt * 16 + 4 * q4 < D)
+            *reinterpret_cast<bf16x4*>(dqg + my_q * a.lddq + h * D + dt * 16 + 4 * q4) = row4(acc);
           const s16x4 bq = trfrag(sm + L.q, L.ldd, 0, dt * 16);
           const s16x4 bo = trfrag(sm + L.d_o, L.ldd, 0, dt * 16);
 #pragma unroll
-          for (int nt = 0; nt < NKT; ++nt) {
-            gK[nt][dt] = mma16(trfrag(sm + L.ds, L.ldk, 0, nt * 16), bq, gK[nt][dt]);
-            gV[nt][dt] = mma16(trfrag(sm + L.p, L.ldk, 0, nt * 16), bo, gV[nt][dt]);
+          for (int nt = 0; nt < NKT; ++nt) {     // dKf^T[d][key], dVf^T[d][key]: lane = key `nt*16 + col`, 4 consecutive d
+            gK[nt][dt] = mma16(bq, trfrag(sm + L.ds, L.ldk, 0, nt * 16), gK[nt][dt]);
+            gV[nt][dt] = mma16(bo, trfrag(sm + L.p, L.ldk, 0, nt * 16), gV[nt][dt]);
           }
         }
       }
@@ -305,19 +306,21 @@ __global__ __launch_bounds__(64) void attn2_kernel(qavit_attn_args a) {
       for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          acc_to_lds(sm + L.dkf, L.ldd, nt * 16, dt * 16, gK[nt][dt]);
-          acc_to_lds(sm + L.dvf, L.ldd, nt * 16, dt * 16, gV[nt][dt]);
+          const int row = nt * 16 + col, c0 = dt * 16 + 4 * q4;            // key row, first of this lane's 4 columns
+          *reinterpret_cast<bf16x4*>(sm + L.dkf + row * L.ldd + c0) = row4(gK[nt][dt]);
+          *reinterpret_cast<bf16x4*>(sm + L.dvf + row * L.ldd + c0) = row4(gV[nt][dt]);
+          if (c0 < D) {
+            if (row >= NKo && row < NK) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = nt * 16 + 4 * q4 + r, cc = dt * 16 + col;
-            if (row >= NKo && row < NK && cc < D) {
-              accSk[(row - NKo) * D + cc] += gK[nt][dt][r];
-              accSv[(row - NKo) * D + cc] += gV[nt][dt][r];
+              for (int r = 0; r < 4; ++r) {
+                accSk[(row - NKo) * D + c0 + r] += gK[nt][dt][r];
+                accSv[(row - NKo) * D + c0 + r] += gV[nt][dt][r];
+              }
             }
-            if (MODE == 1 && row < NKo && cc < D) {
+            if (MODE == 1 && row < NKo) {
               const int64_t kr = attn_krow(a, g, row);
-              dktg[kr * a.lddk + h * D + cc] = (bf16)gK[nt][dt][r];
-              dvtg[kr * a.lddv + h * D + cc] = (bf16)gV[nt][dt][r];
+              *reinterpret_cast<bf16x4*>(dktg + kr * a.lddk + h * D + c0) = row4(gK[nt][dt]);
+              *reinterpret_cast<bf16x4*>(dvtg + kr * a.lddv + h * D + c0) = row4(gV[nt][dt]);
             }
           }
         }
@@ -399,6 +402,9 @@ int attn_bf16_try(const qavit_attn_args& a, bool bwd, int grid, hipStream_t st) 
   if (a.L > 0 && (!al(a.k_tok, 8) || !al(a.v_tok, 8))) return 0;
   if (a.mode == 0 && (!al(a.E_k, 16) || !al(a.E_v, 16))) return 0;
   if (bwd && (a.lddo % 4 || !al(a.d_o, 8))) return 0;
+  // 8-byte row-fragment stores of the transposed products
+  if (!bwd && (a.ldo % 4 || !al(a.o, 8))) return 0;
+  if (bwd && (a.lddq % 4 || !al(a.dq, 8) || (a.L > 0 && (a.lddk % 4 || a.lddv % 4 || !al(a.dk_tok, 8) || !al(a.dv_tok, 8))))) return 0;
   {
     static int use3 = -1;
     if (use3 < 0) { const char* e = getenv("QAVIT_ATTN3"); use3 = e ? atoi(e) : 1; }
