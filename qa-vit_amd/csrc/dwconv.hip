@@ -273,8 +273,26 @@ __device__ __forceinline__ void dw_halo_row(const T* src, float (&xr)[HR], int b
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The tap loops run on PAIRS of adjacent outputs: (o[xx], o[xx+1]) += w * (x[xx+d], x[xx+d+1]) is one v_pk_fma_f32 --
+// two fp32 FMAs per lane per issue slot -- against the row kept as even-aligned and odd-aligned register pairs.
+template <int HR>
+struct RowPairs {
+  f32x2 e[HR / 2];          // (x[2j], x[2j+1])
+  f32x2 o[HR / 2];          // (x[2j+1], x[2j+2])   (last one's .y unused when HR is even)
+  __device__ __forceinline__ void set(const float (&x)[HR]) {
+#pragma unroll
+    for (int j = 0; j < HR / 2; ++j) {
+      e[j] = f32x2{x[2 * j], x[2 * j + 1]};
+      o[j] = f32x2{x[2 * j + 1], (2 * j + 2 < HR) ? x[2 * j + 2] : 0.f};
+    }
+  }
+  __device__ __forceinline__ f32x2 at(int k) const { return (k & 1) ? o[k >> 1] : e[k >> 1]; }     // (x[k], x[k+1]), k constant
+};
+
 template <typename T, int KS, bool FLIP>
-__device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS * KS], float (&o)[8][8], int b, int y0, int x0, int H, int W, int C, int cc) {
+__device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS * KS], f32x2 (&o)[8][4], int b, int y0, int x0, int H, int W, int C, int cc) {
   constexpr int TS = 8, R = KS / 2, HR = TS + 2 * R;
   float xr[HR], xn[HR];
   dw_halo_row<T, HR>(src, xr, b, y0, x0, H, W, C, cc);
@@ -282,17 +300,19 @@ __device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS 
   for (int r = 0; r < HR; ++r) {
     if (r + 1 < HR) dw_halo_row<T, HR>(src, xn, b, y0 + r + 1, x0, H, W, C, cc);     // one row ahead, no further
     asm volatile("" ::: "memory");
+    RowPairs<HR> rp;
+    rp.set(xr);
 #pragma unroll
     for (int yy = 0; yy < TS; ++yy) {
       const int dyy = r - yy;
       if (dyy < 0 || dyy >= KS) continue;
 #pragma unroll
-      for (int xx = 0; xx < TS; ++xx)
+      for (int dxx = 0; dxx < KS; ++dxx) {
+        const int tap = FLIP ? (KS - 1 - dyy) * KS + (KS - 1 - dxx) : dyy * KS + dxx;
+        const f32x2 w2 = f32x2{wt[tap], wt[tap]};
 #pragma unroll
-        for (int dxx = 0; dxx < KS; ++dxx) {
-          const int tap = FLIP ? (KS - 1 - dyy) * KS + (KS - 1 - dxx) : dyy * KS + dxx;
-          o[yy][xx] += wt[tap] * xr[xx + dxx];
-        }
+        for (int p = 0; p < TS / 2; ++p) o[yy][p] = __builtin_elementwise_fma(w2, rp.at(2 * p + dxx), o[yy][p]);
+      }
     }
 #pragma unroll
     for (int ci = 0; ci < HR; ++ci) xr[ci] = xn[ci];
@@ -313,17 +333,17 @@ __global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const floa
   const int TX = W / TS, TPI = (H / TS) * TX, units = B * TPI;
   for (int u = blockIdx.y * 4 + wave; u < units; u += gridDim.y * 4) {
     const int b = u / TPI, t = u - b * TPI, ty = t / TX, tx = t - ty * TX;
-    float o[TS][TS];
+    f32x2 o[TS][TS / 2];
 #pragma unroll
     for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
-      for (int xx = 0; xx < TS; ++xx) o[yy][xx] = bv;
+      for (int p = 0; p < TS / 2; ++p) o[yy][p] = f32x2{bv, bv};
     dw_tile_rows<T, KS, false>(x, wt, o, b, ty * TS - R, tx * TS - R, H, W, C, cc);
     if (cok) {
 #pragma unroll
       for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
-        for (int xx = 0; xx < TS; ++xx) y[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx]);
+        for (int xx = 0; xx < TS; ++xx) y[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx >> 1][xx & 1]);
     }
   }
 }
@@ -347,24 +367,27 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
       float wt[KK];
 #pragma unroll
       for (int i = 0; i < KK; ++i) wt[i] = w[(size_t)cc * KK + i];
-      float o[TS][TS];
+      f32x2 o[TS][TS / 2];
 #pragma unroll
       for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
-        for (int xx = 0; xx < TS; ++xx) o[yy][xx] = 0.f;
+        for (int p = 0; p < TS / 2; ++p) o[yy][p] = f32x2{0.f, 0.f};
       dw_tile_rows<T, KS, true>(dy, wt, o, b, ty * TS - R, tx * TS - R, H, W, C, cc);
       if (cok) {
 #pragma unroll
         for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
-          for (int xx = 0; xx < TS; ++xx) dx[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx]);
+          for (int xx = 0; xx < TS; ++xx) dx[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx >> 1][xx & 1]);
       }
     }
-    float g[TS][TS];
+    f32x2 g[TS][TS / 2];
 #pragma unroll
     for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
-      for (int xx = 0; xx < TS; ++xx) { g[yy][xx] = to_f<T>(dy[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + cc]); ab += g[yy][xx]; }
+      for (int xx = 0; xx < TS; ++xx) {
+        const float v = to_f<T>(dy[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + cc]);
+        g[yy][xx >> 1][xx & 1] = v; ab += v;
+      }
     // dw[dyy][dxx] += sum_{yy,xx} dy[yy][xx] * x[yy+dyy-R][xx+dxx-R]: halo rows of x streamed against the dy tile
     float xr[HR], xn[HR];
     dw_halo_row<T, HR>(x, xr, b, ty * TS - R, tx * TS - R, H, W, C, cc);
@@ -372,16 +395,18 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
     for (int r = 0; r < HR; ++r) {
       if (r + 1 < HR) dw_halo_row<T, HR>(x, xn, b, ty * TS - R + r + 1, tx * TS - R, H, W, C, cc);
       asm volatile("" ::: "memory");
+      RowPairs<HR> rp;
+      rp.set(xr);
 #pragma unroll
       for (int yy = 0; yy < TS; ++yy) {
         const int dyy = r - yy;
         if (dyy < 0 || dyy >= KS) continue;
 #pragma unroll
         for (int dxx = 0; dxx < KS; ++dxx) {
-          float s_ = 0.f;
+          f32x2 s2 = f32x2{0.f, 0.f};
 #pragma unroll
-          for (int xx = 0; xx < TS; ++xx) s_ += g[yy][xx] * xr[xx + dxx];
-          aw[dyy * KS + dxx] += s_;
+          for (int p = 0; p < TS / 2; ++p) s2 = __builtin_elementwise_fma(g[yy][p], rp.at(2 * p + dxx), s2);
+          aw[dyy * KS + dxx] += s2[0] + s2[1];
         }
       }
 #pragma unroll
