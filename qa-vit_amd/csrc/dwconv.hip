@@ -302,10 +302,11 @@ __device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS 
     asm volatile("" ::: "memory");
     RowPairs<HR> rp;
     rp.set(xr);
+    const bool row_in = (y0 + r >= 0) && (y0 + r < H);       // rows outside the map are all zero: nothing to add
 #pragma unroll
     for (int yy = 0; yy < TS; ++yy) {
       const int dyy = r - yy;
-      if (dyy < 0 || dyy >= KS) continue;
+      if (dyy < 0 || dyy >= KS || !row_in) continue;
 #pragma unroll
       for (int dxx = 0; dxx < KS; ++dxx) {
         const int tap = FLIP ? (KS - 1 - dyy) * KS + (KS - 1 - dxx) : dyy * KS + dxx;
@@ -319,9 +320,11 @@ __device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS 
   }
 }
 
-template <typename T, int KS>
-__global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H, int W, int C) {
+// ONE8: the map IS one 8x8 tile (H = W = 8 known at compile time: out-of-map rows / columns and their loads fold away)
+template <typename T, int KS, bool ONE8>
+__global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H_, int W_, int C) {
   constexpr int TS = 8, R = KS / 2, KK = KS * KS;
+  const int H = ONE8 ? 8 : H_, W = ONE8 ? 8 : W_;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.x * 64 + lane;
   const bool cok = c < C;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const floa
   const float bv = bias ? bias[cc] : 0.f;
   const int TX = W / TS, TPI = (H / TS) * TX, units = B * TPI;
   for (int u = blockIdx.y * 4 + wave; u < units; u += gridDim.y * 4) {
-    const int b = u / TPI, t = u - b * TPI, ty = t / TX, tx = t - ty * TX;
+    const int b = ONE8 ? u : u / TPI, t = u - b * TPI, ty = ONE8 ? 0 : t / TX, tx = ONE8 ? 0 : t - ty * TX;
     f32x2 o[TS][TS / 2];
 #pragma unroll
     for (int yy = 0; yy < TS; ++yy)
@@ -348,9 +351,10 @@ __global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const floa
   }
 }
 
-template <typename T, int KS>
-__global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int H, int W, int C) {
+template <typename T, int KS, bool ONE8>
+__global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int H_, int W_, int C) {
   constexpr int TS = 8, R = KS / 2, KK = KS * KS, HR = TS + 2 * R;
+  const int H = ONE8 ? 8 : H_, W = ONE8 ? 8 : W_;
   __shared__ float red[4][64 * KK + 64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c0 = blockIdx.x * 64, c = c0 + lane;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
   float ab = 0.f;
   const int TX = W / TS, TPI = (H / TS) * TX, units = B * TPI;
   for (int u = blockIdx.y * 4 + wave; u < units; u += gridDim.y * 4) {
-    const int b = u / TPI, t = u - b * TPI, ty = t / TX, tx = t - ty * TX;
+    const int b = ONE8 ? u : u / TPI, t = u - b * TPI, ty = ONE8 ? 0 : t / TX, tx = ONE8 ? 0 : t - ty * TX;
     {
       float wt[KK];
 #pragma unroll
@@ -397,10 +401,11 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
       asm volatile("" ::: "memory");
       RowPairs<HR> rp;
       rp.set(xr);
+      const bool row_in = (ty * TS - R + r >= 0) && (ty * TS - R + r < H);
 #pragma unroll
       for (int yy = 0; yy < TS; ++yy) {
         const int dyy = r - yy;
-        if (dyy < 0 || dyy >= KS) continue;
+        if (dyy < 0 || dyy >= KS || !row_in) continue;
 #pragma unroll
         for (int dxx = 0; dxx < KS; ++dxx) {
           f32x2 s2 = f32x2{0.f, 0.f};
@@ -431,6 +436,15 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
                      int B, int H, int W, int C, hipStream_t st) {
   const int N = H * W;
   const int chunks = (C + DW_CH - 1) / DW_CH;
+  static const int pk8 = getenv("QAVIT_DW8_PK") ? atoi(getenv("QAVIT_DW8_PK")) : 1;      // 8x8 maps on the packed-FMA tile kernels (0: the scalar-FMA dwconv_fwd8 / bwd8)
+  if (pk8 && H == 8 && W == 8) {
+    int gy = (B + 3) / 4;
+    const int cap = (bwd ? 256 : 1024) / chunks > 0 ? (bwd ? 256 : 1024) / chunks : 1;
+    if (gy > cap) gy = cap;
+    if (!bwd) hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
+    else hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
+    return check_launch("dwconv8(pk)");
+  }
   if (!bwd && H == 8 && W == 8) {
     int gy8 = (B + 3) / 4;
     const int cap = 1024 / chunks > 0 ? 1024 / chunks : 1;
@@ -445,10 +459,10 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
     const int cap = (bwd ? 512 : 2048) / chunks > 0 ? (bwd ? 512 : 2048) / chunks : 1;
     if (gy > cap) gy = cap;
     if (!bwd) {
-      hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
+      hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
       return check_launch("dwconv_fwdt");
     }
-    hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
+    hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
     return check_launch("dwconv_bwdt");
   }
   if (!bwd) {
