@@ -2,6 +2,7 @@
 // HBM-bound: every activation element is read once and written once; the 3x3 depthwise stencil, both
 // LayerNorms and (in backward) all parameter-gradient partial sums stay in LDS.  One workgroup per image.
 #include "common.cuh"
+#include <stdlib.h>
 #include "../../include/qavit.h"
 #include "launch.h"
 
@@ -395,7 +396,8 @@ extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
   const size_t smem = ((size_t)4 * a->Hs * a->Ws * a->C + 15 * (size_t)a->C) * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_bwd: image tile too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int grid = a->B < 512 ? a->B : 512;
+  static const int cgrid = getenv("QAVIT_CCF_BWD_GRID") ? atoi(getenv("QAVIT_CCF_BWD_GRID")) : 512;
+  const int grid = a->B < cgrid ? a->B : cgrid;
   if (a->C <= 256 && a->Hs * a->Ws >= 15) {             // register-partial kernel (its wave fold needs 60*C floats of the image buffers)
     const int cp = (a->C + 63) / 64;
 #define CCF2(T_, CP_) { if (a->Hs * a->Ws >= 64) { \

@@ -2,6 +2,7 @@
 // tiles + v_mfma_f32_16x16x16_bf16 (frag16.cuh).  The generic fp32 / any-shape versions stay in bank.hip and
 // tokens.hip; each `*_try` returns 1 when it took the launch, 0 when the shape is not covered.
 #include "common.cuh"
+#include <stdlib.h>
 #include "frag16.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
@@ -379,7 +380,8 @@ static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, 
   const size_t smem = (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2 + (size_t)(L::N + 8 * L::C) * 4;
   if (smem > 150 * 1024) return -100;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_bwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((upmix2_bwd_kernel<NT, MT, CT>), dim3(B < 512 ? B : 512), dim3(256), smem, st, (const bf16*)a0, (const bf16*)xc, W, bias, gamma,
+  static const int bgrid = getenv("QAVIT_UPMIX_BWD_GRID") ? atoi(getenv("QAVIT_UPMIX_BWD_GRID")) : 256;      // one workgroup per CU: the dW / dgamma atomic flush, not the images, bounds it
+  hipLaunchKernelGGL((upmix2_bwd_kernel<NT, MT, CT>), dim3(B < bgrid ? B : bgrid), dim3(256), smem, st, (const bf16*)a0, (const bf16*)xc, W, bias, gamma,
                      mean, rstd, (bf16*)o0, dW, dbias, dgamma, dbeta, B);
   return QAVIT_OK;
 }
