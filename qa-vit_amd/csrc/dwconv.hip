@@ -439,7 +439,8 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
   static const int pk8 = getenv("QAVIT_DW8_PK") ? atoi(getenv("QAVIT_DW8_PK")) : 1;      // 8x8 maps on the packed-FMA tile kernels (0: the scalar-FMA dwconv_fwd8 / bwd8)
   if (pk8 && H == 8 && W == 8) {
     int gy = (B + 3) / 4;
-    const int cap = (bwd ? 256 : 1024) / chunks > 0 ? (bwd ? 256 : 1024) / chunks : 1;
+    static const int w8 = getenv("QAVIT_DWT8_BWD_WGS") ? atoi(getenv("QAVIT_DWT8_BWD_WGS")) : 256;
+    const int cap = (bwd ? w8 : 1024) / chunks > 0 ? (bwd ? w8 : 1024) / chunks : 1;
     if (gy > cap) gy = cap;
     if (!bwd) hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
     else hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
@@ -456,7 +457,8 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
   if (tiled && H % 8 == 0 && W % 8 == 0 && H * W > 64) {
     const int units = B * (H / 8) * (W / 8);
     int gy = (units + 3) / 4;
-    const int cap = (bwd ? 512 : 2048) / chunks > 0 ? (bwd ? 512 : 2048) / chunks : 1;
+    static const int wt_ = getenv("QAVIT_DWT_BWD_WGS") ? atoi(getenv("QAVIT_DWT_BWD_WGS")) : 256;
+    const int cap = (bwd ? wt_ : 2048) / chunks > 0 ? (bwd ? wt_ : 2048) / chunks : 1;
     if (gy > cap) gy = cap;
     if (!bwd) {
       hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
