@@ -48,6 +48,8 @@ const char* qavit_last_error(void);
  * a_mode 0: A as stored.
  * a_mode 1: A := (A - ln_mean[m]) * ln_rstd[m] * ln_gamma + ln_beta (nn.LayerNorm fused as prologue: the row
  *           statistics are INPUTS, produced by qavit_row_stats; the normalised rows are never written to HBM).
+ * a_mode 3: as a_mode 1, but ln_mean / ln_rstd are OUTPUTS: the call computes the row statistics itself (inside the K-loop
+ *           kernel's prologue where that kernel applies, by a row_stats launch otherwise) and leaves them for the backward.
  * a_mode 2: A := A * droppath(a_dp) * dropout(a_drop) * gelu'(a_Z)   -- the backward of a layer's epilogue
  *           applied to its incoming gradient; the transformed tile is also written to a_out (dZ).
  * epilogue: v = acc + bias; Z := v (if Z); v = gelu(v) (act==1); v *= dropout; v *= scale; v *= droppath; v += R.

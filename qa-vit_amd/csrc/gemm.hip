@@ -810,6 +810,22 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   if ((a->dp_p > 0.f && a->dp_rows <= 0) || (a->a_dp_p > 0.f && a->a_dp_rows <= 0))
     return set_error(QAVIT_EINVAL, "gemm_nt: drop-path needs rows-per-sample");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->a_mode == 3) {
+    // LayerNorm prologue whose row statistics are OUTPUTS of this call: the K-loop kernel computes them in its prologue;
+    // every other route runs the row_stats kernel first and continues as a_mode 1
+    if (!a->ln_gamma || !a->ln_beta || !a->ln_mean || !a->ln_rstd) return set_error(QAVIT_EINVAL, "gemm_nt: a_mode 3 needs gamma/beta and statistics buffers");
+    if (a->dtype == QAVIT_BF16) {
+      const int took = gemm_nt_big_try(*a, st);
+      if (took < 0) return took;
+      if (took == 1) return QAVIT_OK;
+    }
+    if (a->lda != a->K) return set_error(QAVIT_EINVAL, "gemm_nt: a_mode 3 needs contiguous A rows on this route");
+    const int rc = qavit_row_stats(a->dtype, a->A, a->ln_eps, a->M, a->K, a->ln_mean, a->ln_rstd, stream);
+    if (rc) return rc;
+    qavit_gemm_args b = *a;
+    b.a_mode = 1;
+    return qavit_gemm_nt(&b, stream);
+  }
   if (a->dtype == QAVIT_F32 || a->dtype == QAVIT_BF16) {
     const int took = a->dtype == QAVIT_F32 ? skinny_try<float>(*a, st) : skinny_try<bf16>(*a, st);
     if (took < 0) return took;

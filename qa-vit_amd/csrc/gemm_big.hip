@@ -110,7 +110,7 @@ __device__ __forceinline__ void epilogue16(const qavit_gemm_args& g, const EpiKe
 
 // Preconditions (checked by gemm_nt_big_try): K % 32 == 0; A / a_Z / a_out / B rows 16-byte aligned.
 template <int BM_, int BN_, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int n_tiles_m, int ncb) {
+__global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int n_tiles_m, int ncb, int stats_in) {
   constexpr int TM = BM_ / 32, TN = BN_ / 32;       // 16x16 tiles per wave (rows, cols)
   constexpr int WN = BN_ / 2;                       // columns per wave
   constexpr int WLD = WN + 4;                       // epilogue scratch row stride (floats)
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
     const int m = m0 + sr + 32 * i;
     mu[i] = 0.f; rs[i] = 0.f; rowf[i] = 1.f;
     if (m < g.M) {
-      if (AMODE == 1) { mu[i] = g.ln_mean[m]; rs[i] = g.ln_rstd[m]; }
+      if (AMODE == 1 && !stats_in) { mu[i] = g.ln_mean[m]; rs[i] = g.ln_rstd[m]; }
       if (bwd) {
         rowf[i] = g.a_scale;
         if (g.a_dp_p > 0.f) rowf[i] *= drop_factor(key_adp, (uint32_t)(m / g.a_dp_rows), g.a_dp_p, a_dp_inv);
@@ -167,6 +167,41 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
   }
   if (AMODE == 1) {
     for (int k = tid; k < g.K; k += 256) { Gs[k] = g.ln_gamma[k]; Gs[g.K + k] = g.ln_beta[k]; }
+    if (stats_in) {
+      // a_mode 3: the row statistics are computed here (two passes over this workgroup's A rows, which the K loop reads
+      // again from L1/L2) instead of by a row_stats launch in front of the GEMM; the first column block writes them out
+      // for the backward.  The 8 threads that share a row (sv = tid & 7) are consecutive lanes.
+      const float invK = 1.f / (float)g.K;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const int m = m0 + sr + 32 * i;
+        const int mc = m < g.M ? m : g.M - 1;
+        float s = 0.f;
+        for (int k0 = 0; k0 < g.K; k0 += BK) {
+          const int k = k0 + sv * 8;
+          const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + (size_t)mc * g.lda + (k < g.K ? k : 0));
+          if (k < g.K) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)x[j];
+          }
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s * invK;
+        float q = 0.f;
+        for (int k0 = 0; k0 < g.K; k0 += BK) {
+          const int k = k0 + sv * 8;
+          const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + (size_t)mc * g.lda + (k < g.K ? k : 0));
+          if (k < g.K) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)x[j] - mean; q += d * d; }
+          }
+        }
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        const float rstd = rsqrtf(q * invK + g.ln_eps);
+        mu[i] = mean; rs[i] = rstd;
+        if (cb == 0 && sv == 0 && m < g.M) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }
+      }
+    }
   }
 
   bf16x8 pa[AV], pz[AV], pb[BV];
@@ -298,14 +333,14 @@ int big_launch(const qavit_gemm_args& g, hipStream_t st) {
     attr_done = true;
   }
   const int grid = (n_tiles_m + 7) / 8 * 8 * ncb;
-  hipLaunchKernelGGL((gemm_nt_big_kernel<BM_, BN_, AMODE, EPI>), dim3(grid), dim3(256), smem, st, g, n_tiles_m, ncb);
+  hipLaunchKernelGGL((gemm_nt_big_kernel<BM_, BN_, AMODE, EPI>), dim3(grid), dim3(256), smem, st, g, n_tiles_m, ncb, g.a_mode == 3 ? 1 : 0);
   return QAVIT_OK;
 }
 
 template <int BM_, int BN_>
 int big_modes(const qavit_gemm_args& g, hipStream_t st) {
   const bool full = g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f;
-  if (g.a_mode == 1) return full ? big_launch<BM_, BN_, 1, 1>(g, st) : big_launch<BM_, BN_, 1, 0>(g, st);
+  if (g.a_mode == 1 || g.a_mode == 3) return full ? big_launch<BM_, BN_, 1, 1>(g, st) : big_launch<BM_, BN_, 1, 0>(g, st);
   if (g.a_mode == 2) return full ? big_launch<BM_, BN_, 2, 1>(g, st) : big_launch<BM_, BN_, 2, 0>(g, st);
   return full ? big_launch<BM_, BN_, 0, 1>(g, st) : big_launch<BM_, BN_, 0, 0>(g, st);
 }

@@ -259,7 +259,7 @@ class LinearFn(Function):
         if ln_g is not None:
             ln = (ln_g, ln_b, opts.get("eps", 1e-5))
             stats = (torch.empty(M, dtype=torch.float32, device=x.device), torch.empty(M, dtype=torch.float32, device=x.device))
-            K.row_stats(x2, ln[2], M, Kd, stats[0], stats[1])
+            # a_mode 3: the GEMM computes the row statistics in its own prologue (or launches row_stats itself)
         r2 = None
         if resid is not None:
             r2 = resid.reshape(-1, n)
@@ -267,7 +267,7 @@ class LinearFn(Function):
                 r2 = r2.contiguous()
         esz = Wc.element_size()
         bias_ptr = None if b is None else b.data_ptr() + off * 4
-        a = dict(a_mode=1 if ln else 0, ln=ln, ln_stats=stats, Z=Z, act=act, drop=drop, dp=dp, R=r2, ldr=n, rng=rt.rng)
+        a = dict(a_mode=3 if ln else 0, ln=ln, ln_stats=stats, Z=Z, act=act, drop=drop, dp=dp, R=r2, ldr=n, rng=rt.rng)
         # bias pointer offset: pass a narrow view tensor to keep kernels.gemm_nt simple
         bview = None if b is None else b.detach()[off:off + n]
         K.gemm_nt(x2, Wc, y, M, n, Kd, Kd, Kd, n, bview, B_ptr=Wc.data_ptr() + off * Kd * esz, **a)

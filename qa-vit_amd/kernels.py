@@ -100,7 +100,7 @@ def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None,
     a.bias = _p(bias)
     a.a_mode = a_mode
     a.a_scale = 1.0
-    if a_mode == 1:
+    if a_mode in (1, 3):                      # 1: ln_stats are inputs (row_stats ran); 3: the call computes and writes them
         g, b_, eps = ln
         a.ln_gamma, a.ln_beta, a.ln_eps = g.data_ptr(), b_.data_ptr(), eps
         if ln_stats is not None:
