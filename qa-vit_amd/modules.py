@@ -426,8 +426,8 @@ class PatchEmbed(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------
-# CNN lateral path (second tier, SURVEY.md section 8f N1): convolutions / BatchNorm run on stock PyTorch-ROCm
-# ops (MIOpen) for now; every LayerNorm / Linear inside it already goes through the HIP kernels.
+# CNN lateral path (second tier, SURVEY.md section 8f N1), channel-last on the HIP kernels throughout: depthwise convs =
+# csrc/dwconv.hip, strided 3x3 = im2col + MFMA GEMM, 1x1 = GEMM, BatchNorm(+GELU) = csrc/bnorm.hip; no MIOpen call.
 # ---------------------------------------------------------------------------------------------------
 def _to_tokens(x):
     """[B,C,H,W] -> channel-last tokens [B, H*W, C] (one copy; everything downstream stays channel-last)."""
@@ -488,7 +488,7 @@ class ConvNeXtBlock(nn.Module):
 
 class CNNStemModel(nn.Module):
     """HQAViT_CIFAR100.py:742-793, channel-last throughout: the two strided 3x3 convolutions are im2col + MFMA GEMM,
-    the 1x1 convolutions are GEMMs, the depthwise 7x7 is csrc/dwconv.hip; only BatchNorm / GELU are stock ops."""
+    the 1x1 convolutions are GEMMs, the depthwise 7x7 is csrc/dwconv.hip, BatchNorm(+GELU) is csrc/bnorm.hip."""
 
     def __init__(self, in_ch=3, c2=64, c3=128, c4=256, norm_layer=nn.LayerNorm):
         super().__init__()
