@@ -174,6 +174,13 @@ typedef struct qavit_attn_args {
   void* dv_tok; int64_t lddv;
   float* ws; int64_t ws_floats;
   float* dE_k; float* dE_v; float* dsh_k; float* dsh_v;
+  /* attention-probability dropout = the dropout_p the reference hands to F.scaled_dot_product_attention
+   * (HQAViT_CIFAR100.py:390-392; call sites :461, :524, :587, :624 pass self.dropout.p in training):
+   * O = (softmax(S) * mask / (1 - drop_p)) V.  The mask is a pure function of (rng[0] = seed, rng[1] = step,
+   * drop_site, problem g*H+h, query i, key j) -- see attn_shared.h: attn_drop_factor -- so the backward call
+   * (same drop_p / drop_site / rng contents) regenerates it instead of reading a stored mask.
+   * drop_p == 0 or rng == NULL: no dropout. */
+  float drop_p; int drop_site; const int64_t* rng;
 } qavit_attn_args;
 
 int qavit_attn_fwd(const qavit_attn_args* a, void* stream);

@@ -150,8 +150,10 @@ __device__ __forceinline__ bool stage_keys(const qavit_attn_args& a, const AttnD
 }
 
 // scores of a 16-row query tile -> probabilities in sm[L.s] (row stride NKp)
+// DROP_FWD: the forward's tile leaves as P * dropout factor (the backward keeps P and applies the mask itself)
 template <bool BF>
-__device__ __forceinline__ void scores_softmax(const qavit_attn_args& a, const AttnDims& d, const AttnLds& L, float* sm, int rows, float scale) {
+__device__ __forceinline__ void scores_softmax(const qavit_attn_args& a, const AttnDims& d, const AttnLds& L, float* sm, int rows, float scale,
+                                               const AttnDrop& drop, uint32_t pkey, int q0, bool drop_fwd) {
   const int D = a.D;
   for (int nt = 0; nt * 16 < d.NK; ++nt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -169,7 +171,10 @@ __device__ __forceinline__ void scores_softmax(const qavit_attn_args& a, const A
     if (row < rows) for (int j = part; j < d.NK; j += 4) { const float e = __expf(srow[j] - mx); srow[j] = e; sum += e; }
     sum = group_sum<4>(sum);
     const float inv = 1.f / sum;
-    if (row < rows) for (int j = part; j < d.NK; j += 4) srow[j] *= inv;
+    if (row < rows) {
+      if (drop_fwd && drop.on) for (int j = part; j < d.NK; j += 4) srow[j] *= inv * attn_drop_factor(drop, pkey, q0 + row, j);
+      else for (int j = part; j < d.NK; j += 4) srow[j] *= inv;
+    }
   }
   __syncthreads();
 }
@@ -214,10 +219,12 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(qavit_attn_args a) {
   const int D = a.D;
   const float scale = rsqrtf((float)D);
   bool bad = false;
+  const AttnDrop drop = attn_drop_init(a);
   const T* q = reinterpret_cast<const T*>(a.q);
   T* o = reinterpret_cast<T*>(a.o);
   for (int pid = blockIdx.x; pid < a.G * a.H; pid += gridDim.x) {
     const int g = pid / a.H, h = pid - g * a.H;
+    const uint32_t pkey = attn_drop_pkey(drop, pid);
     __syncthreads();
     bad |= stage_keys<T, BF>(a, d, L, sm, g, h);
     for (int q0 = 0; q0 < a.Nq; q0 += 16) {
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(qavit_attn_args a) {
       __syncthreads();
       bad |= load_rows16<T>(a, g, q0, q, a.ldq, h, rows, D, sm + L.q);
       __syncthreads();
-      scores_softmax<BF>(a, d, L, sm, rows, scale);
+      scores_softmax<BF>(a, d, L, sm, rows, scale, drop, pkey, q0, true);
       for (int dt = 0; dt * 16 < D; ++dt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mma_tile<BF>(sm + L.s, d.NKp, 1, rows, sm + L.vf + dt * 16, D, 1, D - dt * 16, d.NK, acc);
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
   T* dq = reinterpret_cast<T*>(a.dq);
   T* dkt = reinterpret_cast<T*>(a.dk_tok);
   T* dvt = reinterpret_cast<T*>(a.dv_tok);
+  const AttnDrop drop = attn_drop_init(a);
   const int n_e = (a.mode == 0) ? 2 * a.L * a.KC : 0;
   const int n_acc = (SPILL ? 0 : n_e) + 2 * a.S * D;             // accumulators held in LDS (contiguous)
   const int acc0 = (a.mode == 0 && !SPILL) ? L.acc_ek : L.acc_shk;
@@ -271,29 +279,39 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(qavit_attn_args a) {
       load_rows16<T>(a, g, q0, q, a.ldq, h, rows, D, sm + L.q);
       load_rows16<T>(a, g, q0, dO, a.lddo, h, rows, D, sm + L.d_o);
       __syncthreads();
-      scores_softmax<BF>(a, d, L, sm, rows, scale);                          // P in sm[L.s]
-      // dP = dO . Vf^T ;  dVf += P^T . dO
+      scores_softmax<BF>(a, d, L, sm, rows, scale, drop, 0u, q0, false);     // P in sm[L.s]
+      // dP~ = dO . Vf^T  (gradient of the DROPPED probabilities P~ = P * m)
       for (int nt = 0; nt * 16 < d.NK; ++nt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = mma_tile<BF>(sm + L.d_o, D, 1, rows, sm + L.vf + nt * 16 * D, 1, D, d.NK - nt * 16, D, acc);
         tile_to_f32<false>(sm + L.dp + nt * 16, d.NKp, 1, rows, d.NK - nt * 16, acc);
+      }
+      __syncthreads();
+      {  // dP = m * dP~ ; dS = P * (dP - sum_j P*dP) * scale (in place in dp) ; the P tile becomes P~ for the dVf product
+        const int row = lane >> 2, part = lane & 3;
+        float* prow = sm + L.s + row * d.NKp;
+        float* drow = sm + L.dp + row * d.NKp;
+        const uint32_t pkey = attn_drop_pkey(drop, pid);
+        float dot = 0.f;
+        if (row < rows) {
+          if (drop.on) for (int j = part; j < d.NK; j += 4) drow[j] *= attn_drop_factor(drop, pkey, q0 + row, j);
+          for (int j = part; j < d.NK; j += 4) dot += prow[j] * drow[j];
+        }
+        dot = group_sum<4>(dot);
+        if (row < rows) for (int j = part; j < d.NK; j += 4) {
+          const float pj = prow[j];
+          drow[j] = pj * (drow[j] - dot) * scale;
+          if (drop.on) prow[j] = pj * attn_drop_factor(drop, pkey, q0 + row, j);
+        }
+      }
+      __syncthreads();
+      // dVf += P~^T . dO
+      for (int nt = 0; nt * 16 < d.NK; ++nt)
         for (int dt = 0; dt * 16 < D; ++dt) {
           f32x4 av = {0.f, 0.f, 0.f, 0.f};
           av = mma_tile<BF>(sm + L.s + nt * 16, 1, d.NKp, d.NK - nt * 16, sm + L.d_o + dt * 16, D, 1, D - dt * 16, rows, av);
           tile_to_f32<true>(sm + L.dvf + nt * 16 * D + dt * 16, D, 1, d.NK - nt * 16, D - dt * 16, av);
         }
-      }
-      __syncthreads();
-      {  // dS = P * (dP - sum_j P*dP) * scale   (in place in dp)
-        const int row = lane >> 2, part = lane & 3;
-        float* prow = sm + L.s + row * d.NKp;
-        float* drow = sm + L.dp + row * d.NKp;
-        float dot = 0.f;
-        if (row < rows) for (int j = part; j < d.NK; j += 4) dot += prow[j] * drow[j];
-        dot = group_sum<4>(dot);
-        if (row < rows) for (int j = part; j < d.NK; j += 4) drow[j] = prow[j] * (drow[j] - dot) * scale;
-      }
-      __syncthreads();
       // dQ = dS . Kf ;  dKf += dS^T . Q
       for (int dt = 0; dt * 16 < D; ++dt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
   bf16* dktg = reinterpret_cast<bf16*>(a.dk_tok);
   bf16* dvtg = reinterpret_cast<bf16*>(a.dv_tok);
   bool bad = false;
+  const AttnDrop drop = attn_drop_init(a);
 
   for (int i = lane; i < L.total; i += 64) sm[i] = (bf16)0.f;
   wave_sync();
@@ -235,8 +236,25 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
       for (int nt = 0; nt < NKT; ++nt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[nt][r] *= inv;
-        row4_to_lds(sm + L.p + col * LDK + nt * 16 + 4 * q4, s[nt]);
       }
+    }
+    // dropout on the probabilities: the P tile in LDS (operand of P.V and of dVf) holds P*m, the registers keep P
+    f32x4 dm[NKT];
+    if (drop.on) {
+      const uint32_t pkey = attn_drop_pkey(drop, pid);
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt) {
+        f32x4 pd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dm[nt][r] = attn_drop_factor(drop, pkey, col, nt * 16 + 4 * q4 + r);
+          pd[r] = s[nt][r] * dm[nt][r];
+        }
+        row4_to_lds(sm + L.p + col * LDK + nt * 16 + 4 * q4, pd);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt) row4_to_lds(sm + L.p + col * LDK + nt * 16 + 4 * q4, s[nt]);
     }
     wave_sync();
     const int64_t my_q = attn_qrow(a, g, col < a.Nq ? col : 0);     // this lane's query row (col) in the global matrices
@@ -261,6 +279,12 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
         for (int dt = 0; dt < DT; ++dt)
           acc = mma16(rowfrag(sm + L.vf, LDD, nt * 16, dt * 16), rowfrag(sm + L.d_o, LDD, 0, dt * 16), acc);
         dp[nt] = acc;
+      }
+      if (drop.on) {
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dp[nt][r] *= dm[nt][r];
       }
       {
         float dot = 0.f;

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void attn4_kernel(qavit_attn_args a) {
   bf16* dktg = reinterpret_cast<bf16*>(a.dk_tok);
   bf16* dvtg = reinterpret_cast<bf16*>(a.dv_tok);
   bool bad = false;
+  const AttnDrop drop = attn_drop_init(a);
 
   const int nE = (MODE == 0) ? a.L * a.KC : 0;
   const int nS = a.S * D;
@@ -229,11 +230,24 @@ __global__ __launch_bounds__(256) void attn4_kernel(qavit_attn_args a) {
         sum = grp_sum<16>(sum);
         inv_sum[r] = 1.f / sum;
       }
+      // dropout on the probabilities: the P tile in LDS (operand of P.V and of dVf) holds P*m, the registers keep P
+      f32x4 dm[NKT];
+      const uint32_t pkey = drop.on ? attn_drop_pkey(drop, pid) : 0u;
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[nt][r] *= inv_sum[r];
-        acc_to_lds(Wp, L.ldk, 0, nt * 16, s[nt]);
+        if (drop.on) {
+          f32x4 pd;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dm[nt][r] = attn_drop_factor(drop, pkey, q0 + 4 * q4 + r, nt * 16 + col);
+            pd[r] = s[nt][r] * dm[nt][r];
+          }
+          acc_to_lds(Wp, L.ldk, 0, nt * 16, pd);
+        } else {
+          acc_to_lds(Wp, L.ldk, 0, nt * 16, s[nt]);
+        }
       }
       wave_sync();
       const int64_t my_q = attn_qrow(a, g, q0 + (col < rows ? col : 0));      // this lane's query row in the global matrices
@@ -257,6 +271,12 @@ __global__ __launch_bounds__(256) void attn4_kernel(qavit_attn_args a) {
           for (int dt = 0; dt < DT; ++dt)
             acc = mma16(rowfrag(Wdo, L.ldd, 0, dt * 16), rowfrag(sm + L.vf, L.ldd, nt * 16, dt * 16), acc);
           dp[nt] = acc;
+        }
+        if (drop.on) {
+#pragma unroll
+          for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[nt][r] *= dm[nt][r];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

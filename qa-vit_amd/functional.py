@@ -423,9 +423,17 @@ def layer_norm(x, g, b, eps=1e-5, add=None, act=None):
 # ---------------------------------------------------------------------------------------------------
 # attention core
 # ---------------------------------------------------------------------------------------------------
+def _attn_drop(a, spec, rt):
+    p, site = spec.get("drop", (0.0, 0))
+    if p > 0.0:
+        a.drop_p, a.drop_site, a.rng = float(p), int(site), rt.rng.data_ptr()
+
+
 class AttnFn(Function):
     """See include/qavit.h (qavit_attn_args).  ``q_t`` is a 2-D row matrix holding q (and, when ``kv_t`` is
-    None and L > 0, also k and v) at column offsets; gradients come back as whole matrices."""
+    None and L > 0, also k and v) at column offsets; gradients come back as whole matrices.
+    ``spec["drop"] = (p, site)``: the ``dropout_p`` the reference passes to SDPA (HQAViT_CIFAR100.py:390-392); the
+    mask is regenerated in backward from the runtime's (seed, step) words."""
 
     @staticmethod
     def forward(ctx, q_t, kv_t, E_k, E_v, sh_k, sh_v, spec):
@@ -445,6 +453,7 @@ class AttnFn(Function):
             a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
         a.sh_k, a.sh_v = sh_k.data_ptr(), sh_v.data_ptr()
         a.o, a.ldo = o.data_ptr(), HD
+        _attn_drop(a, s, rt)
         guard = rt.nan_guard
         if guard:
             a.nan_flag = rt.nan_flag.data_ptr()
@@ -487,6 +496,7 @@ class AttnFn(Function):
             a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
         a.sh_k, a.sh_v = sh_k.data_ptr(), sh_v.data_ptr()
         a.d_o, a.lddo = d_o.data_ptr(), HD
+        _attn_drop(a, s, rt)
         covered_q = HD * (3 if (kv_t is None and s["L"] > 0) else 1) == q_t.shape[1]
         dq_t = torch.empty_like(q_t) if covered_q else torch.zeros_like(q_t)
         a.dq, a.lddq = dq_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]

@@ -40,6 +40,7 @@ class AttnArgs(C.Structure):
         ("E_k", vp), ("E_v", vp), ("sh_k", vp), ("sh_v", vp), ("o", vp), ("ldo", i64), ("nan_flag", vp),
         ("d_o", vp), ("lddo", i64), ("dq", vp), ("lddq", i64), ("dk_tok", vp), ("lddk", i64), ("dv_tok", vp), ("lddv", i64),
         ("ws", vp), ("ws_floats", i64), ("dE_k", vp), ("dE_v", vp), ("dsh_k", vp), ("dsh_v", vp),
+        ("drop_p", f32), ("drop_site", i32), ("rng", vp),
     ]
 
 

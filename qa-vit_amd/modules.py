@@ -84,7 +84,7 @@ class EfficientSpatialWindowAttention(_Branch):
         self.proj = nn.Linear(d, d)
         self.dropout = nn.Dropout(config.dropout)
         self.norm = nn.LayerNorm(d)
-        self._site = K.new_site()
+        self._site, self._site_attn = K.new_site(), K.new_site()
 
     def forward(self, x):
         B, N, C = x.shape
@@ -108,9 +108,10 @@ class EfficientSpatialWindowAttention(_Branch):
         spec = dict(mode=0, G=B * nw * nw, Nq=ws * ws, L=ws * ws, H=self.num_heads, D=self.head_dim,
                     KC=self.linformer.compressed_len, S=self.global_bank.bank_size, groups_per_b=nw * nw,
                     q_rows_per_b=N, k_rows_per_b=N, q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=C, v_off=2 * C, q_rows=B * N)
+        p = self.dropout.p if self.training else 0.0
+        spec["drop"] = (p, self._site_attn)                    # efficient_attention(q, k, v, self.dropout.p, self.training), :461
         o = F.AttnFn.apply(qkv, None, self.linformer.E_k, self.linformer.E_v,
                            self.global_bank.global_k, self.global_bank.global_v, spec)
-        p = self.dropout.p if self.training else 0.0
         out = F.linear(o.reshape(B, N, C), self.proj.weight, self.proj.bias, drop=(p, self._site))
         self._write(out)
         return out
@@ -132,7 +133,7 @@ class EfficientMultiScaleDilatedAttention(_Branch):
         self.proj = nn.Linear(d, d)
         self.dropout = nn.Dropout(config.dropout)
         self.norm = nn.LayerNorm(d)
-        self._site = K.new_site()
+        self._site, self._site_attn = K.new_site(), K.new_site()
 
     def forward(self, x, x_q=None):
         """``x_q``: optional second alias of the same tensor for the Q projection (lets the caller's fan-out node sum both
@@ -158,9 +159,10 @@ class EfficientMultiScaleDilatedAttention(_Branch):
         spec = dict(mode=0, G=B, Nq=N, L=Lk, H=self.num_heads, D=self.head_dim, KC=self.linformer.compressed_len,
                     S=self.global_bank.bank_size, groups_per_b=1, q_rows_per_b=N, k_rows_per_b=NP,
                     q_off=0, k_off=0, v_off=C, q_rows=B * N)
+        p = self.dropout.p if self.training else 0.0
+        spec["drop"] = (p, self._site_attn)                    # :524
         o = F.AttnFn.apply(q, kv, self.linformer.E_k, self.linformer.E_v,
                            self.global_bank.global_k, self.global_bank.global_v, spec)
-        p = self.dropout.p if self.training else 0.0
         out = F.linear(o.reshape(B, N, C), self.proj.weight, self.proj.bias, drop=(p, self._site))
         self._write(out)
         return out
@@ -184,7 +186,7 @@ class EfficientChannelGroupAttention(_Branch):
         self.proj = nn.Linear(self.compress_c, d)
         self.dropout = nn.Dropout(config.dropout)
         self.norm = nn.LayerNorm(d)
-        self._site = K.new_site()
+        self._site, self._site_attn = K.new_site(), K.new_site()
 
     def forward(self, x):
         B, N, C = x.shape
@@ -201,8 +203,9 @@ class EfficientChannelGroupAttention(_Branch):
         spec = dict(mode=1, G=B * G, Nq=N, L=N, H=H, D=ccg // H, S=bank.bank_size, groups_per_b=G,
                     q_rows_per_b=N * G, k_rows_per_b=N * G, q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=ccg, v_off=2 * ccg,
                     q_rows=B * N * G)
-        o = F.AttnFn.apply(qkv, None, None, None, sh_k, sh_v, spec)
         p = self.dropout.p if self.training else 0.0
+        spec["drop"] = (p, self._site_attn)                    # :587
+        o = F.AttnFn.apply(qkv, None, None, None, sh_k, sh_v, spec)
         out = F.linear(o.reshape(B, N, self.compress_c), self.proj.weight, self.proj.bias, drop=(p, self._site))
         self._write(out)
         return out
@@ -218,7 +221,7 @@ class CrossAttentionBranch(_Branch):
         self.embed_dim, self.num_heads, self.head_dim = d, config.num_heads, d // config.num_heads
         self.q_proj, self.k_proj, self.v_proj, self.proj = nn.Linear(d, d), nn.Linear(d, d), nn.Linear(d, d), nn.Linear(d, d)
         self.dropout = nn.Dropout(config.dropout)
-        self._site = K.new_site()
+        self._site, self._site_attn = K.new_site(), K.new_site()
 
     def forward(self, x):
         B, N, C = x.shape
@@ -229,8 +232,9 @@ class CrossAttentionBranch(_Branch):
         sh_v = F.linear(gv, self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
         spec = dict(mode=1, G=B, Nq=N, L=0, H=self.num_heads, D=self.head_dim, S=bank.bank_size, q_off=0, k_off=0, v_off=0,
                     q_rows=B * N)
-        o = F.AttnFn.apply(q, None, None, None, sh_k, sh_v, spec)
         p = self.dropout.p if self.training else 0.0
+        spec["drop"] = (p, self._site_attn)                    # :624
+        o = F.AttnFn.apply(q, None, None, None, sh_k, sh_v, spec)
         return F.linear(o.reshape(B, N, C), self.proj.weight, self.proj.bias, drop=(p, self._site))
 
 

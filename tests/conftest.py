@@ -95,3 +95,43 @@ def zero_by_construction(name: str) -> bool:
     return (name.endswith("token_upmix.upsample_attn.bias")          # LN over channels removes a per-token constant
             or name.endswith("token_learner.attention.1.bias")       # softmax over tokens ignores a per-column constant
             or (name.startswith("cnn_stem.") and name.endswith(".0.bias")))   # conv bias before train-mode BatchNorm
+
+
+# ---------------------------------------------------------------------------------------------------
+# Host replica of the device counter RNG (qa-vit_amd/csrc/common.cuh: mix32 / rng_key / rng_uniform and
+# attn_shared.h: attn_drop_pkey / attn_drop_factor), so a test can compute the EXACT dropout mask a kernel used.
+# ---------------------------------------------------------------------------------------------------
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x):
+    x = np.asarray(x, dtype=np.uint64) & _M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & _M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def rng_key(seed: int, step: int, site: int):
+    inner = (np.uint64(step & 0xFFFFFFFF) * np.uint64(0x9E3779B9) + np.uint64(site) * np.uint64(0x85EBCA6B) + np.uint64(0x68E31DA4)) & _M32
+    return _mix32(np.uint64(seed & 0xFFFFFFFF) ^ _mix32(inner))
+
+
+def rng_uniform(key, idx):
+    idx = np.asarray(idx, dtype=np.uint64)
+    h = _mix32(((idx * np.uint64(0x9E3779B9)) & _M32) ^ np.asarray(key, dtype=np.uint64))
+    return ((h >> np.uint64(8)).astype(np.float64) * (1.0 / 16777216.0)).astype(np.float32)
+
+
+def attn_keep_mask(seed: int, step: int, site: int, G: int, H: int, Nq: int, NK: int, p: float) -> np.ndarray:
+    """bool [G, H, Nq, NK]: True where the attention probability of (group g, head h, query i, key j) is KEPT."""
+    key = rng_key(seed, step, site)
+    pid = np.arange(G * H, dtype=np.uint64)
+    pkey = _mix32((key + pid * np.uint64(0x9E3779B9)) & _M32)                       # [G*H]
+    i = np.arange(Nq, dtype=np.uint64)[:, None]
+    j = np.arange(NK, dtype=np.uint64)[None, :]
+    idx = (i << np.uint64(16)) | j                                                    # [Nq, NK]
+    u = rng_uniform(pkey[:, None, None], idx[None])
+    return (u >= np.float32(p)).reshape(G, H, Nq, NK)

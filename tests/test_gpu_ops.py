@@ -173,13 +173,34 @@ def test_layernorm(F, dtype):
 
 
 # ---------------------------------------------------------------------------------------------------
-def _ref_attn(q, k, v):
-    return TF.scaled_dot_product_attention(q, k, v)
+def _ref_attn(q, k, v, keep=None, p=0.0):
+    """SDPA; with ``keep`` (bool [G,H,Nq,NK], the mask the kernel used) the reference's dropout_p branch:
+    softmax(S) * keep / (1 - p) @ v  (F.scaled_dot_product_attention's documented math)."""
+    if keep is None:
+        return TF.scaled_dot_product_attention(q, k, v)
+    pr = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(q.shape[-1]), -1)
+    return (pr * keep.to(pr.dtype) / (1.0 - p)) @ v
+
+
+def _drop_setup(drop, G, H, Nq, NK):
+    """-> (spec entry, keep mask on DEV or None) for the CURRENT (seed, step) of the runtime."""
+    if drop <= 0.0:
+        return None, None
+    import importlib
+    from conftest import attn_keep_mask
+    K = importlib.import_module("qa-vit_amd.kernels")
+    site = K.new_site()
+    seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
+    keep = torch.from_numpy(attn_keep_mask(seed, step, site, G, H, Nq, NK, drop)).to(DEV)
+    frac = float(keep.float().mean())
+    assert abs(frac - (1.0 - drop)) < 0.02, frac
+    return (drop, site), keep
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("B,Hs,ws,KC", [(37, 4, 4, 32), (9, 8, 4, 32), (5, 14, 7, 64), (700, 4, 4, 32)])
-def test_attn_swa_like(F, Q, dtype, B, Hs, ws, KC):
+def test_attn_swa_like(F, Q, dtype, B, Hs, ws, KC, drop):
     """mode 0 with the window table: qkv [B*N,3C] -> windows -> Linformer(16->32) + 16 bank rows.
     (5, 14, 7, 64): the 224-px windows -- 49 tokens, 64 Linformer rows (80 keys with the bank).
     (700, 4, 4, 32): 2800 (group, head) problems > the 2048-workgroup cap, so a wave visits several problems and its
@@ -198,6 +219,9 @@ def test_attn_swa_like(F, Q, dtype, B, Hs, ws, KC):
         tbl = torch.tensor(t, dtype=torch.int32, device=DEV)
     spec = dict(mode=0, G=B * nw * nw, Nq=ws * ws, L=ws * ws, H=H, D=D, KC=KC, S=S, groups_per_b=nw * nw, q_rows_per_b=N,
                 k_rows_per_b=N, q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=C, v_off=2 * C, q_rows=B * N)
+    dspec, keep = _drop_setup(drop, B * nw * nw, H, ws * ws, KC + S)
+    if dspec:
+        spec["drop"] = dspec
     o = F.AttnFn.apply(qkv, None, Ek, Ev, bk, bv, spec)
     # reference (same math as oracle.swa without the projections)
     r = [t.detach().clone().float().requires_grad_(True) for t in (qkv, Ek, Ev, bk, bv)]
@@ -209,7 +233,7 @@ def test_attn_swa_like(F, Q, dtype, B, Hs, ws, KC):
     vc = torch.matmul(Evr.T, v.reshape(BW * H, ws * ws, D)).reshape(BW, H, KC, D)
     kb = bkr.expand(BW, -1, -1).reshape(BW, S, H, D).transpose(1, 2)
     vb = bvr.expand(BW, -1, -1).reshape(BW, S, H, D).transpose(1, 2)
-    ro = _ref_attn(q, torch.cat([kc, kb], 2), torch.cat([vc, vb], 2)).transpose(1, 2).reshape(BW, ws * ws, C)
+    ro = _ref_attn(q, torch.cat([kc, kb], 2), torch.cat([vc, vb], 2), keep, drop).transpose(1, 2).reshape(BW, ws * ws, C)
     ro = ro.view(B, nw, nw, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B * N, C)
     assert rel(o, ro) <= tol(dtype)
     go = torch.randn_like(ro)
@@ -221,8 +245,9 @@ def test_attn_swa_like(F, Q, dtype, B, Hs, ws, KC):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("N,NP,KC,B", [(16, 10, 32, 21), (64, 40, 32, 21), (196, 135, 64, 21), (64, 40, 32, 600), (16, 10, 32, 600)])
-def test_attn_msda_like(F, dtype, N, NP, KC, B):
+def test_attn_msda_like(F, dtype, N, NP, KC, B, drop):
     """mode 0, separate q and kv matrices, ragged L (10 / 40 of a 128-row Linformer).  (196, 135, 64) are the 224-px
     dimensions: only the first 128 landmarks are keys (the rest get zero gradient) and the backward keeps E in global
     memory (attn.hip spill layout).  B = 600: 2400 problems > the 2048-workgroup cap (several problems per workgroup)."""
@@ -235,6 +260,9 @@ def test_attn_msda_like(F, dtype, N, NP, KC, B):
     bk, bv = leaf(1, S, C, scale=0.5, seed=74), leaf(1, S, C, scale=0.5, seed=75)
     spec = dict(mode=0, G=B, Nq=N, L=Lk, H=H, D=D, KC=KC, S=S, groups_per_b=1, q_rows_per_b=N, k_rows_per_b=NP,
                 q_off=0, k_off=0, v_off=C, q_rows=B * N)
+    dspec, keep = _drop_setup(drop, B, H, N, KC + S)
+    if dspec:
+        spec["drop"] = dspec
     o = F.AttnFn.apply(q_t, kv_t, Ek, Ev, bk, bv, spec)
     qr, kvr, Ekr, Evr, bkr, bvr = [t.detach().clone().float().requires_grad_(True) for t in (q_t, kv_t, Ek, Ev, bk, bv)]
     q = qr.view(B, N, H, D).transpose(1, 2)
@@ -245,7 +273,7 @@ def test_attn_msda_like(F, dtype, N, NP, KC, B):
     vc = torch.matmul(Evr.T, v.reshape(B * H, 128, D)).reshape(B, H, KC, D)
     kb = bkr.expand(B, -1, -1).reshape(B, S, H, D).transpose(1, 2)
     vb = bvr.expand(B, -1, -1).reshape(B, S, H, D).transpose(1, 2)
-    ro = _ref_attn(q, torch.cat([kc, kb], 2), torch.cat([vc, vb], 2)).transpose(1, 2).reshape(B * N, C)
+    ro = _ref_attn(q, torch.cat([kc, kb], 2), torch.cat([vc, vb], 2), keep, drop).transpose(1, 2).reshape(B * N, C)
     assert rel(o, ro) <= tol(dtype)
     go = torch.randn_like(ro)
     o.backward(go.to(dtype))
@@ -263,8 +291,9 @@ def test_attn_msda_like(F, dtype, N, NP, KC, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("N,B", [(16, 13), (64, 13), (196, 13), (64, 120)])
-def test_attn_cga_like(F, dtype, N, B):
+def test_attn_cga_like(F, dtype, N, B, drop):
     """mode 1, D=4, keys = own tokens + 16 shared rows, channel-group row table.  B = 120: 2880 problems > the cap."""
     G, H, S, ccg = 6, 4, 16, 16
     D = ccg // H
@@ -277,13 +306,16 @@ def test_attn_cga_like(F, dtype, N, B):
                 q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=ccg, v_off=2 * ccg, q_rows=B * N * G)
     # non-leaf shared rows (as in the model: outputs of a Linear on the bank)
     sk, sv = shk_l * 1.0, shv_l * 1.0
+    dspec, keep = _drop_setup(drop, B * G, H, N, N + S)
+    if dspec:
+        spec["drop"] = dspec
     o = F.AttnFn.apply(qkv, None, None, None, sk, sv, spec)
     qr = qkv.detach().clone().float().requires_grad_(True)
     skr, svr = shk.detach().clone().requires_grad_(True), shv.detach().clone().requires_grad_(True)
     x = qr.view(B, N, G, 3, H, D).permute(3, 0, 2, 4, 1, 5).reshape(3, B * G, H, N, D)
     kb = skr.view(1, S, H, D).transpose(1, 2).expand(B * G, -1, -1, -1)
     vb = svr.view(1, S, H, D).transpose(1, 2).expand(B * G, -1, -1, -1)
-    ro = _ref_attn(x[0], torch.cat([x[1], kb], 2), torch.cat([x[2], vb], 2))       # [BG,H,N,D]
+    ro = _ref_attn(x[0], torch.cat([x[1], kb], 2), torch.cat([x[2], vb], 2), keep, drop)       # [BG,H,N,D]
     ro = ro.transpose(1, 2).reshape(B, G, N, ccg).permute(0, 2, 1, 3).reshape(B * N * G, ccg)
     assert rel(o, ro) <= tol(dtype)
     go = torch.randn_like(ro)
@@ -294,19 +326,24 @@ def test_attn_cga_like(F, dtype, N, B):
     assert rel(shv_l.grad, svr.grad) <= tol(dtype, False)
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_attn_cross_like_and_nan_guard(F, dtype):
-    B, N, C, H, S = 19, 16, 192, 4, 16
+@pytest.mark.parametrize("B,N", [(19, 16), (19, 64), (700, 16)])
+def test_attn_cross_like_and_nan_guard(F, dtype, drop, B, N):
+    C, H, S = 192, 4, 16
     D = C // H
     q_t = leaf(B * N, C, seed=90).detach().to(dtype).requires_grad_(True)
     shk, shv = leaf(S, C, seed=91), leaf(S, C, seed=92)
     spec = dict(mode=1, G=B, Nq=N, L=0, H=H, D=D, S=S, q_off=0, k_off=0, v_off=0, q_rows=B * N)
+    dspec, keep = _drop_setup(drop, B, H, N, S)
+    if dspec:
+        spec["drop"] = dspec
     o = F.AttnFn.apply(q_t, None, None, None, shk, shv, spec)
     qr, kr, vr = [t.detach().clone().float().requires_grad_(True) for t in (q_t, shk, shv)]
     q = qr.view(B, N, H, D).transpose(1, 2)
     k = kr.view(1, S, H, D).transpose(1, 2).expand(B, -1, -1, -1)
     v = vr.view(1, S, H, D).transpose(1, 2).expand(B, -1, -1, -1)
-    ro = _ref_attn(q, k, v).transpose(1, 2).reshape(B * N, C)
+    ro = _ref_attn(q, k, v, keep, drop).transpose(1, 2).reshape(B * N, C)
     assert rel(o, ro) <= tol(dtype)
     go = torch.randn_like(ro)
     o.backward(go.to(dtype))
@@ -314,6 +351,16 @@ def test_attn_cross_like_and_nan_guard(F, dtype):
     assert rel(q_t.grad, qr.grad) <= tol(dtype, False)
     assert rel(shk.grad, kr.grad) <= tol(dtype, False)
     assert rel(shv.grad, vr.grad) <= tol(dtype, False)
+    if drop > 0.0:
+        # a new step draws a new mask; the same step replays the same one
+        import importlib
+        K = importlib.import_module("qa-vit_amd.kernels")
+        o_same = F.AttnFn.apply(q_t.detach(), None, None, None, shk.detach(), shv.detach(), spec)
+        assert torch.equal(o_same, o.detach())
+        K.Runtime.get(0).advance()
+        o_new = F.AttnFn.apply(q_t.detach(), None, None, None, shk.detach(), shv.detach(), spec)
+        assert not torch.equal(o_new, o.detach())
+        return
     # efficient_attention: any NaN in the inputs -> the WHOLE output is zeros (HQAViT_CIFAR100.py:356-357)
     bad = q_t.detach().clone()
     bad[5, 7] = float("nan")
