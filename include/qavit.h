@@ -369,7 +369,9 @@ int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, float* 
 /* dst_a = src_a, dst_b = src_b (n fp32 each, n % 4 == 0, 16-byte aligned): forward-time snapshot of the bank's K / V rows
  * (the reference's torch.cat / Linear-on-expand copies, HQAViT_CIFAR100.py:398-399, :576-577) in one launch */
 int qavit_copy2(const float* src_a, const float* src_b, float* dst_a, float* dst_b, int64_t n, void* stream);
-/* out[0] = sqrt(sum g^2) over a flat buffer (two-pass, deterministic order within a block) */
+/* out[0] = sqrt(sum g^2) over a flat buffer (two-pass, deterministic order within a block);
+ * out[1] = max(out[1], out[0]) with NaN sticky: the largest norm any call has seen (`out` is float[2], zero at start),
+ * so one host read after N captured steps checks every one of them. */
 int qavit_l2norm(const float* g, int64_t n, float* partial, float* out, void* stream);
 
 #ifdef __cplusplus

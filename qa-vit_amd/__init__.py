@@ -11,9 +11,10 @@ Public surface (mirrors the reference's importable names):
 from .config import HQAViTConfig, HQAViTTinyINConfig, QAViTConfig, qavit32_config  # noqa: F401
 from .filler import fill_module, fill_tensor  # noqa: F401
 from .models import HQAViT, QAViT  # noqa: F401
-from .harness import BatchStager, ModelEMA, Trainer, TrainingConfig, mix_plan  # noqa: F401
+from .harness import BatchStager, FineTuneConfig, GradientMonitor, ModelEMA, Trainer, TrainingConfig, mix_plan  # noqa: F401
+from . import harness  # noqa: F401
 from .parallel import DataParallel  # noqa: F401
 from . import lib  # noqa: F401
 
 __all__ = ["HQAViT", "HQAViTConfig", "HQAViTTinyINConfig", "QAViT", "QAViTConfig", "qavit32_config",
-           "BatchStager", "ModelEMA", "Trainer", "TrainingConfig", "mix_plan", "DataParallel", "fill_module", "fill_tensor", "lib"]
+           "BatchStager", "FineTuneConfig", "GradientMonitor", "ModelEMA", "Trainer", "TrainingConfig", "mix_plan", "DataParallel", "fill_module", "fill_tensor", "lib"]

@@ -475,7 +475,12 @@ __global__ __launch_bounds__(256) void l2_final_kernel(const float* partial, int
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    out[0] = nrm;
+    const float mx = out[1];                       // running maximum over calls; a NaN sticks
+    out[1] = (nrm > mx || nrm != nrm) ? nrm : mx;
+  }
 }
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const uint8_t* skip, int64_t n,
                                                     const float* lr_dev, float b1, float b2, float eps, float wd,

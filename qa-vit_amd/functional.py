@@ -11,6 +11,7 @@ Conventions
 import ctypes as C
 import math
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -24,7 +25,12 @@ from . import lib as L
 # packed weights
 # ---------------------------------------------------------------------------------------------------
 class _PackEntry:
-    __slots__ = ("params", "versions", "dst", "dstT", "rows", "cols", "desc_rows")
+    __slots__ = ("refs", "versions", "ptrs", "dst", "dstT", "rows", "cols")
+
+    def params(self):
+        """The live parameter tensors, or None once any of them has been garbage-collected."""
+        ps = [r() for r in self.refs]
+        return None if any(p is None for p in ps) else ps
 
 
 class WeightPack:
@@ -32,20 +38,32 @@ class WeightPack:
 
     One ``refresh()`` launch re-packs every registered weight (the descriptor table lives on the device),
     so a training step pays one kernel for all ~200 weights; it is also what a captured hipGraph replays
-    at the top of each step."""
+    at the top of each step.
+
+    Staleness: a copy is stale when (i) a torch optimizer stepped (``_version`` moved), (ii) something wrote the
+    parameters through raw pointers -- the fused AdamW kernel, a graph replay -- and called ``mark_stale()``, or
+    (iii) the parameter's storage was re-bound (``p.data = ...``, ``.to()``; the descriptor table caches ``data_ptr``).
+    ``get()`` checks all three, so ``model.eval()(x)`` right after ``Trainer.step()`` / ``replay()`` sees the new weights.
+    Entries hold weak references: a dead model's weights are dropped at the next refresh."""
 
     def __init__(self, device):
         self.device = device
         self.entries = {}      # (ids, dtype) -> _PackEntry
         self._tables = {}      # dtype -> (device bytes tensor, n_desc, max_elems)
+        self._retired = []     # descriptor tables a captured hipGraph may still replay: kept alive, never reused
+        self._stale = False
 
     @staticmethod
     def _as2d(w):
         return w.reshape(w.shape[0], -1)
 
+    def mark_stale(self):
+        """The parameters were written behind autograd's back (raw-pointer optimiser kernel, graph replay)."""
+        self._stale = True
+
     def _make(self, params, dtype):
         e = _PackEntry()
-        e.params = params
+        e.refs = [weakref.ref(p) for p in params]
         rows = sum(p.shape[0] for p in params)
         cols = self._as2d(params[0]).shape[1]
         e.rows, e.cols = rows, cols
@@ -53,12 +71,13 @@ class WeightPack:
         e.dst = None if single_f32 else torch.empty(rows, cols, dtype=dtype, device=self.device)
         e.dstT = torch.empty(cols, rows, dtype=dtype, device=self.device)
         e.versions = [-1] * len(params)
+        e.ptrs = [p.data_ptr() for p in params]
         return e
 
-    def _descs(self, e):
+    def _descs(self, e, params):
         out, off = [], 0
         esz = e.dstT.element_size()
-        for p in e.params:
+        for p in params:
             r = p.shape[0]
             d = L.PackDesc()
             d.src = self._as2d(p).data_ptr()
@@ -67,6 +86,7 @@ class WeightPack:
             d.rows, d.cols, d.ldT, d.pad = r, e.cols, e.rows, 0
             out.append(d)
             off += r
+        e.ptrs = [p.data_ptr() for p in params]
         return out
 
     def _launch(self, descs, dtype):
@@ -76,40 +96,65 @@ class WeightPack:
         K.pack_weights(dtype, raw, len(descs), mx)
         return raw, len(descs), mx
 
+    def _drop_table(self, dtype):
+        tab = self._tables.pop(dtype, None)
+        if tab is not None:
+            self._retired.append(tab[0])
+
     def refresh(self, dtype=None):
         """Re-pack every registered weight (one launch per compute dtype in use)."""
         dts = {k[1] for k in self.entries} if dtype is None else {dtype}
         for dt in dts:
+            live = {}
+            moved = False
+            for key, e in list(self.entries.items()):
+                if key[1] != dt:
+                    continue
+                ps = e.params()
+                if ps is None:                                  # the model was freed
+                    del self.entries[key]
+                    moved = True
+                    continue
+                live[key] = ps
+                moved |= any(a != p.data_ptr() for a, p in zip(e.ptrs, ps))
+            if moved:
+                self._drop_table(dt)
             tab = self._tables.get(dt)
             if tab is None:
                 descs = []
-                for (ids, d), e in self.entries.items():
-                    if d == dt:
-                        descs.extend(self._descs(e))
+                for key, ps in live.items():
+                    descs.extend(self._descs(self.entries[key], ps))
                 if not descs:
                     continue
                 self._tables[dt] = self._launch(descs, dt)
             else:
                 K.pack_weights(dt, tab[0], tab[1], tab[2])
-            for (ids, d), e in self.entries.items():
-                if d == dt:
-                    e.versions = [p._version for p in e.params]
+            for key, ps in live.items():
+                self.entries[key].versions = [p._version for p in ps]
+        if dtype is None:
+            self._stale = False
 
     def get(self, params, dtype):
         """-> (W [rows, cols], W^T [cols, rows]) in ``dtype`` for a weight or a row-stack of weights."""
         if isinstance(params, torch.Tensor):
             params = [params]
+        if self._stale:
+            self.refresh()
         key = (tuple(id(p) for p in params), dtype)
         e = self.entries.get(key)
+        if e is not None and e.params() is None:               # an id re-used by a new tensor after the old one died
+            del self.entries[key]
+            self._drop_table(dtype)
+            e = None
         if e is None:
             e = self._make(params, dtype)
             self.entries[key] = e
-            self._tables.pop(dtype, None)
-            self._launch(self._descs(e), dtype)          # first use: pack just this one
-            e.versions = [p._version for p in e.params]
-        elif any(v != p._version for v, p in zip(e.versions, e.params)):
-            self.refresh(dtype)                           # an optimizer stepped: re-pack everything once
-        W = e.dst if e.dst is not None else self._as2d(e.params[0]).detach()
+            self._drop_table(dtype)
+            self._launch(self._descs(e, params), dtype)          # first use: pack just this one
+            e.versions = [p._version for p in params]
+        elif any(v != p._version for v, p in zip(e.versions, params)) or any(a != p.data_ptr() for a, p in zip(e.ptrs, params)):
+            self.refresh(dtype)                           # an optimizer stepped / storage was re-bound: re-pack everything once
+        W = e.dst if e.dst is not None else self._as2d(params[0]).detach()
         return W, e.dstT
 
 

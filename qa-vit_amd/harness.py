@@ -10,6 +10,11 @@ smoothing; per-tensor clip 0.1 for names containing ``cnn_stem`` / ``dwconv`` th
 MI355X-first structure: parameters, gradients and Adam moments live in FLAT fp32 buffers (parameters and
 ``.grad`` are views), so clipping + AdamW is two kernels, gradient all-reduce works on contiguous buckets, and
 the whole step (weight re-pack, forward, backward, optimiser) is capturable in one hipGraph.
+
+Two recipes: ``TrainingConfig`` = HQAViT_CIFAR100.py's pre-training loop (OneCycle per iteration, two clips, EMA);
+``FineTuneConfig`` = HQAViT_Tiny_Cifar10.py's transfer loop (BASELINE config 1): two parameter groups (names containing
+``head`` at base_lr * head_lr_multiplier, :327-342), LinearLR(0.1 -> 1) warm-up then CosineAnnealingLR stepped once per
+EPOCH (:384, :481-496, :520-523 -- call ``Trainer.epoch_end()``), one global clip at 1.0, label smoothing 0.1, no EMA.
 """
 import math
 from copy import deepcopy
@@ -37,8 +42,9 @@ class TrainingConfig:
     local_clip: float = 0.1          # per-tensor clip for 'cnn_stem' / 'dwconv' (:1416-1418)
     use_amp: bool = True
     amp_dtype: str = "bfloat16"
-    use_ema: bool = False
+    use_ema: bool = True
     ema_decay: float = 0.999
+    ema_decay_warmup: float = 0.99   # decay ramps from this to ema_decay over the warm-up epochs (:1634-1638)
     beta1: float = 0.9
     beta2: float = 0.999
     eps: float = 1e-8
@@ -49,6 +55,54 @@ class TrainingConfig:
     cutmix_alpha: float = 1.0
     mix_prob: float = 0.6
     device_mix: bool = False
+
+
+@dataclass
+class FineTuneConfig:
+    """HQAViT_Tiny_Cifar10.FineTuneConfig (:34-64), the fields the step consumes, same names/defaults."""
+    batch_size: int = 256
+    epochs: int = 100
+    warmup_epochs: int = 5
+    base_lr: float = 1e-4
+    head_lr_multiplier: float = 10.0
+    min_lr: float = 1e-6
+    weight_decay: float = 0.05
+    label_smoothing: float = 0.1
+    max_grad_norm: float = 1.0
+    use_amp: bool = True
+    amp_dtype: str = "bfloat16"
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    # absent from the transfer recipe (kept so Trainer reads one interface)
+    local_clip: float = 0.0
+    use_ema: bool = False
+    device_mix: bool = False
+
+
+def finetune_lr(epoch_idx: int, cfg: "FineTuneConfig"):
+    """LR of the (backbone, head) groups during 0-based epoch ``epoch_idx`` = after ``epoch_idx`` per-epoch scheduler
+    steps of HQAViT_Tiny_Cifar10.main's pair of schedulers (:481-496, :520-523): LinearLR(start 0.1, end 1,
+    total_iters = warmup_epochs) for the first warmup_epochs steps, then CosineAnnealingLR(T_max = epochs - warmup_epochs,
+    eta_min = min_lr -- the same ABSOLUTE floor for both groups) in its chainable form, which from lr = base equals the
+    closed form below."""
+    warm, tmax = cfg.warmup_epochs, cfg.epochs - cfg.warmup_epochs
+    out = []
+    for base in (cfg.base_lr, cfg.base_lr * cfg.head_lr_multiplier):
+        if epoch_idx <= warm:
+            f = 0.1 + 0.9 * (epoch_idx / warm) if warm > 0 else 1.0
+            out.append(base * f)
+        else:
+            t = epoch_idx - warm
+            out.append(cfg.min_lr + (base - cfg.min_lr) * (1.0 + math.cos(math.pi * t / tmax)) / 2.0)
+    return tuple(out)
+
+
+def ema_decay_for_epoch(epoch: int, cfg: "TrainingConfig") -> float:
+    """EMA decay during 1-based ``epoch`` (HQAViT_CIFAR100.py:1634-1638): linear ramp over the warm-up epochs."""
+    if epoch <= cfg.warmup_epochs:
+        return cfg.ema_decay_warmup + (cfg.ema_decay - cfg.ema_decay_warmup) * (epoch / cfg.warmup_epochs)
+    return cfg.ema_decay
 
 
 def mix_plan(u: torch.Tensor, lam_cut: torch.Tensor, lam_mix: torch.Tensor, cfg: "TrainingConfig", H: int, W: int) -> torch.Tensor:
@@ -250,18 +304,34 @@ class Trainer:
         self.local_clip_seg = torch.tensor(segs, dtype=torch.int64, device=dev).reshape(-1, 2) if segs else None
         self.local_clip_ws = torch.zeros(2 * max(len(segs), 1), dtype=torch.float32, device=dev)
         self.total_steps = total_steps
-        warm = warmup_steps if warmup_steps is not None else max(1, int(total_steps * cfg.warmup_epochs / max(cfg.epochs, 1)))
-        table = [onecycle_lr(i, total_steps, cfg.base_lr, warm / total_steps) for i in range(total_steps)]
-        self.lr_table = torch.tensor(table, dtype=torch.float32, device=dev)
-        self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)       # scheduler steps taken
+        self.finetune = isinstance(cfg, FineTuneConfig)
+        if self.finetune:
+            # two parameter groups: names containing 'head' (HQAViT_Tiny_Cifar10.py:333) -> [lo, hi) element ranges of the
+            # flat buffers, one AdamW launch per contiguous range; LR table indexed by EPOCH: [epochs + 1, 2]
+            self.group_ranges = []                      # (group id 0 backbone / 1 head, lo, hi)
+            for nme, o, sz in zip(self.names, self.offsets, sizes):
+                gid = 1 if "head" in nme else 0
+                if self.group_ranges and self.group_ranges[-1][0] == gid:
+                    self.group_ranges[-1] = (gid, self.group_ranges[-1][1], o + sz)
+                else:
+                    self.group_ranges.append((gid, o, o + sz))
+            table = [finetune_lr(e, cfg) for e in range(cfg.epochs + 1)]
+            self.lr_table = torch.tensor(table, dtype=torch.float32, device=dev)          # [epochs + 1, 2]
+            self.lr_dev = torch.zeros(2, dtype=torch.float32, device=dev)
+        else:
+            warm = warmup_steps if warmup_steps is not None else max(1, int(total_steps * cfg.warmup_epochs / max(cfg.epochs, 1)))
+            table = [onecycle_lr(i, total_steps, cfg.base_lr, warm / total_steps) for i in range(total_steps)]
+            self.lr_table = torch.tensor(table, dtype=torch.float32, device=dev)
+            self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_idx = torch.zeros(1, dtype=torch.int64, device=dev)       # scheduler steps taken (finetune: epochs finished)
         self.step_f = torch.zeros(1, dtype=torch.float32, device=dev)       # Adam step count (1-based at use)
-        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gnorm = torch.zeros(2, dtype=torch.float32, device=dev)        # [this step's global grad norm, running max (NaN sticks)]
         self.partial = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
-        self.ema = None
+        self.ema_flat = None
         if cfg.use_ema:
             self.ema_flat = self.flat_p.clone()
+            self.ema_w = torch.full((1,), 1.0 - cfg.ema_decay, dtype=torch.float32, device=dev)   # 1 - decay, device-resident: a captured step follows set_ema_decay
         self.graph = None
         self._static_x = self._static_y = None
         self.rt = K.Runtime.get(dev) if dev.type == "cuda" else None
@@ -310,13 +380,45 @@ class Trainer:
         if cfg.local_clip > 0 and self.local_clip_seg is not None:
             K.local_clip(self.flat_g, self.local_clip_seg, cfg.local_clip, self.local_clip_ws)
         K.l2norm(self.flat_g, self.partial, self.gnorm)
-        torch.index_select(self.lr_table, 0, torch.clamp(self.step_idx, max=self.total_steps - 1), out=self.lr_dev)
         self.step_f += 1.0
-        K.adamw(self.flat_p, self.flat_g, self.m, self.v, self.skip, self.lr_dev, cfg.beta1, cfg.beta2, cfg.eps,
-                cfg.weight_decay, self.step_f, self.gnorm, cfg.max_grad_norm)
-        self.step_idx += 1
-        if cfg.use_ema:
-            self.ema_flat.lerp_(self.flat_p, 1.0 - cfg.ema_decay)
+        if self.finetune:
+            self.lr_dev.copy_(torch.index_select(self.lr_table, 0, torch.clamp(self.step_idx, max=self.lr_table.shape[0] - 1)).reshape(2))
+            for gid, lo, hi in self.group_ranges:
+                K.adamw(self.flat_p[lo:hi], self.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], self.skip[lo:hi], self.lr_dev[gid:gid + 1],
+                        cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, self.step_f, self.gnorm, cfg.max_grad_norm)
+        else:
+            torch.index_select(self.lr_table, 0, torch.clamp(self.step_idx, max=self.total_steps - 1), out=self.lr_dev)
+            K.adamw(self.flat_p, self.flat_g, self.m, self.v, self.skip, self.lr_dev, cfg.beta1, cfg.beta2, cfg.eps,
+                    cfg.weight_decay, self.step_f, self.gnorm, cfg.max_grad_norm)
+            self.step_idx += 1                          # OneCycle: one scheduler step per iteration
+        F.pack_for(self.device).mark_stale()            # the packed compute-dtype weights no longer match the parameters
+        if self.ema_flat is not None:
+            torch.lerp(self.ema_flat, self.flat_p, self.ema_w, out=self.ema_flat)
+
+    def epoch_end(self):
+        """The per-epoch ``scheduler.step()`` of the transfer recipe (HQAViT_Tiny_Cifar10.py:384); no-op for OneCycle."""
+        if self.finetune:
+            self.step_idx += 1
+
+    def set_ema_decay(self, decay: float):
+        """ModelEMA.set_decay (HQAViT_CIFAR100.py:182-184); device-resident, so a captured step follows it."""
+        self.ema_w.fill_(1.0 - float(decay))
+
+    @torch.no_grad()
+    def ema_model(self) -> nn.Module:
+        """The EMA weights as an eval-mode copy of the model (ModelEMA.ema, HQAViT_CIFAR100.py:131-137): parameters from
+        the flat EMA buffer, buffers copied from the live model (:151-156)."""
+        if self.ema_flat is None:
+            raise RuntimeError("cfg.use_ema is False")
+        ema = deepcopy(self.model).eval()               # Parameter.__deepcopy__ clones each view: the flat buffers stay behind
+        for p in ema.parameters():
+            p.grad = None
+        ep = dict(ema.named_parameters())
+        sizes = [p.numel() for p in self.params]
+        for nme, o, sz in zip(self.names, self.offsets, sizes):
+            ep[nme].requires_grad_(False)
+            ep[nme].copy_(self.ema_flat[o:o + sz].view_as(ep[nme]))
+        return ema
 
     def fwd_bwd(self, x, y):
         """forward + loss + backward (+ gradient all-reduce): the unit BASELINE.json's metric times."""
@@ -331,10 +433,24 @@ class Trainer:
         return loss
 
     # ------------------------------------------------------------------------------------------
-    def capture(self, x, y, with_optim: bool = True, warmup: int = 3):
-        """Capture the whole step into one hipGraph (torch.cuda.CUDAGraph).  ``x``/``y`` give the static shapes."""
+    def _state(self):
+        """Everything a step mutates: flat parameters (the bank included) and Adam moments, step counters, EMA, the model's
+        buffers (BatchNorm running statistics, ``update_count``), the dropout RNG words."""
+        st = [self.flat_p, self.m, self.v, self.step_f, self.step_idx, self.gnorm, self.rt.rng]
+        if self.ema_flat is not None:
+            st.append(self.ema_flat)
+        st.extend(b for _, b in self.model.named_buffers())
+        return st
+
+    def capture(self, x, y, with_optim: bool = True, warmup: int = 3, debug_dot: Optional[str] = None):
+        """Capture the whole step into one hipGraph (torch.cuda.CUDAGraph).  ``x``/``y`` give the static shapes.
+        The ``warmup`` eager steps that precede the capture (allocator / workspace / table warm-up) run real optimiser
+        steps; every piece of training state is snapshotted before and restored after them, so capturing does not
+        advance the run (parameters, Adam moments, LR position, bank, BatchNorm statistics, RNG all stay where they were).
+        ``debug_dot``: path for hipGraphDebugDotPrint's dump of the captured graph (node kinds and edges)."""
         self.model.train()
         self._static_x, self._static_y = x.clone(), y.clone()
+        saved = [t.clone() for t in self._state()]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -344,12 +460,20 @@ class Trainer:
                     self._optim()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for t, v in zip(self._state(), saved):
+                t.copy_(v)
+        F.pack_for(self.device).mark_stale()
         g = torch.cuda.CUDAGraph()
+        if debug_dot:
+            g.enable_debug_mode()
         with torch.cuda.graph(g):
             loss = self._fwd_bwd(self._static_x, self._static_y)
             if with_optim:
                 self._optim()
             self.loss.copy_(loss)
+        if debug_dot:
+            g.debug_dump(debug_dot)
         self.graph = g
         return g
 
@@ -358,7 +482,13 @@ class Trainer:
             self._static_x.copy_(x, non_blocking=True)
             self._static_y.copy_(y, non_blocking=True)
         self.graph.replay()
+        F.pack_for(self.device).mark_stale()            # the replayed AdamW moved the parameters past the packed copies
         return self.loss
 
     def grad_norm(self) -> float:
-        return float(self.gnorm.item())
+        return float(self.gnorm[0].item())
+
+    def grad_norm_max(self) -> float:
+        """Largest global gradient norm any step has seen since construction (NaN / inf stick): lets a test check EVERY
+        step of a back-to-back replay run with one host read."""
+        return float(self.gnorm[1].item())

@@ -49,7 +49,7 @@ def _worker(rank, world, port, out):
         losses.append(float(tr.step(x, y)))
         dp.after_step()
     torch.cuda.synchronize()
-    res = dict(losses=losses, gnorm=float(tr.gnorm), n_buckets=len(dp.reducer.bounds),
+    res = dict(losses=losses, gnorm=tr.grad_norm(), n_buckets=len(dp.reducer.bounds),
                p_sum=float(tr.flat_p.double().sum()), p_abs=float(tr.flat_p.double().abs().sum()),
                bank=float(model.global_bank.global_k.double().abs().sum()), count=int(model.global_bank.update_count),
                g_abs=float(tr.flat_g.double().abs().sum()))

@@ -46,9 +46,19 @@ def test_eval_logits_and_taps_vs_reference(tag, golden, Q):
         h.remove()
     worst = []
     for n, t in taps.items():
-        if n in ("patch_embed", "pos_drop"):       # pos_embed add is fused into patch_embed here: different tap meaning
+        if n == "pos_drop":
+            continue
+        if n == "patch_embed":
+            # the pos_embed add is fused into the patch-embed LayerNorm kernel here: this module's output is the reference's
+            # pos_drop tap (= patch_embed(x) + pos_embed in eval, HQAViT_CIFAR100.py:1249-1251); minus pos_embed it is the
+            # reference's patch_embed tap
+            if prefix + "pos_drop" in golden.files:
+                worst.append((max_rel(sig(t), golden[prefix + "pos_drop"]), "pos_drop"))
+            worst.append((max_rel(sig(t.float() - model.pos_embed.detach()), golden[prefix + "patch_embed"]), "patch_embed"))
             continue
         worst.append((max_rel(sig(t), golden[prefix + n]), n))
+    if prefix + "patch_embed" in golden.files:
+        assert "patch_embed" in {n for _, n in worst}
     worst.sort(reverse=True)
     assert worst and worst[0][0] <= 5e-4, worst[:5]
     assert max_rel(logits.float().cpu().numpy(), golden[f"{tag}/eval_logits"]) <= LOGIT_TOL
@@ -288,13 +298,13 @@ def test_graph_capture_matches_eager(Q, golden):
             for _ in range(6):
                 ls.append(tr.step(x, y).item())
         else:
-            tr.capture(x, y, warmup=3)                # 3 eager warm-up steps + 1 captured run
-            ls = [None] * 3                          # capture records, it does not execute: replays are steps 3, 4
-            for _ in range(2):
+            tr.capture(x, y, warmup=3)                # warm-up steps are rolled back: replay i is training step i
+            for _ in range(6):
                 ls.append(tr.replay().item())
+            assert int(model.global_bank.update_count) == 6 * 24 and int(tr.step_idx) == 6
         losses[mode] = ls
-    assert abs(losses["graph"][3] - losses["eager"][3]) <= 1e-3 * abs(losses["eager"][3]), losses
-    assert abs(losses["graph"][4] - losses["eager"][4]) <= 1e-3 * abs(losses["eager"][4]), losses
+    for i in range(6):
+        assert abs(losses["graph"][i] - losses["eager"][i]) <= 1e-3 * abs(losses["eager"][i]), (i, losses)
 
 
 def test_graph_replays_back_to_back_stay_finite(Q):
@@ -311,16 +321,30 @@ def test_graph_replays_back_to_back_stay_finite(Q):
     x = torch.randn(B, 3, 32, 32, generator=g).cuda()
     y = torch.randint(0, 100, (B,), generator=g).cuda()
     tr = Q.Trainer(model, Q.TrainingConfig(batch_size=B, use_amp=True), total_steps=100000, warmup_steps=1000, compute_dtype=torch.bfloat16)
-    tr.capture(x, y, with_optim=True, warmup=2)
-    worst = 0.0
+    import os
+    import re
+    import tempfile
+    dot = os.path.join(tempfile.mkdtemp(), "step.dot")
+    tr.capture(x, y, with_optim=True, warmup=2, debug_dot=dot)
+    # the captured step must hold no memset node (hipGraphDebugDotPrint labels nodes by kind)
+    if os.path.exists(dot):
+        txt = open(dot).read()
+        kinds = {}
+        for m in re.finditer(r'label="[^"]*?(KERNEL|MEMSET|MEMCPY|EMPTY|EVENT|HOST|GRAPH)', txt, flags=re.I):
+            k = m.group(1).upper()
+            kinds[k] = kinds.get(k, 0) + 1
+        print("graph node kinds:", kinds)
+        assert kinds.get("KERNEL", 0) > 500, kinds
+        assert kinds.get("MEMSET", 0) == 0, kinds
     for rounds in range(2):
         for _ in range(20):
             tr.replay()
         torch.cuda.synchronize()
-        gn, ls = float(tr.gnorm), float(tr.loss)
+        gn, ls = tr.grad_norm(), float(tr.loss)
         assert gn == gn and ls == ls, (gn, ls)
-        worst = max(worst, gn)
-    assert worst < 1e3, worst
+    # the running maximum covers EVERY replayed step (finite garbage in a middle step would be clipped away and invisible above)
+    worst = tr.grad_norm_max()
+    assert worst == worst and worst < 1e2, worst
 
 
 def test_device_mix_apply_and_mixed_step(Q):
@@ -377,3 +401,218 @@ def test_batch_stager_double_buffers(Q):
     torch.cuda.synchronize()
     assert [s[0] for s in seen] == [0, 1, 0, 1, 0]
     assert all(abs(v - k * 8 * 3 * 32 * 32) < 1e-3 and yy == k for k, (_, v, yy) in enumerate(seen))
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: the literal drop-in loop, config 1's recipe, EMA, bf16 gates for the other variants, pack staleness
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_r2():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r2.npz"))
+
+
+def test_drop_in_loop_torch_optim_and_model_ema(golden, golden_r2, Q):
+    """The reference's own loop shape on the HIP module, unchanged (HQAViT_CIFAR100.py:1401-1443): torch.optim.AdamW over
+    model.parameters(), OneCycleLR per iteration, per-name clip_grad_norm_ 0.1, global clip 0.5, optimizer.step(),
+    zero_grad() (set_to_none), scheduler.step(), ModelEMA.update -- against the 3-step traces the real reference recorded
+    with exactly this code (golden_v1 ``harness/*``, golden_r2 ``ema/*``)."""
+    model = build(Q, "c100", dropout=0.0, drop_path=0.0).train()
+    zero_dropout(model)
+    x = torch.from_numpy(golden["c100/x"]).cuda()
+    y = torch.from_numpy(golden["c100/y"]).cuda()
+    ema = Q.ModelEMA(model, decay=0.999)
+    opt = torch.optim.AdamW(model.parameters(), lr=6e-4, weight_decay=0.06, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=6e-4, total_steps=100, pct_start=0.1, anneal_strategy="cos",
+                                                div_factor=25.0, final_div_factor=1e4)
+    losses, gnorms = [], []
+    for step in range(3):
+        loss = torch.nn.functional.cross_entropy(model(x), y, label_smoothing=0.12)
+        loss.backward()
+        for n, p in model.named_parameters():
+            if ("cnn_stem" in n or "dwconv" in n) and p.grad is not None:
+                torch.nn.utils.clip_grad_norm_([p], max_norm=0.1)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        ema.update(model)
+        losses.append(loss.item())
+        gnorms.append(float(gn))
+    assert max_rel(np.array(losses), golden["harness/loss"]) <= 5e-4, (losses, golden["harness/loss"])
+    assert max_rel(np.array(gnorms), golden["harness/gnorm_after_local_clip"]) <= 5e-3, (gnorms, golden["harness/gnorm_after_local_clip"])
+    params = dict(model.named_parameters())
+    for k in golden.files:
+        if k.startswith("harness/param/"):
+            n = k[len("harness/param/"):]
+            assert max_rel(params[n].detach().reshape(-1)[:256].cpu().numpy(), golden[k]) <= 2e-3, n
+    assert int(model.global_bank.update_count) == int(golden["harness/update_count"])
+    ep = dict(ema.ema.named_parameters())
+    for k in golden_r2.files:
+        if k.startswith("ema/param/"):
+            n = k[len("ema/param/"):]
+            assert max_rel(ep[n].detach().reshape(-1)[:256].cpu().numpy(), golden_r2[k]) <= 1e-4, n
+    eb = dict(ema.ema.named_buffers())
+    assert max_rel(eb["cnn_stem.stem.1.running_mean"].cpu().numpy(), golden_r2["ema/buffer/cnn_stem.stem.1.running_mean"]) <= 1e-4
+    assert int(eb["global_bank.update_count"]) == int(golden_r2["ema/buffer/global_bank.update_count"])
+    # the same loop under the reference's autocast(bf16) context runs the bf16 kernels and stays close to the fp32 trace
+    m2 = build(Q, "c100", dropout=0.0, drop_path=0.0).train()
+    zero_dropout(m2)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=6e-4, weight_decay=0.06)
+    sched2 = torch.optim.lr_scheduler.OneCycleLR(opt2, max_lr=6e-4, total_steps=100, pct_start=0.1, anneal_strategy="cos",
+                                                 div_factor=25.0, final_div_factor=1e4)
+    l2 = []
+    for step in range(3):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m2(x)
+            assert out.dtype == torch.bfloat16
+            loss = torch.nn.functional.cross_entropy(out, y, label_smoothing=0.12)
+        loss.backward()
+        for n, p in m2.named_parameters():
+            if ("cnn_stem" in n or "dwconv" in n) and p.grad is not None:
+                torch.nn.utils.clip_grad_norm_([p], max_norm=0.1)
+        torch.nn.utils.clip_grad_norm_(m2.parameters(), 0.5)
+        opt2.step()
+        opt2.zero_grad()
+        sched2.step()
+        l2.append(loss.item())
+    assert max_rel(np.array(l2), golden["harness/loss"]) <= 2e-2, (l2, golden["harness/loss"])
+
+
+def test_trainer_ema_vs_reference_model_ema(golden, golden_r2, Q):
+    """Trainer's flat-buffer EMA (one lerp per step) == the reference's ModelEMA trace; closed form of the decay warm-up."""
+    model = build(Q, "c100", dropout=0.0, drop_path=0.0).train()
+    zero_dropout(model)
+    cfg = Q.TrainingConfig(use_amp=False, use_ema=True, ema_decay=0.999)
+    tr = Q.Trainer(model, cfg, total_steps=100, warmup_steps=10, compute_dtype=torch.float32)
+    x = torch.from_numpy(golden["c100/x"]).cuda()
+    y = torch.from_numpy(golden["c100/y"]).cuda()
+    for _ in range(3):
+        tr.step(x, y)
+    ema = tr.ema_model()
+    assert not ema.training
+    ep = dict(ema.named_parameters())
+    for k in golden_r2.files:
+        if k.startswith("ema/param/"):
+            n = k[len("ema/param/"):]
+            assert max_rel(ep[n].detach().reshape(-1)[:256].cpu().numpy(), golden_r2[k]) <= 1e-4, n
+    eb = dict(ema.named_buffers())
+    assert max_rel(eb["cnn_stem.stem.1.running_mean"].cpu().numpy(), golden_r2["ema/buffer/cnn_stem.stem.1.running_mean"]) <= 1e-4
+    with torch.no_grad():
+        assert ema(x).shape == (4, 100)
+    tr.set_ema_decay(0.5)
+    before = tr.ema_flat.clone()
+    tr.step(x, y)
+    assert max_rel((tr.ema_flat - before).cpu().numpy(), (0.5 * (tr.flat_p - before)).cpu().numpy()) <= 1e-5
+
+
+def test_config1_finetune_recipe_vs_reference(golden_r2, Q):
+    """BASELINE config 1's recipe (HQAViT_Tiny_Cifar10.py: 2 parameter groups with the head at 10x, clip 1.0, label smoothing
+    0.1, LinearLR warm-up -> CosineAnnealingLR stepped per EPOCH) on Trainer(FineTuneConfig), against the 6-step / 3-epoch
+    trace the reference's own get_param_groups + torch schedulers produced (tests/golden/make_golden_r2.py)."""
+    hp = golden_r2["cfg1/hparams"]
+    epochs, warm, iters = int(hp[6]), int(hp[7]), int(hp[8])
+    mcfg = Q.HQAViTConfig(dropout=0.0, drop_path=0.0)
+    mcfg.num_classes = 10
+    model = Q.HQAViT(mcfg)
+    Q.fill_module(model)
+    model = model.cuda().train()
+    zero_dropout(model)
+    cfg = Q.FineTuneConfig(epochs=epochs, warmup_epochs=warm, use_amp=False)
+    assert (cfg.base_lr, cfg.head_lr_multiplier, cfg.min_lr, cfg.weight_decay, cfg.label_smoothing, cfg.max_grad_norm) == tuple(hp[:6])
+    tr = Q.Trainer(model, cfg, total_steps=epochs * iters, compute_dtype=torch.float32)
+    sizes = [0, 0]
+    for gid, lo, hi in tr.group_ranges:
+        sizes[gid] += int((tr.skip[lo:hi] == 0).sum()) + sum(p.numel() for p, n in zip(tr.params, tr.names)
+                                                              if lo <= tr.offsets[tr.names.index(n)] < hi and Q.harness.never_trained(n))
+    assert sizes == golden_r2["cfg1/group_sizes"].tolist(), (sizes, golden_r2["cfg1/group_sizes"])
+    x = torch.from_numpy(golden_r2["cfg1/x"]).cuda()
+    y = torch.from_numpy(golden_r2["cfg1/y"]).cuda()
+    losses, gnorms, lrs = [], [], []
+    for epoch in range(epochs):
+        for _ in range(iters):
+            losses.append(tr.step(x, y).item())
+            gnorms.append(tr.grad_norm())
+        lrs.append(tr.lr_dev.tolist())
+        tr.epoch_end()
+    assert max_rel(np.array(lrs), golden_r2["cfg1/lr"][:epochs]) <= 1e-6, (lrs, golden_r2["cfg1/lr"])
+    assert max_rel(np.array(losses), golden_r2["cfg1/loss"]) <= 5e-4, (losses, golden_r2["cfg1/loss"])
+    assert max_rel(np.array(gnorms), golden_r2["cfg1/gnorm"]) <= 5e-3, (gnorms, golden_r2["cfg1/gnorm"])
+    params = dict(model.named_parameters())
+    for k in golden_r2.files:
+        if k.startswith("cfg1/param/"):
+            n = k[len("cfg1/param/"):]
+            assert max_rel(params[n].detach().reshape(-1)[:256].cpu().numpy(), golden_r2[k]) <= 2e-3, n
+    assert int(model.global_bank.update_count) == int(golden_r2["cfg1/update_count"])
+
+
+BF16_LOGIT_TOL = 5e-2
+
+
+@pytest.mark.parametrize("tag", list(MODELS))
+def test_bf16_eval_logits_vs_reference(tag, golden, Q):
+    """The dtype the benchmark runs, on EVERY variant (C100, Tiny-IN's attn4 path, QA-ViT @32 and @224, the v2 stem):
+    bf16 eval logits against the fp32 logits of the real reference, max-rel <= 5e-2 (torch's own bf16 autocast deviates
+    2.6e-2 on the C100 logits)."""
+    model = build(Q, tag).eval()
+    x = torch.from_numpy(golden[f"{tag}/x"]).cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(x)
+    assert out.dtype == torch.bfloat16
+    r = max_rel(out.float().cpu().numpy(), golden[f"{tag}/eval_logits"])
+    print(f"{tag}: bf16 logits max-rel {r:.3e}")
+    assert r <= BF16_LOGIT_TOL, r
+
+
+@pytest.mark.parametrize("tag", ["tin", "q224", "v2_224"])
+def test_bf16_train_step_vs_reference(tag, golden, Q):
+    """bf16 forward+backward of the non-C100 variants against the reference's fp32 step: loss, and the gradient norms of
+    the large tensors (cosine-level agreement is what bf16 allows)."""
+    model = build(Q, tag, dropout=0.0, drop_path=0.0).train()
+    zero_dropout(model)
+    model.compute_dtype = torch.bfloat16
+    x = torch.from_numpy(golden[f"{tag}/x"]).cuda()
+    y = torch.from_numpy(golden[f"{tag}/y"]).cuda()
+    logits = model(x)
+    loss = torch.nn.functional.cross_entropy(logits.float(), y, label_smoothing=MODELS[tag][3])
+    loss.backward()
+    assert max_rel(logits.detach().float().cpu().numpy(), golden[f"{tag}/train_logits"]) <= BF16_LOGIT_TOL
+    assert abs(loss.item() - float(golden[f"{tag}/train_loss"])) <= 2e-2 * float(golden[f"{tag}/train_loss"])
+    params = dict(model.named_parameters())
+    names = golden[f"{tag}/grad_names"].tolist()
+    ref = golden[f"{tag}/grad_norms"]
+    got = np.array([0.0 if params[n].grad is None else params[n].grad.norm().item() for n in names])
+    big = ref >= 0.05 * ref.max()
+    ratio = got[big] / ref[big]
+    assert ratio.min() >= 0.85 and ratio.max() <= 1.15, (ratio.min(), ratio.max())
+    assert np.isfinite(got).all()
+
+
+def test_weight_pack_follows_the_optimizer(Q, golden):
+    """Evaluation right after Trainer.step() / replay() must read the UPDATED weights (the fused AdamW writes through raw
+    pointers, so torch's version counters do not move): bf16 and fp32 logits equal those of a fresh model loaded from
+    state_dict()."""
+    x = torch.from_numpy(golden["c100/x"]).cuda()
+    y = torch.from_numpy(golden["c100/y"]).cuda()
+    model = build(Q, "c100", dropout=0.0, drop_path=0.0)
+    zero_dropout(model)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        model.eval()(x)                                    # packs exist before the Trainer re-binds the storage
+    tr = Q.Trainer(model, Q.TrainingConfig(use_amp=True, base_lr=5e-2), total_steps=100, warmup_steps=1, compute_dtype=torch.bfloat16)
+    for mode in ("eager", "graph"):
+        if mode == "eager":
+            tr.step(x, y)
+        else:
+            tr.capture(x, y, warmup=1)
+            tr.replay()
+        fresh = Q.HQAViT(Q.HQAViTConfig(dropout=0.0, drop_path=0.0)).cuda()
+        fresh.load_state_dict(model.state_dict(), strict=True)
+        fresh.eval()
+        model.eval()
+        with torch.no_grad():
+            for dt in (torch.bfloat16, torch.float32):
+                model.compute_dtype = fresh.compute_dtype = dt
+                a, b = model(x).float(), fresh(x).float()
+                assert max_rel(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6, (mode, dt)
+        model.compute_dtype = torch.bfloat16
+        model.train()

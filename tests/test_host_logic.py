@@ -1,7 +1,9 @@
 """CPU-side logic of the product: module tree / state_dict contract, filler, schedules, parameter bookkeeping."""
 import math
+import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import MODELS
@@ -181,3 +183,72 @@ def test_reference_named_shims_resolve(golden, Q):
         model = getattr(mod, cls)(getattr(mod, cfg)())
         if tag is not None:
             assert sorted(model.state_dict().keys()) == golden[f"{tag}/state_keys"].tolist(), name
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: config 1's per-epoch two-group schedule, EMA decay warm-up, init distributions (golden_r2.npz)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_r2():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r2.npz"))
+
+
+def test_finetune_schedule_matches_torch_schedulers(golden_r2, Q):
+    """harness.finetune_lr (closed form) == the LR both parameter groups had under the reference's own construction
+    (CosineAnnealingLR then LinearLR on one AdamW, stepped per epoch; HQAViT_Tiny_Cifar10.py:481-496, :520-523), recorded
+    from torch's schedulers with the script's FineTuneConfig defaults, and the 3-epoch variant of the recipe trace."""
+    hp = golden_r2["sched/hparams"]
+    cfg = Q.FineTuneConfig()
+    assert (cfg.base_lr, cfg.head_lr_multiplier, cfg.min_lr, cfg.epochs, cfg.warmup_epochs) == tuple(hp)
+    ref = golden_r2["sched/lr"]
+    got = np.array([Q.harness.finetune_lr(e, cfg) for e in range(ref.shape[0])])
+    assert np.abs(got - ref).max() <= 1e-12 + 1e-9 * ref.max(), (got, ref)
+    hp1 = golden_r2["cfg1/hparams"]
+    cfg1 = Q.FineTuneConfig(epochs=int(hp1[6]), warmup_epochs=int(hp1[7]))
+    ref1 = golden_r2["cfg1/lr"]
+    got1 = np.array([Q.harness.finetune_lr(e, cfg1) for e in range(ref1.shape[0])])
+    assert np.abs(got1 - ref1).max() <= 1e-12 + 1e-9 * ref1.max(), (got1, ref1)
+
+
+def test_ema_decay_warmup_rule(Q):
+    """HQAViT_CIFAR100.py:1634-1638: decay = 0.99 + (0.999 - 0.99) * epoch / warmup_epochs for epoch <= warmup_epochs."""
+    cfg = Q.TrainingConfig()
+    assert cfg.use_ema and cfg.ema_decay == 0.999 and cfg.ema_decay_warmup == 0.99 and cfg.warmup_epochs == 20
+    f = Q.harness.ema_decay_for_epoch
+    assert abs(f(1, cfg) - (0.99 + 0.009 / 20)) < 1e-12 and abs(f(10, cfg) - 0.9945) < 1e-12
+    assert f(20, cfg) == pytest.approx(0.999) and f(21, cfg) == 0.999 and f(400, cfg) == 0.999
+
+
+@pytest.mark.parametrize("tag", ["c100", "q32"])
+def test_init_distributions_match_reference(tag, golden_r2, Q):
+    """HQAViT.__init__/_init_weights (HQAViT_CIFAR100.py:1146-1224; `self.apply` runs last, so every Conv2d -- the custom
+    depthwise init of :664-666 included -- ends up kaiming_normal(fan_out), every Linear trunc_normal(0.02) with zero bias,
+    every LayerNorm (1, 0)): per-parameter moments of a fresh model here against the moments recorded from a fresh
+    REFERENCE model.  Constants must be equal; random tensors must agree in mean and std within sampling error."""
+    torch.manual_seed(1)
+    if tag == "c100":
+        model = Q.HQAViT(Q.HQAViTConfig())
+    else:
+        model = Q.QAViT(Q.qavit32_config(), "v1")
+    names = golden_r2[f"init/{tag}/names"].tolist()
+    mom = golden_r2[f"init/{tag}/moments"]
+    params = dict(model.named_parameters())
+    assert list(params) == names
+    bad = []
+    for n, (mean, std, lo, hi, numel) in zip(names, mom):
+        t = params[n].detach().float()
+        assert t.numel() == int(numel), n
+        m2 = float(t.mean())
+        s2 = float(t.std()) if t.numel() > 1 else 0.0
+        if std == 0.0 or lo == hi:                                   # a constant fill
+            if not (float(t.min()) == lo and float(t.max()) == hi):
+                bad.append((n, "const", lo, hi, float(t.min()), float(t.max())))
+            continue
+        k = float(numel)
+        tol_mean = 6.0 * std * np.sqrt(2.0 / k) + 1e-12              # both sides are samples
+        tol_std = 6.0 / np.sqrt(2.0 * k) * np.sqrt(2.0) + 0.0
+        if abs(m2 - mean) > tol_mean or abs(s2 / std - 1.0) > max(tol_std, 0.02 if k >= 4096 else tol_std):
+            bad.append((n, "moments", mean, std, m2, s2, k))
+        if not (float(t.abs().max()) <= 1.6 * max(abs(lo), abs(hi)) + 1e-12 or k < 64):
+            bad.append((n, "range", lo, hi, float(t.min()), float(t.max())))
+    assert not bad, bad[:8]

@@ -16,7 +16,7 @@ for i in range(80):
     tr.replay()
     if every and (i + 1) % every == 0:
         torch.cuda.synchronize()
-        gn = float(tr.gnorm)
+        gn = tr.grad_norm()
         print(i + 1, float(tr.loss), gn, flush=True)
         if gn != gn or gn > 1e3:
             offenders = []
@@ -28,4 +28,4 @@ for i in range(80):
             print("offenders:", offenders[:12], len(offenders), flush=True)
             break
 torch.cuda.synchronize()
-print("final", float(tr.loss.item()), float(tr.gnorm))
+print("final", float(tr.loss.item()), tr.grad_norm())

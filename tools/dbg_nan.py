@@ -16,12 +16,12 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
         if mode in ("graph", "nosync"): tr.replay()
         else: tr.step(x, y)
         if (mode != "nosync") or i in (34, 59, 79, 99, 129):
-            gn = float(tr.gnorm); ls = float(tr.loss)
+            gn = tr.grad_norm(); ls = float(tr.loss)
             if gn != gn or gn == float("inf") or ls != ls:
                 print("step", i, "gnorm", gn, "loss", ls, flush=True)
                 first = i; break
     if first is None:
-        print(trial, "no nan in 130 steps; gnorm", float(tr.gnorm), flush=True); continue
+        print(trial, "no nan in 130 steps; gnorm", tr.grad_norm(), flush=True); continue
     bad_p = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
     bad_g = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
     bad_b = [n for n, b in model.named_buffers() if b.dtype.is_floating_point and not torch.isfinite(b).all()]

@@ -13,4 +13,4 @@ tr = Q.Trainer(model, Q.TrainingConfig(use_amp=(dt == torch.bfloat16)), total_st
 for _ in range(n):
     tr.step(x, y)
 torch.cuda.synchronize()
-print("done", float(tr.gnorm))
+print("done", tr.grad_norm())
