@@ -325,13 +325,18 @@ int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, const float* g
  * for backward; ws = float[3*C] scratch.  training == 0: normalises with the running statistics.
  * bwd: dx, and dgamma / dbeta [C] ACCUMULATE (either may be NULL); ws = float[2*C] scratch; `training` as in forward
  * (0: save_mean / save_rstd hold the running mean and rsqrt(running_var + eps), treated as constants).
- * C must be a multiple of 8 (bf16) / 4 (fp32) with 256 % (C/vec) == 0; rows 16-byte aligned. */
+ * C must be a multiple of 8 (bf16) / 4 (fp32) with 256 % (C/vec) == 0; rows 16-byte aligned.
+ * Data-parallel "exact" statistics (SyncBN, SURVEY.md 8e exception 2): both directions are two passes over ws, so the
+ * caller may run them apart -- phase 1 = statistics only (ws[0..2C) holds this rank's column sums), all-reduce (SUM)
+ * ws[0..2C) across ranks, phase 2 = apply with M_total = the rows of all ranks; phase 0 = both passes back to back
+ * (M_total <= 0 means M).  Backward's dgamma / dbeta must stay this rank's own sums (the gradient all-reduce adds the
+ * other ranks'): pass the pre-all-reduce copy as ws_param (NULL = ws). */
 int qavit_bn_fwd(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float momentum, float eps, int act,
-                 float* save_mean, float* save_rstd, float* ws, int training, void* stream);
+                 float* save_mean, float* save_rstd, float* ws, int training, int phase, int64_t M_total, void* stream);
 int qavit_bn_bwd(int dtype, const void* dy, const void* x, int M, int C, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_rstd, int act, int training, void* dx, float* dgamma, float* dbeta,
-                 float* ws, void* stream);
+                 float* ws, int phase, int64_t M_total, const float* ws_param, void* stream);
 /* nn.LayerNorm([C,H,W]) of the ConvNeXt-Tiny style stem (HQAViTv2_CIFAR100.py:766, :777, :791) on channel-last tokens
  * x [B, N=H*W, C]: each SAMPLE is normalised over its N*C elements; w / b keep the reference's [C][N] layout.  N*C must be
  * 4096, 8192 or 16384, C % 4 == 0, rows 16-byte aligned.  mean / rstd [B] are written by fwd and read by bwd; bwd writes

@@ -52,12 +52,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, const float* 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, T* y, const float* gamma, const float* beta, const float* ws,
                                                        float* running_mean, float* running_var, float* save_mean, float* save_rstd,
-                                                       float momentum, float eps, int act, int training, int M, int C) {
+                                                       float momentum, float eps, int act, int training, int M, int C, int64_t Mtot) {
   constexpr int VEC = BV<T>::N;
   typedef typename BV<T>::type vec_t;
   const int tpr = C / VEC, rpp = 256 / tpr;
   const int cg = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
-  const float invM = 1.f / (float)M;
+  const float invM = 1.f / (float)Mtot;                  // Mtot = rows behind the statistics (all ranks' rows when they were all-reduced)
   float mu[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, T* y, const f
     if (training && blockIdx.x == 0 && r0 == 0) {
       save_mean[c] = mean; save_rstd[c] = rstd;
       if (running_mean) {
-        const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        const float unb = Mtot > 1 ? var * ((float)Mtot / (float)(Mtot - 1)) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
       }
@@ -131,12 +131,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* dy, const T*
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                                           const float* ws, T* dx, float* dgamma, float* dbeta, int act, int training, int M, int C) {
+                                                           const float* ws, T* dx, float* dgamma, float* dbeta, int act, int training, int M, int C,
+                                                           int64_t Mtot, const float* ws_param) {
   constexpr int VEC = BV<T>::N;
   typedef typename BV<T>::type vec_t;
   const int tpr = C / VEC, rpp = 256 / tpr;
   const int cg = threadIdx.x % tpr, r0 = threadIdx.x / tpr;
-  const float invM = 1.f / (float)M;
+  const float invM = 1.f / (float)Mtot;
   float mu[VEC], rs[VEC], ga[VEC], be[VEC], k1[VEC], k2[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T*
     k1[j] = training ? ws[c] * invM : 0.f;             // eval mode: the statistics are constants, dx = gamma * rstd * dy'
     k2[j] = training ? ws[C + c] * invM : 0.f;
     if (blockIdx.x == 0 && r0 == 0) {
-      if (dbeta) atomic_add_f(dbeta + c, ws[c]);
-      if (dgamma) atomic_add_f(dgamma + c, ws[C + c]);
+      if (dbeta) atomic_add_f(dbeta + c, ws_param[c]);          // parameter gradients: THIS rank's sums (the gradient all-reduce adds the others)
+      if (dgamma) atomic_add_f(dgamma + c, ws_param[C + c]);
     }
   }
   for (int m = blockIdx.x * rpp + r0; m < M; m += gridDim.x * rpp) {
@@ -185,37 +186,44 @@ inline void stats_grid(int M, int C, int vec, int& grid, int& rows_per_wg) {
 
 template <typename T>
 int bn_fwd_t(const void* x, void* y, int M, int C, const float* gamma, const float* beta, float* rm, float* rv, float momentum, float eps,
-             int act, float* save_mean, float* save_rstd, float* ws, int training, hipStream_t st) {
+             int act, float* save_mean, float* save_rstd, float* ws, int training, int phase, int64_t Mtot, hipStream_t st) {
   constexpr int VEC = BV<T>::N;
   if (!bn_shape_ok<T>(x, y, x, C)) return set_error(QAVIT_EINVAL, "bn_fwd: C must be a multiple of the 16-byte vector with 256 % (C/vec) == 0, 16-byte aligned rows");
-  if (training) {
+  if (Mtot <= 0) Mtot = M;
+  if (training && phase != 2) {
     zero_f32(ws, (size_t)3 * C, st);
     int grid, rows;
     stats_grid(M, C, VEC, grid, rows);
     hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), st, (const T*)x, rm, ws, M, C, rows);
   }
+  if (phase == 1) return check_launch("bn_fwd(stats)");
   const int rpp = 256 / (C / VEC);
   int g2 = (M + rpp - 1) / rpp;
   if (g2 > 2048) g2 = 2048;
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(g2), dim3(256), 0, st, (const T*)x, (T*)y, gamma, beta, ws, rm, rv, save_mean, save_rstd,
-                     momentum, eps, act, training, M, C);
+                     momentum, eps, act, training, M, C, Mtot);
   return check_launch("bn_fwd");
 }
 
 template <typename T>
 int bn_bwd_t(const void* dy, const void* x, int M, int C, const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
-             int training, void* dx, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
+             int training, void* dx, float* dgamma, float* dbeta, float* ws, int phase, int64_t Mtot, const float* ws_param, hipStream_t st) {
   constexpr int VEC = BV<T>::N;
   if (!bn_shape_ok<T>(x, dy, dx, C)) return set_error(QAVIT_EINVAL, "bn_bwd: unsupported channel count / alignment");
-  zero_f32(ws, (size_t)2 * C, st);
-  int grid, rows;
-  stats_grid(M, C, VEC, grid, rows);
-  hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd,
-                     ws, act, M, C, rows);
+  if (Mtot <= 0) Mtot = M;
+  if (!ws_param) ws_param = ws;
+  if (phase != 2) {
+    zero_f32(ws, (size_t)2 * C, st);
+    int grid, rows;
+    stats_grid(M, C, VEC, grid, rows);
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), dim3(grid), dim3(256), (size_t)2 * C * sizeof(float), st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd,
+                       ws, act, M, C, rows);
+  }
+  if (phase == 1) return check_launch("bn_bwd(stats)");
   const int rpp = 256 / (C / VEC);
   int g2 = (M + rpp - 1) / rpp;
   if (g2 > 2048) g2 = 2048;
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g2), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd, ws, (T*)dx, dgamma, dbeta, act, training, M, C);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g2), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd, ws, (T*)dx, dgamma, dbeta, act, training, M, C, Mtot, ws_param);
   return check_launch("bn_bwd");
 }
 
@@ -227,22 +235,23 @@ using namespace qv;
 
 extern "C" int qavit_bn_fwd(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int act,
-                            float* save_mean, float* save_rstd, float* ws, int training, void* stream) {
-  if (!x || !y || !gamma || !beta || M <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "bn_fwd: bad arguments");
+                            float* save_mean, float* save_rstd, float* ws, int training, int phase, int64_t M_total, void* stream) {
+  if (!x || !y || !gamma || !beta || M <= 0 || C <= 0 || phase < 0 || phase > 2) return set_error(QAVIT_EINVAL, "bn_fwd: bad arguments");
   if (training && (!save_mean || !save_rstd || !ws)) return set_error(QAVIT_EINVAL, "bn_fwd: training needs save_mean / save_rstd / ws[3*C]");
   if (!training && (!running_mean || !running_var)) return set_error(QAVIT_EINVAL, "bn_fwd: eval needs the running statistics");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == QAVIT_F32) return bn_fwd_t<float>(x, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training, st);
-  if (dtype == QAVIT_BF16) return bn_fwd_t<bf16>(x, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training, st);
+  if (dtype == QAVIT_F32) return bn_fwd_t<float>(x, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training, phase, M_total, st);
+  if (dtype == QAVIT_BF16) return bn_fwd_t<bf16>(x, y, M, C, gamma, beta, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training, phase, M_total, st);
   return set_error(QAVIT_EINVAL, "bn_fwd: unknown dtype");
 }
 
 extern "C" int qavit_bn_bwd(int dtype, const void* dy, const void* x, int M, int C, const float* gamma, const float* beta,
                             const float* save_mean, const float* save_rstd, int act, int training, void* dx, float* dgamma, float* dbeta,
-                            float* ws, void* stream) {
+                            float* ws, int phase, int64_t M_total, const float* ws_param, void* stream) {
+  if (phase < 0 || phase > 2) return set_error(QAVIT_EINVAL, "bn_bwd: phase must be 0, 1 or 2");
   if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_rstd || !ws || M <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "bn_bwd: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == QAVIT_F32) return bn_bwd_t<float>(dy, x, M, C, gamma, beta, save_mean, save_rstd, act, training, dx, dgamma, dbeta, ws, st);
-  if (dtype == QAVIT_BF16) return bn_bwd_t<bf16>(dy, x, M, C, gamma, beta, save_mean, save_rstd, act, training, dx, dgamma, dbeta, ws, st);
+  if (dtype == QAVIT_F32) return bn_bwd_t<float>(dy, x, M, C, gamma, beta, save_mean, save_rstd, act, training, dx, dgamma, dbeta, ws, phase, M_total, ws_param, st);
+  if (dtype == QAVIT_BF16) return bn_bwd_t<bf16>(dy, x, M, C, gamma, beta, save_mean, save_rstd, act, training, dx, dgamma, dbeta, ws, phase, M_total, ws_param, st);
   return set_error(QAVIT_EINVAL, "bn_bwd: unknown dtype");
 }

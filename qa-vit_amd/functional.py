@@ -1087,7 +1087,13 @@ class DropoutFn(Function):
 
 class BatchNormFn(Function):
     """nn.BatchNorm2d (+ exact GELU when ``act``) on channel-last rows [M, C] -- csrc/bnorm.hip.  Running statistics
-    are updated in place by the forward kernel in training mode (the caller bumps ``num_batches_tracked``)."""
+    are updated in place by the forward kernel in training mode (the caller bumps ``num_batches_tracked``).
+
+    ``BatchNormFn.sync`` (set by parallel.DataParallel(bn_sync="exact")): callable(stats fp32 [2C]) -> world size that
+    SUM-all-reduces the column statistics in place.  Training-mode forward and backward then run as statistics pass ->
+    all-reduce -> apply pass over the GLOBAL batch (SyncBN; SURVEY.md 8e exception 2), which makes an N-rank step equal
+    the single-process step on the concatenated batch."""
+    sync = None
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, training):
@@ -1099,24 +1105,38 @@ class BatchNormFn(Function):
         save_mean = torch.empty(Cc, dtype=torch.float32, device=dev) if training else None
         save_rstd = torch.empty(Cc, dtype=torch.float32, device=dev) if training else None
         ws = torch.empty(3 * Cc, dtype=torch.float32, device=dev) if training else None
-        K.bn_fwd(x, y, M, Cc, weight, bias, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training)
+        sync = BatchNormFn.sync if training else None
+        m_total = 0
+        if sync is not None:
+            K.bn_fwd(x, y, M, Cc, weight, bias, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training, phase=1)
+            m_total = M * int(sync(ws[:2 * Cc]))             # the pivot (ws[2C:]) is the replicated running mean: identical on all ranks
+            K.bn_fwd(x, y, M, Cc, weight, bias, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training, phase=2, m_total=m_total)
+        else:
+            K.bn_fwd(x, y, M, Cc, weight, bias, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training)
         if not training:                                   # eval backward: the running statistics are constants
             save_mean = running_mean.detach().clone()
             save_rstd = torch.rsqrt(running_var.detach() + eps)
-        ctx.meta = (M, Cc, bool(act), bool(training))
+        ctx.meta = (M, Cc, bool(act), bool(training), m_total)
         ctx.save_for_backward(x, weight, bias, save_mean, save_rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias, save_mean, save_rstd = ctx.saved_tensors
-        M, Cc, act, training = ctx.meta
+        M, Cc, act, training, m_total = ctx.meta
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         gbuf, gret = grad_sink(weight)
         bbuf, bret = grad_sink(bias)
         ws = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
-        K.bn_bwd(dy, x, M, Cc, weight, bias, save_mean, save_rstd, act, training, dx, gbuf, bbuf, ws)
+        sync = BatchNormFn.sync if (training and m_total > 0) else None
+        if sync is not None:
+            K.bn_bwd(dy, x, M, Cc, weight, bias, save_mean, save_rstd, act, training, dx, gbuf, bbuf, ws, phase=1)
+            local = ws.clone()                              # dgamma / dbeta stay this rank's sums; the gradient all-reduce adds the rest
+            sync(ws)
+            K.bn_bwd(dy, x, M, Cc, weight, bias, save_mean, save_rstd, act, training, dx, gbuf, bbuf, ws, phase=2, m_total=m_total, ws_param=local)
+        else:
+            K.bn_bwd(dy, x, M, Cc, weight, bias, save_mean, save_rstd, act, training, dx, gbuf, bbuf, ws)
         return dx, _ret(gret, weight), _ret(bret, bias), None, None, None, None, None, None
 
 

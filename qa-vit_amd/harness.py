@@ -442,12 +442,14 @@ class Trainer:
         st.extend(b for _, b in self.model.named_buffers())
         return st
 
-    def capture(self, x, y, with_optim: bool = True, warmup: int = 3, debug_dot: Optional[str] = None):
+    def capture(self, x, y, with_optim: bool = True, warmup: int = 3, inspect: bool = False, debug_dot: Optional[str] = None):
         """Capture the whole step into one hipGraph (torch.cuda.CUDAGraph).  ``x``/``y`` give the static shapes.
         The ``warmup`` eager steps that precede the capture (allocator / workspace / table warm-up) run real optimiser
         steps; every piece of training state is snapshotted before and restored after them, so capturing does not
         advance the run (parameters, Adam moments, LR position, bank, BatchNorm statistics, RNG all stay where they were).
-        ``debug_dot``: path for hipGraphDebugDotPrint's dump of the captured graph (node kinds and edges)."""
+        ``inspect``: keep the hipGraph_t and leave its node census (graphinfo.node_kinds) in ``self.graph_nodes``;
+        ``debug_dot``: with ``inspect``, path for hipGraphDebugDotPrint's dump of the captured graph."""
+        inspect = inspect or bool(debug_dot)
         self.model.train()
         self._static_x, self._static_y = x.clone(), y.clone()
         saved = [t.clone() for t in self._state()]
@@ -464,16 +466,19 @@ class Trainer:
             for t, v in zip(self._state(), saved):
                 t.copy_(v)
         F.pack_for(self.device).mark_stale()
-        g = torch.cuda.CUDAGraph()
-        if debug_dot:
-            g.enable_debug_mode()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if inspect else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss = self._fwd_bwd(self._static_x, self._static_y)
             if with_optim:
                 self._optim()
             self.loss.copy_(loss)
-        if debug_dot:
-            g.debug_dump(debug_dot)
+        self.graph_nodes = None
+        if inspect:
+            from . import graphinfo
+            raw = g.raw_cuda_graph()
+            self.graph_nodes = graphinfo.node_kinds(raw)
+            if debug_dot:
+                graphinfo.dot_print(raw, debug_dot)
         self.graph = g
         return g
 

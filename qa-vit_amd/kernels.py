@@ -393,16 +393,16 @@ def bn_supported(dtype, Cc: int) -> bool:
     return Cc % vec == 0 and Cc // vec <= 256 and 256 % (Cc // vec) == 0 and Cc <= 2048
 
 
-def bn_fwd(x, y, M, Cc, gamma, beta, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training):
+def bn_fwd(x, y, M, Cc, gamma, beta, running_mean, running_var, momentum, eps, act, save_mean, save_rstd, ws, training, phase=0, m_total=0):
     L.check(L.load().qavit_bn_fwd(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(),
                                   _p(running_mean), _p(running_var), float(momentum), float(eps), int(act),
-                                  _p(save_mean), _p(save_rstd), _p(ws), int(training), stream()), "bn_fwd")
+                                  _p(save_mean), _p(save_rstd), _p(ws), int(training), int(phase), int(m_total), stream()), "bn_fwd")
 
 
-def bn_bwd(dy, x, M, Cc, gamma, beta, save_mean, save_rstd, act, training, dx, dgamma, dbeta, ws):
+def bn_bwd(dy, x, M, Cc, gamma, beta, save_mean, save_rstd, act, training, dx, dgamma, dbeta, ws, phase=0, m_total=0, ws_param=None):
     L.check(L.load().qavit_bn_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(),
                                   save_mean.data_ptr(), save_rstd.data_ptr(), int(act), int(training), dx.data_ptr(), _p(dgamma), _p(dbeta),
-                                  ws.data_ptr(), stream()), "bn_bwd")
+                                  ws.data_ptr(), int(phase), int(m_total), _p(ws_param), stream()), "bn_bwd")
 
 
 def spatial_ln_supported(N, Cc):

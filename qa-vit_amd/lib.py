@@ -104,8 +104,8 @@ _SIGS = {
     "qavit_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_chan_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_chan_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
-    "qavit_bn_fwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, i32, vp]),
-    "qavit_bn_bwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "qavit_bn_fwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, i32, i32, i64, vp]),
+    "qavit_bn_bwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i64, vp, vp]),
     "qavit_spatial_ln_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "qavit_spatial_ln_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "qavit_dropout": (i32, [i32, vp, vp, i64, f32, i32, vp, vp]),

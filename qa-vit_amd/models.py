@@ -182,6 +182,8 @@ class QAViT(_Base):
         with torch.autocast("cuda", enabled=False):
             T = self.patch_embed(x, self.pos_embed)
             T = F.dropout(T, self.pos_drop.p, self._pos_site, self.training)
-            for blk in self.blocks:
+            for i, blk in enumerate(self.blocks):
+                if i > 0 and i % 2 == 0:                   # data-parallel: gradients of blocks >= i are complete once backward passes here
+                    T = self._sync(T, f"blocks.{i}")
                 T = blk(T)
             return self._head(T)

@@ -14,8 +14,10 @@ Design (SURVEY.md sections 5 and 8e):
     are all-reduced (SUM) before the clamp/update -- 24 (C100) sequential 12 KB collectives per forward,
     latency-bound; exact mode is the default, ``bank_sync="local"`` keeps per-rank banks and re-broadcasts
     rank 0's bank every ``bank_broadcast_every`` steps.
-  * exception 2, BatchNorm in the CNN stem: per-rank statistics (standard DDP semantics); buffers are broadcast
-    from rank 0 at construction.
+  * exception 2, BatchNorm in the CNN stem (4 layers): ``bn_sync="exact"`` (default) all-reduces the per-channel column
+    sums between the statistics pass and the apply pass of csrc/bnorm.hip, forward and backward (SyncBN: 2 x 4 small
+    collectives per step), so an N-rank step equals the single-process step on the global batch; ``bn_sync="local"``
+    keeps per-rank statistics (stock DDP semantics).  Buffers are broadcast from rank 0 at construction.
   * dropout / drop-path RNG streams differ per rank (seed + rank).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -158,7 +160,7 @@ class DataParallel:
     """
 
     def __init__(self, model: torch.nn.Module, group=None, bucket_bytes: int = 4 << 20, bank_sync: str = "exact",
-                 bank_broadcast_every: int = 50, seed: int = 0x5EED):
+                 bank_broadcast_every: int = 50, seed: int = 0x5EED, bn_sync: str = "exact"):
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs torch.distributed.init_process_group first")
         self.model, self.group = model, group
@@ -176,6 +178,14 @@ class DataParallel:
             model.set_bank_sync(self._bank_all_reduce if bank_sync == "exact" else None)
         if hasattr(model, "_sync_reducer"):
             model._sync_reducer = self.reducer
+        if bn_sync not in ("exact", "local"):
+            raise ValueError("bn_sync must be 'exact' or 'local'")
+        from .functional import BatchNormFn
+        BatchNormFn.sync = self._bn_all_reduce if (bn_sync == "exact" and self.world > 1) else None
+
+    def _bn_all_reduce(self, stats: torch.Tensor) -> int:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+        return self.world
 
     def _bank_all_reduce(self, acc: torch.Tensor, local_batch: int) -> int:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
@@ -184,10 +194,16 @@ class DataParallel:
     def bind(self, trainer):
         names, offsets = trainer.names, trainer.offsets
         stage_tags = []
-        for tag in ("stage4_blocks", "fuse4", "stage3_blocks", "fuse3", "stage2_blocks", "fuse2", "stage1_blocks"):
-            # gradients of everything ordered at or before `tag` are complete when backward passes the sync
-            # point placed BEFORE that module group in forward
-            stage_tags.append((tag, _prefix_pred(tag)))
+        if hasattr(self.model, "blocks"):                  # QAViT: sync points before blocks 2, 4, 6, ... (models.QAViT.forward)
+            nblk = len(self.model.blocks)
+            for i in range(nblk - 1, 0, -1):
+                if i % 2 == 0:
+                    stage_tags.append((f"blocks.{i}", _blocks_pred(i)))
+        else:
+            for tag in ("stage4_blocks", "fuse4", "stage3_blocks", "fuse3", "stage2_blocks", "fuse2", "stage1_blocks"):
+                # gradients of everything ordered at or before `tag` are complete when backward passes the sync
+                # point placed BEFORE that module group in forward
+                stage_tags.append((tag, _prefix_pred(tag)))
         self.reducer.plan(names, offsets, stage_tags)
         self.reducer.attach(trainer.flat_g)
 
@@ -207,4 +223,17 @@ def _prefix_pred(tag: str):
 
     def pred(name: str) -> bool:
         return name.startswith(ok)
+    return pred
+
+
+def _blocks_pred(i: int):
+    def pred(name: str) -> bool:
+        if name.startswith(("head.", "norm.")):
+            return True
+        if name.startswith("blocks."):
+            try:
+                return int(name.split(".")[1]) >= i
+            except ValueError:
+                return False
+        return False
     return pred

@@ -36,6 +36,9 @@ def _worker(rank, world, port, out):
     model = Q.HQAViT(cfg).cuda().train()
     if rank == 0:
         Q.fill_module(model)
+    for m in model.modules():                             # SplitFusion.cat_mlp hard-wires Dropout(0.1) (HQAViT_CIFAR100.py:930)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
     dp = par.DataParallel(model)
     tr = Q.Trainer(model, Q.TrainingConfig(batch_size=16, use_amp=False), total_steps=100, warmup_steps=10,
                    reducer=dp.reducer, compute_dtype=torch.float32, order=par.bucket_order)
@@ -49,18 +52,66 @@ def _worker(rank, world, port, out):
         losses.append(float(tr.step(x, y)))
         dp.after_step()
     torch.cuda.synchronize()
-    res = dict(losses=losses, gnorm=tr.grad_norm(), n_buckets=len(dp.reducer.bounds),
+    probe = {n: p.detach().reshape(-1)[:64].cpu().clone() for n, p in model.named_parameters()
+             if n in ("head.weight", "cnn_stem.stem.1.weight", "cnn_stem.stage3.1.bias", "stage1_blocks.0.quad_block.swa.qkv.weight", "global_bank.global_k")}
+    res = dict(losses=losses, gnorm=tr.grad_norm(), n_buckets=len(dp.reducer.bounds), probe=probe,
+               bn_mean=model.cnn_stem.stem[1].running_mean.cpu().clone(), bn_var=model.cnn_stem.stage1[1].running_var.cpu().clone(),
+               flat_g=tr.flat_g.cpu().clone(), names=tr.names, offsets=tr.offsets,
                p_sum=float(tr.flat_p.double().sum()), p_abs=float(tr.flat_p.double().abs().sum()),
-               bank=float(model.global_bank.global_k.double().abs().sum()), count=int(model.global_bank.update_count),
+               bank=float(model.global_bank.global_k.detach().double().abs().sum()), count=int(model.global_bank.update_count),
                g_abs=float(tr.flat_g.double().abs().sum()))
     torch.save(res, os.path.join(out, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
+def _single_process_reference():
+    """The same two optimiser steps in ONE process on the concatenated B = 16 batch (what the reference's single-GPU loop
+    computes): the target the exact data-parallel modes (bank statistics, SyncBN) must reproduce."""
+    sys.path.insert(0, ROOT)
+    import qavit_amd as Q
+    cfg = Q.HQAViTConfig(dropout=0.0, drop_path=0.0)
+    model = Q.HQAViT(cfg).cuda().train()
+    Q.fill_module(model)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    tr = Q.Trainer(model, Q.TrainingConfig(batch_size=16, use_amp=False), total_steps=100, warmup_steps=10, compute_dtype=torch.float32)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(16, 3, 32, 32, generator=g).cuda()
+    Y = torch.randint(0, 100, (16,), generator=g).cuda()
+    losses = [float(tr.step(X, Y)) for _ in range(2)]
+    torch.cuda.synchronize()
+    return model, tr, losses
+
+
 def test_two_rank_step_keeps_replicas_identical(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    r0, r1 = torch.load(tmp_path / "r0.pt", weights_only=False), torch.load(tmp_path / "r1.pt", weights_only=False)
+    # ---- 2 ranks x 8 images == one process x 16 images (exact bank statistics + SyncBN): parameters after two optimiser
+    # steps, the last step's averaged gradient, the bank, BatchNorm running statistics, the global gradient norm
+    model, tr, losses = _single_process_reference()
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    assert abs(0.5 * (r0["losses"][0] + r1["losses"][0]) - losses[0]) <= 1e-5 * abs(losses[0])       # step 0: identical weights
+    assert abs(0.5 * (r0["losses"][1] + r1["losses"][1]) - losses[1]) <= 1e-4 * abs(losses[1])
+    params = dict(model.named_parameters())
+    for n, v in r0["probe"].items():
+        assert rel(v, params[n].detach().reshape(-1)[:64].cpu()) <= 1e-4, n
+    assert rel(r0["bn_mean"], model.cnn_stem.stem[1].running_mean.cpu()) <= 1e-5
+    assert rel(r0["bn_var"], model.cnn_stem.stage1[1].running_var.cpu()) <= 1e-5
+    assert abs(r0["gnorm"] - tr.grad_norm()) <= 1e-4 * tr.grad_norm()
+    ref_g = {n: tr.flat_g[o:o + p.numel()].cpu() for n, o, p in zip(tr.names, tr.offsets, tr.params)}
+    gmax = max(float(v.abs().max()) for v in ref_g.values())
+    worst = []
+    from conftest import zero_by_construction
+    for n, o in zip(r0["names"], r0["offsets"]):
+        if zero_by_construction(n):                         # exactly-zero gradients: what is there is round-off
+            continue
+        g0 = r0["flat_g"][o:o + ref_g[n].numel()]
+        worst.append((float((g0 - ref_g[n]).abs().max()) / max(float(ref_g[n].abs().max()), 1e-3 * gmax), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 2e-3, worst[:5]
     assert r0["n_buckets"] >= 3
     # replicas: identical parameters, averaged gradients, bank and counter after two optimiser steps
     for k in ("p_sum", "p_abs", "bank", "g_abs", "gnorm"):
