@@ -191,6 +191,41 @@ int64_t qavit_attn_ws_floats(const qavit_attn_args* a);
 int qavit_nan_guard(int dtype, void* x, int64_t n, int* flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Fused attention BRANCH for 16-token problems (every HQA-ViT CIFAR block works on 16 learned tokens): ONE launch for
+ *   out = dropout( proj( efficient_attention( q, K_full, V_full, dropout_p ) ) )
+ * with q / k / v computed in the kernel from the branch input x (= norm1's output):
+ *   kind 0, SWA   (HQAViT_CIFAR100.py:441-469): qkv(x) on the one 4x4 window; K_full = [E_k^T k ; bank_k], V likewise
+ *   kind 1, MSDA  (:496-532): q = qkv(x)[:, :C]; k, v = qkv(pooled)[:, C:], pooled[j] = mean_s x[idx[j*stride+s]], j < L;
+ *                 K_full = [E_k[:L]^T k ; bank_k]   (the reference's zero padding to 128 rows is algebraic)
+ *   kind 2, cross (:613-626): q = q_proj(x); K_full = sh_k, V_full = sh_v (k_proj / v_proj of the bank, computed by the caller)
+ * Shapes are fixed: T = 16 tokens, C = 192, H = 4 heads of D = 48, S = 16 shared rows, KC = 32 Linformer rows; bf16 only.
+ * Weights come in MFMA FRAGMENT order (qavit_pack_desc.pad = 1): wqkv_frag = packed [3C, C] (kind 2: [C, C]), wproj_frag =
+ * packed [C, C].  Dropout masks follow the unfused kernels' contracts exactly (attention: attn_shared.h attn_drop_factor
+ * with problem id = image * H + head; proj: the qavit_gemm_nt epilogue's drop_factor(key(site), row * C + col)), so a
+ * forward through this kernel and a backward through the unfused chain see the same masks.
+ * nan_flag (int[2], zero at rest): the reference's NaN -> zeros rule; when set the call rewrites `out` as
+ * dropout(bias) rows (= proj of an all-zero attention output) and clears the flag.
+ * o_save (optional, leading dimension ldo): the attention output O [B*T, C], operand of backward's dW_proj.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_branch_args {
+  int dtype; int kind;
+  int B, T, C, H, D, KC, S, L;
+  const void* x; int64_t ldx;
+  const void* wqkv_frag; const float* bqkv;
+  const void* wproj_frag; const float* bproj;
+  const float* E_k; const float* E_v;
+  const float* sh_k; const float* sh_v;
+  const int32_t* pool_idx; int pool_stride;
+  void* out; int64_t ldo;
+  void* o_save;
+  float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
+  int* nan_flag;
+} qavit_branch_args;
+
+int qavit_branch_supported(int kind, int T, int C, int H, int D, int KC, int S, int L);   /* 1 if qavit_branch_fwd covers the shape */
+int qavit_branch_fwd(const qavit_branch_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * TokenLearner mixing (HQAViT_CIFAR100.py:996-1000): p = softmax over the N axis of scores[B,N,M];
  * xc[B,M,C] = p^T x.  bwd: dx (direct path) and dscores.
  * ------------------------------------------------------------------------------------------------- */
@@ -353,7 +388,11 @@ int qavit_chan_scale_add_bwd(int dtype, const void* dy, const void* u, const flo
                              int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
 /* y = dropout(x) (pos_drop, HQAViT_CIFAR100.py:1251); bwd is the same call on dy */
 int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream);
-/* packed weights: dst = cast(src) and dstT = cast(src)^T for 2-D [rows, cols] fp32 params; descriptor table on device */
+/* packed weights: dst = cast(src) and dstT = cast(src)^T for 2-D [rows, cols] fp32 params; descriptor table on device.
+ * pad = 1: dst is written in MFMA FRAGMENT order for v_mfma_f32_16x16x32_bf16 instead of row-major (rows % 16 == 0,
+ * cols % 32 == 0): the 16-row x 32-column fragment (t, s) is 1 KB at ((t * (cols/32) + s) * 512) elements, and inside it
+ * lane l's 8 elements are src[16 t + l % 16][32 s + 8 (l / 16) .. + 8] -- a wave reads it with one 16-byte load per lane,
+ * and a run of fragments is a linear copy into LDS (csrc/branch_fwd.hip). */
 typedef struct qavit_pack_desc { const float* src; void* dst; void* dstT; int rows; int cols; int ldT; int pad; } qavit_pack_desc;
 /* dst[r*cols + c] = src[r][c]; dstT[c*ldT + r] = src[r][c] (ldT >= rows lets several sources stack into one
  * transposed matrix, e.g. CGA's q/k/v projections) */

@@ -57,7 +57,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const qavit_pack_desc* descs,
       const int r = tr * 32 + ty + i, c = tc * 32 + tx;
       const float v = (r < d.rows && c < d.cols) ? d.src[(size_t)r * d.cols + c] : 0.f;
       tile[ty + i][tx] = v;
-      if (d.dst && r < d.rows && c < d.cols) reinterpret_cast<T*>(d.dst)[(size_t)r * d.cols + c] = from_f<T>(v);
+      if (d.dst && r < d.rows && c < d.cols) {
+        size_t o = (size_t)r * d.cols + c;
+        if (d.pad == 1)                                    // MFMA fragment order (include/qavit.h, qavit_pack_desc)
+          o = ((size_t)((r >> 4) * (d.cols >> 5) + (c >> 5)) * 64 + (size_t)(((c & 31) >> 3) * 16 + (r & 15))) * 8 + (c & 7);
+        reinterpret_cast<T*>(d.dst)[o] = from_f<T>(v);
+      }
     }
     __syncthreads();
     if (d.dstT) {

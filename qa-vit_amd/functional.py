@@ -25,7 +25,7 @@ from . import lib as L
 # packed weights
 # ---------------------------------------------------------------------------------------------------
 class _PackEntry:
-    __slots__ = ("refs", "versions", "ptrs", "dst", "dstT", "rows", "cols")
+    __slots__ = ("refs", "versions", "ptrs", "dst", "dstT", "rows", "cols", "frag")
 
     def params(self):
         """The live parameter tensors, or None once any of them has been garbage-collected."""
@@ -61,12 +61,21 @@ class WeightPack:
         """The parameters were written behind autograd's back (raw-pointer optimiser kernel, graph replay)."""
         self._stale = True
 
-    def _make(self, params, dtype):
+    def _make(self, params, dtype, frag=False):
         e = _PackEntry()
         e.refs = [weakref.ref(p) for p in params]
         rows = sum(p.shape[0] for p in params)
         cols = self._as2d(params[0]).shape[1]
         e.rows, e.cols = rows, cols
+        e.frag = frag
+        if frag:                                           # MFMA fragment order (qavit_pack_desc.pad = 1): one buffer, no transpose
+            if any(p.shape[0] % 16 for p in params) or cols % 32:
+                raise RuntimeError("fragment-packed weights need rows % 16 == 0 and cols % 32 == 0")
+            e.dst = torch.empty(rows * cols, dtype=dtype, device=self.device)
+            e.dstT = None
+            e.versions = [-1] * len(params)
+            e.ptrs = [p.data_ptr() for p in params]
+            return e
         single_f32 = dtype == torch.float32 and len(params) == 1
         e.dst = None if single_f32 else torch.empty(rows, cols, dtype=dtype, device=self.device)
         e.dstT = torch.empty(cols, rows, dtype=dtype, device=self.device)
@@ -76,14 +85,14 @@ class WeightPack:
 
     def _descs(self, e, params):
         out, off = [], 0
-        esz = e.dstT.element_size()
+        esz = (e.dstT if e.dstT is not None else e.dst).element_size()
         for p in params:
             r = p.shape[0]
             d = L.PackDesc()
             d.src = self._as2d(p).data_ptr()
             d.dst = 0 if e.dst is None else e.dst.data_ptr() + off * e.cols * esz
-            d.dstT = e.dstT.data_ptr() + off * esz
-            d.rows, d.cols, d.ldT, d.pad = r, e.cols, e.rows, 0
+            d.dstT = 0 if e.dstT is None else e.dstT.data_ptr() + off * esz
+            d.rows, d.cols, d.ldT, d.pad = r, e.cols, e.rows, (1 if e.frag else 0)
             out.append(d)
             off += r
         e.ptrs = [p.data_ptr() for p in params]
@@ -156,6 +165,29 @@ class WeightPack:
             self.refresh(dtype)                           # an optimizer stepped / storage was re-bound: re-pack everything once
         W = e.dst if e.dst is not None else self._as2d(params[0]).detach()
         return W, e.dstT
+
+    def get_frag(self, params, dtype=torch.bfloat16):
+        """-> the weight (or row-stack of weights) in MFMA fragment order (include/qavit.h, qavit_pack_desc.pad = 1): the
+        operand image of the fused branch kernels.  Refreshed with everything else."""
+        if isinstance(params, torch.Tensor):
+            params = [params]
+        if self._stale:
+            self.refresh()
+        key = (tuple(id(p) for p in params), dtype, "frag")
+        e = self.entries.get(key)
+        if e is not None and e.params() is None:
+            del self.entries[key]
+            self._drop_table(dtype)
+            e = None
+        if e is None:
+            e = self._make(params, dtype, frag=True)
+            self.entries[key] = e
+            self._drop_table(dtype)
+            self._launch(self._descs(e, params), dtype)
+            e.versions = [p._version for p in params]
+        elif any(v != p._version for v, p in zip(e.versions, params)) or any(a != p.data_ptr() for a, p in zip(e.ptrs, params)):
+            self.refresh(dtype)
+        return e.dst
 
 
 _packs = {}
@@ -472,6 +504,48 @@ def _attn_drop(a, spec, rt):
     p, site = spec.get("drop", (0.0, 0))
     if p > 0.0:
         a.drop_p, a.drop_site, a.rng = float(p), int(site), rt.rng.data_ptr()
+
+
+def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool_idx=None, pool_stride=0, Lk=0,
+                   attn_drop=(0.0, 0), proj_drop=(0.0, 0), want_o=False):
+    """One launch for a whole attention branch on 16-token problems (csrc/branch_fwd.hip; include/qavit.h qavit_branch_args):
+    ``kind`` 0 = SWA, 1 = MSDA, 2 = cross.  ``x`` [B, 16, 192] bf16 (norm1's output); ``wqkv`` / ``wproj`` are the fp32
+    parameters (read through the fragment-packed copies of the WeightPack); ``sh_k`` / ``sh_v`` fp32 [16, 192] (the bank, or
+    its k_proj / v_proj for cross).  No autograd: the caller owns the backward.  -> out [B, 16, 192] (and O when ``want_o``)."""
+    K._require_cuda(x)
+    rt = _rt(x)
+    B, T, Cc = x.shape
+    x2 = x.reshape(B * T, Cc)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    pack = pack_for(x.device)
+    a = L.BranchArgs()
+    a.dtype, a.kind = K.dt_code(x.dtype), kind
+    a.B, a.T, a.C, a.H, a.D = B, T, Cc, 4, Cc // 4
+    a.KC, a.S, a.L = (E_k.shape[1] if E_k is not None else 0), sh_k.shape[-2], Lk
+    a.x, a.ldx = x2.data_ptr(), Cc
+    a.wqkv_frag, a.bqkv = pack.get_frag(wqkv).data_ptr(), bqkv.data_ptr()
+    a.wproj_frag, a.bproj = pack.get_frag(wproj).data_ptr(), bproj.data_ptr()
+    if E_k is not None:
+        a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
+    a.sh_k, a.sh_v = sh_k.data_ptr(), sh_v.data_ptr()
+    if pool_idx is not None:
+        a.pool_idx, a.pool_stride = pool_idx.data_ptr(), pool_stride
+    out = torch.empty(B * T, Cc, dtype=x.dtype, device=x.device)
+    a.out, a.ldo = out.data_ptr(), Cc
+    o = None
+    if want_o:
+        o = torch.empty_like(out)
+        a.o_save = o.data_ptr()
+    a.attn_drop_p, a.attn_drop_site = float(attn_drop[0]), int(attn_drop[1])
+    a.proj_drop_p, a.proj_drop_site = float(proj_drop[0]), int(proj_drop[1])
+    if attn_drop[0] > 0.0 or proj_drop[0] > 0.0:
+        a.rng = rt.rng.data_ptr()
+    if rt.nan_guard:
+        a.nan_flag = rt.nan_flag.data_ptr()
+    K.branch_fwd(a)
+    out = out.reshape(B, T, Cc)
+    return (out, o) if want_o else out
 
 
 class AttnFn(Function):

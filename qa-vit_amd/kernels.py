@@ -229,6 +229,14 @@ def attn_ws_floats(a) -> int:
     return int(L.load().qavit_attn_ws_floats(C.byref(a)))
 
 
+def branch_supported(kind, T, Cc, H, D, KC, S, Lk) -> bool:
+    return bool(L.load().qavit_branch_supported(kind, T, Cc, H, D, KC, S, Lk))
+
+
+def branch_fwd(a):
+    L.check(L.load().qavit_branch_fwd(C.byref(a), stream()), "branch_fwd")
+
+
 def nan_guard(x, flag):
     L.check(L.load().qavit_nan_guard(dt_code(x.dtype), x.data_ptr(), x.numel(), flag.data_ptr(), stream()), "nan_guard")
 

@@ -44,6 +44,18 @@ class AttnArgs(C.Structure):
     ]
 
 
+class BranchArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("kind", i32),
+        ("B", i32), ("T", i32), ("C", i32), ("H", i32), ("D", i32), ("KC", i32), ("S", i32), ("L", i32),
+        ("x", vp), ("ldx", i64), ("wqkv_frag", vp), ("bqkv", vp), ("wproj_frag", vp), ("bproj", vp),
+        ("E_k", vp), ("E_v", vp), ("sh_k", vp), ("sh_v", vp), ("pool_idx", vp), ("pool_stride", i32),
+        ("out", vp), ("ldo", i64), ("o_save", vp),
+        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
+        ("nan_flag", vp),
+    ]
+
+
 class CcfArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("flags", i32), ("B", i32), ("Hs", i32), ("Ws", i32), ("C", i32),
@@ -73,6 +85,8 @@ _SIGS = {
     "qavit_attn_bwd": (i32, [C.POINTER(AttnArgs), vp]),
     "qavit_attn_ws_floats": (i64, [C.POINTER(AttnArgs)]),
     "qavit_nan_guard": (i32, [i32, vp, i64, vp, vp]),
+    "qavit_branch_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "qavit_branch_fwd": (i32, [C.POINTER(BranchArgs), vp]),
     "qavit_tokmix_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_tokmix_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_upmix_fwd": (i32, [i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -736,3 +736,105 @@ def test_splitfusion_helpers_match_torch(F, dtype):
     ref.backward(go)
     for a_, b_, nm in ((t, tr_, "t"), (r, rr, "r"), (g_, gr, "g"), (fw, fr, "fw")):
         assert rel(a_.grad, b_.grad) <= tol(dtype, False) * 2, nm
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused attention branch (csrc/branch_fwd.hip): one launch = qkv GEMM + Linformer + bank + softmax(+dropout) + PV + proj(+dropout)
+# ---------------------------------------------------------------------------------------------------
+def _branch_reference(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, idx, stride, keep, p_attn):
+    """The reference chain in fp32 torch (HQAViT_CIFAR100.py:441-469 / :496-532 / :613-626 without the bank write)."""
+    B, T, C = x.shape
+    H, D = 4, C // 4
+    if kind == 2:
+        q = TF.linear(x, wqkv, bqkv).view(B, T, H, D).transpose(1, 2)
+        k = bk.view(1, -1, H, D).transpose(1, 2).expand(B, -1, -1, -1)
+        v = bv.view(1, -1, H, D).transpose(1, 2).expand(B, -1, -1, -1)
+        o = _ref_attn(q, k, v, keep, p_attn)
+    else:
+        if kind == 0:
+            qkv = TF.linear(x, wqkv, bqkv).view(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv[0], qkv[1], qkv[2]
+            Lk = T
+        else:
+            pooled = x[:, idx.long()].view(B, -1, stride, C).mean(2)
+            Lk = pooled.shape[1]
+            q = TF.linear(x, wqkv[:C], bqkv[:C]).view(B, T, H, D).transpose(1, 2)
+            kv = TF.linear(pooled, wqkv[C:], bqkv[C:]).view(B, Lk, 2, H, D).permute(2, 0, 3, 1, 4)
+            k, v = kv[0], kv[1]
+        kc = torch.matmul(Ek[:Lk].T, k.reshape(B * H, Lk, D)).reshape(B, H, -1, D)
+        vc = torch.matmul(Ev[:Lk].T, v.reshape(B * H, Lk, D)).reshape(B, H, -1, D)
+        kb = bk.expand(B, -1, -1).reshape(B, -1, H, D).transpose(1, 2)
+        vb = bv.expand(B, -1, -1).reshape(B, -1, H, D).transpose(1, 2)
+        o = _ref_attn(q, torch.cat([kc, kb], 2), torch.cat([vc, vb], 2), keep, p_attn)
+    o = o.transpose(1, 2).reshape(B, T, C)
+    return TF.linear(o, wproj, bproj), o
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+@pytest.mark.parametrize("B", [5, 64, 1030])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_fused_branch_forward(F, Q, kind, B, drop):
+    """bf16 fused branch against the fp32 torch chain on the same (bf16-rounded) inputs; with dropout the reference uses the
+    exact masks the kernel drew (attention mask from the host RNG replica; proj mask read off the kept entries).
+    B = 5: a ragged last tile (4 images per workgroup); B = 1030: more tiles than one round of workgroups."""
+    import importlib
+    from conftest import attn_keep_mask
+    K = importlib.import_module("qa-vit_amd.kernels")
+    T, C, H, S, KC = 16, 192, 4, 16, 32
+    x = leaf(B, T, C, seed=300).detach().to(torch.bfloat16)
+    n_qkv = C if kind == 2 else 3 * C
+    wqkv, bqkv = leaf(n_qkv, C, scale=0.08, seed=301).detach(), leaf(n_qkv, scale=0.1, seed=302).detach()
+    wproj, bproj = leaf(C, C, scale=0.08, seed=303).detach(), leaf(C, scale=0.1, seed=304).detach()
+    Ek = Ev = idx = None
+    stride, Lk = 0, 0
+    if kind != 2:
+        rows = 16 if kind == 0 else 128
+        Ek, Ev = leaf(rows, KC, scale=0.3, seed=305).detach(), leaf(rows, KC, scale=0.3, seed=306).detach()
+        Lk = 16
+    if kind == 1:
+        t = [y * 4 + xx for d in (1, 2) for y in range(0, 4, d) for xx in range(0, 4, d)]
+        stride = 2
+        t = t[: (len(t) // stride) * stride]
+        idx = torch.tensor(t, dtype=torch.int32, device=DEV)
+        Lk = len(t) // stride
+    bk, bv = leaf(1, S, C, scale=0.5, seed=307).detach(), leaf(1, S, C, scale=0.5, seed=308).detach()
+    sa, sp = K.new_site(), K.new_site()
+    seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
+    NK = S if kind == 2 else KC + S
+    keep = None
+    if drop > 0:
+        keep = torch.from_numpy(attn_keep_mask(seed, step, sa, B, H, T, NK, drop)).to(DEV)
+    out, o = F.branch_forward(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk.reshape(S, C), bv.reshape(S, C), idx, stride, Lk,
+                              attn_drop=(drop, sa), proj_drop=(drop, sp), want_o=True)
+    wq_r, wp_r = wqkv.to(torch.bfloat16).float(), wproj.to(torch.bfloat16).float()         # the kernel reads bf16 weights
+    ref, o_ref = _branch_reference(kind, x.float(), wq_r, bqkv, wp_r, bproj, Ek, Ev, bk, bv, idx, stride, keep, drop)
+    assert rel(o.reshape(B, T, C), o_ref) <= 3e-2
+    if drop > 0:
+        kept = out != 0
+        frac = kept.float().mean().item()
+        assert abs(frac - (1 - drop)) < 0.02, frac
+        assert rel(out[kept], (ref / (1 - drop))[kept]) <= 3e-2
+        # the proj mask is the GEMM epilogue's contract: drop_factor(key(site), row * C + col)
+        from conftest import rng_key, rng_uniform
+        u = rng_uniform(rng_key(seed, step, sp), np.arange(B * T * C, dtype=np.uint64)).reshape(B, T, C)
+        assert np.array_equal(u >= np.float32(drop), kept.cpu().numpy())
+    else:
+        assert rel(out, ref) <= 3e-2
+    # the unfused kernels on the same operands agree more tightly (same bf16 rounding points except q/k/v staying in fp32 -> bf16 once)
+    if drop == 0.0:
+        if kind == 0:
+            qkv = F.linear(x, wqkv, bqkv).reshape(B * T, 3 * C)
+            spec = dict(mode=0, G=B, Nq=T, L=T, H=H, D=C // H, KC=KC, S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=T, q_off=0, k_off=C, v_off=2 * C, q_rows=B * T)
+            o2 = F.AttnFn.apply(qkv, None, Ek, Ev, bk, bv, spec)
+        elif kind == 1:
+            pooled = F.GatherPoolFn.apply(x, idx, stride)
+            kv = F.linear(pooled, wqkv, bqkv, rows=(C, 2 * C)).reshape(B * Lk, 2 * C)
+            q = F.linear(x, wqkv, bqkv, rows=(0, C)).reshape(B * T, C)
+            spec = dict(mode=0, G=B, Nq=T, L=Lk, H=H, D=C // H, KC=KC, S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=Lk, q_off=0, k_off=0, v_off=C, q_rows=B * T)
+            o2 = F.AttnFn.apply(q, kv, Ek, Ev, bk, bv, spec)
+        else:
+            q = F.linear(x, wqkv, bqkv).reshape(B * T, C)
+            spec = dict(mode=1, G=B, Nq=T, L=0, H=H, D=C // H, S=S, q_off=0, k_off=0, v_off=0, q_rows=B * T)
+            o2 = F.AttnFn.apply(q, None, None, None, bk.reshape(S, C), bv.reshape(S, C), spec)
+        out2 = F.linear(o2.reshape(B, T, C), wproj, bproj)
+        assert rel(out, out2) <= 2e-2
