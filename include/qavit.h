@@ -220,6 +220,7 @@ typedef struct qavit_branch_args {
   void* o_save;
   float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
   int* nan_flag;
+  int reserved;   /* must be 0 */
 } qavit_branch_args;
 
 int qavit_branch_supported(int kind, int T, int C, int H, int D, int KC, int S, int L);   /* 1 if qavit_branch_fwd covers the shape */

@@ -14,6 +14,7 @@ LIB = os.path.join(HERE, "libqavit_hip.so")
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS += os.environ.get("QAVIT_EXTRA_HIPCC_FLAGS", "").split()       # diagnostic builds, e.g. -DQAVIT_BRANCH_STAMPS (tools/branch_stamps.py)
 
 
 def _hipcc():

@@ -2,19 +2,33 @@
 //   out = dropout( proj( SDPA( q(x), [Linformer(k(x'), v(x')) ; bank rows], dropout_p ) ) )
 // in ONE launch -- the chain HQAViT_CIFAR100.py:441-469 (SWA: one 4x4 window = the 16 tokens), :496-532 (MSDA: keys from
 // the pooled dilated landmarks x'), :613-626 (cross: keys = projections of the bank) runs as  qkv GEMM -> Linformer ->
-// bank concat -> softmax (+ attention dropout) -> P.V -> proj GEMM (+ bias, dropout)  with Q / K / V / P / O never leaving
-// LDS.  bf16 operands, fp32 accumulation (v_mfma_f32_16x16x32_bf16 for the two GEMMs, 16x16x16 for the 16 x 48 x 48 core).
+// bank concat -> softmax (+ attention dropout) -> P.V -> proj GEMM (+ bias, dropout).  bf16 operands, fp32 accumulation.
 //
-// Decomposition: a workgroup of 4 waves owns 4 images, ONE IMAGE PER WAVE (its 16 x 192 token tile is 6 MFMA operand
-// fragments held in registers for the whole QKV GEMM).  Weights are what the images share: they stream through LDS in
-// 48-column chunks (3 MFMA tiles x 6 k-steps = 18 KB) -- q_h, k_h, v_h of head h, then the head's attention core, ... then
-// the 4 chunks of proj -- double buffered: chunk i+1 lands (global_load_lds, 16 B per lane, no registers) while chunk i's
-// 18 MFMAs per wave run; one barrier per chunk.  The packed weight image (qavit_pack_desc.pad = 1) is already in MFMA
-// fragment order, so a chunk is a linear 18 KB copy and every fragment read is one conflict-free ds_read_b128.
-// Products are formed TRANSPOSED (A = weights, B = tokens): a lane's 4 accumulator values are 4 consecutive columns of one
-// token row = one 8-byte store into the row-major LDS tiles the attention core (the attn3_bf16.hip schedule) reads.
-// Per-CU floor at B = 1024: every CU must take in all 288 KB of the branch's weights for its 64 rows, ~3 us at L2 rates,
-// about the MFMA time of those rows (390 MFMAs x 16 cycles per wave) -- the two overlap.
+// DECOMPOSITION.  A workgroup of 8 waves (two per SIMD: the chain is full of single-wave latencies and of VALU work -- softmax,
+// dropout hashes, conversions -- that one wave per SIMD issues at half rate) owns a tile of 4 images (64 token rows).
+//   QKV + attention phase: WAVE = (HEAD, IMAGE PAIR).  A wave computes q, k, v of its head for its 2 images and runs their 2
+//     attention cores -- every weight fragment it reads from LDS feeds 2 MFMAs, and the cores are independent chains the
+//     scheduler interleaves.  (Wave = image, the first design, read every fragment once per MFMA: 1.1 MB of LDS reads per
+//     tile, which is what bounded it.)
+//   proj phase: WAVE = (IMAGE, COLUMN HALF).  The heads' outputs meet in one LDS tile per image; a wave multiplies its image's
+//     16 x 192 attention output with 96 rows of the proj weight.
+// Weights stream through an LDS ring in K-STEP CHUNKS: chunk (part, s) = the 12 MFMA tiles (192 rows: 4 heads x 48) of q, k or
+// v -- or of proj -- at k-step s, 12 fragments of 1 KB (qavit_pack_desc.pad = 1: fragment order, so a fragment is one
+// global_load_lds wave-instruction, 16 B per lane, no registers, and one conflict-free ds_read_b128).  5 ring slots, 4
+// chunks in flight incl. the one consumed, counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads would drain them).
+//
+// REGISTER-RESIDENT CHAIN.  Between the QKV GEMM and the attention output nothing goes through LDS: each product is formed
+// in the orientation whose ACCUMULATOR layout is the next product's OPERAND layout (16x16 MFMA: an accumulator register quad
+// holds 4 consecutive rows of one column; a 16x16x16 operand quad holds 4 consecutive k of one row / column):
+//   q_h   = (W_q x^T)^T    "transposed" GEMM   acc = q[query = lane%16][4 consecutive d]          -> B operand of S^T
+//   k_h   = x W_k^T        plain GEMM          acc = k[4 consecutive tokens][d = lane%16]         -> A operand of Kf^T
+//   Kf^T  = k^T E_k                            acc = Kf[key = lane%16][4 consecutive d]           -> A operand of S^T
+//   S^T   = Kf Q^T (+ bank rows from LDS)      acc = S[query = lane%16][4 consecutive keys]       -> softmax on registers
+//   P                                          the same registers, bf16                           -> B operand of O^T
+//   v_h   = x W_v^T        plain GEMM          acc = v[4 consecutive tokens][d = lane%16]         -> B operand of Vf
+//   Vf    = E_v^T v                            acc = Vf[4 consecutive keys][d = lane%16]          -> A operand of O^T
+//   O^T   = Vf^T P^T (+ bank rows from LDS)    acc = O[query = lane%16][4 consecutive d]          -> 8-byte segments of the O tile
+//   out   = (W_p O^T)^T    "transposed" GEMM on the O tile read back as 16x16x32 operands         -> 8-byte row segments
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
@@ -26,284 +40,443 @@ namespace qv {
 namespace {
 
 constexpr int BT = 16, BC = 192, BD = 48, BH = 4;          // tokens per image, channels, head dim, heads
-constexpr int KST = BC / 32, TPC = 3;                      // k-steps of 32, 16-column MFMA tiles per chunk (= one head's q, k or v)
-constexpr int CHUNK_BYTES = TPC * KST * 1024;              // 18432
-constexpr int LDD = BD + 4, LDK = 48 + 4, LDE = 32 + 4, LDO = BC + 8;
-// per-wave LDS tiles (bf16 elements)
-constexpr int W_Q = 0, W_KT = 16 * LDD, W_VT = 2 * 16 * LDD, W_KF = 3 * 16 * LDD, W_VF = W_KF + 48 * LDD, W_P = W_VF + 48 * LDD,
-              W_O = W_P + 16 * LDK, W_TOTAL = W_O + 16 * LDO;
-constexpr int WAVE_BYTES = W_TOTAL * 2;                    // 23040
-constexpr int LDB = BC + 8;                                // shared bank tiles [16][LDB] (all heads), read in place by the key / value fragments
-constexpr int SM_E = 2 * CHUNK_BYTES, SM_BANK = SM_E + 2 * 16 * LDE * 2, SM_WAVE = SM_BANK + 2 * 16 * LDB * 2,
-              SM_TOTAL = SM_WAVE + 4 * WAVE_BYTES;         // 144128 bytes: one workgroup per CU
+constexpr int NI = 4;                                      // images per workgroup tile
+constexpr int NW = 8;                                      // waves per workgroup
+constexpr int NIW = 2;                                     // images per wave in the QKV / attention phase
+constexpr int KST = BC / 32;                               // k-steps of 32
+constexpr int CT = BC / 16;                                // 16-row MFMA tiles of a 192-row weight block: fragments per chunk
+constexpr int CHUNK_BYTES = CT * 1024;                     // 12288
+constexpr int RING = 5, AHEAD = 4;                         // ring slots; chunks in flight incl. the one being consumed (the slot chunk c + AHEAD
+                                                           // lands in was consumed in iteration c - 1, behind this iteration's barrier)
+constexpr int GLDS_PER_CHUNK = 2;                          // LDS-DMA instructions per wave per chunk (12 fragments + 4 repeats over 8 waves)
+constexpr int LDB = BC + 8, LDO = BC + 8;                  // shared bank tiles [16][LDB]; per-image O / output tiles [16][LDO]
+constexpr int SM_BANK = RING * CHUNK_BYTES, SM_BIAS = SM_BANK + 2 * 16 * LDB * 2, SM_OUT = SM_BIAS + 4 * BC * 4,
+              OUT_BYTES = 16 * LDO * 2, SM_X = SM_OUT + NI * OUT_BYTES, SM_P = SM_X + NI * OUT_BYTES;
+// 61440 ring + 12800 bank + 3072 biases + 25600 O / output tiles + 25600 token tiles (+ 25600 landmark tiles, MSDA) = 128512 (154112) bytes
+constexpr int sm_total(int kind) { return kind == 1 ? SM_P + NI * OUT_BYTES : SM_P; }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-__device__ __forceinline__ void row4_lds(bf16* dst, const f32x4& acc) {
+__device__ __forceinline__ bf16x4 cvt4(const f32x4& acc) {
   bf16x4 v;
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = (bf16)acc[r];
-  *reinterpret_cast<bf16x4*>(dst) = v;
+  return v;
 }
 __device__ __forceinline__ bool nan4(const f32x4& v) { return (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]); }
+__device__ __forceinline__ f32x4 mma16b(bf16x4 a, bf16x4 b, f32x4 c) { return mma16(as_s16(a), as_s16(b), c); }
 
-// one 18 KB weight chunk global -> LDS: 18 fragments of 1 KB, dealt to the 4 waves; lane-linear image (base + lane * 16)
-__device__ __forceinline__ void issue_chunk(const char* gsrc, char* ldst, int wave, int lane) {
+// chunk = the 12 fragments {(tile t0 + j, k-step s)} of a fragment-packed [*, 192] weight (fragment (t, s) sits at (t * KST + s)
+// KB).  Wave w fetches j = w and j = w + 8 (waves 4..7: fragment 11 again, same bytes), so every wave issues exactly
+// GLDS_PER_CHUNK instructions and a counted `s_waitcnt vmcnt(2 k)` means "all but the k newest chunks have landed" for all.
+__device__ __forceinline__ void issue_chunk(const char* wpacked, int t0, int s, char* slot, int wave, int lane) {
 #pragma unroll
-  for (int f = 0; f < 5; ++f) {
-    const int fr = wave + 4 * f;
-    if (fr < TPC * KST)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + fr * 1024 + lane * 16), (lds_void_t*)(ldst + fr * 1024), 16, 0, 0);
+  for (int f = 0; f < GLDS_PER_CHUNK; ++f) {
+    int j = wave + 8 * f;
+    j = j < CT ? j : CT - 1;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(wpacked + (size_t)((t0 + j) * KST + s) * 1024 + lane * 16), (lds_void_t*)(slot + j * 1024), 16, 0, 0);
   }
 }
-
-// acc[t] (+)= W_chunk[t] . X^T : 18 MFMAs, weight fragments from the LDS chunk, token fragments from registers
-__device__ __forceinline__ void chunk_gemm(const char* wbuf, const bf16x8 (&xf)[KST], f32x4 (&acc)[TPC], int lane) {
-#pragma unroll
-  for (int s = 0; s < KST; ++s)
-#pragma unroll
-    for (int t = 0; t < TPC; ++t) {
-      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wbuf + ((t * KST + s) * 64 + lane) * 16);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[s], acc[t], 0, 0, 0);
-    }
+// `newer` = chunks issued after the one about to be consumed (0 .. AHEAD-1).  This wave's share of it has landed once at most
+// those are outstanding; the barrier makes it true for all waves.
+__device__ __forceinline__ void ring_wait(int newer) {     // called with unrolled-loop constants: the chain folds
+  if (newer >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (newer == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (newer == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 }
 
 // KIND 0 = SWA, 1 = MSDA, 2 = cross
 template <int KIND>
-__global__ __launch_bounds__(256) void branch_fwd_kernel(qavit_branch_args a) {
+__global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
-  constexpr int MODE0 = (KIND != 2);                       // Linformer + bank keys (SWA / MSDA) vs bank-projection keys only (cross)
+  constexpr bool MODE0 = (KIND != 2);                      // Linformer + bank keys (SWA / MSDA) vs bank-projection keys only (cross)
   constexpr int KT0 = MODE0 ? 2 : 0, NKT = KT0 + 1, DT = 3, NKo = KT0 * 16;
-  constexpr int NQKV = MODE0 ? 12 : 4, NCH = NQKV + 4;
+  constexpr int NPART = MODE0 ? 3 : 1, NQKV = NPART * KST, NCH = NQKV + KST;      // chunks per tile: 24 (cross: 12)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
-  bf16* ws = reinterpret_cast<bf16*>(smraw + SM_WAVE + wave * WAVE_BYTES);
-  bf16* sek = reinterpret_cast<bf16*>(smraw + SM_E);
-  bf16* sev = sek + 16 * LDE;
   bf16* sbk = reinterpret_cast<bf16*>(smraw + SM_BANK);
   bf16* sbv = sbk + 16 * LDB;
+  float* sbias = reinterpret_cast<float*>(smraw + SM_BIAS);
+  bf16* so_all = reinterpret_cast<bf16*>(smraw + SM_OUT);
+  bf16* sx_all = reinterpret_cast<bf16*>(smraw + SM_X);                  // the 4 images' token tiles [16][LDO] (MSDA: + landmark tiles)
+  bf16* sp_all = reinterpret_cast<bf16*>(smraw + (KIND == 1 ? SM_P : SM_X));
   const int S = a.S, NK = NKo + S;
   const float scale = rsqrtf((float)BD);
   const bf16* xg = reinterpret_cast<const bf16*>(a.x);
   bf16* og = reinterpret_cast<bf16*>(a.out);
+  bf16* osv = reinterpret_cast<bf16*>(a.o_save);
   const char* wqkv = reinterpret_cast<const char*>(a.wqkv_frag);
   const char* wproj = reinterpret_cast<const char*>(a.wproj_frag);
   bool bad = false;
+#ifdef QAVIT_BRANCH_STAMPS   // diagnostic build only (tools/branch_stamps.py): s_memtime at the phase boundaries, 16 words per workgroup into o_save
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.o_save) + (size_t)blockIdx.x * 16;
+#define STAMP(k) do { if (tid == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+  STAMP(0);
 
+  // chunk c of the tile's schedule: q k-steps, k k-steps, v k-steps (cross: q only), then proj k-steps
+  auto issue = [&](int c) {
+    char* slot = smraw + (c % RING) * CHUNK_BYTES;
+    if (c < NQKV) issue_chunk(wqkv, (c / KST) * CT, c % KST, slot, wave, lane);
+    else issue_chunk(wproj, 0, c - NQKV, slot, wave, lane);
+  };
+  // ONE tile per workgroup (grid = ceil(B / 4)): its first chunks are on their way before anything else happens
+  const int tile = blockIdx.x;
+#pragma unroll
+  for (int c = 0; c < AHEAD; ++c) issue(c);
+
+  const bool adrop = a.attn_drop_p > 0.f && a.rng != nullptr;       // uniform
   AttnDrop drop;
-  drop.on = a.attn_drop_p > 0.f && a.rng != nullptr;
-  drop.p = a.attn_drop_p;
-  drop.inv_keep = drop.on ? 1.f / (1.f - a.attn_drop_p) : 1.f;
-  drop.key = drop.on ? rng_key(a.rng, a.attn_drop_site) : 0u;
+  drop.on = adrop;
+  drop.p = adrop ? a.attn_drop_p : 0.f;
+  drop.inv_keep = adrop ? 1.f / (1.f - a.attn_drop_p) : 1.f;
+  drop.key = adrop ? rng_key(a.rng, a.attn_drop_site) : 0u;
   const bool pdrop = a.proj_drop_p > 0.f && a.rng != nullptr;
   const uint32_t pkey_proj = pdrop ? rng_key(a.rng, a.proj_drop_site) : 0u;
-  const float pinv = pdrop ? 1.f / (1.f - a.proj_drop_p) : 1.f;
+  const float pp = pdrop ? a.proj_drop_p : 0.f, pinv = pdrop ? 1.f / (1.f - a.proj_drop_p) : 1.f;
 
-  for (int i = lane; i < W_TOTAL; i += 64) ws[i] = (bf16)0.f;
-  for (int i = tid; i < 2 * 16 * LDE; i += 256) sek[i] = (bf16)0.f;
-  __syncthreads();
+  // ---------------- global loads of the prologue, all issued before any is consumed ----------------
+  // token tiles: wave w stages rows 8 (w & 1) .. + 8 of image w >> 1 (16-byte pieces, 24 per row)
+  const int simg_raw = tile * NI + (wave >> 1);
+  const int simg = simg_raw < a.B ? simg_raw : a.B - 1;
+  bf16x8 xr[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24;
+    xr[it] = *reinterpret_cast<const bf16x8*>(xg + ((size_t)simg * BT + row) * a.ldx + 8 * c8);
+  }
+  // Linformer matrices as MFMA operand quads: lane holds E[l = 4 q4 + i][j = 16 jt + col], rows l >= L read as zero (the
+  // reference's zero padding is algebraic; MSDA has 10 landmarks in the 16-row tile)
+  float ek[KT0 > 0 ? KT0 : 1][4], ev[KT0 > 0 ? KT0 : 1][4];
   if (MODE0) {
-    const int EC = a.KC >> 2;                              // Linformer matrices: first L rows (zero padding of the rest is algebraic)
-    for (int i = tid; i < a.L * EC; i += 256) {
-      const int l = i / EC, ch = i - l * EC;
-      const f32x4 ek = *reinterpret_cast<const f32x4*>(a.E_k + (size_t)l * a.KC + 4 * ch);
-      const f32x4 ev = *reinterpret_cast<const f32x4*>(a.E_v + (size_t)l * a.KC + 4 * ch);
+#pragma unroll
+    for (int jt = 0; jt < KT0; ++jt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int l = 4 * q4 + i, lc = l < a.L ? l : 0;
+        ek[jt][i] = a.E_k[(size_t)lc * a.KC + jt * 16 + col];
+        ev[jt][i] = a.E_v[(size_t)lc * a.KC + jt * 16 + col];
+      }
+  }
+  // biases [3C qkv | C proj] and the shared key / value rows of every head (the bank, or its projections for cross)
+  constexpr int NB4 = (MODE0 ? 3 * BC : BC) / 4;
+  f32x4 bq = {0.f, 0.f, 0.f, 0.f}, bp = {0.f, 0.f, 0.f, 0.f};
+  if (tid < NB4) bq = *reinterpret_cast<const f32x4*>(a.bqkv + 4 * tid);
+  if (tid < BC / 4) bp = *reinterpret_cast<const f32x4*>(a.bproj + 4 * tid);
+  f32x4 kk[2], vv[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {                         // 16 rows x 48 chunks of 4 = 768 = 1.5 x 512
+    const int e0 = tid + 512 * it, e = e0 < 768 ? e0 : 0, sr = e / (BC >> 2), ch = e - sr * (BC >> 2);
+    kk[it] = *reinterpret_cast<const f32x4*>(a.sh_k + (size_t)sr * BC + 4 * ch);
+    vv[it] = *reinterpret_cast<const f32x4*>(a.sh_v + (size_t)sr * BC + 4 * ch);
+  }
+  // ---------------- ... and their consumers ----------------
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24;
+    *reinterpret_cast<bf16x8*>(sx_all + (wave >> 1) * (16 * LDO) + row * LDO + 8 * c8) = xr[it];
+  }
+  bf16x4 ekf[KT0 > 0 ? KT0 : 1], evf[KT0 > 0 ? KT0 : 1];
+  if (MODE0) {
+#pragma unroll
+    for (int jt = 0; jt < KT0; ++jt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = 4 * q4 + i < a.L;
+        ekf[jt][i] = (bf16)(ok ? ek[jt][i] : 0.f);
+        evf[jt][i] = (bf16)(ok ? ev[jt][i] : 0.f);
+      }
+  }
+  if (tid < NB4) *reinterpret_cast<f32x4*>(sbias + 4 * tid) = bq;
+  if (tid < BC / 4) *reinterpret_cast<f32x4*>(sbias + 3 * BC + 4 * tid) = bp;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = tid + 512 * it;
+    if (e < 768) {
+      const int sr = e / (BC >> 2), ch = e - sr * (BC >> 2);
       bf16x4 kb, vb;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { kb[j] = (bf16)ek[j]; vb[j] = (bf16)ev[j]; }
-      *reinterpret_cast<bf16x4*>(sek + l * LDE + 4 * ch) = kb;
-      *reinterpret_cast<bf16x4*>(sev + l * LDE + 4 * ch) = vb;
+      for (int j = 0; j < 4; ++j) { bad |= (kk[it][j] != kk[it][j]) | (vv[it][j] != vv[it][j]); kb[j] = (bf16)kk[it][j]; vb[j] = (bf16)vv[it][j]; }
+      *reinterpret_cast<bf16x4*>(sbk + sr * LDB + 4 * ch) = kb;
+      *reinterpret_cast<bf16x4*>(sbv + sr * LDB + 4 * ch) = vb;
     }
   }
-  // shared key / value rows of every head: the bank (SWA / MSDA) or its projections (cross), fp32 -> bf16 once per workgroup
-  for (int e = tid; e < S * (BC >> 2); e += 256) {
-    const int sr = e / (BC >> 2), ch = e - sr * (BC >> 2);
-    const f32x4 k = *reinterpret_cast<const f32x4*>(a.sh_k + (size_t)sr * BC + 4 * ch);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a.sh_v + (size_t)sr * BC + 4 * ch);
-    bf16x4 kb, vb;
+  STAMP(1);
+  if (KIND == 1) {
+    // MSDA landmarks: pooled[j] = mean_s x[idx[j * stride + s]] (HQAViT_CIFAR100.py:499-501), j < L; fp32 mean, one rounding; rows
+    // j >= L are zero.  Wave w: image w >> 1, k-steps 3 (w & 1) .. + 3, from the staged token tile (two waves staged it: barrier).
+    __syncthreads();
+    const bf16* sx = sx_all + (wave >> 1) * (16 * LDO);
+    bf16* sp = sp_all + (wave >> 1) * (16 * LDO);
+    const int j = col < a.L ? col : 0;
+    const float inv = 1.f / (float)a.pool_stride;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { bad |= (k[j] != k[j]) | (v[j] != v[j]); kb[j] = (bf16)k[j]; vb[j] = (bf16)v[j]; }
-    *reinterpret_cast<bf16x4*>(sbk + sr * LDB + 4 * ch) = kb;
-    *reinterpret_cast<bf16x4*>(sbv + sr * LDB + 4 * ch) = vb;
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int s2 = 3 * (wave & 1) + s3;
+      float sum[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+      for (int t = 0; t < a.pool_stride; ++t) {
+        const int src = a.pool_idx[j * a.pool_stride + t];
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sx + src * LDO + 32 * s2 + 8 * q4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] += (float)v[e];
+      }
+      bf16x8 o8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = (bf16)(col < a.L ? sum[e] * inv : 0.f);
+      *reinterpret_cast<bf16x8*>(sp + col * LDO + 32 * s2 + 8 * q4) = o8;
+    }
   }
+  STAMP(2);
+  __syncthreads();              // tiles and constants staged; every ordinary load above (and the ring's first chunks) drained: vmcnt is 0 here
+  STAMP(3);
 
-  const int ntiles = (a.B + 3) >> 2;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int img_raw = tile * 4 + wave;
+  const int h = wave & 3;                                  // this wave's head and its two images in the QKV / attention phase
+  const int i0 = NIW * (wave >> 2);
+  int imgs[NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) { const int ir = tile * NI + i0 + i; imgs[i] = ir < a.B ? ir : a.B - 1; }
+  const bf16* sxw = sx_all + i0 * (16 * LDO) + col * LDO + 8 * q4;       // this lane's fragment base in its images' token tiles
+  const bf16* spw = sp_all + i0 * (16 * LDO) + col * LDO + 8 * q4;       // ... and landmark tiles (MSDA; else the token tiles)
+
+  // Ring step for chunk c of the tile's schedule: wait until it has landed (chunks c+1 .. c+3 may stay in flight), then refill
+  // the slot chunk c - 1 used.  A k-step chunk of a QKV part = 3 fragments (this head's tiles) x 2 images = 6 MFMAs per wave.
+#define QV_RING_STEP(c)                                                                         \
+  do {                                                                                          \
+    ring_wait((NCH - 1 - (c)) < (AHEAD - 1) ? (NCH - 1 - (c)) : (AHEAD - 1));                   \
+    if ((c) + AHEAD < NCH) issue((c) + AHEAD);                                                  \
+  } while (0)
+
+  bf16x4 qf[NIW][DT];
+  {
+    f32x4 acc[NIW][DT];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) acc[i][t] = *reinterpret_cast<const f32x4*>(sbias + h * BD + t * 16 + 4 * q4);
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      QV_RING_STEP(s);
+      const char* slot = smraw + (s % RING) * CHUNK_BYTES;
+      bf16x8 wf[DT], xf[NIW];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sxw + i * (16 * LDO) + 32 * s);
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], acc[i][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) qf[i][t] = cvt4(acc[i][t]);
+  }
+  STAMP(4);
+  bf16x4 kff[NIW][KT0 > 0 ? KT0 : 1][DT];
+  if (MODE0) {
+    // ---- k: plain GEMM (acc quad = 4 consecutive tokens of column d = 16 t + col), then Kf^T = k^T E_k ----
+    f32x4 acc[NIW][DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const float b = sbias[BC + h * BD + t * 16 + col];
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) acc[i][t] = f32x4{b, b, b, b};
+    }
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      QV_RING_STEP(KST + s);
+      const char* slot = smraw + ((KST + s) % RING) * CHUNK_BYTES;
+      bf16x8 wf[DT], xf[NIW];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const bf16x4 ktf = cvt4(acc[i][t]);
+#pragma unroll
+        for (int jt = 0; jt < KT0; ++jt) kff[i][jt][t] = cvt4(mma16b(ktf, ekf[jt], f32x4{0.f, 0.f, 0.f, 0.f}));   // Kf[key = 16 jt + col][16 t + 4 q4 ..]
+      }
+  }
+  STAMP(5);
+  // ---- S^T[key][query] = K_full Q^T, softmax over keys on registers, attention dropout: independent images ----
+  bf16x4 pfr[NIW][NKT];
+  {
+    s16x4 bkf[DT];                                         // the shared key rows of this head, read in place from the bank tile
+#pragma unroll
+    for (int t = 0; t < DT; ++t) bkf[t] = rowfrag(sbk, LDB, 0, h * BD + t * 16);
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      f32x4 sc[NKT];
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt) {
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < DT; ++t) acc2 = mma16(nt < KT0 ? as_s16(kff[i][nt < KT0 ? nt : 0][t]) : bkf[t], as_s16(qf[i][t]), acc2);
+        sc[nt] = acc2;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = nt * 16 + 4 * q4 + r < NK;
+          sc[nt][r] = ok ? sc[nt][r] * scale : -INFINITY;
+          mx = fmaxf(mx, sc[nt][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __expf(sc[nt][r] - mx); sc[nt][r] = e; sum += e; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[nt][r] *= inv;
+      if (adrop) {                                         // two keys per hash (drop_factor pairs 2m, 2m+1)
+        const uint32_t pkey = attn_drop_pkey(drop, imgs[i] * BH + h);
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[nt][r] *= attn_drop_factor(drop, pkey, col, nt * 16 + 4 * q4 + r);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NKT; ++nt) pfr[i][nt] = cvt4(sc[nt]);
+    }
+  }
+  STAMP(6);
+  bf16x4 vff[NIW][KT0 > 0 ? KT0 : 1][DT];
+  if (MODE0) {
+    // ---- v: plain GEMM, then Vf = E_v^T v (acc quad = 4 consecutive keys of column d) ----
+    f32x4 acc[NIW][DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const float b = sbias[2 * BC + h * BD + t * 16 + col];
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) acc[i][t] = f32x4{b, b, b, b};
+    }
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      QV_RING_STEP(2 * KST + s);
+      const char* slot = smraw + ((2 * KST + s) % RING) * CHUNK_BYTES;
+      bf16x8 wf[DT], xf[NIW];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const bf16x4 vtf = cvt4(acc[i][t]);
+#pragma unroll
+        for (int jt = 0; jt < KT0; ++jt) vff[i][jt][t] = cvt4(mma16b(evf[jt], vtf, f32x4{0.f, 0.f, 0.f, 0.f}));   // Vf[key = 16 jt + 4 q4 ..][16 t + col]
+      }
+  }
+  STAMP(7);
+  // ---- O^T[d][query] = V_full^T P^T -> columns 48 h .. of each image's O tile.  A NaN anywhere in q / k / v reaches O (the
+  // softmax and both products propagate it), so this is where efficient_attention's NaN rule is checked. ----
+  {
+    s16x4 bvf[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) bvf[t] = trfrag(sbv, LDB, 0, h * BD + t * 16);
+#pragma unroll
+    for (int i = 0; i < NIW; ++i)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NKT; ++nt) acc2 = mma16(nt < KT0 ? as_s16(vff[i][nt < KT0 ? nt : 0][t]) : bvf[t], as_s16(pfr[i][nt]), acc2);
+        bad |= nan4(acc2);
+        *reinterpret_cast<bf16x4*>(so_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(acc2);
+      }
+  }
+  STAMP(8);
+  // ================= proj: out = dropout(O . Wproj^T + b): WAVE = (IMAGE, COLUMN HALF), 6 output tiles, 6 k-step chunks =================
+  {
+    const int pi = wave >> 1, half = wave & 1;
+    const int img_raw = tile * NI + pi;
     const bool valid = img_raw < a.B;
     const int img = valid ? img_raw : a.B - 1;
-    __syncthreads();                                       // nobody still reads a weight buffer of the previous tile; E / bank are staged
-    issue_chunk(wqkv, smraw, wave, lane);                  // chunk 0 = q of head 0: lands while the token tile is fetched
-    // ---------------- this image's token tile as MFMA operand fragments: token = col, k = 32 s + 8 q4 .. + 8 ----------------
-    bf16x8 xf[KST], pf[KST];
-    {
-      const bf16* xr = xg + ((size_t)img * BT + col) * a.ldx + 8 * q4;
+    const bf16* so = so_all + pi * (16 * LDO);
+    bf16* sout = sx_all + pi * (16 * LDO);                 // the token tiles are dead once every wave is past its v phase (= past the
+    bf16x8 of8[KST];                                       // barrier of the first proj chunk): they collect the output rows
+    f32x4 acc[CT / 2];
 #pragma unroll
-      for (int s = 0; s < KST; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xr + 32 * s);
-      if (KIND == 1) {
-        // MSDA landmarks: pooled[j] = mean_s x[idx[j * stride + s]] (HQAViT_CIFAR100.py:499-501), j < L; fp32 mean, one rounding
-        const int j = col < a.L ? col : 0;
-        const float inv = 1.f / (float)a.pool_stride;
+    for (int jj = 0; jj < CT / 2; ++jj) acc[jj] = *reinterpret_cast<const f32x4*>(sbias + 3 * BC + (6 * half + jj) * 16 + 4 * q4);
 #pragma unroll
-        for (int s = 0; s < KST; ++s) {
-          float sum[8];
+    for (int s = 0; s < KST; ++s) {
+      QV_RING_STEP(NQKV + s);                              // s == 0: this barrier also publishes the 4 heads' O quads
+      if (s == 0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sum[e] = 0.f;
-          for (int t = 0; t < a.pool_stride; ++t) {
-            const int src = a.pool_idx[j * a.pool_stride + t];
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xg + ((size_t)img * BT + src) * a.ldx + 32 * s + 8 * q4);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum[e] += (float)v[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pf[s][e] = (bf16)(col < a.L ? sum[e] * inv : 0.f);
-        }
+        for (int s2 = 0; s2 < KST; ++s2) of8[s2] = *reinterpret_cast<const bf16x8*>(so + col * LDO + 32 * s2 + 8 * q4);
       }
+      const char* slot = smraw + ((NQKV + s) % RING) * CHUNK_BYTES;
+      bf16x8 wf[CT / 2];
+#pragma unroll
+      for (int jj = 0; jj < CT / 2; ++jj) wf[jj] = *reinterpret_cast<const bf16x8*>(slot + ((6 * half + jj) * 64 + lane) * 16);
+#pragma unroll
+      for (int jj = 0; jj < CT / 2; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], of8[s], acc[jj], 0, 0, 0);
     }
-    bf16x8 of[KST];
-
+    STAMP(9);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      __syncthreads();                                     // chunk i has landed (the barrier's fence drains vmcnt); buffer (i+1)&1 is free
-      if (i + 1 < NCH) {
-        const int n = i + 1;
-        const char* src;
-        if (n < NQKV) {
-          const int hh = MODE0 ? n / 3 : n, part = MODE0 ? n % 3 : 0;
-          src = wqkv + (size_t)(part * 4 + hh) * CHUNK_BYTES;      // packed rows: [q heads 0..3 | k heads | v heads], 48 rows per chunk
-        } else {
-          src = wproj + (size_t)(n - NQKV) * CHUNK_BYTES;
-        }
-        issue_chunk(src, smraw + (n & 1) * CHUNK_BYTES, wave, lane);
+    for (int jj = 0; jj < CT / 2; ++jj) {
+      if (pdrop) {
+        const uint32_t base = (uint32_t)(img * BT + col) * (uint32_t)BC + (uint32_t)((6 * half + jj) * 16 + 4 * q4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jj][r] *= drop_factor(pkey_proj, base + r, pp, pinv);
       }
-      const char* wbuf = smraw + (i & 1) * CHUNK_BYTES;
-      if (i < NQKV) {
-        const int h = MODE0 ? i / 3 : i, part = MODE0 ? i % 3 : 0;
-        f32x4 acc[TPC];
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = *reinterpret_cast<const f32x4*>(a.bqkv + part * BC + h * BD + t * 16 + 4 * q4);
-        if (KIND == 1 && part > 0) chunk_gemm(wbuf, pf, acc, lane);
-        else chunk_gemm(wbuf, xf, acc, lane);
-        bf16* dst = ws + (part == 0 ? W_Q : (part == 1 ? W_KT : W_VT));
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) {
-          bad |= nan4(acc[t]);
-          row4_lds(dst + col * LDD + t * 16 + 4 * q4, acc[t]);
-        }
-        if (part == (MODE0 ? 2 : 0)) {
-          // ================= attention core of head h (schedule of attn3_bf16.hip, operands already in LDS) =================
-          wave_sync();
-          if (MODE0) {
-            // Kf^T[d][j] = sum_l kt[l][d] E_k[l][j]   (Linformer, HQAViT_CIFAR100.py:332-352)
-#pragma unroll
-            for (int jt = 0; jt < KT0; ++jt)
-#pragma unroll
-              for (int dt = 0; dt < DT; ++dt) {
-                f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
-                ak = mma16(trfrag(ws + W_KT, LDD, 0, dt * 16), trfrag(sek, LDE, 0, jt * 16), ak);
-                av = mma16(trfrag(ws + W_VT, LDD, 0, dt * 16), trfrag(sev, LDE, 0, jt * 16), av);
-                row4_lds(ws + W_KF + (jt * 16 + col) * LDD + dt * 16 + 4 * q4, ak);
-                row4_lds(ws + W_VF + (jt * 16 + col) * LDD + dt * 16 + 4 * q4, av);
-              }
-            wave_sync();
-          }
-          // S^T[key][query], softmax over keys on registers
-          f32x4 sc[NKT];
-#pragma unroll
-          for (int nt = 0; nt < NKT; ++nt) {
-            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-              acc2 = mma16(nt < KT0 ? rowfrag(ws + W_KF, LDD, nt * 16, dt * 16) : rowfrag(sbk, LDB, 0, h * BD + dt * 16),
-                           rowfrag(ws + W_Q, LDD, 0, dt * 16), acc2);
-            sc[nt] = acc2;
-          }
-          {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const bool ok = nt * 16 + 4 * q4 + r < NK;
-                sc[nt][r] = ok ? sc[nt][r] * scale : -INFINITY;
-                mx = fmaxf(mx, sc[nt][r]);
-              }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NKT; ++nt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { const float e = __expf(sc[nt][r] - mx); sc[nt][r] = e; sum += e; }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.f / sum;
-            const uint32_t pkey = drop.on ? attn_drop_pkey(drop, img * BH + h) : 0u;
-#pragma unroll
-            for (int nt = 0; nt < NKT; ++nt) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float pv = sc[nt][r] * inv;
-                if (drop.on) pv *= attn_drop_factor(drop, pkey, col, nt * 16 + 4 * q4 + r);
-                sc[nt][r] = pv;
-              }
-              row4_lds(ws + W_P + col * LDK + nt * 16 + 4 * q4, sc[nt]);
-            }
-          }
-          wave_sync();
-          // O^T[d][query] = sum_key Vf[key][d] P[query][key]  ->  columns h*48 .. of the O tile
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int nt = 0; nt < NKT; ++nt)
-              acc2 = mma16(nt < KT0 ? trfrag(ws + W_VF, LDD, nt * 16, dt * 16) : trfrag(sbv, LDB, 0, h * BD + dt * 16),
-                           rowfrag(ws + W_P, LDK, 0, nt * 16), acc2);
-            bad |= nan4(acc2);
-            row4_lds(ws + W_O + col * LDO + h * BD + dt * 16 + 4 * q4, acc2);
-          }
-          wave_sync();
-        }
-      } else {
-        // ================= proj: out = dropout(O . Wproj^T + b), 48 output columns per chunk =================
-        const int pc = i - NQKV;
-        if (pc == 0) {
-#pragma unroll
-          for (int s = 0; s < KST; ++s) of[s] = *reinterpret_cast<const bf16x8*>(ws + W_O + col * LDO + 32 * s + 8 * q4);
-          if (a.o_save && valid) {                         // attention output rows (operand of backward's dW_proj): 16-byte stores
-            bf16* osv = reinterpret_cast<bf16*>(a.o_save);
-#pragma unroll
-            for (int s = 0; s < KST; ++s) *reinterpret_cast<bf16x8*>(osv + ((size_t)img * BT + col) * a.ldo + 32 * s + 8 * q4) = of[s];
-          }
-          wave_sync();                                     // the O tile is in registers: its LDS image now collects the output rows
-        }
-        f32x4 acc[TPC];
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = *reinterpret_cast<const f32x4*>(a.bproj + pc * 48 + t * 16 + 4 * q4);
-        chunk_gemm(wbuf, of, acc, lane);
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) {
-          if (pdrop) {
-            const uint32_t base = (uint32_t)(img * BT + col) * (uint32_t)BC + (uint32_t)(pc * 48 + t * 16 + 4 * q4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] *= drop_factor(pkey_proj, base + r, a.proj_drop_p, pinv);
-          }
-          row4_lds(ws + W_O + col * LDO + pc * 48 + t * 16 + 4 * q4, acc[t]);
-        }
-      }
+      *reinterpret_cast<bf16x4*>(sout + col * LDO + (6 * half + jj) * 16 + 4 * q4) = cvt4(acc[jj]);
     }
-    // ---------------- output rows: LDS tile -> global, 16-byte pieces (24 per 384-byte row) ----------------
+    // ---------------- output rows: LDS tile -> global, 16-byte pieces (this wave's 96 columns: 12 per row) ----------------
     wave_sync();
+#ifndef QAVIT_BRANCH_STAMPS
+    if (osv && valid) {                                    // attention output rows (operand of backward's dW_proj): this wave's k-steps
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int s2 = 3 * half + s3;
+        *reinterpret_cast<bf16x8*>(osv + ((size_t)img * BT + col) * a.ldo + 32 * s2 + 8 * q4) = of8[s2];
+      }
+    }
+#endif
     if (valid) {
 #pragma unroll
-      for (int it = 0; it < 6; ++it) {
-        const int p = lane + 64 * it, row = p / 24, c8 = p - row * 24;
-        *reinterpret_cast<bf16x8*>(og + ((size_t)img * BT + row) * a.ldo + 8 * c8) = *reinterpret_cast<const bf16x8*>(ws + W_O + row * LDO + 8 * c8);
+      for (int it = 0; it < 3; ++it) {
+        const int p = lane + 64 * it, row = p / 12, c8 = 12 * half + p % 12;
+        *reinterpret_cast<bf16x8*>(og + ((size_t)img * BT + row) * a.ldo + 8 * c8) = *reinterpret_cast<const bf16x8*>(sout + row * LDO + 8 * c8);
       }
     }
-    wave_sync();
   }
+  STAMP(10);
+#undef QV_RING_STEP
+  STAMP(11);
   if (a.nan_flag && __any(bad) && lane == 0) atomicOr(a.nan_flag, 1);
+#undef STAMP
 }
 
 // efficient_attention's NaN rule (HQAViT_CIFAR100.py:356-357, :394-395) behind the fused branch: a NaN anywhere in q / k / v
@@ -345,7 +518,6 @@ int branch_validate(const qavit_branch_args* a) {
   if (!al16(a->x) || !al16(a->out) || !al16(a->wqkv_frag) || !al16(a->wproj_frag) || !al16(a->bqkv) || !al16(a->bproj) || !al16(a->sh_k) || !al16(a->sh_v) ||
       (a->o_save && !al16(a->o_save)) || a->ldx % 8 || a->ldo % 8)
     return set_error(QAVIT_EINVAL, "branch: operands must be 16-byte aligned with leading dimensions a multiple of 8 elements");
-  if (a->kind != 2 && (!al16(a->E_k) || !al16(a->E_v))) return set_error(QAVIT_EINVAL, "branch: Linformer matrices must be 16-byte aligned");
   return QAVIT_OK;
 }
 
@@ -366,16 +538,15 @@ extern "C" int qavit_branch_fwd(const qavit_branch_args* a, void* stream) {
   int rc = branch_validate(a);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int ntiles = (a->B + 3) / 4;
-  const int grid = ntiles < 1024 ? ntiles : 1024;
+  const int grid = (a->B + NI - 1) / NI;                   // one 4-image tile per workgroup
   static bool attr_done[3] = {false, false, false};
 #define QV_BRANCH_LAUNCH(K)                                                                                                             \
   do {                                                                                                                                   \
     if (!attr_done[K]) {                                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_TOTAL); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, sm_total(K)); \
       attr_done[K] = true;                                                                                                               \
     }                                                                                                                                    \
-    hipLaunchKernelGGL((branch_fwd_kernel<K>), dim3(grid), dim3(256), SM_TOTAL, st, *a);                                                \
+    hipLaunchKernelGGL((branch_fwd_kernel<K>), dim3(grid), dim3(512), sm_total(K), st, *a);                                             \
   } while (0)
   if (a->kind == 0) QV_BRANCH_LAUNCH(0);
   else if (a->kind == 1) QV_BRANCH_LAUNCH(1);

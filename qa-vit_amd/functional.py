@@ -61,7 +61,7 @@ class WeightPack:
         """The parameters were written behind autograd's back (raw-pointer optimiser kernel, graph replay)."""
         self._stale = True
 
-    def _make(self, params, dtype, frag=False):
+    def _make(self, params, dtype, frag=0):
         e = _PackEntry()
         e.refs = [weakref.ref(p) for p in params]
         rows = sum(p.shape[0] for p in params)
@@ -92,7 +92,7 @@ class WeightPack:
             d.src = self._as2d(p).data_ptr()
             d.dst = 0 if e.dst is None else e.dst.data_ptr() + off * e.cols * esz
             d.dstT = 0 if e.dstT is None else e.dstT.data_ptr() + off * esz
-            d.rows, d.cols, d.ldT, d.pad = r, e.cols, e.rows, (1 if e.frag else 0)
+            d.rows, d.cols, d.ldT, d.pad = r, e.cols, e.rows, int(e.frag)
             out.append(d)
             off += r
         e.ptrs = [p.data_ptr() for p in params]
@@ -166,21 +166,22 @@ class WeightPack:
         W = e.dst if e.dst is not None else self._as2d(params[0]).detach()
         return W, e.dstT
 
-    def get_frag(self, params, dtype=torch.bfloat16):
-        """-> the weight (or row-stack of weights) in MFMA fragment order (include/qavit.h, qavit_pack_desc.pad = 1): the
-        operand image of the fused branch kernels.  Refreshed with everything else."""
+    def get_frag(self, params, dtype=torch.bfloat16, order=1):
+        """-> the weight (or row-stack of weights) in MFMA fragment order (include/qavit.h, qavit_pack_desc.pad = ``order``:
+        1 = plain k order, 2 = paired-quads k order): the operand image of the fused branch kernels.  Refreshed with
+        everything else."""
         if isinstance(params, torch.Tensor):
             params = [params]
         if self._stale:
             self.refresh()
-        key = (tuple(id(p) for p in params), dtype, "frag")
+        key = (tuple(id(p) for p in params), dtype, "frag%d" % order)
         e = self.entries.get(key)
         if e is not None and e.params() is None:
             del self.entries[key]
             self._drop_table(dtype)
             e = None
         if e is None:
-            e = self._make(params, dtype, frag=True)
+            e = self._make(params, dtype, frag=order)
             self.entries[key] = e
             self._drop_table(dtype)
             self._launch(self._descs(e, params), dtype)

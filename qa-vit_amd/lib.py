@@ -52,7 +52,7 @@ class BranchArgs(C.Structure):
         ("E_k", vp), ("E_v", vp), ("sh_k", vp), ("sh_v", vp), ("pool_idx", vp), ("pool_stride", i32),
         ("out", vp), ("ldo", i64), ("o_save", vp),
         ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
-        ("nan_flag", vp),
+        ("nan_flag", vp), ("reserved", i32),
     ]
 
 

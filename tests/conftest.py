@@ -125,6 +125,15 @@ def rng_uniform(key, idx):
     return ((h >> np.uint64(8)).astype(np.float64) * (1.0 / 16777216.0)).astype(np.float32)
 
 
+def drop_keep(key, idx, p):
+    """bool: element kept by common.cuh drop_factor(key, idx, p): elements 2m, 2m+1 share the hash of m (low / high 16 bits)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    h = _mix32((((idx >> np.uint64(1)) * np.uint64(0x9E3779B9)) & _M32) ^ np.asarray(key, dtype=np.uint64))
+    u16 = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    return u16 >= thr
+
+
 def attn_keep_mask(seed: int, step: int, site: int, G: int, H: int, Nq: int, NK: int, p: float) -> np.ndarray:
     """bool [G, H, Nq, NK]: True where the attention probability of (group g, head h, query i, key j) is KEPT."""
     key = rng_key(seed, step, site)
@@ -133,5 +142,4 @@ def attn_keep_mask(seed: int, step: int, site: int, G: int, H: int, Nq: int, NK:
     i = np.arange(Nq, dtype=np.uint64)[:, None]
     j = np.arange(NK, dtype=np.uint64)[None, :]
     idx = (i << np.uint64(16)) | j                                                    # [Nq, NK]
-    u = rng_uniform(pkey[:, None, None], idx[None])
-    return (u >= np.float32(p)).reshape(G, H, Nq, NK)
+    return drop_keep(pkey[:, None, None], idx[None], p).reshape(G, H, Nq, NK)

@@ -815,9 +815,9 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
         assert abs(frac - (1 - drop)) < 0.02, frac
         assert rel(out[kept], (ref / (1 - drop))[kept]) <= 3e-2
         # the proj mask is the GEMM epilogue's contract: drop_factor(key(site), row * C + col)
-        from conftest import rng_key, rng_uniform
-        u = rng_uniform(rng_key(seed, step, sp), np.arange(B * T * C, dtype=np.uint64)).reshape(B, T, C)
-        assert np.array_equal(u >= np.float32(drop), kept.cpu().numpy())
+        from conftest import rng_key, drop_keep
+        keep_p = drop_keep(rng_key(seed, step, sp), np.arange(B * T * C, dtype=np.uint64), drop).reshape(B, T, C)
+        assert np.array_equal(keep_p, kept.cpu().numpy())
     else:
         assert rel(out, ref) <= 3e-2
     # the unfused kernels on the same operands agree more tightly (same bf16 rounding points except q/k/v staying in fp32 -> bf16 once)
