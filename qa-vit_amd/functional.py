@@ -358,50 +358,56 @@ class LinearFn(Function):
     def backward(ctx, dy):
         x2, w, b, ln_g, ln_b, Z, mean, rstd = ctx.saved_tensors
         M, n, Kd, off, act, drop, dp, xshape, has_res = ctx.meta
-        rt = _rt(x2)
-        dy2 = dy.reshape(M, n)
-        if not dy2.is_contiguous():
-            dy2 = dy2.contiguous()
-        need_t = bool(act) or drop[0] > 0.0 or dp[0] > 0.0
-        need_dx = ctx.needs_input_grad[0]
-        need_dw = w.requires_grad
-        Wc, Wt = pack_for(x2.device).get(w, x2.dtype)
-        esz = Wt.element_size()
-        dz = dy2
-        dx = None
-        if need_dx or need_t:
-            dz = torch.empty_like(dy2) if (need_t and (need_dw or (b is not None and b.requires_grad))) else dy2
-            dxn = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
-            bwd = None
-            if need_t:
-                bwd = dict(Z=Z, ldz=n, act=act, drop=drop, dp=dp, out=dz if dz is not dy2 else None, ldo=n)
-            K.gemm_nt(dy2, Wt, dxn, M, Kd, n, n, Wt.shape[1], Kd, None, a_mode=2 if need_t else 0, bwd=bwd, rng=rt.rng,
-                      B_ptr=Wt.data_ptr() + off * esz)
-            if ln_g is not None:
-                gbuf, _ = grad_sink(ln_g)
-                bbuf, _ = grad_sink(ln_b)
-                dx = torch.empty_like(dxn)
-                K.layernorm_bwd(dxn, x2, ln_g, mean, rstd, dx, gbuf, bbuf, M, Kd)
-            else:
-                dx = dxn
-        if need_dw or (b is not None and b.requires_grad):
-            wbuf, _ = grad_sink(w)
-            bbuf2, _ = grad_sink(b)
-            if wbuf is None:   # bias-only gradient: still use the kernel with a scratch C
-                wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
-            lnarg = (ln_g, ln_b, mean, rstd) if ln_g is not None else None
-            DeferDW.arm()
-            if SideStream.enabled:
-                with SideStream.fork(x2.device, dz, x2, mean, rstd):
-                    K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
-                              C_ptr=wbuf.data_ptr() + off * Kd * 4,
-                              colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
-            else:
+        dx = _linear_bwd(x2, w, b, dy.reshape(M, n), off, n, ctx.needs_input_grad[0], ln_g, ln_b, Z, mean, rstd, act, drop, dp)
+        dres = dy if has_res else None
+        return (dx.reshape(xshape) if (dx is not None and ctx.needs_input_grad[0]) else None), None, None, None, None, dres, None
+
+
+def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, mean=None, rstd=None, act=0, drop=(0.0, 0), dp=(0.0, 0, 1)):
+    """Backward of y = droppath(dropout(act(LN(x2) @ w[off:off+n]^T + b[off:off+n]))) for row matrices: returns dx (or None) and
+    accumulates dW / db into the parameters' .grad (deferred grouped weight-gradient GEMMs).  Shared by LinearFn and BranchFn."""
+    M, Kd = x2.shape
+    rt = _rt(x2)
+    if not dy2.is_contiguous():
+        dy2 = dy2.contiguous()
+    need_t = bool(act) or drop[0] > 0.0 or dp[0] > 0.0
+    need_dw = w.requires_grad
+    Wc, Wt = pack_for(x2.device).get(w, x2.dtype)
+    esz = Wt.element_size()
+    dz = dy2
+    dx = None
+    if need_dx or need_t:
+        dz = torch.empty_like(dy2) if (need_t and (need_dw or (b is not None and b.requires_grad))) else dy2
+        dxn = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
+        bwd = None
+        if need_t:
+            bwd = dict(Z=Z, ldz=n, act=act, drop=drop, dp=dp, out=dz if dz is not dy2 else None, ldo=n)
+        K.gemm_nt(dy2, Wt, dxn, M, Kd, n, n, Wt.shape[1], Kd, None, a_mode=2 if need_t else 0, bwd=bwd, rng=rt.rng,
+                  B_ptr=Wt.data_ptr() + off * esz)
+        if ln_g is not None:
+            gbuf, _ = grad_sink(ln_g)
+            bbuf, _ = grad_sink(ln_b)
+            dx = torch.empty_like(dxn)
+            K.layernorm_bwd(dxn, x2, ln_g, mean, rstd, dx, gbuf, bbuf, M, Kd)
+        else:
+            dx = dxn
+    if need_dw or (b is not None and b.requires_grad):
+        wbuf, _ = grad_sink(w)
+        bbuf2, _ = grad_sink(b)
+        if wbuf is None:   # bias-only gradient: still use the kernel with a scratch C
+            wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+        lnarg = (ln_g, ln_b, mean, rstd) if ln_g is not None else None
+        DeferDW.arm()
+        if SideStream.enabled:
+            with SideStream.fork(x2.device, dz, x2, mean, rstd):
                 K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
                           C_ptr=wbuf.data_ptr() + off * Kd * 4,
                           colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
-        dres = dy if has_res else None
-        return (dx.reshape(xshape) if (dx is not None and need_dx) else None), None, None, None, None, dres, None
+        else:
+            K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
+                      C_ptr=wbuf.data_ptr() + off * Kd * 4,
+                      colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
+    return dx
 
 
 def linear(x, w, b=None, *, ln=None, act=None, drop=None, dp=None, resid=None, rows=None, eps=1e-5, train=True):
@@ -549,6 +555,92 @@ def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool
     return (out, o) if want_o else out
 
 
+class BranchFn(Function):
+    """A whole attention branch on 16-token problems as ONE forward launch (csrc/branch_fwd.hip).  ``meta``: kind (0 SWA,
+    1 MSDA, 2 cross), pool_idx / pool_stride / Lk (MSDA), attn_drop / proj_drop = (p, site).
+    Backward runs the unfused kernels on recomputed projections: q / k / v are cheap to re-derive (one GEMM launch, no
+    attention forward) and are not worth 19 MB of stores per branch in the forward; the attention output O the proj weight
+    gradient needs is the one tensor the forward kernel saves.  Dropout masks are pure functions of (seed, step, site,
+    element), identical in the fused forward and the unfused backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, meta):
+        need = any(ctx.needs_input_grad)
+        res = branch_forward(meta["kind"], x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k.reshape(-1, x.shape[-1]), sh_v.reshape(-1, x.shape[-1]),
+                             meta.get("pool_idx"), meta.get("pool_stride", 0), meta.get("Lk", x.shape[1] if meta["kind"] == 0 else 0), meta["attn_drop"], meta["proj_drop"], want_o=need)
+        if not need:
+            return res
+        out, o = res
+        # The bank is mutated in place later in the same forward (GlobalTokenBank.write); the reference's SDPA backward sees
+        # the values its forward used (torch.cat made a copy), so snapshot shared rows that alias a parameter (as AttnFn does).
+        sk_s, sv_s = sh_k, sh_v
+        if sh_k.is_leaf and sh_v.is_leaf:
+            sk_s, sv_s = K.copy2(sh_k, sh_v)
+        ctx.sh_alias = (sh_k, sh_v)
+        ctx.meta = meta
+        ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o = ctx.saved_tensors
+        sh_k_in, sh_v_in = ctx.sh_alias
+        m = ctx.meta
+        kind = m["kind"]
+        B, T, Cc = x.shape
+        H, D = 4, Cc // 4
+        S = sk_s.reshape(-1, Cc).shape[0]
+        x2 = x.reshape(B * T, Cc)
+        # ---- proj backward: dO = (dout * mask) Wproj ; dWproj += (dout * mask)^T O ; dbproj
+        d_o = _linear_bwd(o, wproj, bproj, dout.reshape(B * T, Cc), 0, Cc, True, drop=m["proj_drop"])
+        # ---- recompute the projections (no gradient tracking), then the attention-core backward
+        with torch.no_grad():
+            if kind == 0:
+                qkv = linear(x2, wqkv, bqkv)
+                spec = dict(mode=0, G=B, Nq=T, L=T, H=H, D=D, KC=E_k.shape[1], S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=T,
+                            q_off=0, k_off=Cc, v_off=2 * Cc, q_rows=B * T, drop=m["attn_drop"])
+                dq_t, _, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(qkv, None, E_k, E_v, sk_s, sv_s, sh_k_in, sh_v_in, spec, d_o)
+                dx = _linear_bwd(x2, wqkv, bqkv, dq_t, 0, 3 * Cc, ctx.needs_input_grad[0])
+            elif kind == 1:
+                idx, stride, Lk = m["pool_idx"], m["pool_stride"], m["Lk"]
+                NP = idx.numel() // stride
+                pooled = torch.empty(B, NP, Cc, dtype=x.dtype, device=x.device)
+                K.gather_pool_fwd(x.contiguous(), idx, pooled, B, T, NP, stride, Cc)
+                p2 = pooled.reshape(B * NP, Cc)
+                q = linear(x2, wqkv, bqkv, rows=(0, Cc))
+                kv = linear(p2, wqkv, bqkv, rows=(Cc, 2 * Cc))
+                spec = dict(mode=0, G=B, Nq=T, L=Lk, H=H, D=D, KC=E_k.shape[1], S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=NP,
+                            q_off=0, k_off=0, v_off=Cc, q_rows=B * T, drop=m["attn_drop"])
+                dq_t, dkv_t, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(q, kv, E_k, E_v, sk_s, sv_s, sh_k_in, sh_v_in, spec, d_o)
+                dxq = _linear_bwd(x2, wqkv, bqkv, dq_t, 0, Cc, ctx.needs_input_grad[0])
+                dpool = _linear_bwd(p2, wqkv, bqkv, dkv_t, Cc, 2 * Cc, ctx.needs_input_grad[0])
+                dx = None
+                if ctx.needs_input_grad[0]:
+                    dxp = torch.empty(B, T, Cc, dtype=x.dtype, device=x.device)
+                    K.gather_pool_bwd(dpool.reshape(B, NP, Cc).contiguous(), idx, dxp, B, T, NP, stride, Cc)
+                    dx = dxq.reshape(B, T, Cc) + dxp
+            else:
+                q = linear(x2, wqkv, bqkv)
+                spec = dict(mode=1, G=B, Nq=T, L=0, H=H, D=D, S=S, q_off=0, k_off=0, v_off=0, q_rows=B * T, drop=m["attn_drop"])
+                dq_t, _, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(q, None, None, None, sk_s.reshape(S, Cc), sv_s.reshape(S, Cc),
+                                                                    sh_k_in, sh_v_in, spec, d_o)
+                dx = _linear_bwd(x2, wqkv, bqkv, dq_t, 0, Cc, ctx.needs_input_grad[0])
+        gE_k = _ret(ek_ret, E_k) if ek_ret is not None else None
+        gE_v = _ret(ev_ret, E_v) if ev_ret is not None else None
+        return (dx.reshape(B, T, Cc) if dx is not None else None), None, None, None, None, gE_k, gE_v, \
+            _ret(sk_ret, sh_k_in), _ret(sv_ret, sh_v_in), None
+
+
+def branch_ok(kind, x, Lk, KC, S, heads) -> bool:
+    """Does the fused branch kernel cover this call?  (bf16, 16 tokens x 192 channels, 4 heads of 48, 16 shared rows, KC = 32)"""
+    if x.dtype != torch.bfloat16 or x.dim() != 3 or not x.is_cuda or os.environ.get("QAVIT_FUSED_BRANCH", "1") == "0":
+        return False
+    B, T, Cc = x.shape
+    if heads == 0 or Cc % heads:
+        return False
+    return K.branch_supported(kind, T, Cc, heads, Cc // heads, KC, S, Lk)
+
+
 class AttnFn(Function):
     """See include/qavit.h (qavit_attn_args).  ``q_t`` is a 2-D row matrix holding q (and, when ``kv_t`` is
     None and L > 0, also k and v) at column offsets; gradients come back as whole matrices.
@@ -599,55 +691,60 @@ class AttnFn(Function):
     def backward(ctx, d_o):
         q_t, kv_t, E_k, E_v, sh_k, sh_v = ctx.saved_tensors
         sh_k_in, sh_v_in = ctx.sh_alias
-        s = ctx.spec
-        rt = _rt(q_t)
-        HD = s["H"] * s["D"]
-        if not d_o.is_contiguous():
-            d_o = d_o.contiguous()
-        src_kv = q_t if kv_t is None else kv_t
-        a = K.attn_args(q_t.dtype, s["mode"], s["G"], s["Nq"], s["L"], s["H"], s["D"], s.get("KC", 0), s["S"],
-                        s.get("groups_per_b", 0), s.get("q_rows_per_b", 0), s.get("k_rows_per_b", 0), s.get("q_tbl"), s.get("k_tbl"))
-        esz = q_t.element_size()
-        a.q, a.ldq = q_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]
-        if s["L"] > 0:
-            a.k_tok, a.ldk = src_kv.data_ptr() + s["k_off"] * esz, src_kv.shape[1]
-            a.v_tok, a.ldv = src_kv.data_ptr() + s["v_off"] * esz, src_kv.shape[1]
-        if s["mode"] == 0:
-            a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
-        a.sh_k, a.sh_v = sh_k.data_ptr(), sh_v.data_ptr()
-        a.d_o, a.lddo = d_o.data_ptr(), HD
-        _attn_drop(a, s, rt)
-        covered_q = HD * (3 if (kv_t is None and s["L"] > 0) else 1) == q_t.shape[1]
-        dq_t = torch.empty_like(q_t) if covered_q else torch.zeros_like(q_t)
-        a.dq, a.lddq = dq_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]
-        dkv_t = None
-        if s["L"] > 0:
-            if kv_t is None:
-                dst = dq_t
-            else:
-                # every row and column written by the kernel?  (MSDA at 224 px keeps only the first 128 landmarks: the rest get 0)
-                covered_kv = 2 * HD == kv_t.shape[1] and s["G"] * s["L"] == kv_t.shape[0]
-                dkv_t = torch.empty_like(kv_t) if covered_kv else torch.zeros_like(kv_t)
-                dst = dkv_t
-            a.dk_tok, a.lddk = dst.data_ptr() + s["k_off"] * esz, dst.shape[1]
-            a.dv_tok, a.lddv = dst.data_ptr() + s["v_off"] * esz, dst.shape[1]
-        ek_buf, ek_ret = grad_sink(E_k) if s["mode"] == 0 else (None, None)
-        ev_buf, ev_ret = grad_sink(E_v) if s["mode"] == 0 else (None, None)
-        sk_buf, sk_ret = grad_sink(sh_k_in)
-        sv_buf, sv_ret = grad_sink(sh_v_in)
-        a.dE_k, a.dE_v = K._p(ek_buf), K._p(ev_buf)
-        a.dsh_k, a.dsh_v = K._p(sk_buf), K._p(sv_buf)
-        nws = K.attn_ws_floats(a)
-        ws = rt.workspace("attn_bwd", nws)
-        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
-        K.attn_bwd(a)
+        dq_t, dkv_t, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(q_t, kv_t, E_k, E_v, sh_k, sh_v, sh_k_in, sh_v_in, ctx.spec, d_o)
         return dq_t, dkv_t, _ret(ek_ret, E_k) if ek_ret is not None else None, _ret(ev_ret, E_v) if ev_ret is not None else None, \
             _ret(sk_ret, sh_k_in), _ret(sv_ret, sh_v_in), None
 
 
-# ---------------------------------------------------------------------------------------------------
-# token-axis operators
-# ---------------------------------------------------------------------------------------------------
+def _attn_bwd(q_t, kv_t, E_k, E_v, sh_k, sh_v, sh_k_in, sh_v_in, s, d_o):
+    """Attention-core backward (qavit_attn_bwd): ``sh_k`` / ``sh_v`` are the forward-time VALUES of the shared rows, ``sh_k_in`` /
+    ``sh_v_in`` the tensors whose gradient they feed (the bank parameters accumulate in place).  -> dq_t, dkv_t and the
+    autograd returns for E_k, E_v, sh_k_in, sh_v_in (None where the gradient went straight into .grad).  Shared by AttnFn and
+    BranchFn."""
+    rt = _rt(q_t)
+    HD = s["H"] * s["D"]
+    if not d_o.is_contiguous():
+        d_o = d_o.contiguous()
+    src_kv = q_t if kv_t is None else kv_t
+    a = K.attn_args(q_t.dtype, s["mode"], s["G"], s["Nq"], s["L"], s["H"], s["D"], s.get("KC", 0), s["S"],
+                    s.get("groups_per_b", 0), s.get("q_rows_per_b", 0), s.get("k_rows_per_b", 0), s.get("q_tbl"), s.get("k_tbl"))
+    esz = q_t.element_size()
+    a.q, a.ldq = q_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]
+    if s["L"] > 0:
+        a.k_tok, a.ldk = src_kv.data_ptr() + s["k_off"] * esz, src_kv.shape[1]
+        a.v_tok, a.ldv = src_kv.data_ptr() + s["v_off"] * esz, src_kv.shape[1]
+    if s["mode"] == 0:
+        a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
+    a.sh_k, a.sh_v = sh_k.data_ptr(), sh_v.data_ptr()
+    a.d_o, a.lddo = d_o.data_ptr(), HD
+    _attn_drop(a, s, rt)
+    covered_q = HD * (3 if (kv_t is None and s["L"] > 0) else 1) == q_t.shape[1]
+    dq_t = torch.empty_like(q_t) if covered_q else torch.zeros_like(q_t)
+    a.dq, a.lddq = dq_t.data_ptr() + s["q_off"] * esz, q_t.shape[1]
+    dkv_t = None
+    if s["L"] > 0:
+        if kv_t is None:
+            dst = dq_t
+        else:
+            # every row and column written by the kernel?  (MSDA at 224 px keeps only the first 128 landmarks: the rest get 0)
+            covered_kv = 2 * HD == kv_t.shape[1] and s["G"] * s["L"] == kv_t.shape[0]
+            dkv_t = torch.empty_like(kv_t) if covered_kv else torch.zeros_like(kv_t)
+            dst = dkv_t
+        a.dk_tok, a.lddk = dst.data_ptr() + s["k_off"] * esz, dst.shape[1]
+        a.dv_tok, a.lddv = dst.data_ptr() + s["v_off"] * esz, dst.shape[1]
+    ek_buf, ek_ret = grad_sink(E_k) if s["mode"] == 0 else (None, None)
+    ev_buf, ev_ret = grad_sink(E_v) if s["mode"] == 0 else (None, None)
+    sk_buf, sk_ret = grad_sink(sh_k_in)
+    sv_buf, sv_ret = grad_sink(sh_v_in)
+    a.dE_k, a.dE_v = K._p(ek_buf), K._p(ev_buf)
+    a.dsh_k, a.dsh_v = K._p(sk_buf), K._p(sv_buf)
+    nws = K.attn_ws_floats(a)
+    ws = rt.workspace("attn_bwd", nws)
+    a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+    K.attn_bwd(a)
+    return dq_t, dkv_t, ek_ret, ev_ret, sk_ret, sv_ret
+
+
 class TokMixFn(Function):
     @staticmethod
     def forward(ctx, scores, x):
@@ -1015,6 +1112,7 @@ class FanOutFn(Function):
     @staticmethod
     def forward(ctx, x, k):
         ctx.k = k
+        ctx.set_materialize_grads(False)                   # an alias nobody differentiated through arrives as None, not as zeros
         return tuple(x.view_as(x) for _ in range(k))
 
     @staticmethod

@@ -104,6 +104,14 @@ class EfficientSpatialWindowAttention(_Branch):
                                 t.append((wy * ws + ty) * Hs + wx * ws + tx)
                 return t
             tbl = K.Runtime.get(x.device).table(("win", Hs, ws), build)
+        p = self.dropout.p if self.training else 0.0
+        if nw == 1 and F.branch_ok(0, x, N, self.linformer.compressed_len, self.global_bank.bank_size, self.num_heads):
+            # one window = the image's tokens: the whole branch is one launch (csrc/branch_fwd.hip)
+            out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
+                                   self.global_bank.global_k, self.global_bank.global_v,
+                                   dict(kind=0, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+            self._write(out)
+            return out
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias).reshape(B * N, 3 * C)
         spec = dict(mode=0, G=B * nw * nw, Nq=ws * ws, L=ws * ws, H=self.num_heads, D=self.head_dim,
                     KC=self.linformer.compressed_len, S=self.global_bank.bank_size, groups_per_b=nw * nw,
@@ -152,6 +160,14 @@ class EfficientMultiScaleDilatedAttention(_Branch):
             return t[: (len(t) // stride) * stride]
         idx = K.Runtime.get(x.device).table(("msda", Hs, tuple(self.dilation_factors), stride), build)
         NP = idx.numel() // stride
+        p = self.dropout.p if self.training else 0.0
+        same = x_q is x or (x_q.data_ptr() == x.data_ptr() and x_q.shape == x.shape and x_q.stride() == x.stride())
+        if same and NP <= 16 and F.branch_ok(1, x, NP, self.linformer.compressed_len, self.global_bank.bank_size, self.num_heads):
+            out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
+                                   self.global_bank.global_k, self.global_bank.global_v,
+                                   dict(kind=1, pool_idx=idx, pool_stride=stride, Lk=NP, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+            self._write(out)
+            return out
         pooled = F.GatherPoolFn.apply(x, idx, stride)
         kv = F.linear(pooled, self.qkv.weight, self.qkv.bias, rows=(C, 2 * C)).reshape(B * NP, 2 * C)
         q = F.linear(x_q, self.qkv.weight, self.qkv.bias, rows=(0, C)).reshape(B * N, C)
@@ -226,10 +242,14 @@ class CrossAttentionBranch(_Branch):
     def forward(self, x):
         B, N, C = x.shape
         bank = self.global_bank
-        q = F.linear(x, self.q_proj.weight, self.q_proj.bias).reshape(B * N, C)
         gk, gv = F.bank_snapshot(bank)                                                                         # see CGA
         sh_k = F.linear(gk, self.k_proj.weight, self.k_proj.bias).reshape(bank.bank_size, C)
         sh_v = F.linear(gv, self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
+        p = self.dropout.p if self.training else 0.0
+        if F.branch_ok(2, x, 0, 0, bank.bank_size, self.num_heads):
+            return F.BranchFn.apply(x, self.q_proj.weight, self.q_proj.bias, self.proj.weight, self.proj.bias, None, None, sh_k, sh_v,
+                                    dict(kind=2, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+        q = F.linear(x, self.q_proj.weight, self.q_proj.bias).reshape(B * N, C)
         spec = dict(mode=1, G=B, Nq=N, L=0, H=self.num_heads, D=self.head_dim, S=bank.bank_size, q_off=0, k_off=0, v_off=0,
                     q_rows=B * N)
         p = self.dropout.p if self.training else 0.0
