@@ -121,7 +121,9 @@ int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, c
 int qavit_row_stats(int dtype, const void* x, float eps, int rows, int C, float* mean, float* rstd, void* stream);
 int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                         const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                        int rows, int C, float* dadd, int add_rows, const float* beta, int act, void* stream);
+                        int rows, int C, float* dadd, int add_rows, const float* beta, int act, const void* dres, void* stream);
+/* dres (optional, same shape / dtype as dx): dx = LN_backward(dy) + dres -- the other gradient that meets this one at x (a
+ * residual connection around the normalised branch), added in the same pass instead of a separate elementwise kernel. */
 
 /* The four branch norms of a QuadAttentionBlock (norm_{swa,msda,cga,cross}, HQAViT_CIFAR100.py:1046-1049,1075-1078) act on
  * four same-shape tensors that are independent of each other: n <= 4 inputs per grid.  Host arrays of device pointers. */
@@ -414,6 +416,12 @@ int qavit_local_clip(float* g, const int64_t* seg, int nseg, float clip, float* 
 /* dst_a = src_a, dst_b = src_b (n fp32 each, n % 4 == 0, 16-byte aligned): forward-time snapshot of the bank's K / V rows
  * (the reference's torch.cat / Linear-on-expand copies, HQAViT_CIFAR100.py:398-399, :576-577) in one launch */
 int qavit_copy2(const float* src_a, const float* src_b, float* dst_a, float* dst_b, int64_t n, void* stream);
+/* Label-smoothed cross entropy with reduction = 'mean' (nn.CrossEntropyLoss(label_smoothing), HQAViT_CIFAR100.py:1373), loss and
+ * gradient in one launch: loss[0] = mean_i ( - sum_c t_ic log softmax(logits_i)_c ), dlogits = (softmax - t) / B (NULL: loss only),
+ * t_i = (1 - ls) * (lam * onehot(y_a[i]) + (1 - lam) * onehot(y_b[i])) + ls / C.  y_b == NULL: plain labels (lam = 1); lam_dev is a
+ * DEVICE scalar (the MixUp / CutMix lambda of :1404-1408, decided on the device inside a captured step). */
+int qavit_ce_label_smooth(int dtype, const void* logits, const int64_t* y_a, const int64_t* y_b, const float* lam_dev,
+                          float label_smoothing, int B, int C, float* loss, void* dlogits, void* stream);
 /* out[0] = sqrt(sum g^2) over a flat buffer (two-pass, deterministic order within a block);
  * out[1] = max(out[1], out[0]) with NaN sticky: the largest norm any call has seen (`out` is float[2], zero at start),
  * so one host read after N captured steps checks every one of them. */

@@ -163,7 +163,8 @@ template <> struct V4<bf16> { typedef bf16x4 type; };
 
 template <typename T, int NP, int RB, int NW>
 __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, const float* gamma, const float* mean,
-                                                      const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act) {
+                                                      const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act,
+                                                      const T* dres = nullptr) {
   // RB rows per wave per iteration: all their loads are issued before the first reduction, so a wave keeps
   // 2*RB*NP vector loads in flight instead of 2 (the row loop is a pure load -> reduce -> store latency chain).
   typedef typename V4<T>::type v4;
@@ -177,7 +178,7 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
     for (int j = 0; j < 4; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; gm[i][j] = (c + j < C) ? gamma[c + j] : 0.f; bt[i][j] = (act && c + j < C) ? beta[c + j] : 0.f; }
   }
   for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
-    v4 xv[RB][NP], dv[RB][NP];
+    v4 xv[RB][NP], dv[RB][NP], rv[RB][NP];
     float mu[RB], rs[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -189,6 +190,7 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
         if (c < C) {
           xv[r][i] = *reinterpret_cast<const v4*>(x + (size_t)row * C + c);
           dv[r][i] = *reinterpret_cast<const v4*>(dy + (size_t)row * C + c);
+          if (dres) rv[r][i] = *reinterpret_cast<const v4*>(dres + (size_t)row * C + c);      // uniform: the other gradient that meets this one at x
         }
       }
     }
@@ -226,7 +228,7 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
           if (c < C) {
             v4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = from_f<T>(rs[r] * (g[i][j] - c2 - xh[i][j] * c1));
+            for (int j = 0; j < 4; ++j) o[j] = from_f<T>(rs[r] * (g[i][j] - c2 - xh[i][j] * c1) + (dres ? to_f<T>(rv[r][i][j]) : 0.f));
             *reinterpret_cast<v4*>(dx + (size_t)(row0 + r) * C + c) = o;
           }
         }
@@ -255,8 +257,9 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
 
 template <typename T, int NP, int RB, int NW>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
-                                                               const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act) {
-  layernorm_bwd_v4_body<T, NP, RB, NW>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, beta, act);
+                                                               const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act,
+                                                               const T* dres) {
+  layernorm_bwd_v4_body<T, NP, RB, NW>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, beta, act, dres);
 }
 struct LnBwd4 { const void* dy[4]; const void* x[4]; const float* gamma[4]; const float* mean[4]; const float* rstd[4]; void* dx[4]; float* dgamma[4]; float* dbeta[4]; };
 template <typename T, int NP, int RB, int NW>
@@ -313,7 +316,7 @@ extern "C" int qavit_row_stats(int dtype, const void* x, float eps, int rows, in
 
 extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                                    const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                                   int rows, int C, float* dadd, int add_rows, const float* beta, int act, void* stream) {
+                                   int rows, int C, float* dadd, int add_rows, const float* beta, int act, const void* dres, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: bad arguments");
   if (act && !beta) return set_error(QAVIT_EINVAL, "layernorm_bwd: the fused-GELU gradient needs beta");
   if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "layernorm_bwd: C > 1024 unsupported");
@@ -325,12 +328,14 @@ extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, con
   const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
   const bool v4ok = !dadd && (C % 4 == 0) && C <= 1024 &&
                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) % (4 * esz) == 0);
+  if (dres && (!v4ok || (reinterpret_cast<uintptr_t>(dres) % (4 * esz)) != 0))
+    return set_error(QAVIT_EINVAL, "layernorm_bwd: dres needs C % 4 == 0, no dadd and vector-aligned operands");
   if (v4ok) {
     const int np = (C + 255) / 256;
     constexpr int NW = 16;
     grid = (rows + 4 * NW - 1) / (4 * NW);
     if (grid > v4_cap) grid = v4_cap;
-#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_, (NP_ <= 2 ? 4 : 2), NW>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C, beta, act)
+#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_, (NP_ <= 2 ? 4 : 2), NW>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C, beta, act, (const T_*)dres)
     if (dtype == QAVIT_F32) { if (np == 1) LNV(float, 1); else if (np == 2) LNV(float, 2); else LNV(float, 4); }
     else if (dtype == QAVIT_BF16) { if (np == 1) LNV(bf16, 1); else if (np == 2) LNV(bf16, 2); else LNV(bf16, 4); }
     else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
@@ -378,7 +383,7 @@ extern "C" int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy
     v4ok = ((reinterpret_cast<uintptr_t>(x[i]) | reinterpret_cast<uintptr_t>(dy[i]) | reinterpret_cast<uintptr_t>(dx[i])) % (4 * esz)) == 0;
   if (!v4ok || (dtype != QAVIT_F32 && dtype != QAVIT_BF16)) {          // odd shapes: one launch each through the general entry point
     for (int i = 0; i < n; ++i) {
-      const int rc = qavit_layernorm_bwd(dtype, dy[i], x[i], gamma[i], mean[i], rstd[i], dx[i], dgamma[i], dbeta[i], rows, C, nullptr, 0, nullptr, 0, stream);
+      const int rc = qavit_layernorm_bwd(dtype, dy[i], x[i], gamma[i], mean[i], rstd[i], dx[i], dgamma[i], dbeta[i], rows, C, nullptr, 0, nullptr, 0, nullptr, stream);
       if (rc) return rc;
     }
     return QAVIT_OK;

@@ -326,6 +326,8 @@ class LinearFn(Function):
             x2 = x2.contiguous()
         M = x2.shape[0]
         off, n = opts.get("rows") or (0, w.shape[0])
+        Kfull = w.shape[1] if w.dim() == 2 else w[0].numel()
+        koff = (opts.get("cols") or (0, Kfull))[0]          # cols = (k_off, k_len): y = x @ w[rows, k_off:k_off+k_len]^T (x has k_len columns)
         Wc, Wt = pack_for(x.device).get(w, x.dtype)
         y = torch.empty(M, n, dtype=x.dtype, device=x.device)
         act = 1 if opts.get("act") == "gelu" else 0
@@ -348,22 +350,29 @@ class LinearFn(Function):
         a = dict(a_mode=3 if ln else 0, ln=ln, ln_stats=stats, Z=Z, act=act, drop=drop, dp=dp, R=r2, ldr=n, rng=rt.rng)
         # bias pointer offset: pass a narrow view tensor to keep kernels.gemm_nt simple
         bview = None if b is None else b.detach()[off:off + n]
-        K.gemm_nt(x2, Wc, y, M, n, Kd, Kd, Kd, n, bview, B_ptr=Wc.data_ptr() + off * Kd * esz, **a)
+        K.gemm_nt(x2, Wc, y, M, n, Kd, Kd, Kfull, n, bview, B_ptr=Wc.data_ptr() + (off * Kfull + koff) * esz, **a)
         ctx.opts = dict(opts)
-        ctx.meta = (M, n, Kd, off, act, drop, dp, x.shape, resid is not None)
+        ctx.meta = (M, n, Kd, off, act, drop, dp, x.shape, resid is not None, koff)
         ctx.save_for_backward(x2, w, b, ln_g, ln_b, Z, stats[0] if stats else None, stats[1] if stats else None)
+        if opts.get("alias"):
+            ctx.set_materialize_grads(False)
+            return y.reshape(*x.shape[:-1], n), x.view_as(x)
         return y.reshape(*x.shape[:-1], n)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         x2, w, b, ln_g, ln_b, Z, mean, rstd = ctx.saved_tensors
-        M, n, Kd, off, act, drop, dp, xshape, has_res = ctx.meta
-        dx = _linear_bwd(x2, w, b, dy.reshape(M, n), off, n, ctx.needs_input_grad[0], ln_g, ln_b, Z, mean, rstd, act, drop, dp)
+        M, n, Kd, off, act, drop, dp, xshape, has_res, koff = ctx.meta
+        if dy is None:                                      # only the alias was differentiated through
+            return dalias, None, None, None, None, None, None
+        dx = _linear_bwd(x2, w, b, dy.reshape(M, n), off, n, ctx.needs_input_grad[0], ln_g, ln_b, Z, mean, rstd, act, drop, dp, koff,
+                         dres=dalias)
         dres = dy if has_res else None
         return (dx.reshape(xshape) if (dx is not None and ctx.needs_input_grad[0]) else None), None, None, None, None, dres, None
 
 
-def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, mean=None, rstd=None, act=0, drop=(0.0, 0), dp=(0.0, 0, 1)):
+def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, mean=None, rstd=None, act=0, drop=(0.0, 0), dp=(0.0, 0, 1), koff=0,
+                dres=None, dx_add=None):
     """Backward of y = droppath(dropout(act(LN(x2) @ w[off:off+n]^T + b[off:off+n]))) for row matrices: returns dx (or None) and
     accumulates dW / db into the parameters' .grad (deferred grouped weight-gradient GEMMs).  Shared by LinearFn and BranchFn."""
     M, Kd = x2.shape
@@ -382,38 +391,55 @@ def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, me
         bwd = None
         if need_t:
             bwd = dict(Z=Z, ldz=n, act=act, drop=drop, dp=dp, out=dz if dz is not dy2 else None, ldo=n)
+        # dx_add [M, Kd]: another gradient of the same x, added in this GEMM's residual epilogue (no LayerNorm behind it)
         K.gemm_nt(dy2, Wt, dxn, M, Kd, n, n, Wt.shape[1], Kd, None, a_mode=2 if need_t else 0, bwd=bwd, rng=rt.rng,
-                  B_ptr=Wt.data_ptr() + off * esz)
+                  B_ptr=Wt.data_ptr() + (koff * Wt.shape[1] + off) * esz, R=dx_add if ln_g is None else None, ldr=Kd)
         if ln_g is not None:
             gbuf, _ = grad_sink(ln_g)
             bbuf, _ = grad_sink(ln_b)
             dx = torch.empty_like(dxn)
-            K.layernorm_bwd(dxn, x2, ln_g, mean, rstd, dx, gbuf, bbuf, M, Kd)
+            r2 = None
+            if dres is not None:
+                r2 = dres.reshape(M, Kd)
+                if not K.ln_dres_ok(x2, r2, Kd):
+                    r2 = None
+            K.layernorm_bwd(dxn, x2, ln_g, mean, rstd, dx, gbuf, bbuf, M, Kd, dres=r2)
+            if dres is not None and r2 is None:
+                dx = dx + dres.reshape(M, Kd)
         else:
-            dx = dxn
+            dx = dxn if dres is None else dxn + dres.reshape(M, Kd)
     if need_dw or (b is not None and b.requires_grad):
         wbuf, _ = grad_sink(w)
         bbuf2, _ = grad_sink(b)
         if wbuf is None:   # bias-only gradient: still use the kernel with a scratch C
             wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
         lnarg = (ln_g, ln_b, mean, rstd) if ln_g is not None else None
+        Kfull = w.numel() // w.shape[0]
         DeferDW.arm()
         if SideStream.enabled:
             with SideStream.fork(x2.device, dz, x2, mean, rstd):
-                K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
-                          C_ptr=wbuf.data_ptr() + off * Kd * 4,
+                K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kfull, None, ln=lnarg,
+                          C_ptr=wbuf.data_ptr() + (off * Kfull + koff) * 4,
                           colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
         else:
-            K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kd, None, ln=lnarg,
-                      C_ptr=wbuf.data_ptr() + off * Kd * 4,
+            K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kfull, None, ln=lnarg,
+                      C_ptr=wbuf.data_ptr() + (off * Kfull + koff) * 4,
                       colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
     return dx
 
 
-def linear(x, w, b=None, *, ln=None, act=None, drop=None, dp=None, resid=None, rows=None, eps=1e-5, train=True):
+def linear(x, w, b=None, *, ln=None, act=None, drop=None, dp=None, resid=None, rows=None, cols=None, eps=1e-5, train=True, alias=False):
+    """``rows=(off, n)``: output rows off..off+n of ``w``; ``cols=(k_off, k_len)``: the K-slice w[:, k_off:k_off+k_len] (x has k_len
+    columns) -- with ``resid`` it turns a Linear on a concatenation into accumulating GEMMs, no ``cat`` buffer."""
     ln_g, ln_b = ln if ln is not None else (None, None)
-    opts = dict(act=act, drop=drop, dp=dp, rows=rows, eps=eps, train=train)
-    return LinearFn.apply(x, w, b, ln_g, ln_b, resid, opts)
+    # alias=True (LayerNorm-prologue Linears): -> (y, x_alias); the gradient that arrives on x_alias (x's other consumer) is added
+    # inside the LayerNorm-backward kernel instead of by an elementwise add of autograd's
+    want_alias = bool(alias) and ln is not None and torch.is_grad_enabled() and x.requires_grad
+    opts = dict(act=act, drop=drop, dp=dp, rows=rows, cols=cols, eps=eps, train=train, alias=want_alias)
+    out = LinearFn.apply(x, w, b, ln_g, ln_b, resid, opts)
+    if alias and not want_alias:
+        return out, x
+    return out
 
 
 class LinearStack3Fn(Function):
@@ -429,7 +455,7 @@ class LinearStack3Fn(Function):
         ws = [w1, w2, w3]
         Wc, Wt = pack_for(x.device).get(ws, x.dtype)
         n = Wc.shape[0]
-        bias = torch.cat([b1.detach(), b2.detach(), b3.detach()])
+        bias = pack_for(x.device).get([b1, b2, b3], torch.float32)[0].reshape(-1)       # stacked by the per-step pack launch, not a cat per call
         y = torch.empty(M, n, dtype=x.dtype, device=x.device)
         K.gemm_nt(x2, Wc, y, M, n, Kd, Kd, Kd, n, bias)
         ctx.save_for_backward(x2, w1, b1, w2, b2, w3, b3)
@@ -466,8 +492,12 @@ class LinearStack3Fn(Function):
 # LayerNorm (stand-alone) with optional broadcast add (pos_embed)
 # ---------------------------------------------------------------------------------------------------
 class LayerNormFn(Function):
+    """``alias=True``: also returns a second handle on ``x`` for the residual connection around the normalised branch; the
+    gradient arriving on it is ADDED inside the LayerNorm-backward kernel (qavit_layernorm_bwd dres) instead of by an
+    elementwise add of autograd's."""
+
     @staticmethod
-    def forward(ctx, x, g, b, add, eps, act=False):
+    def forward(ctx, x, g, b, add, eps, act=False, alias=False):
         Cc = x.shape[-1]
         x2 = x.reshape(-1, Cc)
         if not x2.is_contiguous():
@@ -481,12 +511,18 @@ class LayerNormFn(Function):
         ctx.save_for_backward(x2, g, b, add, mean, rstd)
         ctx.xshape = x.shape
         ctx.act = bool(act)
+        ctx.alias = bool(alias)
+        if alias:
+            ctx.set_materialize_grads(False)
+            return y.reshape(x.shape), x.view_as(x)
         return y.reshape(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         x2, g, b, add, mean, rstd = ctx.saved_tensors
         rows, Cc = x2.shape
+        if dy is None:                                      # only the alias was differentiated through
+            return dalias, None, None, None, None, None, None
         dy2 = dy.reshape(rows, Cc)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -494,14 +530,26 @@ class LayerNormFn(Function):
         bbuf, _ = grad_sink(b)
         abuf, _ = grad_sink(add)
         dx = torch.empty_like(x2)
+        dres = None
+        if dalias is not None:
+            dres = dalias.reshape(rows, Cc)
+            if not K.ln_dres_ok(x2, dres, Cc, abuf):
+                dres = None
         K.layernorm_bwd(dy2, x2, g, mean, rstd, dx, gbuf, bbuf, rows, Cc, abuf, 0 if add is None else add.numel() // Cc,
-                        beta=b.detach() if ctx.act else None, act=ctx.act)
-        return dx.reshape(ctx.xshape), None, None, None, None, None
+                        beta=b.detach() if ctx.act else None, act=ctx.act, dres=dres)
+        dx = dx.reshape(ctx.xshape)
+        if dalias is not None and dres is None:
+            dx = dx + dalias
+        return dx, None, None, None, None, None, None
 
 
-def layer_norm(x, g, b, eps=1e-5, add=None, act=None):
-    """LayerNorm (+ pos_embed-style broadcast add); ``act="gelu"`` fuses the exact GELU that follows it."""
-    return LayerNormFn.apply(x, g, b, add, eps, act == "gelu")
+def layer_norm(x, g, b, eps=1e-5, add=None, act=None, alias=False):
+    """LayerNorm (+ pos_embed-style broadcast add); ``act="gelu"`` fuses the exact GELU that follows it.  ``alias=True`` -> (y,
+    x_alias): use ``x_alias`` for the residual connection (see LayerNormFn)."""
+    if alias and torch.is_grad_enabled() and x.requires_grad:
+        return LayerNormFn.apply(x, g, b, add, eps, act == "gelu", True)
+    y = LayerNormFn.apply(x, g, b, add, eps, act == "gelu")
+    return (y, x) if alias else y
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -612,13 +660,12 @@ class BranchFn(Function):
                 spec = dict(mode=0, G=B, Nq=T, L=Lk, H=H, D=D, KC=E_k.shape[1], S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=NP,
                             q_off=0, k_off=0, v_off=Cc, q_rows=B * T, drop=m["attn_drop"])
                 dq_t, dkv_t, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(q, kv, E_k, E_v, sk_s, sv_s, sh_k_in, sh_v_in, spec, d_o)
-                dxq = _linear_bwd(x2, wqkv, bqkv, dq_t, 0, Cc, ctx.needs_input_grad[0])
                 dpool = _linear_bwd(p2, wqkv, bqkv, dkv_t, Cc, 2 * Cc, ctx.needs_input_grad[0])
-                dx = None
+                dxp = None
                 if ctx.needs_input_grad[0]:
-                    dxp = torch.empty(B, T, Cc, dtype=x.dtype, device=x.device)
+                    dxp = torch.empty(B * T, Cc, dtype=x.dtype, device=x.device)
                     K.gather_pool_bwd(dpool.reshape(B, NP, Cc).contiguous(), idx, dxp, B, T, NP, stride, Cc)
-                    dx = dxq.reshape(B, T, Cc) + dxp
+                dx = _linear_bwd(x2, wqkv, bqkv, dq_t, 0, Cc, ctx.needs_input_grad[0], dx_add=dxp)     # dq Wq + (landmark-path gradient)
             else:
                 q = linear(x2, wqkv, bqkv)
                 spec = dict(mode=1, G=B, Nq=T, L=0, H=H, D=D, S=S, q_off=0, k_off=0, v_off=0, q_rows=B * T, drop=m["attn_drop"])
@@ -1311,6 +1358,32 @@ class BatchNormFn(Function):
         else:
             K.bn_bwd(dy, x, M, Cc, weight, bias, save_mean, save_rstd, act, training, dx, gbuf, bbuf, ws)
         return dx, _ret(gret, weight), _ret(bret, bias), None, None, None, None, None, None
+
+
+class CrossEntropyFn(Function):
+    """nn.CrossEntropyLoss(label_smoothing) -- optionally the MixUp / CutMix pair loss lam * CE(y_a) + (1 - lam) * CE(y_b) with a
+    device-resident lam -- as one kernel that also leaves the logit gradient (csrc/loss.hip); backward scales it by the incoming
+    gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, y_a, y_b, lam, ls):
+        K._require_cuda(logits)
+        lg = logits.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        need = logits.requires_grad
+        d = torch.empty_like(lg) if need else None
+        K.ce_label_smooth(lg, y_a, y_b, lam, ls, loss, d)
+        ctx.save_for_backward(d)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return (d * g.to(d.dtype)) if d is not None else None, None, None, None, None
+
+
+def cross_entropy(logits, y, label_smoothing=0.0, y_b=None, lam=None):
+    return CrossEntropyFn.apply(logits, y, y_b, lam, float(label_smoothing))
 
 
 def dropout(x, p, site, training):

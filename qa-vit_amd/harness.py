@@ -346,12 +346,9 @@ class Trainer:
             self.reducer.begin_step()
         if self.cfg.device_mix:
             x, y_b, lam = self._mix(x, y)
-            logits = self.model(x).float()
-            ls = self.cfg.label_smoothing
-            loss = lam * TF.cross_entropy(logits, y, label_smoothing=ls) + (1.0 - lam) * TF.cross_entropy(logits, y_b, label_smoothing=ls)
+            loss = F.cross_entropy(self.model(x), y, self.cfg.label_smoothing, y_b=y_b, lam=lam.reshape(1).float())
         else:
-            logits = self.model(x)
-            loss = TF.cross_entropy(logits.float(), y, label_smoothing=self.cfg.label_smoothing)
+            loss = F.cross_entropy(self.model(x), y, self.cfg.label_smoothing)
         loss.backward()
         F.SideStream.join(self.device)                     # weight-gradient GEMMs ran on the side stream
         if self.reducer is not None:

@@ -199,10 +199,17 @@ def layernorm_bwd_multi(dys, xs, gammas, means, rstds, dxs, dgammas, dbetas, row
             "layernorm_bwd_multi")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0, beta=None, act=0):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0, beta=None, act=0, dres=None):
     L.check(L.load().qavit_layernorm_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, Cc, _p(dadd), add_rows,
-                                         _p(beta), int(act), stream()), "layernorm_bwd")
+                                         _p(beta), int(act), _p(dres), stream()), "layernorm_bwd")
+
+
+def ln_dres_ok(x, dres, Cc, dadd=None) -> bool:
+    """Can qavit_layernorm_bwd add ``dres`` in its own pass?  (vector path: C % 4 == 0, aligned, same dtype / shape, no dadd)"""
+    vec = 4 * x.element_size()
+    return (dres is not None and dadd is None and Cc % 4 == 0 and Cc <= 1024 and dres.dtype == x.dtype and dres.numel() == x.numel()
+            and dres.is_contiguous() and dres.data_ptr() % vec == 0 and x.data_ptr() % vec == 0)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -456,6 +463,12 @@ def copy2(a, b):
     out = torch.empty(2, n, dtype=torch.float32, device=a.device)
     L.check(L.load().qavit_copy2(a.data_ptr(), b.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), n, stream()), "copy2")
     return out[0].view(a.shape), out[1].view(b.shape)
+
+
+def ce_label_smooth(logits, y_a, y_b, lam_dev, ls, loss, dlogits):
+    B, Cc = logits.shape
+    L.check(L.load().qavit_ce_label_smooth(dt_code(logits.dtype), logits.data_ptr(), y_a.data_ptr(), _p(y_b), _p(lam_dev), float(ls), B, Cc,
+                                           loss.data_ptr(), _p(dlogits), stream()), "ce_label_smooth")
 
 
 def l2norm(g, partial, out):

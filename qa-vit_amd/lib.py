@@ -80,7 +80,7 @@ _SIGS = {
     "qavit_row_stats": (i32, [i32, vp, f32, i32, i32, vp, vp, vp]),
     "qavit_row_stats_multi": (i32, [i32, i32, vp, f32, i32, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_multi": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
-    "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp]),
+    "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]),
     "qavit_attn_fwd": (i32, [C.POINTER(AttnArgs), vp]),
     "qavit_attn_bwd": (i32, [C.POINTER(AttnArgs), vp]),
     "qavit_attn_ws_floats": (i64, [C.POINTER(AttnArgs)]),
@@ -127,6 +127,7 @@ _SIGS = {
     "qavit_rng_advance": (i32, [vp, vp]),
     "qavit_adamw": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, f32, vp]),
     "qavit_l2norm": (i32, [vp, i64, vp, vp, vp]),
+    "qavit_ce_label_smooth": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp]),
     "qavit_local_clip": (i32, [vp, vp, i32, f32, vp, vp]),
     "qavit_copy2": (i32, [vp, vp, vp, vp, i64, vp]),
 }

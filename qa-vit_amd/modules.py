@@ -305,17 +305,18 @@ class CCFFFN(nn.Module):
         self._site = K.new_site()
 
     def branch(self, x, pre_norm: nn.LayerNorm):
-        """-> u = dropout(fc2(mid(gelu(fc1(LN(x)))))) ; the caller applies gamma, drop-path and the residual."""
+        """-> (u, x_alias): u = dropout(fc2(mid(gelu(fc1(LN(x)))))); the caller applies gamma, drop-path and the residual, for
+        which it uses ``x_alias`` (its gradient joins the LayerNorm's in one kernel)."""
         B, N, C = x.shape
         Hs = _hw(N)
         rt = self._rt
-        h = F.linear(x, self.fc1.weight, self.fc1.bias, ln=(pre_norm.weight, pre_norm.bias), eps=pre_norm.eps, act="gelu")
+        h, xa = F.linear(x, self.fc1.weight, self.fc1.bias, ln=(pre_norm.weight, pre_norm.bias), eps=pre_norm.eps, act="gelu", alias=True)
         n1 = (self.dwconv_norm.weight, self.dwconv_norm.bias) if rt.ccf_norm else (None, None)
         n2 = (self.post_dwconv_norm.weight, self.post_dwconv_norm.bias) if rt.ccf_norm else (None, None)
         mid = F.ccf_mid(h, n1[0], n1[1], n2[0], n2[1], self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
                                self.dwconv.scale if rt.dw_scale else None, Hs, Hs, 1e-5)
         p = self.dropout.p if self.training else 0.0
-        return F.linear(mid, self.fc2.weight, self.fc2.bias, drop=(p, self._site))
+        return F.linear(mid, self.fc2.weight, self.fc2.bias, drop=(p, self._site)), xa
 
 
 class DropPath(nn.Module):
@@ -353,7 +354,8 @@ class QuadAttentionBlock(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         tr = self.training
-        xn = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # xr = x again, for the residual: its gradient joins norm1's inside the LayerNorm-backward kernel
+        xn, xr = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, alias=True)
         # norm1's output feeds four branches (MSDA twice): one k-way gradient sum instead of autograd's pairwise adds
         xns = F.FanOutFn.apply(xn, 5) if (torch.is_grad_enabled() and xn.requires_grad) else (xn,) * 5
         args = []
@@ -366,10 +368,10 @@ class QuadAttentionBlock(nn.Module):
         p = mlp.dropout.p if tr else 0.0
         dp = (self._dp if tr else 0.0)
         h = F.linear(fused, mlp.fc1.weight, mlp.fc1.bias, act="gelu", drop=(p, mlp._s1))
-        x = F.linear(h, mlp.fc2.weight, mlp.fc2.bias, drop=(p, mlp._s2), dp=(dp, self._dp1, N), resid=x)
-        u = self.ccf_ffn.branch(x, self.norm2)
+        x = F.linear(h, mlp.fc2.weight, mlp.fc2.bias, drop=(p, mlp._s2), dp=(dp, self._dp1, N), resid=xr)
+        u, xr2 = self.ccf_ffn.branch(x, self.norm2)
         gamma = self.ccf_ffn.gamma if self._rt.ccf_norm else None
-        return F.ScaleAddFn.apply(x, u, gamma, (dp, self._dp2, N))
+        return F.ScaleAddFn.apply(xr2, u, gamma, (dp, self._dp2, N))
 
 
 class TokenLearner(nn.Module):
@@ -382,8 +384,8 @@ class TokenLearner(nn.Module):
 
     def forward(self, x):
         ln, fc = self.attention[0], self.attention[1]
-        scores = F.linear(x, fc.weight, fc.bias, ln=(ln.weight, ln.bias), eps=ln.eps)
-        return F.TokMixFn.apply(scores, x)
+        scores, xa = F.linear(x, fc.weight, fc.bias, ln=(ln.weight, ln.bias), eps=ln.eps, alias=True)
+        return F.TokMixFn.apply(scores, xa)
 
 
 class TokenUpMix(nn.Module):
@@ -667,6 +669,7 @@ class SplitFusion(nn.Module):
         else:
             self.register_buffer("fusion_weights", torch.tensor([0.75, 0.25]))
         self.final_norm = nn.LayerNorm(embed_dim)
+        self._site = K.new_site()
 
     def forward(self, T, R):
         gn, gf = self.gate_norm, self.gate_fc
@@ -680,9 +683,13 @@ class SplitFusion(nn.Module):
         else:
             t_add = T1 + torch.sigmoid(gl) * R1
         c0, c1 = self.cat_mlp[0], self.cat_mlp[1]
-        h = F.linear(torch.cat([T2, R2], -1), c0.weight, c0.bias)
+        # Linear(2C -> C) on cat([T, R]) = T W[:, :C]^T + R W[:, C:]^T + b: two accumulating GEMMs, no 2C-wide cat buffer (and no
+        # slice copies of its gradient)
+        Cc = T2.shape[-1]
+        h = F.linear(T2, c0.weight, c0.bias, cols=(0, Cc))
+        h = F.linear(R2, c0.weight, None, cols=(Cc, Cc), resid=h)
         h = F.layer_norm(h, c1.weight, c1.bias, c1.eps, act="gelu")
-        h = TF.dropout(h, self.cat_mlp[3].p, self.training)
+        h = F.dropout(h, self.cat_mlp[3].p, self._site, self.training)
         fn = self.final_norm
         if isinstance(self.fusion_weights, nn.Parameter) and self.fusion_weights.numel() == 2 and (t_add.numel() * t_add.element_size()) % 16 == 0:
             mixed = F.Mix2Fn.apply(t_add, T3 + h, self.fusion_weights)

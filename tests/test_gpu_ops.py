@@ -838,3 +838,25 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
             o2 = F.AttnFn.apply(q, None, None, None, bk.reshape(S, C), bv.reshape(S, C), spec)
         out2 = F.linear(o2.reshape(B, T, C), wproj, bproj)
         assert rel(out, out2) <= 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C", [(4, 100), (37, 10), (1024, 100), (1500, 200)])
+def test_cross_entropy_label_smoothing(F, dtype, B, C):
+    """One-kernel CE (loss + gradient) against torch's nn.CrossEntropyLoss(label_smoothing), plain and as the MixUp pair loss."""
+    lg = leaf(B, C, seed=400).detach().to(dtype).requires_grad_(True)
+    g = torch.Generator().manual_seed(5)
+    ya, yb = torch.randint(0, C, (B,), generator=g).to(DEV), torch.randint(0, C, (B,), generator=g).to(DEV)
+    lam = torch.tensor([0.37], device=DEV)
+    for ls in (0.0, 0.12):
+        for mixed in (False, True):
+            lg.grad = None
+            loss = F.cross_entropy(lg, ya, ls, y_b=yb if mixed else None, lam=lam if mixed else None)
+            (loss * 3.0).backward()
+            r = lg.detach().float().clone().requires_grad_(True)
+            ref = TF.cross_entropy(r, ya, label_smoothing=ls)
+            if mixed:
+                ref = 0.37 * ref + 0.63 * TF.cross_entropy(r, yb, label_smoothing=ls)
+            (ref * 3.0).backward()
+            assert abs(float(loss) - float(ref)) <= 2e-5 * abs(float(ref)), (ls, mixed)
+            assert rel(lg.grad, r.grad) <= (1e-5 if dtype == torch.float32 else 1e-2), (ls, mixed)
