@@ -5,8 +5,8 @@
 
 A "step" is one full training step of HQAViT(HQAViTConfig()) on a synthetic 32x32x3 batch of 1024 images per
 GPU (BASELINE.json configs[2]/[3]): weight re-pack, forward, loss, backward, gradient all-reduce (N > 1),
-clipping and fused AdamW -- nothing is skipped inside the timed region.  bf16 activations, fp32 accumulate
-and master weights; reference-default dropout / drop-path.  Inputs are resident in HBM before timing starts.
+clipping, fused AdamW and the EMA update -- nothing is skipped inside the timed region.  bf16 activations, fp32 accumulate
+and master weights; reference-default dropout (the proj / MLP dropouts AND the dropout_p the reference hands to SDPA) and drop-path.  Inputs are resident in HBM before timing starts.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     : the dominant kernel family of the step, timed per launch with HIP events on the launch stream
@@ -25,7 +25,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFLOP_PER_IMG_TRAIN = 1293.0       # fwd+bwd algorithmic work, HQA-ViT CIFAR-100
+MFLOP_PER_IMG_TRAIN = 1293.0       # fwd+bwd work AS THE REFERENCE COMPUTES IT, HQA-ViT CIFAR-100
+# Work the path actually NEEDS (utilisation must not be inflated by work that is skipped).  Per block and image the
+# reference computes and discards: 2/3 of MSDA's qkv(x) (2.36 MFLOP), 118 all-zero rows of the 128-row Linformer product (2.90),
+# cross-attention's k/v projections of the batch-invariant bank once per image (2.36) = 7.62 MFLOP x 8 blocks = 61 forward,
+# x3 for forward + backward = 183; and the train-mode bank write applies Linear(192,192) to every token where only the 16 mean rows
+# need it (35.4 -> 7.1 over the 24 writes: 28.3).  1293 - 183 - 28 = 1082.
+NEEDED_MFLOP_PER_IMG_TRAIN = 1082.0
+# needed forward work of one fused attention branch per image (SURVEY.md 8d per-block table): qkv + Linformer + SDPA + proj
+BRANCH_MFLOP_PER_IMG = {0: 3.54 + 0.39 + 0.59 + 1.18, 1: 1.18 + 2.21 + 0.25 + 0.59 + 1.18, 2: 1.18 + 0.20 + 1.18}
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
@@ -105,6 +113,10 @@ class KernelTimer:
             fl = 4.0 * g.G * g.H * g.Nq * nk * g.D + (4.0 * g.G * g.H * g.KC * g.L * g.D if g.mode == 0 else 0.0)
             by = (g.G * g.Nq + 2 * g.G * g.L) * g.H * g.D * e + g.G * g.Nq * g.H * g.D * e
             return (fl, float(by)) if name == "qavit_attn_fwd" else (2.5 * fl, 2.5 * by)
+        if name == "qavit_branch_fwd":
+            g = self._obj(a[0])
+            by = g.B * g.T * g.C * 2 * (3 if g.o_save else 2) + (4 if g.kind != 2 else 2) * g.C * g.C * 2
+            return BRANCH_MFLOP_PER_IMG[g.kind] * 1e6 * g.B, float(by)
         if name in ("qavit_layernorm_fwd", "qavit_layernorm_bwd", "qavit_row_stats"):
             e = esz[a[0]]
             if name == "qavit_layernorm_fwd": rows, Cc, k = a[6], a[7], 2
@@ -246,15 +258,17 @@ def main():
 
     with_optim = not args.fwd_bwd_only
     mode = "eager"
+    capture_error = None
     run = (lambda: tr.step(x, y)) if with_optim else (lambda: tr.fwd_bwd(x, y))
     if not args.no_graph:
         try:
             tr.capture(x, y, with_optim=with_optim, warmup=3)
             run = lambda: tr.replay()           # noqa: E731
             mode = "hipgraph"
-        except Exception as e:                  # collectives / allocator that cannot be captured: stay eager
+        except Exception as e:                  # collectives / allocator that cannot be captured: stay eager, and SAY SO in the JSON line
+            capture_error = f"{type(e).__name__}: {e}"
             if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+                print(f"[bench] graph capture failed ({capture_error}); running eager", file=sys.stderr)
             torch.cuda.synchronize()
             tr.graph = None
 
@@ -293,8 +307,14 @@ def main():
                    "launch": mode, "dropout": cfg.dropout, "drop_path": cfg.drop_path, "final_loss": round(loss_val, 4)},
     }
     step_tflops = value * (MFLOP_PER_IMG_TRAIN if args.config == "c100" else 6490.0) * 1e6 / 1e12     # 1,293 / 6,490 MFLOP per image
-    out["config"]["algorithmic_tflops_per_s"] = round(step_tflops, 2)
+    out["config"]["algorithmic_tflops_per_s"] = round(step_tflops, 2)                     # the reference's own operation count
     out["config"]["algorithmic_mfma_frac"] = round(step_tflops / (PEAK_BF16_TFLOPS * world), 5)
+    if args.config == "c100":
+        need = value * NEEDED_MFLOP_PER_IMG_TRAIN * 1e6 / 1e12                             # what the path needs (skipped work not counted)
+        out["config"]["needed_tflops_per_s"] = round(need, 2)
+        out["config"]["needed_mfma_frac"] = round(need / (PEAK_BF16_TFLOPS * world), 5)
+    if capture_error is not None:
+        out["config"]["graph_capture_error"] = capture_error
 
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         # one instrumented eager step of the same workload: per-call HIP-event timing of every C-ABI entry point
@@ -322,6 +342,15 @@ def main():
                     traffic = traffic.get("hbm_bytes_per_kernel")
             except Exception:
                 traffic = None
+        # MFMA utilisation from hardware counters (rocprofv3 --pmc pass folded by tools/pmc_mfma.py into profiles/mfma_util.json)
+        mfma_util = None
+        mp = os.path.join(ROOT, "profiles", "mfma_util.json")
+        if os.path.exists(mp):
+            try:
+                mj = json.load(open(mp))
+                mfma_util = {k: v["mfma_util_pct"] for k, v in mj.items() if isinstance(v, dict) and "mfma_util_pct" in v}
+            except Exception:
+                mfma_util = None
         ach, peak, unit = (tfl, peak_fl, "TFLOP/s") if mfma_bound else (gbs, PEAK_HBM_GBS, "GB/s")
         out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name, "achieved": round(ach, 3), "peak": peak,
                            "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic,
@@ -329,6 +358,7 @@ def main():
                            "flops_per_launch": round(d["flops"] / d["launches"]), "bytes_per_launch": round(d["bytes"] / d["launches"]),
                            "tflops": round(tfl, 2), "gbytes_per_s": round(gbs, 1), "event_bracket_overhead_us": round(kt.empty_ms * 1e3, 2),
                            "device_ms_per_step_all_entry_points": round(sum(v["ms"] for v in fam.values()), 3),
+                           "mfma_util_pct_by_family_pmc": mfma_util,
                            "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                             "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                                             "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}

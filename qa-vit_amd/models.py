@@ -64,7 +64,7 @@ class _Base(nn.Module):
         return F.linear(F.TokenMeanFn.apply(T), self.head.weight, self.head.bias)
 
 
-_LATERAL_STREAM = os.environ.get("QAVIT_LATERAL_STREAM", "0") != "0"
+_LATERAL_STREAM = os.environ.get("QAVIT_LATERAL_STREAM", "1") != "0"
 _SIDE = {}
 
 
