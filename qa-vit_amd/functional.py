@@ -249,11 +249,14 @@ class DeferDW:
 
     @classmethod
     def flush(cls):
+        """Launch what is queued and wait for it (data-parallel sync points: the bucket about to be reduced must be complete)."""
         K.DeferredTN.flush()
+        K.DeferredTN.join()
 
     @classmethod
     def finish(cls):
         K.DeferredTN.flush()
+        K.DeferredTN.join()
         K.DeferredTN.enabled = False
         cls._armed = False
 

@@ -140,7 +140,14 @@ class DeferredTN:
     enabled = False
     home_stream = None  # raw stream handle of the backward pass that armed the queue; other streams launch at once
     queue = []          # (GemmTnArgs, keepalive tuple)
-    MAX = int(os.environ.get("QAVIT_DW_QUEUE", "96"))
+    # ASYNC (opt-in, QAVIT_DW_ASYNC=1): the grouped launches go to a stream of their own, forked off the backward stream every MAX
+    # problems and joined when backward ends (or at a data-parallel sync point) -- a graph branch under hipGraph capture.  Measured
+    # SLOWER on MI355X (B = 1024 step: 16.3 ms grouped at the end of backward, 17.2-17.5 ms with the weight gradients beside the dX
+    # chain): these are chip-filling, atomic-bound kernels, and what they take from the latency-bound chain exceeds what they hide.
+    ASYNC = os.environ.get("QAVIT_DW_ASYNC", "0") != "0"
+    MAX = int(os.environ.get("QAVIT_DW_QUEUE", "24" if ASYNC else "96"))
+    _side = {}
+    _dirty = set()
 
     @classmethod
     def flush(cls):
@@ -148,7 +155,34 @@ class DeferredTN:
             return
         q, cls.queue = cls.queue, []
         arr = (L.GemmTnArgs * len(q))(*[a for a, _ in q])
-        L.check(L.load().qavit_gemm_tn_grouped(arr, len(q), stream()), "gemm_tn_grouped")
+        if not cls.ASYNC:
+            L.check(L.load().qavit_gemm_tn_grouped(arr, len(q), stream()), "gemm_tn_grouped")
+            return
+        dev = torch.cuda.current_device()
+        side = cls._side.get(dev)
+        if side is None:
+            side = cls._side[dev] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)                              # every operand queued so far has been produced
+        with torch.cuda.stream(side):
+            L.check(L.load().qavit_gemm_tn_grouped(arr, len(q), stream()), "gemm_tn_grouped")
+        for _, keep in q:                                   # the caching allocator must not hand these blocks out before the side stream is done
+            for t in keep:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(side)
+                elif isinstance(t, tuple):
+                    for u in t:
+                        if isinstance(u, torch.Tensor):
+                            u.record_stream(side)
+        cls._dirty.add(dev)
+
+    @classmethod
+    def join(cls):
+        """The current stream waits for the weight-gradient stream (before anything reads .grad)."""
+        dev = torch.cuda.current_device()
+        if dev in cls._dirty:
+            torch.cuda.current_stream(dev).wait_stream(cls._side[dev])
+            cls._dirty.discard(dev)
 
 
 def gemm_tn(A, Bm, Cgrad, M, N, K, lda, ldb, ldc, colsum=None, ln=None, A_ptr=None, B_ptr=None, C_ptr=None, colsum_ptr=None):
