@@ -71,7 +71,10 @@ __host__ __device__ inline int64_t attn_ws_per_wave(const qavit_attn_args& a) {
 
 static inline int attn_grid(const qavit_attn_args& a, bool bwd) {
   const int64_t problems = (int64_t)a.G * a.H;
-  static const int bwd_cap = getenv("QAVIT_ATTN_BWD_CAP") ? atoi(getenv("QAVIT_ATTN_BWD_CAP")) : 2048;
+  // 1792 = 7 waves per CU x 256 CUs: the small-problem backward (attn3, 22 KB of LDS per wave) has exactly 7 resident waves per CU,
+  // so every workgroup of the launch is resident at once.  At 2048 the last 256 start when the first finish and the launch takes
+  // two "rounds" of 2 problems each instead of one round of 2-3 (measured: 1.54 -> 1.32 ms of attention backward per step).
+  static const int bwd_cap = getenv("QAVIT_ATTN_BWD_CAP") ? atoi(getenv("QAVIT_ATTN_BWD_CAP")) : 1792;
   static const int fwd_cap = getenv("QAVIT_ATTN_FWD_CAP") ? atoi(getenv("QAVIT_ATTN_FWD_CAP")) : 2048;
   int64_t cap = bwd ? bwd_cap : fwd_cap;          // bwd: bounded so the partial-sum workspace stays small
   int64_t g = problems < cap ? problems : cap;
