@@ -860,3 +860,14 @@ def test_cross_entropy_label_smoothing(F, dtype, B, C):
             (ref * 3.0).backward()
             assert abs(float(loss) - float(ref)) <= 2e-5 * abs(float(ref)), (ls, mixed)
             assert rel(lg.grad, r.grad) <= (1e-5 if dtype == torch.float32 else 1e-2), (ls, mixed)
+
+
+def test_integration_example_runs(Q):
+    """INTEGRATION.md's ctypes listing (tools/integration_example.py) runs as written and matches SDPA."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "integration_example.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max-rel error" in r.stdout
