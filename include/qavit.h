@@ -207,7 +207,8 @@ int qavit_nan_guard(int dtype, void* x, int64_t n, int* flag, void* stream);
  * forward through this kernel and a backward through the unfused chain see the same masks.
  * nan_flag (int[2], zero at rest): the reference's NaN -> zeros rule; when set the call rewrites `out` as
  * dropout(bias) rows (= proj of an all-zero attention output) and clears the flag.
- * o_save (optional, leading dimension ldo): the attention output O [B*T, C], operand of backward's dW_proj.
+ * o_save (optional, leading dimension ldo): the attention output O [B*T, C], operand of backward's dW_proj; q_save / kv_save /
+ * pooled_save: see the struct.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct qavit_branch_args {
   int dtype; int kind;
@@ -223,6 +224,10 @@ typedef struct qavit_branch_args {
   float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
   int* nan_flag;
   int reserved;   /* must be 0 */
+  /* optional saves for the backward pass (q_save == NULL: none): q rows [B*T, ldq_save] at column 0; k at column 0 and v at
+   * column C of kv_save [B*rows, ldkv_save], rows = T per image (SWA; kv_save = q_save + C elements gives the usual [B*T, 3C]
+   * qkv matrix) or L landmark rows per image (MSDA); pooled_save [B*L, C] = MSDA's pooled landmarks.  kind 2 saves q only. */
+  void* q_save; int64_t ldq_save; void* kv_save; int64_t ldkv_save; void* pooled_save;
 } qavit_branch_args;
 
 int qavit_branch_supported(int kind, int T, int C, int H, int D, int KC, int S, int L);   /* 1 if qavit_branch_fwd covers the shape */

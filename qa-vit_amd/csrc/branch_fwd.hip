@@ -89,8 +89,11 @@ __device__ __forceinline__ void ring_wait(int newer) {     // called with unroll
   __builtin_amdgcn_s_barrier();
 }
 
-// KIND 0 = SWA, 1 = MSDA, 2 = cross
-template <int KIND>
+// KIND 0 = SWA, 1 = MSDA, 2 = cross.  SAVE: also write q / k / v (and MSDA's pooled landmarks) for the backward pass.  k and v leave
+// the plain GEMM in operand layout (4 tokens of one column per lane -- 2-byte scattered stores); with SAVE the same weight and
+// token fragments run a second, transposed MFMA whose accumulator quads are 8-byte row segments: +72 MFMAs per wave (no extra
+// LDS reads) instead of a recompute GEMM launch per branch in backward.
+template <int KIND, bool SAVE>
 __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   constexpr bool MODE0 = (KIND != 2);                      // Linformer + bank keys (SWA / MSDA) vs bank-projection keys only (cross)
@@ -240,8 +243,12 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   const int h = wave & 3;                                  // this wave's head and its two images in the QKV / attention phase
   const int i0 = NIW * (wave >> 2);
   int imgs[NIW];
+  bool vimg[NIW];
 #pragma unroll
-  for (int i = 0; i < NIW; ++i) { const int ir = tile * NI + i0 + i; imgs[i] = ir < a.B ? ir : a.B - 1; }
+  for (int i = 0; i < NIW; ++i) { const int ir = tile * NI + i0 + i; vimg[i] = ir < a.B; imgs[i] = vimg[i] ? ir : a.B - 1; }
+  bf16* qsv = reinterpret_cast<bf16*>(a.q_save);
+  bf16* kvsv = reinterpret_cast<bf16*>(a.kv_save);
+  const int kv_rows = (KIND == 1) ? a.L : BT;              // key-token rows per image in kv_save
   const bf16* sxw = sx_all + i0 * (16 * LDO) + col * LDO + 8 * q4;       // this lane's fragment base in its images' token tiles
   const bf16* spw = sp_all + i0 * (16 * LDO) + col * LDO + 8 * q4;       // ... and landmark tiles (MSDA; else the token tiles)
 
@@ -277,18 +284,25 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
     for (int i = 0; i < NIW; ++i)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) qf[i][t] = cvt4(acc[i][t]);
+      for (int t = 0; t < DT; ++t) {
+        qf[i][t] = cvt4(acc[i][t]);
+        if (SAVE && vimg[i]) *reinterpret_cast<bf16x4*>(qsv + ((size_t)imgs[i] * BT + col) * a.ldq_save + h * BD + t * 16 + 4 * q4) = qf[i][t];
+      }
   }
   STAMP(4);
   bf16x4 kff[NIW][KT0 > 0 ? KT0 : 1][DT];
   if (MODE0) {
     // ---- k: plain GEMM (acc quad = 4 consecutive tokens of column d = 16 t + col), then Kf^T = k^T E_k ----
-    f32x4 acc[NIW][DT];
+    f32x4 acc[NIW][DT], accT[SAVE ? NIW : 1][DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const float b = sbias[BC + h * BD + t * 16 + col];
 #pragma unroll
       for (int i = 0; i < NIW; ++i) acc[i][t] = f32x4{b, b, b, b};
+      if (SAVE) {
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + BC + h * BD + t * 16 + 4 * q4);
+      }
     }
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
@@ -302,7 +316,18 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
+        for (int i = 0; i < NIW; ++i) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
+          if (SAVE) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
+        }
+    }
+    if (SAVE) {                                            // k rows for backward: token = col (MSDA: landmark rows < L), 8-byte segments
+#pragma unroll
+      for (int i = 0; i < NIW; ++i)
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          if (vimg[i] && col < kv_rows)
+            *reinterpret_cast<bf16x4*>(kvsv + ((size_t)imgs[i] * kv_rows + col) * a.ldkv_save + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
     }
 #pragma unroll
     for (int i = 0; i < NIW; ++i)
@@ -368,12 +393,16 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   bf16x4 vff[NIW][KT0 > 0 ? KT0 : 1][DT];
   if (MODE0) {
     // ---- v: plain GEMM, then Vf = E_v^T v (acc quad = 4 consecutive keys of column d) ----
-    f32x4 acc[NIW][DT];
+    f32x4 acc[NIW][DT], accT[SAVE ? NIW : 1][DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const float b = sbias[2 * BC + h * BD + t * 16 + col];
 #pragma unroll
       for (int i = 0; i < NIW; ++i) acc[i][t] = f32x4{b, b, b, b};
+      if (SAVE) {
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + 2 * BC + h * BD + t * 16 + 4 * q4);
+      }
     }
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
@@ -387,7 +416,18 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
+        for (int i = 0; i < NIW; ++i) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
+          if (SAVE) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
+        }
+    }
+    if (SAVE) {                                            // v rows: the column block after k's in kv_save
+#pragma unroll
+      for (int i = 0; i < NIW; ++i)
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+          if (vimg[i] && col < kv_rows)
+            *reinterpret_cast<bf16x4*>(kvsv + ((size_t)imgs[i] * kv_rows + col) * a.ldkv_save + BC + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
     }
 #pragma unroll
     for (int i = 0; i < NIW; ++i)
@@ -469,6 +509,9 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
       for (int it = 0; it < 3; ++it) {
         const int p = lane + 64 * it, row = p / 12, c8 = 12 * half + p % 12;
         *reinterpret_cast<bf16x8*>(og + ((size_t)img * BT + row) * a.ldo + 8 * c8) = *reinterpret_cast<const bf16x8*>(sout + row * LDO + 8 * c8);
+        if (SAVE && KIND == 1 && a.pooled_save && row < a.L)      // the landmark rows (operand of backward's dW_kv), from their LDS tile
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.pooled_save) + ((size_t)img * a.L + row) * BC + 8 * c8) =
+              *reinterpret_cast<const bf16x8*>(sp_all + pi * (16 * LDO) + row * LDO + 8 * c8);
       }
     }
   }
@@ -514,6 +557,12 @@ int branch_validate(const qavit_branch_args* a) {
   if (a->kind != 2 && (a->KC != 32 || a->L <= 0 || a->L > 16 || !a->E_k || !a->E_v))
     return set_error(QAVIT_EINVAL, "branch: SWA / MSDA need Linformer matrices with KC = 32 and 1 <= L <= 16");
   if (a->kind == 1 && (!a->pool_idx || a->pool_stride <= 0)) return set_error(QAVIT_EINVAL, "branch: MSDA needs the landmark index table");
+  if (a->q_save) {
+    if ((reinterpret_cast<uintptr_t>(a->q_save) & 7) || a->ldq_save % 4) return set_error(QAVIT_EINVAL, "branch: q_save needs 8-byte alignment and ld % 4 == 0");
+    if (a->kind != 2 && (!a->kv_save || (reinterpret_cast<uintptr_t>(a->kv_save) & 7) || a->ldkv_save % 4))
+      return set_error(QAVIT_EINVAL, "branch: kv_save (with q_save) needs 8-byte alignment and ld % 4 == 0");
+    if (a->pooled_save && (reinterpret_cast<uintptr_t>(a->pooled_save) & 15)) return set_error(QAVIT_EINVAL, "branch: pooled_save needs 16-byte alignment");
+  }
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (!al16(a->x) || !al16(a->out) || !al16(a->wqkv_frag) || !al16(a->wproj_frag) || !al16(a->bqkv) || !al16(a->bproj) || !al16(a->sh_k) || !al16(a->sh_v) ||
       (a->o_save && !al16(a->o_save)) || a->ldx % 8 || a->ldo % 8)
@@ -539,18 +588,19 @@ extern "C" int qavit_branch_fwd(const qavit_branch_args* a, void* stream) {
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = (a->B + NI - 1) / NI;                   // one 4-image tile per workgroup
-  static bool attr_done[3] = {false, false, false};
-#define QV_BRANCH_LAUNCH(K)                                                                                                             \
+  static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+  const bool save = a->q_save != nullptr;
+#define QV_BRANCH_LAUNCH(K, S)                                                                                                           \
   do {                                                                                                                                   \
-    if (!attr_done[K]) {                                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, sm_total(K)); \
-      attr_done[K] = true;                                                                                                               \
+    if (!attr_done[K][S]) {                                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, sm_total(K)); \
+      attr_done[K][S] = true;                                                                                                            \
     }                                                                                                                                    \
-    hipLaunchKernelGGL((branch_fwd_kernel<K>), dim3(grid), dim3(512), sm_total(K), st, *a);                                             \
+    hipLaunchKernelGGL((branch_fwd_kernel<K, S>), dim3(grid), dim3(512), sm_total(K), st, *a);                                          \
   } while (0)
-  if (a->kind == 0) QV_BRANCH_LAUNCH(0);
-  else if (a->kind == 1) QV_BRANCH_LAUNCH(1);
-  else QV_BRANCH_LAUNCH(2);
+  if (a->kind == 0) { if (save) QV_BRANCH_LAUNCH(0, true); else QV_BRANCH_LAUNCH(0, false); }
+  else if (a->kind == 1) { if (save) QV_BRANCH_LAUNCH(1, true); else QV_BRANCH_LAUNCH(1, false); }
+  else { if (save) QV_BRANCH_LAUNCH(2, true); else QV_BRANCH_LAUNCH(2, false); }
 #undef QV_BRANCH_LAUNCH
   if (a->nan_flag) {
     const int64_t n = (int64_t)a->B * BT * BC;

@@ -565,7 +565,7 @@ def _attn_drop(a, spec, rt):
 
 
 def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool_idx=None, pool_stride=0, Lk=0,
-                   attn_drop=(0.0, 0), proj_drop=(0.0, 0), want_o=False):
+                   attn_drop=(0.0, 0), proj_drop=(0.0, 0), want_o=False, save=False):
     """One launch for a whole attention branch on 16-token problems (csrc/branch_fwd.hip; include/qavit.h qavit_branch_args):
     ``kind`` 0 = SWA, 1 = MSDA, 2 = cross.  ``x`` [B, 16, 192] bf16 (norm1's output); ``wqkv`` / ``wproj`` are the fp32
     parameters (read through the fragment-packed copies of the WeightPack); ``sh_k`` / ``sh_v`` fp32 [16, 192] (the bank, or
@@ -595,6 +595,26 @@ def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool
     if want_o:
         o = torch.empty_like(out)
         a.o_save = o.data_ptr()
+    saved = None
+    if save:                                               # q / k / v (and MSDA's landmarks) for the backward pass, written by the kernel
+        esz = x.element_size()
+        if kind == 0:
+            qkv = torch.empty(B * T, 3 * Cc, dtype=x.dtype, device=x.device)
+            a.q_save, a.ldq_save = qkv.data_ptr(), 3 * Cc
+            a.kv_save, a.ldkv_save = qkv.data_ptr() + Cc * esz, 3 * Cc
+            saved = (qkv,)
+        elif kind == 1:
+            q = torch.empty(B * T, Cc, dtype=x.dtype, device=x.device)
+            kv = torch.empty(B * Lk, 2 * Cc, dtype=x.dtype, device=x.device)
+            pooled = torch.empty(B * Lk, Cc, dtype=x.dtype, device=x.device)
+            a.q_save, a.ldq_save = q.data_ptr(), Cc
+            a.kv_save, a.ldkv_save = kv.data_ptr(), 2 * Cc
+            a.pooled_save = pooled.data_ptr()
+            saved = (q, kv, pooled)
+        else:
+            q = torch.empty(B * T, Cc, dtype=x.dtype, device=x.device)
+            a.q_save, a.ldq_save = q.data_ptr(), Cc
+            saved = (q,)
     a.attn_drop_p, a.attn_drop_site = float(attn_drop[0]), int(attn_drop[1])
     a.proj_drop_p, a.proj_drop_site = float(proj_drop[0]), int(proj_drop[1])
     if attn_drop[0] > 0.0 or proj_drop[0] > 0.0:
@@ -603,25 +623,29 @@ def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool
         a.nan_flag = rt.nan_flag.data_ptr()
     K.branch_fwd(a)
     out = out.reshape(B, T, Cc)
+    if save:
+        return out, o, saved
     return (out, o) if want_o else out
 
 
 class BranchFn(Function):
     """A whole attention branch on 16-token problems as ONE forward launch (csrc/branch_fwd.hip).  ``meta``: kind (0 SWA,
     1 MSDA, 2 cross), pool_idx / pool_stride / Lk (MSDA), attn_drop / proj_drop = (p, site).
-    Backward runs the unfused kernels on recomputed projections: q / k / v are cheap to re-derive (one GEMM launch, no
-    attention forward) and are not worth 19 MB of stores per branch in the forward; the attention output O the proj weight
-    gradient needs is the one tensor the forward kernel saves.  Dropout masks are pure functions of (seed, step, site,
+    Backward runs the unfused kernels (proj dX / dW, attention-core backward, qkv dX / dW) on what the forward kernel saved:
+    q / k / v (k and v through a second, transposed MFMA on the same fragments -- cheaper than a recompute GEMM launch per
+    branch), MSDA's pooled landmarks and the attention output O.  Dropout masks are pure functions of (seed, step, site,
     element), identical in the fused forward and the unfused backward kernels."""
 
     @staticmethod
     def forward(ctx, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, meta):
         need = any(ctx.needs_input_grad)
         res = branch_forward(meta["kind"], x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k.reshape(-1, x.shape[-1]), sh_v.reshape(-1, x.shape[-1]),
-                             meta.get("pool_idx"), meta.get("pool_stride", 0), meta.get("Lk", x.shape[1] if meta["kind"] == 0 else 0), meta["attn_drop"], meta["proj_drop"], want_o=need)
+                             meta.get("pool_idx"), meta.get("pool_stride", 0), meta.get("Lk", x.shape[1] if meta["kind"] == 0 else 0), meta["attn_drop"], meta["proj_drop"],
+                             want_o=need, save=need)
         if not need:
             return res
-        out, o = res
+        out, o, saved = res
+        ctx.n_saved = len(saved)
         # The bank is mutated in place later in the same forward (GlobalTokenBank.write); the reference's SDPA backward sees
         # the values its forward used (torch.cat made a copy), so snapshot shared rows that alias a parameter (as AttnFn does).
         sk_s, sv_s = sh_k, sh_v
@@ -629,12 +653,13 @@ class BranchFn(Function):
             sk_s, sv_s = K.copy2(sh_k, sh_v)
         ctx.sh_alias = (sh_k, sh_v)
         ctx.meta = meta
-        ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o)
+        ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o, *saved)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o = ctx.saved_tensors
+        x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o = ctx.saved_tensors[:10]
+        saved = ctx.saved_tensors[10:]
         sh_k_in, sh_v_in = ctx.sh_alias
         m = ctx.meta
         kind = m["kind"]
@@ -644,10 +669,10 @@ class BranchFn(Function):
         x2 = x.reshape(B * T, Cc)
         # ---- proj backward: dO = (dout * mask) Wproj ; dWproj += (dout * mask)^T O ; dbproj
         d_o = _linear_bwd(o, wproj, bproj, dout.reshape(B * T, Cc), 0, Cc, True, drop=m["proj_drop"])
-        # ---- recompute the projections (no gradient tracking), then the attention-core backward
+        # ---- the attention-core backward on the saved projections, then the projections' own backward
         with torch.no_grad():
             if kind == 0:
-                qkv = linear(x2, wqkv, bqkv)
+                qkv = saved[0]
                 spec = dict(mode=0, G=B, Nq=T, L=T, H=H, D=D, KC=E_k.shape[1], S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=T,
                             q_off=0, k_off=Cc, v_off=2 * Cc, q_rows=B * T, drop=m["attn_drop"])
                 dq_t, _, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(qkv, None, E_k, E_v, sk_s, sv_s, sh_k_in, sh_v_in, spec, d_o)
@@ -655,11 +680,7 @@ class BranchFn(Function):
             elif kind == 1:
                 idx, stride, Lk = m["pool_idx"], m["pool_stride"], m["Lk"]
                 NP = idx.numel() // stride
-                pooled = torch.empty(B, NP, Cc, dtype=x.dtype, device=x.device)
-                K.gather_pool_fwd(x.contiguous(), idx, pooled, B, T, NP, stride, Cc)
-                p2 = pooled.reshape(B * NP, Cc)
-                q = linear(x2, wqkv, bqkv, rows=(0, Cc))
-                kv = linear(p2, wqkv, bqkv, rows=(Cc, 2 * Cc))
+                q, kv, p2 = saved
                 spec = dict(mode=0, G=B, Nq=T, L=Lk, H=H, D=D, KC=E_k.shape[1], S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=NP,
                             q_off=0, k_off=0, v_off=Cc, q_rows=B * T, drop=m["attn_drop"])
                 dq_t, dkv_t, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(q, kv, E_k, E_v, sk_s, sv_s, sh_k_in, sh_v_in, spec, d_o)
@@ -670,7 +691,7 @@ class BranchFn(Function):
                     K.gather_pool_bwd(dpool.reshape(B, NP, Cc).contiguous(), idx, dxp, B, T, NP, stride, Cc)
                 dx = _linear_bwd(x2, wqkv, bqkv, dq_t, 0, Cc, ctx.needs_input_grad[0], dx_add=dxp)     # dq Wq + (landmark-path gradient)
             else:
-                q = linear(x2, wqkv, bqkv)
+                q = saved[0]
                 spec = dict(mode=1, G=B, Nq=T, L=0, H=H, D=D, S=S, q_off=0, k_off=0, v_off=0, q_rows=B * T, drop=m["attn_drop"])
                 dq_t, _, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(q, None, None, None, sk_s.reshape(S, Cc), sv_s.reshape(S, Cc),
                                                                     sh_k_in, sh_v_in, spec, d_o)

@@ -53,6 +53,7 @@ class BranchArgs(C.Structure):
         ("out", vp), ("ldo", i64), ("o_save", vp),
         ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
         ("nan_flag", vp), ("reserved", i32),
+        ("q_save", vp), ("ldq_save", i64), ("kv_save", vp), ("ldkv_save", i64), ("pooled_save", vp),
     ]
 
 

@@ -820,6 +820,21 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
         assert np.array_equal(keep_p, kept.cpu().numpy())
     else:
         assert rel(out, ref) <= 3e-2
+    # the projections the kernel saves for the backward pass (k / v through its second, transposed MFMA)
+    if drop == 0.0:
+        out_s, o_s, saved = F.branch_forward(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk.reshape(S, C), bv.reshape(S, C), idx, stride, Lk,
+                                             want_o=True, save=True)
+        assert torch.equal(out_s, out) and torch.equal(o_s, o)
+        xf32 = x.float().reshape(B * T, C)
+        if kind == 0:
+            assert rel(saved[0], TF.linear(xf32, wq_r, bqkv)) <= 2e-2
+        elif kind == 1:
+            pooled_ref = x.float()[:, idx.long()].view(B, -1, stride, C).mean(2).reshape(B * Lk, C)
+            assert rel(saved[2], pooled_ref) <= 1e-2
+            assert rel(saved[0], TF.linear(xf32, wq_r[:C], bqkv[:C])) <= 2e-2
+            assert rel(saved[1], TF.linear(pooled_ref.to(torch.bfloat16).float(), wq_r[C:], bqkv[C:])) <= 2e-2
+        else:
+            assert rel(saved[0], TF.linear(xf32, wq_r, bqkv)) <= 2e-2
     # the unfused kernels on the same operands agree more tightly (same bf16 rounding points except q/k/v staying in fp32 -> bf16 once)
     if drop == 0.0:
         if kind == 0:
