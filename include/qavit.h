@@ -121,9 +121,19 @@ int qavit_layernorm_fwd(int dtype, const void* x, void* y, const float* gamma, c
 int qavit_row_stats(int dtype, const void* x, float eps, int rows, int C, float* mean, float* rstd, void* stream);
 int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                         const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                        int rows, int C, float* dadd, int add_rows, const float* beta, int act, const void* dres, void* stream);
+                        int rows, int C, float* dadd, int add_rows, const float* beta, int act, const void* dres, float* part_ws, void* stream);
 /* dres (optional, same shape / dtype as dx): dx = LN_backward(dy) + dres -- the other gradient that meets this one at x (a
- * residual connection around the normalised branch), added in the same pass instead of a separate elementwise kernel. */
+ * residual connection around the normalised branch), added in the same pass instead of a separate elementwise kernel.
+ * part_ws (optional, float[qavit_layernorm_bwd_parts(rows, C)][2][C], 16-byte aligned; needs C % 4 == 0 and vector-aligned
+ * operands): the kernel leaves its per-workgroup partial sums of (dgamma, dbeta) there with plain stores and does NOT touch
+ * dgamma / dbeta; qavit_ln_param_reduce adds them later -- one launch for all the LayerNorms of a backward pass.  The per-workgroup
+ * same-address float atomics this replaces were ~45 % of the kernel at 16k rows. */
+int qavit_layernorm_bwd_parts(int rows, int C);
+typedef struct qavit_ln_reduce_desc {
+  const float* parts; int nparts; int C;     /* [nparts][2][C] */
+  float* dgamma; float* dbeta;               /* += (either may be NULL) */
+} qavit_ln_reduce_desc;
+int qavit_ln_param_reduce(const qavit_ln_reduce_desc* d, int n, void* stream);
 
 /* The four branch norms of a QuadAttentionBlock (norm_{swa,msda,cga,cross}, HQAViT_CIFAR100.py:1046-1049,1075-1078) act on
  * four same-shape tensors that are independent of each other: n <= 4 inputs per grid.  Host arrays of device pointers. */
@@ -131,7 +141,8 @@ int qavit_row_stats_multi(int dtype, int n, const void* const* x, float eps, int
                           float* const* rstd, void* stream);
 int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy, const void* const* x, const float* const* gamma,
                               const float* const* mean, const float* const* rstd, void* const* dx,
-                              float* const* dgamma, float* const* dbeta, int rows, int C, void* stream);
+                              float* const* dgamma, float* const* dbeta, int rows, int C, float* const* part_ws, void* stream);
+/* part_ws: NULL, or n workspaces as in qavit_layernorm_bwd (C % 4 == 0, C <= 512, vector-aligned operands) */
 
 /* ---------------------------------------------------------------------------------------------------
  * Attention core of the four branches: O = softmax(Q K_full^T / sqrt(D)) V_full per (group g, head h), with
@@ -424,9 +435,10 @@ int qavit_copy2(const float* src_a, const float* src_b, float* dst_a, float* dst
 /* Label-smoothed cross entropy with reduction = 'mean' (nn.CrossEntropyLoss(label_smoothing), HQAViT_CIFAR100.py:1373), loss and
  * gradient in one launch: loss[0] = mean_i ( - sum_c t_ic log softmax(logits_i)_c ), dlogits = (softmax - t) / B (NULL: loss only),
  * t_i = (1 - ls) * (lam * onehot(y_a[i]) + (1 - lam) * onehot(y_b[i])) + ls / C.  y_b == NULL: plain labels (lam = 1); lam_dev is a
- * DEVICE scalar (the MixUp / CutMix lambda of :1404-1408, decided on the device inside a captured step). */
+ * DEVICE scalar (the MixUp / CutMix lambda of :1404-1408, decided on the device inside a captured step).
+ * ws = float[1 + ceil(B / 16)], ws[0] zero on first use; the call leaves it zero again (arrival ticket of the deterministic loss sum). */
 int qavit_ce_label_smooth(int dtype, const void* logits, const int64_t* y_a, const int64_t* y_b, const float* lam_dev,
-                          float label_smoothing, int B, int C, float* loss, void* dlogits, void* stream);
+                          float label_smoothing, int B, int C, float* loss, void* dlogits, float* ws, void* stream);
 /* out[0] = sqrt(sum g^2) over a flat buffer (two-pass, deterministic order within a block);
  * out[1] = max(out[1], out[0]) with NaN sticky: the largest norm any call has seen (`out` is float[2], zero at start),
  * so one host read after N captured steps checks every one of them. */

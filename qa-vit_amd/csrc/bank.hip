@@ -128,9 +128,10 @@ __global__ __launch_bounds__(256) void bank_reduce_kernel(const float* ws, float
 // slot's row is folded here in a fixed order (threads = (group, 4-column vector), groups stride over the partials, then
 // an LDS fold over the groups) -- the single-GPU write is stats -> apply, deterministic, no reduce launch.  Without
 // ``parts`` the row comes from ``acc`` (already summed, and all-reduced across ranks when data-parallel).
-__global__ __launch_bounds__(1024) void bank_apply_kernel(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
+__global__ __launch_bounds__(1024) void bank_apply_kernel(float* __restrict__ acc, const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                          float* __restrict__ bank_k, float* __restrict__ bank_v,
                                                           int64_t* update_count, int S, int C, float inv_batch, int mode,
-                                                          const float* parts, int nparts) {
+                                                          const float* __restrict__ parts, int nparts) {
   extern __shared__ __attribute__((aligned(16))) float u[];   // [C] + fold scratch [groups][C]
   const int s = blockIdx.x;
   if (parts) {
@@ -138,12 +139,28 @@ __global__ __launch_bounds__(1024) void bank_apply_kernel(float* acc, const floa
     const int C4 = C >> 2, groups = (int)blockDim.x / C4;
     const int g = threadIdx.x / C4, c4 = threadIdx.x - g * C4;
     if (g < groups) {
-      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-      for (int p_ = g; p_ < nparts; p_ += groups) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(parts + ((size_t)p_ * S + s) * C + 4 * c4);
-        a4[0] += v[0]; a4[1] += v[1]; a4[2] += v[2]; a4[3] += v[3];
+      // four independent partial sums: the loads of a thread are a latency chain otherwise (nparts / groups round trips)
+      f32x4 a4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* base = parts + (size_t)s * C + 4 * c4;
+      const size_t stride = (size_t)S * C;
+      int p_ = g;
+      for (; p_ + 3 * groups < nparts; p_ += 4 * groups) {
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(base + (size_t)(p_ + q * groups) * stride);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a4[q][0] += v[q][0]; a4[q][1] += v[q][1]; a4[q][2] += v[q][2]; a4[q][3] += v[q][3]; }
       }
-      *reinterpret_cast<f32x4*>(fold + g * C + 4 * c4) = a4;
+      for (; p_ < nparts; p_ += groups) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p_ * stride);
+        a4[0][0] += v[0]; a4[0][1] += v[1]; a4[0][2] += v[2]; a4[0][3] += v[3];
+      }
+      f32x4 t4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t4[j] = (a4[0][j] + a4[1][j]) + (a4[2][j] + a4[3][j]);
+      *reinterpret_cast<f32x4*>(fold + g * C + 4 * c4) = t4;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -164,21 +181,33 @@ __global__ __launch_bounds__(1024) void bank_apply_kernel(float* acc, const floa
     if (atomicAdd(ticket, 1) == S - 1) { update_count[0] += 1; *ticket = 0; }
   }
   // upd_k = Wc u + bc: one WAVE per output row (lanes stride over k: coalesced 256-byte reads of the weight row, then a wave
-  // reduction).  A thread per row read its 768-byte row with 192 scattered 4-byte loads and made this tiny kernel 12 us.
+  // reduction), four rows in flight per wave (their weight loads are issued before the first reduction).
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (int)blockDim.x >> 6;
-  for (int c = wv; c < C; c += nwv) {
-    const float* wr = Wc + (size_t)c * C;
-    float part = 0.f;
-    for (int k = lane; k < C; k += 64) part += u[k] * wr[k];
-    part = wave_sum(part);
-    if (lane == 0) {
-      const float dotk = part + bc[c];
-      const float uk = fminf(fmaxf(dotk, -cu), cu);
-      const float uv = fminf(fmaxf(u[c], -cu), cu);
-      const float nk = bank_k[s * C + c] + rate * uk;
-      const float nv = bank_v[s * C + c] + rate * uv;
-      bank_k[s * C + c] = fminf(fmaxf(nk, -cb), cb);
-      bank_v[s * C + c] = fminf(fmaxf(nv, -cb), cb);
+  for (int c0 = wv; c0 < C; c0 += 4 * nwv) {
+    float part[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + q * nwv;
+      part[q] = 0.f;
+      if (c < C) {
+        const float* wr = Wc + (size_t)c * C;
+        for (int k = lane; k < C; k += 64) part[q] += u[k] * wr[k];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[q] = wave_sum(part[q]);
+    if (lane < 4) {
+      const int c = c0 + lane * nwv;
+      if (c < C) {
+        const float pq = lane == 0 ? part[0] : lane == 1 ? part[1] : lane == 2 ? part[2] : part[3];
+        const float dotk = pq + bc[c];
+        const float uk = fminf(fmaxf(dotk, -cu), cu);
+        const float uv = fminf(fmaxf(u[c], -cu), cu);
+        const float nk = bank_k[s * C + c] + rate * uk;
+        const float nv = bank_v[s * C + c] + rate * uv;
+        bank_k[s * C + c] = fminf(fmaxf(nk, -cb), cb);
+        bank_v[s * C + c] = fminf(fmaxf(nv, -cb), cb);
+      }
     }
   }
 }

@@ -882,25 +882,15 @@ extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* s
     if (g.dtype != QAVIT_BF16 && g.dtype != QAVIT_F32) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: unknown dtype");
   }
   if (!legacy) {
-    // bf16 problems: wide-tile kernel, grouped by tile class.  fp32 problems: the single-problem path.
-    int done = 0;
-    while (done < n) {
-      if (a[done].dtype != QAVIT_BF16) {
-        const int rc = launch_gemm_tn<float>(a[done], st);
-        if (rc) return rc;
-        ++done;
-        continue;
-      }
-      int e = done;
-      while (e < n && a[e].dtype == QAVIT_BF16) ++e;
-      const int rc = gemm_tn_wide(a + done, e - done, st);
-      if (rc) return rc;
-      for (int i = done; i < e; ++i) {                 // odd strides / alignments: generic 64x64-tile kernel
-        if (gemm_tn_wide_ok(a[i])) continue;
-        const int rc2 = launch_gemm_tn<bf16>(a[i], st);
-        if (rc2) return rc2;
-      }
-      done = e;
+    // bf16 problems: wide-tile kernel, grouped by tile class over the WHOLE list (the problems are independent, so a
+    // stray fp32 problem in the queue must not cut a class group short).  fp32 problems and odd strides / alignments:
+    // the single-problem path.
+    const int rc = gemm_tn_wide(a, n, st);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+      if (a[i].dtype == QAVIT_BF16 && gemm_tn_wide_ok(a[i])) continue;
+      const int rc2 = a[i].dtype == QAVIT_BF16 ? launch_gemm_tn<bf16>(a[i], st) : launch_gemm_tn<float>(a[i], st);
+      if (rc2) return rc2;
     }
     return QAVIT_OK;
   }

@@ -6,8 +6,18 @@
 // 64-row chunk feeds IN*JN*2 MFMAs per wave between barriers.  Operands are staged row-major ([m][n], [m][k]: 16-byte
 // coalesced loads, register-prefetched one chunk ahead); the m-contiguous MFMA fragments come from
 // ds_read_b64_tr_b16.  Row strides are 16 elements over the tile width, i.e. 8 banks (mod 32) per row, so the four
-// rows of a transposed read fall in disjoint bank groups.  Partial results of the M-splits are added with fp32
-// atomics; up to TNW_GROUP problems of one tile class share a launch (the dW GEMMs of a backward pass are independent).
+// rows of a transposed read fall in disjoint bank groups.
+//
+// Scheduling is stream-K: up to TNW_GROUP problems of one tile class share a launch (the dW GEMMs of a backward pass
+// are independent); the launch's work is the list of (problem, tile, 64- or 128-row chunk) units in that order, cut
+// into EQUAL contiguous ranges, one per workgroup, with as many workgroups as the chip holds at once.  A workgroup
+// accumulates in registers while its range stays inside one tile and adds its partial result with fp32 atomics when it
+// leaves the tile, so a launch has no tail round (the fixed rows-per-split grid it replaces ran 576 workgroups on 512
+// slots: two rounds for 1.1 rounds of work) and the atomics stay at one or two flushes per workgroup.
+//
+// Tile classes: N side 32 / 64 / 128 / 192 columns, K side 32 / 64 / 96 / 128 columns on four waves (2 x 2), and a
+// 192-column K class on eight waves (2 x 4, 128-row chunks) so that the K = 192 layers -- most of the model -- read
+// each operand row once (two 128-wide tiles re-read A and spent a third of their MFMAs on padding).
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
@@ -33,13 +43,14 @@ __device__ __forceinline__ bf16x8 trf(const bf16* tile, int ld, int m0, int c0) 
   return r;
 }
 
-constexpr int MC = 64;            // rows of M per staged chunk
 constexpr int TNW_GROUP = 24;
 
 struct TnwGroup {
   int n;
-  int wg_start[TNW_GROUP + 1];
-  int tn[TNW_GROUP], tk[TNW_GROUP], rows[TNW_GROUP];
+  int per;                            // units per workgroup
+  int dbg;
+  int unit_start[TNW_GROUP + 1];      // prefix sums of tiles * chunks
+  int tn[TNW_GROUP], chunks[TNW_GROUP];
   qavit_gemm_tn_args p[TNW_GROUP];
 };
 
@@ -47,29 +58,38 @@ constexpr int pow2ceil(int v) { return v <= 4 ? 4 : v <= 8 ? 8 : v <= 16 ? 16 : 
 
 // staging geometry of one operand with W columns: column group cg (8 columns) is FIXED per thread, so LayerNorm
 // gamma/beta and the column sums live in registers
-template <int W>
+template <int NT, int W, int MC>
 struct Stage {
   static constexpr int CG = W / 8;              // live column groups
   static constexpr int CGS = pow2ceil(CG);      // slots (power of two)
-  static constexpr int RP = 256 / CGS;          // rows per pass
+  static constexpr int RP = NT / CGS;           // rows per pass
   static constexpr int PASS = MC / RP;
   static constexpr int LD = W + 16;
+};
+
+// class geometry: waves 2 x WB, a wave owns IN x JN MFMA blocks; MC = rows of M per staged chunk
+template <int IN, int JN, int WB>
+struct Cls {
+  static constexpr int NT = 128 * WB;
+  static constexpr int MC = WB == 4 ? 128 : 64;
+  static constexpr int TNW = 32 * IN, TKW = 16 * WB * JN;
+  typedef Stage<NT, TNW, MC> SA;
+  typedef Stage<NT, TKW, MC> SB;
 };
 
 // Preconditions (gemm_tn_wide checks them, other problems take the generic kernel): A, B 16-byte aligned,
 // lda, ldb, N, K multiples of 8.  The staging loads are UNCONDITIONAL (row / column indices are clamped into the
 // operand and the out-of-range vectors are zeroed when they are committed to LDS): a load under a lane-dependent
 // branch makes the compiler wait for it at the join, which serialises the chunk's 16 loads into 16 round trips.
-template <int IN, int JN>
-__device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* At, bf16* Bt, int bx, int by, int bz, int rows_per_split) {
-  constexpr int TNW = 32 * IN, TKW = 32 * JN;
-  typedef Stage<TNW> SA;
-  typedef Stage<TKW> SB;
+template <int IN, int JN, int WB>
+__device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* At, bf16* Bt, int bx, int by, int mbeg, int mend, int dbg) {
+  typedef Cls<IN, JN, WB> CL;
+  constexpr int TNW = CL::TNW, TKW = CL::TKW, MC = CL::MC, NT = CL::NT;
+  typedef typename CL::SA SA;
+  typedef typename CL::SB SB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave & 1, wb = wave >> 1;
   const int n0 = bx * TNW, k0 = by * TKW;
-  const int mbeg = bz * rows_per_split;
-  const int mend = (mbeg + rows_per_split < g.M) ? mbeg + rows_per_split : g.M;
   if (mbeg >= mend) return;                            // uniform per workgroup
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
@@ -166,6 +186,7 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
     }
   }
   const int fr = lane & 15, fq = lane >> 4;
+  if (!(dbg & 1))
 #pragma unroll
   for (int i = 0; i < IN; ++i)
 #pragma unroll
@@ -175,36 +196,73 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
         const int n = n0 + (wa * IN + i) * 16 + fq * 4 + r, k = k0 + (wb * JN + j) * 16 + fr;
         if (n < g.N && k < g.K) atomic_add_f(g.C + (size_t)n * g.ldc + k, acc[i][j][r]);
       }
-  if (want_csum) {                                   // uniform per workgroup
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(At);       // [TNW]
-    for (int i = tid; i < TNW; i += 256) red[i] = 0.f;
-    __syncthreads();
-    if (cga < SA::CG) {
+  if (want_csum && !(dbg & 2)) {                     // uniform per workgroup
+    // lanes l and l ^ CGS, l ^ 2 CGS ... of a wave hold the same column group (other rows): fold them with shuffles, then the
+    // waves through LDS (plain stores; the LDS-atomic version of this spent 16-way same-address conflicts per column)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(red + 8 * cga + j, csum[j]);
+    for (int off = SA::CGS; off < 64; off <<= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) csum[j] += __shfl_xor(csum[j], off);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(At);       // [waves][8 * CGS]
+    constexpr int NWV = NT / 64, RW = 8 * (SA::CGS < 64 ? SA::CGS : 64);
+    if (lane < SA::CGS && cga < SA::CG) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave * RW + 8 * cga + j] = csum[j];
     }
     __syncthreads();
-    for (int i = tid; i < TNW; i += 256) if (n0 + i < g.N) atomic_add_f(g.colsum + n0 + i, red[i]);
+    for (int i = tid; i < TNW; i += NT) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) t += red[w * RW + i];
+      if (n0 + i < g.N) atomic_add_f(g.colsum + n0 + i, t);
+    }
+    __syncthreads();                                 // At is staged again by the next range of this workgroup
   }
 }
 
-template <int IN, int JN>
-__global__ __launch_bounds__(256) void gemm_tn_wide_kernel(TnwGroup G) {
-  __shared__ __attribute__((aligned(16))) bf16 At[MC * Stage<32 * IN>::LD];   // [m][n]
-  __shared__ __attribute__((aligned(16))) bf16 Bt[MC * Stage<32 * JN>::LD];   // [m][k]
-  const int bid = blockIdx.x;
+template <int IN, int JN, int WB>
+__global__ __launch_bounds__(128 * WB) void gemm_tn_wide_kernel(TnwGroup G) {
+  typedef Cls<IN, JN, WB> CL;
+  __shared__ __attribute__((aligned(16))) bf16 At[CL::MC * CL::SA::LD];   // [m][n]
+  __shared__ __attribute__((aligned(16))) bf16 Bt[CL::MC * CL::SB::LD];   // [m][k]
+  const int total = G.unit_start[G.n];
+  int u = blockIdx.x * G.per;
+  int uend = u + G.per;
+  if (uend > total) uend = total;
   int i = 0;
-#pragma unroll
-  for (int j = 1; j < TNW_GROUP; ++j) if (j < G.n && bid >= G.wg_start[j]) i = j;
-  const int local = bid - G.wg_start[i];
-  const int tiles = G.tn[i] * G.tk[i];
-  const int bz = local / tiles, t = local - bz * tiles;
-  const int by = t / G.tn[i], bx = t - by * G.tn[i];
-  tn_wide_body<IN, JN>(G.p[i], At, Bt, bx, by, bz, G.rows[i]);
+  while (u < uend) {                                   // every quantity here is uniform over the workgroup
+    while (u >= G.unit_start[i + 1]) ++i;
+    const int chunks = G.chunks[i];
+    const int local = u - G.unit_start[i];
+    const int t = local / chunks, c0 = local - t * chunks;
+    int c1 = c0 + (uend - u);
+    if (c1 > chunks) c1 = chunks;
+    const int tn = G.tn[i];
+    const int by = t / tn, bx = t - by * tn;
+    const int M = G.p[i].M;
+    const int mend = c1 * CL::MC < M ? c1 * CL::MC : M;
+    tn_wide_body<IN, JN, WB>(G.p[i], At, Bt, bx, by, c0 * CL::MC, mend, G.dbg);
+    u += c1 - c0;
+  }
 }
 
-int tile_class(int n, int which = 0) {           // 32-column units per workgroup tile: 1, 2, 4 or 6
+// workgroups the chip holds at once, per class (two 4-wave workgroups or one 8-wave workgroup per CU)
+int resident_wgs(int wb) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  static int per_cu = -1;
+  if (per_cu < 0) { const char* e = getenv("QAVIT_TN_WG_PER_CU"); per_cu = e ? atoi(e) : 0; }
+  if (wb == 4) return cus;
+  return cus * (per_cu > 0 ? per_cu : 2);
+}
+
+int tile_class(int n, int which = 0) {           // N side: 32-column units per tile (1, 2, 4, 6); K side: 32-column units (1, 2, 3, 4) or 6 = the 192-wide eight-wave class
   static int force[2] = {-1, -1};
   if (force[0] < 0) {
     const char* e = getenv("QAVIT_TN_CN"); force[0] = e ? atoi(e) : 0;
@@ -213,52 +271,41 @@ int tile_class(int n, int which = 0) {           // 32-column units per workgrou
   if (n > 128 && force[which]) return force[which];
   if (n <= 32) return 1;
   if (n <= 64) return 2;
-  if (which == 1) {                // K side: <= 128-wide tiles keep the accumulators at <= 96 registers (two workgroups per CU)
-    static int k96 = -1;
-    if (k96 < 0) { const char* e = getenv("QAVIT_TN_K96"); k96 = e ? atoi(e) : 0; }   // measured: no gain (more classes = more launches)
-    if (k96 && n % 96 == 0 && n % 128 != 0) return 3;     // 96, 192, 576: exact 96-wide tiles instead of padded 128-wide ones
-    return 4;
-  }
+  if (which == 1 && n <= 96) return 3;
   if (n <= 128) return 4;
   if (n <= 192) return 6;
   const int p128 = (n + 127) / 128 * 128, p192 = (n + 191) / 192 * 192;
   return p128 < p192 ? 4 : 6;
 }
 
-template <int IN, int JN>
+template <int IN, int JN, int WB>
 void launch_class(const qavit_gemm_tn_args* const* probs, int n, hipStream_t st) {
-  constexpr int TNW = 32 * IN, TKW = 32 * JN;
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("QAVIT_TN_WGS"); target = e ? atoi(e) : 256; }
+  typedef Cls<IN, JN, WB> CL;
+  static int min_units = -1;
+  if (min_units < 0) { const char* e = getenv("QAVIT_TN_MIN_UNITS"); min_units = e ? atoi(e) : 4; if (min_units < 1) min_units = 1; }
   int done = 0;
   while (done < n) {
     const int cnt = (n - done < TNW_GROUP) ? (n - done) : TNW_GROUP;
-    // rows per split: long chains amortise the atomic epilogue; shorten them until the launch fills the chip
-    int rows = 4096;
-    for (;;) {
-      long wg = 0;
-      for (int i = 0; i < cnt; ++i) {
-        const qavit_gemm_tn_args& g = *probs[done + i];
-        wg += (long)((g.N + TNW - 1) / TNW) * ((g.K + TKW - 1) / TKW) * ((g.M + rows - 1) / rows);
-      }
-      if (wg >= target || rows <= 128) break;
-      rows >>= 1;
-    }
     TnwGroup G;
     G.n = cnt;
-    int wg = 0;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QAVIT_TN_DBG"); dbg = e ? atoi(e) : 0; } G.dbg = dbg; }
+    int units = 0;
     for (int i = 0; i < cnt; ++i) {
       const qavit_gemm_tn_args& g = *probs[done + i];
       G.p[i] = g;
-      G.tn[i] = (g.N + TNW - 1) / TNW; G.tk[i] = (g.K + TKW - 1) / TKW;
-      int r = g.splits > 0 ? (g.M + g.splits - 1) / g.splits : rows;
-      r = (r + MC - 1) / MC * MC;
-      G.rows[i] = r;
-      G.wg_start[i] = wg;
-      wg += G.tn[i] * G.tk[i] * ((g.M + r - 1) / r);
+      G.tn[i] = (g.N + CL::TNW - 1) / CL::TNW;
+      G.chunks[i] = (g.M + CL::MC - 1) / CL::MC;
+      G.unit_start[i] = units;
+      units += G.tn[i] * ((g.K + CL::TKW - 1) / CL::TKW) * G.chunks[i];
     }
-    G.wg_start[cnt] = wg;
-    hipLaunchKernelGGL((gemm_tn_wide_kernel<IN, JN>), dim3(wg), dim3(256), 0, st, G);
+    for (int i = cnt; i <= TNW_GROUP; ++i) G.unit_start[i] = units;
+    // equal contiguous ranges over the resident workgroups; short launches use fewer, longer ranges (each range
+    // ends in a tile-sized atomic flush)
+    int wgs = resident_wgs(WB);
+    if (units < wgs * min_units) wgs = (units + min_units - 1) / min_units;
+    G.per = (units + wgs - 1) / wgs;
+    wgs = (units + G.per - 1) / G.per;
+    hipLaunchKernelGGL((gemm_tn_wide_kernel<IN, JN, WB>), dim3(wgs), dim3(CL::NT), 0, st, G);
     done += cnt;
   }
 }
@@ -266,10 +313,11 @@ void launch_class(const qavit_gemm_tn_args* const* probs, int n, hipStream_t st)
 typedef void (*class_fn)(const qavit_gemm_tn_args* const*, int, hipStream_t);
 template <int IN> class_fn pick_j(int jc) {
   switch (jc) {
-    case 1: return launch_class<IN, 1>;
-    case 2: return launch_class<IN, 2>;
-    case 3: return launch_class<IN, 3>;
-    default: return launch_class<IN, 4>;
+    case 1: return launch_class<IN, 1, 2>;
+    case 2: return launch_class<IN, 2, 2>;
+    case 3: return launch_class<IN, 3, 2>;
+    case 4: return launch_class<IN, 4, 2>;
+    default: return launch_class<IN, 3, 4>;
   }
 }
 class_fn pick(int ic, int jc) {
@@ -290,10 +338,10 @@ bool gemm_tn_wide_ok(const qavit_gemm_tn_args& g) {
 }
 
 int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st) {
-  static const int ncls[4] = {1, 2, 4, 6}, kcls[4] = {1, 2, 3, 4};
+  static const int ncls[4] = {1, 2, 4, 6}, kcls[5] = {1, 2, 3, 4, 6};
   const qavit_gemm_tn_args* sel[256];
   for (int ci = 0; ci < 4; ++ci)
-    for (int cj = 0; cj < 4; ++cj) {
+    for (int cj = 0; cj < 5; ++cj) {
       int cnt = 0;
       for (int i = 0; i < n; ++i) {
         if (gemm_tn_wide_ok(a[i]) && tile_class(a[i].N, 0) == ncls[ci] && tile_class(a[i].K, 1) == kcls[cj]) {

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
       const int c = lane + 64 * i;
       if (c < C) {
         float d = to_f<T>(gr[c]);
+        if (dar) atomic_add_f(dar + c, d);                          // y = act(LN(x)) + add: the add sees dy itself
         xh[i] = (to_f<T>(xr[c]) - mu) * rs;
         if (act) d *= gelu_grad_f(xh[i] * gamma[c] + beta[c]);      // y = gelu(LN(x)): gradient wrt the LN output
         g[i] = d * gamma[c];
@@ -120,7 +121,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
         pb[i] += d;
         c1 += g[i] * xh[i];
         c2 += g[i];
-        if (dar) atomic_add_f(dar + c, d);
       } else { xh[i] = 0.f; g[i] = 0.f; }
     }
     c1 = wave_sum(c1) * invC;
@@ -151,6 +151,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
   }
 }
 
+template <typename T> struct V4sel;
+template <> struct V4sel<float> { typedef f32x4 type; };
+template <> struct V4sel<bf16> { typedef bf16x4 type; };
+
+// dadd[(row % add_rows), c] += dy[row, c]: the gradient of the broadcast add (pos_embed) is the batch sum of dy.  The flat view has
+// period P = add_rows * C; a thread owns 4 consecutive elements of the period and walks a slice of the repeats (coalesced 8 / 16-byte
+// loads), then adds once -- gridDim.y same-address atomics per element instead of one per row.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_dadd_kernel(const T* dy, float* dadd, long total, int P, int reps_per_slice) {
+  typedef typename V4sel<T>::type v4;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= P) return;
+  const long r0 = (long)blockIdx.y * reps_per_slice;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+  for (int r = 0; r < reps_per_slice; ++r) {
+    const long idx = (r0 + r) * P + e;
+    if (idx + 3 < total) {
+      const v4 v = *reinterpret_cast<const v4*>(dy + idx);
+      a0 += to_f<T>(v[0]); a1 += to_f<T>(v[1]); a2 += to_f<T>(v[2]); a3 += to_f<T>(v[3]);
+    }
+  }
+  atomic_add_f(dadd + e, a0); atomic_add_f(dadd + e + 1, a1); atomic_add_f(dadd + e + 2, a2); atomic_add_f(dadd + e + 3, a3);
+}
+
 }  // namespace qv
 
 using namespace qv;
@@ -164,7 +189,7 @@ template <> struct V4<bf16> { typedef bf16x4 type; };
 template <typename T, int NP, int RB, int NW>
 __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, const float* gamma, const float* mean,
                                                       const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act,
-                                                      const T* dres = nullptr) {
+                                                      const T* dres = nullptr, float* parts = nullptr) {
   // RB rows per wave per iteration: all their loads are issued before the first reduction, so a wave keeps
   // 2*RB*NP vector loads in flight instead of 2 (the row loop is a pure load -> reduce -> store latency chain).
   typedef typename V4<T>::type v4;
@@ -245,11 +270,14 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
     for (int t = threadIdx.x; t < 512; t += 64 * NW) {          // 256 channels x {gamma, beta}
       const int which = t >> 8, cc = t & 255, c = cc + 256 * i;
       float* dst = which ? dbeta : dgamma;
-      if (c < C && dst) {
+      if (c < C && (dst || parts)) {
         float sacc = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) sacc += red[which][w][cc];
-        atomic_add_f(dst + c, sacc);
+        // parts: this workgroup's row of [gridDim.x][2][C] partial sums (plain store; qavit_ln_param_reduce folds them later) --
+        // gridDim.x same-address float atomics per channel were ~45 % of this kernel's time
+        if (parts) parts[((size_t)blockIdx.x * 2 + which) * C + c] = sacc;
+        else atomic_add_f(dst + c, sacc);
       }
     }
   }
@@ -258,15 +286,55 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
 template <typename T, int NP, int RB, int NW>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                                const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act,
-                                                               const T* dres) {
-  layernorm_bwd_v4_body<T, NP, RB, NW>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, beta, act, dres);
+                                                               const T* dres, float* parts) {
+  layernorm_bwd_v4_body<T, NP, RB, NW>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, beta, act, dres, parts);
 }
-struct LnBwd4 { const void* dy[4]; const void* x[4]; const float* gamma[4]; const float* mean[4]; const float* rstd[4]; void* dx[4]; float* dgamma[4]; float* dbeta[4]; };
+struct LnBwd4 { const void* dy[4]; const void* x[4]; const float* gamma[4]; const float* mean[4]; const float* rstd[4]; void* dx[4]; float* dgamma[4]; float* dbeta[4]; float* parts[4]; };
 template <typename T, int NP, int RB, int NW>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_multi_kernel(LnBwd4 P, int rows, int C) {
   const int i = blockIdx.y;
   layernorm_bwd_v4_body<T, NP, RB, NW>(reinterpret_cast<const T*>(P.dy[i]), reinterpret_cast<const T*>(P.x[i]), P.gamma[i], P.mean[i], P.rstd[i],
-                                       reinterpret_cast<T*>(P.dx[i]), P.dgamma[i], P.dbeta[i], rows, C, nullptr, 0);
+                                       reinterpret_cast<T*>(P.dx[i]), P.dgamma[i], P.dbeta[i], rows, C, nullptr, 0, nullptr, P.parts[i]);
+}
+
+// dgamma / dbeta += sum over the partial rows a layernorm_bwd launch left in ``parts`` ([nparts][2][C]): one workgroup per LayerNorm,
+// threads = (group, 4-float vector of the 2C-wide row), groups stride over the rows with four loads in flight, LDS fold, then ONE
+// atomic per channel (atomic because a shared parameter may collect from several LayerNorm calls).
+struct LnReduceGroup { int n; qavit_ln_reduce_desc d[64]; };
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnReduceGroup G) {
+  __shared__ __attribute__((aligned(16))) float fold[4096];
+  const qavit_ln_reduce_desc d = G.d[blockIdx.x];
+  const int W = 2 * d.C, V = W >> 2, groups = 1024 / V;
+  const int g = threadIdx.x / V, v = threadIdx.x - g * V;
+  if (g < groups) {
+    f32x4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* base = d.parts + 4 * v;
+    int p = g;
+    for (; p + 3 * groups < d.nparts; p += 4 * groups) {
+      f32x4 t[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const f32x4*>(base + (size_t)(p + q * groups) * W);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[q][0] += t[q][0]; a[q][1] += t[q][1]; a[q][2] += t[q][2]; a[q][3] += t[q][3]; }
+    }
+    for (; p < d.nparts; p += groups) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(base + (size_t)p * W);
+      a[0][0] += t[0]; a[0][1] += t[1]; a[0][2] += t[2]; a[0][3] += t[3];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (a[0][j] + a[1][j]) + (a[2][j] + a[3][j]);
+    *reinterpret_cast<f32x4*>(fold + g * W + 4 * v) = o;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < W; c += 1024) {
+    float t = 0.f;
+    for (int q = 0; q < groups; ++q) t += fold[q * W + c];
+    float* dst = c < d.C ? d.dgamma : d.dbeta;
+    if (dst) atomic_add_f(dst + (c < d.C ? c : c - d.C), t);
+  }
 }
 
 static int ln_pl(int C) { const int p = (C + 63) / 64; return p <= 1 ? 1 : p <= 2 ? 2 : p <= 3 ? 3 : p <= 4 ? 4 : p <= 8 ? 8 : 16; }
@@ -314,28 +382,52 @@ extern "C" int qavit_row_stats(int dtype, const void* x, float eps, int rows, in
   return check_launch("row_stats");
 }
 
+extern "C" int qavit_layernorm_bwd_parts(int rows, int C) {
+  (void)C;
+  static const int cap = getenv("QAVIT_LNB_GRID") ? atoi(getenv("QAVIT_LNB_GRID")) : 256;
+  int grid = (rows + 63) / 64;            // 16 waves x 4 rows per workgroup and pass
+  if (grid > cap) grid = cap;
+  return grid < 1 ? 1 : grid;
+}
+
 extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                                    const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
-                                   int rows, int C, float* dadd, int add_rows, const float* beta, int act, const void* dres, void* stream) {
+                                   int rows, int C, float* dadd, int add_rows, const float* beta, int act, const void* dres, float* part_ws, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: bad arguments");
   if (act && !beta) return set_error(QAVIT_EINVAL, "layernorm_bwd: the fused-GELU gradient needs beta");
   if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "layernorm_bwd: C > 1024 unsupported");
   if (dadd && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd: add_rows must be positive");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t esz0 = dtype == QAVIT_F32 ? 4 : 2;
+  if (dadd && C % 4 == 0 && reinterpret_cast<uintptr_t>(dy) % (4 * esz0) == 0 && (dtype == QAVIT_F32 || dtype == QAVIT_BF16)) {
+    // batch sum of dy in a launch of its own; the LayerNorm gradient below then runs without dadd (vector kernel)
+    const long total = (long)rows * C;
+    const int P = add_rows * C;
+    const int reps = (int)((total + P - 1) / P);
+    const int gx = (P / 4 + 255) / 256;
+    int slices = 512 / gx;
+    if (slices < 1) slices = 1;
+    if (slices > reps) slices = reps;
+    const int per = (reps + slices - 1) / slices;
+    slices = (reps + per - 1) / per;
+    if (dtype == QAVIT_F32) hipLaunchKernelGGL((ln_dadd_kernel<float>), dim3(gx, slices), dim3(256), 0, st, (const float*)dy, dadd, total, P, per);
+    else hipLaunchKernelGGL((ln_dadd_kernel<bf16>), dim3(gx, slices), dim3(256), 0, st, (const bf16*)dy, dadd, total, P, per);
+    dadd = nullptr;
+  }
   int grid = (rows + 3) / 4;
   if (grid > 512) grid = 512;     // every workgroup ends with 2*C same-address atomics: keep the flush small
-  static const int v4_cap = getenv("QAVIT_LNB_GRID") ? atoi(getenv("QAVIT_LNB_GRID")) : 256;
   const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
   const bool v4ok = !dadd && (C % 4 == 0) && C <= 1024 &&
                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) % (4 * esz) == 0);
   if (dres && (!v4ok || (reinterpret_cast<uintptr_t>(dres) % (4 * esz)) != 0))
     return set_error(QAVIT_EINVAL, "layernorm_bwd: dres needs C % 4 == 0, no dadd and vector-aligned operands");
+  if (part_ws && (!v4ok || (reinterpret_cast<uintptr_t>(part_ws) & 15)))
+    return set_error(QAVIT_EINVAL, "layernorm_bwd: part_ws needs C % 4 == 0, vector-aligned operands and a 16-byte aligned workspace");
   if (v4ok) {
     const int np = (C + 255) / 256;
     constexpr int NW = 16;
-    grid = (rows + 4 * NW - 1) / (4 * NW);
-    if (grid > v4_cap) grid = v4_cap;
-#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_, (NP_ <= 2 ? 4 : 2), NW>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C, beta, act, (const T_*)dres)
+    grid = qavit_layernorm_bwd_parts(rows, C);
+#define LNV(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_kernel<T_, NP_, (NP_ <= 2 ? 4 : 2), NW>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, (const T_*)x, gamma, mean, rstd, (T_*)dx, dgamma, dbeta, rows, C, beta, act, (const T_*)dres, part_ws)
     if (dtype == QAVIT_F32) { if (np == 1) LNV(float, 1); else if (np == 2) LNV(float, 2); else LNV(float, 4); }
     else if (dtype == QAVIT_BF16) { if (np == 1) LNV(bf16, 1); else if (np == 2) LNV(bf16, 2); else LNV(bf16, 4); }
     else return set_error(QAVIT_EINVAL, "layernorm_bwd: unknown dtype");
@@ -374,7 +466,7 @@ extern "C" int qavit_row_stats_multi(int dtype, int n, const void* const* x, flo
 
 extern "C" int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy, const void* const* x, const float* const* gamma,
                                          const float* const* mean, const float* const* rstd, void* const* dx,
-                                         float* const* dgamma, float* const* dbeta, int rows, int C, void* stream) {
+                                         float* const* dgamma, float* const* dbeta, int rows, int C, float* const* part_ws, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || n <= 0 || n > 4 || rows <= 0 || C <= 0)
     return set_error(QAVIT_EINVAL, "layernorm_bwd_multi: bad arguments (1 <= n <= 4)");
   const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
@@ -383,21 +475,37 @@ extern "C" int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy
     v4ok = ((reinterpret_cast<uintptr_t>(x[i]) | reinterpret_cast<uintptr_t>(dy[i]) | reinterpret_cast<uintptr_t>(dx[i])) % (4 * esz)) == 0;
   if (!v4ok || (dtype != QAVIT_F32 && dtype != QAVIT_BF16)) {          // odd shapes: one launch each through the general entry point
     for (int i = 0; i < n; ++i) {
-      const int rc = qavit_layernorm_bwd(dtype, dy[i], x[i], gamma[i], mean[i], rstd[i], dx[i], dgamma[i], dbeta[i], rows, C, nullptr, 0, nullptr, 0, nullptr, stream);
+      const int rc = qavit_layernorm_bwd(dtype, dy[i], x[i], gamma[i], mean[i], rstd[i], dx[i], dgamma[i], dbeta[i], rows, C, nullptr, 0, nullptr, 0, nullptr,
+                                         part_ws ? part_ws[i] : nullptr, stream);
       if (rc) return rc;
     }
     return QAVIT_OK;
   }
   LnBwd4 P;
-  for (int i = 0; i < n; ++i) { P.dy[i] = dy[i]; P.x[i] = x[i]; P.gamma[i] = gamma[i]; P.mean[i] = mean[i]; P.rstd[i] = rstd[i]; P.dx[i] = dx[i]; P.dgamma[i] = dgamma[i]; P.dbeta[i] = dbeta[i]; }
+  for (int i = 0; i < n; ++i) { P.dy[i] = dy[i]; P.x[i] = x[i]; P.gamma[i] = gamma[i]; P.mean[i] = mean[i]; P.rstd[i] = rstd[i]; P.dx[i] = dx[i]; P.dgamma[i] = dgamma[i]; P.dbeta[i] = dbeta[i]; P.parts[i] = part_ws ? part_ws[i] : nullptr; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   constexpr int NW = 16;
-  int grid = (rows + 4 * NW - 1) / (4 * NW);
-  if (grid > 256) grid = 256;
+  const int grid = qavit_layernorm_bwd_parts(rows, C);
   const int np = (C + 255) / 256;
 #define LNVM(T_, NP_) hipLaunchKernelGGL((layernorm_bwd_v4_multi_kernel<T_, NP_, 4, NW>), dim3(grid, n), dim3(64 * NW), 0, st, P, rows, C)
   if (dtype == QAVIT_F32) { if (np == 1) LNVM(float, 1); else LNVM(float, 2); }
   else { if (np == 1) LNVM(bf16, 1); else LNVM(bf16, 2); }
 #undef LNVM
   return check_launch("layernorm_bwd_multi");
+}
+
+extern "C" int qavit_ln_param_reduce(const qavit_ln_reduce_desc* d, int n, void* stream) {
+  if (!d || n <= 0) return set_error(QAVIT_EINVAL, "ln_param_reduce: empty list");
+  for (int i = 0; i < n; ++i) {
+    if (!d[i].parts || d[i].nparts <= 0 || d[i].C <= 0 || d[i].C % 4 || d[i].C > 1024 || (reinterpret_cast<uintptr_t>(d[i].parts) & 15))
+      return set_error(QAVIT_EINVAL, "ln_param_reduce: bad descriptor (C % 4 == 0, C <= 1024, 16-byte aligned partial sums)");
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int done = 0; done < n; done += 64) {
+    LnReduceGroup G;
+    G.n = n - done < 64 ? n - done : 64;
+    for (int i = 0; i < G.n; ++i) G.d[i] = d[done + i];
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(G.n), dim3(1024), 0, st, G);
+  }
+  return check_launch("ln_param_reduce");
 }

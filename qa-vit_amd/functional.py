@@ -244,6 +244,7 @@ class DeferDW:
             return False                                    # not inside a backward pass
         cls._armed = True
         K.DeferredTN.enabled = True
+        K.DeferredLN.enabled = True
         K.DeferredTN.home_stream = K.stream()                # backward starts on the caller's stream; only its dW GEMMs are queued
         return True
 
@@ -251,13 +252,16 @@ class DeferDW:
     def flush(cls):
         """Launch what is queued and wait for it (data-parallel sync points: the bucket about to be reduced must be complete)."""
         K.DeferredTN.flush()
+        K.DeferredLN.flush()
         K.DeferredTN.join()
 
     @classmethod
     def finish(cls):
         K.DeferredTN.flush()
+        K.DeferredLN.flush()
         K.DeferredTN.join()
         K.DeferredTN.enabled = False
+        K.DeferredLN.enabled = False
         cls._armed = False
 
 
@@ -533,6 +537,7 @@ class LayerNormFn(Function):
         bbuf, _ = grad_sink(b)
         abuf, _ = grad_sink(add)
         dx = torch.empty_like(x2)
+        DeferDW.arm()                                       # parameter gradients: partial sums now, one reduce launch when backward ends
         dres = None
         if dalias is not None:
             dres = dalias.reshape(rows, Cc)

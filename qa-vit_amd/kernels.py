@@ -138,26 +138,55 @@ class DeferredTN:
     """Queue of weight-gradient GEMMs (see qavit_gemm_tn_grouped).  ``enabled`` is switched on by the autograd layer
     for the duration of a backward pass; queued problems keep their operand tensors alive until ``flush``."""
     enabled = False
-    home_stream = None  # raw stream handle of the backward pass that armed the queue; other streams launch at once
-    queue = []          # (GemmTnArgs, keepalive tuple)
+    home_stream = None  # raw stream handle of the backward pass that armed the queue; problems queued from other streams are adopted at flush
+    queue = []          # (GemmTnArgs, keepalive tuple, torch stream if queued from a foreign stream)
     # ASYNC (opt-in, QAVIT_DW_ASYNC=1): the grouped launches go to a stream of their own, forked off the backward stream every MAX
     # problems and joined when backward ends (or at a data-parallel sync point) -- a graph branch under hipGraph capture.  Measured
     # SLOWER on MI355X (B = 1024 step: 16.3 ms grouped at the end of backward, 17.2-17.5 ms with the weight gradients beside the dX
     # chain): these are chip-filling, atomic-bound kernels, and what they take from the latency-bound chain exceeds what they hide.
     ASYNC = os.environ.get("QAVIT_DW_ASYNC", "0") != "0"
-    MAX = int(os.environ.get("QAVIT_DW_QUEUE", "24" if ASYNC else "96"))
+    MAX = int(os.environ.get("QAVIT_DW_QUEUE", "24" if ASYNC else "256"))
+    SPLIT_FOREIGN = os.environ.get("QAVIT_DW_SPLIT_FOREIGN", "0") != "0"
     _side = {}
     _dirty = set()
+
+    @classmethod
+    def _adopt_foreign(cls, q):
+        """Problems queued from another stream (the lateral CNN path's backward): the launching stream waits for that stream's work
+        so far, and the caching allocator is told the operands are read here."""
+        cur = None
+        seen = set()
+        for _, keep, st in q:
+            if st is None:
+                continue
+            if cur is None:
+                cur = torch.cuda.current_stream()
+            if st.cuda_stream == cur.cuda_stream:
+                continue
+            if st.cuda_stream not in seen:
+                seen.add(st.cuda_stream)
+                cur.wait_stream(st)
+            for t in keep:
+                for u in (t if isinstance(t, tuple) else (t,)):
+                    if isinstance(u, torch.Tensor):
+                        u.record_stream(cur)
 
     @classmethod
     def flush(cls):
         if not cls.queue:
             return
         q, cls.queue = cls.queue, []
-        arr = (L.GemmTnArgs * len(q))(*[a for a, _ in q])
         if not cls.ASYNC:
-            L.check(L.load().qavit_gemm_tn_grouped(arr, len(q), stream()), "gemm_tn_grouped")
+            # this stream's problems first: the launch that has to wait for the other stream should not hold them back
+            parts = ([e for e in q if e[2] is None], [e for e in q if e[2] is not None]) if cls.SPLIT_FOREIGN else (q,)
+            for part in parts:
+                if part:
+                    arr = (L.GemmTnArgs * len(part))(*[a for a, _, _ in part])
+                    cls._adopt_foreign(part)
+                    L.check(L.load().qavit_gemm_tn_grouped(arr, len(part), stream()), "gemm_tn_grouped")
             return
+        arr = (L.GemmTnArgs * len(q))(*[a for a, _, _ in q])
+        cls._adopt_foreign(q)
         dev = torch.cuda.current_device()
         side = cls._side.get(dev)
         if side is None:
@@ -166,7 +195,7 @@ class DeferredTN:
         side.wait_stream(main)                              # every operand queued so far has been produced
         with torch.cuda.stream(side):
             L.check(L.load().qavit_gemm_tn_grouped(arr, len(q), stream()), "gemm_tn_grouped")
-        for _, keep in q:                                   # the caching allocator must not hand these blocks out before the side stream is done
+        for _, keep, _ in q:                                # the caching allocator must not hand these blocks out before the side stream is done
             for t in keep:
                 if isinstance(t, torch.Tensor):
                     t.record_stream(side)
@@ -179,6 +208,8 @@ class DeferredTN:
     @classmethod
     def join(cls):
         """The current stream waits for the weight-gradient stream (before anything reads .grad)."""
+        if not cls._dirty:
+            return
         dev = torch.cuda.current_device()
         if dev in cls._dirty:
             torch.cuda.current_stream(dev).wait_stream(cls._side[dev])
@@ -198,8 +229,9 @@ def gemm_tn(A, Bm, Cgrad, M, N, K, lda, ldb, ldc, colsum=None, ln=None, A_ptr=No
         g, b_, mean, rstd = ln
         a.ln_gamma, a.ln_beta, a.ln_mean, a.ln_rstd = g.data_ptr(), b_.data_ptr(), mean.data_ptr(), rstd.data_ptr()
     a.splits = 0
-    if DeferredTN.enabled and (DeferredTN.home_stream is None or DeferredTN.home_stream == stream()):
-        DeferredTN.queue.append((a, (A, Bm, Cgrad, colsum, ln)))
+    if DeferredTN.enabled:
+        foreign = DeferredTN.home_stream is not None and DeferredTN.home_stream != stream()
+        DeferredTN.queue.append((a, (A, Bm, Cgrad, colsum, ln), torch.cuda.current_stream() if foreign else None))
         if len(DeferredTN.queue) >= DeferredTN.MAX:
             DeferredTN.flush()
         return
@@ -227,16 +259,63 @@ def row_stats_multi(xs, eps, rows, Cc, means, rstds):
             "row_stats_multi")
 
 
+class DeferredLN:
+    """LayerNorm parameter gradients of a backward pass: the backward kernels leave per-workgroup partial sums in a workspace
+    (``part_ws`` of qavit_layernorm_bwd) and ONE qavit_ln_param_reduce launch adds them all when the pass ends (same life cycle
+    as DeferredTN: armed by functional.DeferDW, flushed at the end of backward and at data-parallel sync points)."""
+    enabled = False
+    ON = os.environ.get("QAVIT_DEFER_LN", "1") != "0"
+    queue = []          # (LnReduceDesc, keepalive tuple, torch stream if queued from a foreign stream)
+
+    @classmethod
+    def parts_for(cls, x, dy, dx, rows, Cc, cap=1024):
+        """Workspace for one LayerNorm backward, or None when the partial-sum path does not apply."""
+        if not (cls.enabled and cls.ON) or Cc % 4 or Cc > cap:
+            return None
+        vec = 4 * x.element_size()
+        if (x.data_ptr() | dy.data_ptr() | dx.data_ptr()) % vec:
+            return None
+        n = L.load().qavit_layernorm_bwd_parts(rows, Cc)
+        return torch.empty(n * 2 * Cc, dtype=torch.float32, device=x.device), n
+
+    @classmethod
+    def push(cls, ws, n, Cc, dgamma, dbeta, keep=()):
+        d = L.LnReduceDesc()
+        d.parts, d.nparts, d.C = ws.data_ptr(), n, Cc
+        d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)
+        foreign = DeferredTN.home_stream is not None and DeferredTN.home_stream != stream()
+        cls.queue.append((d, (ws, dgamma, dbeta) + tuple(keep), torch.cuda.current_stream() if foreign else None))
+
+    @classmethod
+    def flush(cls):
+        if not cls.queue:
+            return
+        q, cls.queue = cls.queue, []
+        DeferredTN._adopt_foreign(q)
+        arr = (L.LnReduceDesc * len(q))(*[d for d, _, _ in q])
+        L.check(L.load().qavit_ln_param_reduce(arr, len(q), stream()), "ln_param_reduce")
+
+
 def layernorm_bwd_multi(dys, xs, gammas, means, rstds, dxs, dgammas, dbetas, rows, Cc):
+    parts = [DeferredLN.parts_for(xs[i], dys[i], dxs[i], rows, Cc, cap=512) for i in range(len(xs))]
+    if any(p is None for p in parts):
+        parts = None
     L.check(L.load().qavit_layernorm_bwd_multi(dt_code(xs[0].dtype), len(xs), _ptr_arr(dys), _ptr_arr(xs), _ptr_arr(gammas), _ptr_arr(means),
-                                               _ptr_arr(rstds), _ptr_arr(dxs), _ptr_arr(dgammas), _ptr_arr(dbetas), rows, Cc, stream()),
+                                               _ptr_arr(rstds), _ptr_arr(dxs), _ptr_arr(dgammas), _ptr_arr(dbetas), rows, Cc,
+                                               _ptr_arr([p[0] for p in parts]) if parts else None, stream()),
             "layernorm_bwd_multi")
+    if parts:
+        for i, (ws, n) in enumerate(parts):
+            DeferredLN.push(ws, n, Cc, dgammas[i], dbetas[i])
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=None, add_rows=0, beta=None, act=0, dres=None):
+    part = DeferredLN.parts_for(x, dy, dx, rows, Cc) if (dgamma is not None or dbeta is not None) else None
     L.check(L.load().qavit_layernorm_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, Cc, _p(dadd), add_rows,
-                                         _p(beta), int(act), _p(dres), stream()), "layernorm_bwd")
+                                         _p(beta), int(act), _p(dres), part[0].data_ptr() if part else None, stream()), "layernorm_bwd")
+    if part:
+        DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
 
 
 def ln_dres_ok(x, dres, Cc, dadd=None) -> bool:
@@ -501,8 +580,9 @@ def copy2(a, b):
 
 def ce_label_smooth(logits, y_a, y_b, lam_dev, ls, loss, dlogits):
     B, Cc = logits.shape
+    ws = Runtime.get(logits.device).workspace("ce_ticket", 1 + (B + 15) // 16 + 4096, zero=True)     # ticket + per-workgroup partial losses
     L.check(L.load().qavit_ce_label_smooth(dt_code(logits.dtype), logits.data_ptr(), y_a.data_ptr(), _p(y_b), _p(lam_dev), float(ls), B, Cc,
-                                           loss.data_ptr(), _p(dlogits), stream()), "ce_label_smooth")
+                                           loss.data_ptr(), _p(dlogits), ws.data_ptr(), stream()), "ce_label_smooth")
 
 
 def l2norm(g, partial, out):

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqavit_hip.so")
+LIB_PATH = os.environ.get("QAVIT_LIB") or os.path.join(_HERE, "libqavit_hip.so")     # QAVIT_LIB: A/B another build of the same C-ABI
 
 F32, BF16 = 0, 1
 
@@ -21,6 +21,10 @@ class GemmArgs(C.Structure):
         ("Z", vp), ("ldz", i64), ("act", i32), ("drop_p", f32), ("drop_site", i32), ("scale", f32),
         ("dp_p", f32), ("dp_site", i32), ("dp_rows", i32), ("R", vp), ("ldr", i64), ("rng", vp),
     ]
+
+
+class LnReduceDesc(C.Structure):
+    _fields_ = [("parts", vp), ("nparts", i32), ("C", i32), ("dgamma", vp), ("dbeta", vp)]
 
 
 class GemmTnArgs(C.Structure):
@@ -80,8 +84,10 @@ _SIGS = {
     "qavit_layernorm_fwd": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, i32, i32, vp]),
     "qavit_row_stats": (i32, [i32, vp, f32, i32, i32, vp, vp, vp]),
     "qavit_row_stats_multi": (i32, [i32, i32, vp, f32, i32, i32, vp, vp, vp]),
-    "qavit_layernorm_bwd_multi": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
-    "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]),
+    "qavit_layernorm_bwd_multi": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
+    "qavit_layernorm_bwd_parts": (i32, [i32, i32]),
+    "qavit_ln_param_reduce": (i32, [vp, i32, vp]),
     "qavit_attn_fwd": (i32, [C.POINTER(AttnArgs), vp]),
     "qavit_attn_bwd": (i32, [C.POINTER(AttnArgs), vp]),
     "qavit_attn_ws_floats": (i64, [C.POINTER(AttnArgs)]),
@@ -128,7 +134,7 @@ _SIGS = {
     "qavit_rng_advance": (i32, [vp, vp]),
     "qavit_adamw": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, f32, vp]),
     "qavit_l2norm": (i32, [vp, i64, vp, vp, vp]),
-    "qavit_ce_label_smooth": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp]),
+    "qavit_ce_label_smooth": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp]),
     "qavit_local_clip": (i32, [vp, vp, i32, f32, vp, vp]),
     "qavit_copy2": (i32, [vp, vp, vp, vp, i64, vp]),
 }

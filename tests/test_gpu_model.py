@@ -261,7 +261,7 @@ def test_module_surface_contracts(Q, golden):
     b.load_state_dict(a.state_dict(), strict=True)
     x = torch.from_numpy(golden["c100/x"]).cuda()
     with torch.no_grad():
-        # not bit-equal: parameter-gradient-free here, but several forward kernels reduce with fp32 atomics (order varies between calls)
+        # not bit-equal: a few forward kernels reduce with fp32 atomics, whose order varies between calls
         assert max_rel(b(x).cpu().numpy(), a(x).cpu().numpy()) <= 1e-5
     feats = {}
     def keep(m, i, o):

@@ -23,7 +23,9 @@ for rows, C in ((65536, 192), (16384, 192), (65536, 64), (65536, 256)):
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     K.row_stats(x, 1e-5, rows, C, mean, rstd)
     t_b = timeit(lambda: K.layernorm_bwd(dy, x, gm, mean, rstd, dx, dg, db, rows, C))
+    t_b0 = timeit(lambda: K.layernorm_bwd(dy, x, gm, mean, rstd, dx, None, None, rows, C))          # no parameter-gradient flush
+    t_br = timeit(lambda: K.layernorm_bwd(dy, x, gm, mean, rstd, dx, dg, db, rows, C, dres=y))       # + the residual gradient
     t_s = timeit(lambda: K.row_stats(x, 1e-5, rows, C, mean, rstd))
     t_f = timeit(lambda: K.layernorm_fwd(x, y, gm, bt, 1e-5, rows, C, mean, rstd))
     mb = rows * C * 2 / 1e6
-    print(f"rows={rows} C={C}: bwd {t_b:6.1f} us ({3*mb/t_b:6.0f} GB/s)  stats {t_s:6.1f} us ({mb/t_s:6.0f} GB/s)  fwd {t_f:6.1f} us ({2*mb/t_f:6.0f} GB/s)")
+    print(f"rows={rows} C={C}: bwd {t_b:6.1f} us ({3*mb/t_b:6.0f} GB/s; without dgamma/dbeta {t_b0:6.1f} us; with dres {t_br:6.1f} us)  stats {t_s:6.1f} us ({mb/t_s:6.0f} GB/s)  fwd {t_f:6.1f} us ({2*mb/t_f:6.0f} GB/s)")
