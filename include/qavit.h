@@ -330,10 +330,12 @@ int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const
 int64_t qavit_bank_ws_floats(int B, int N, int C, int S);
 /* acc == NULL in bank_stats: the per-workgroup partials stay in ws ([nparts = ws_floats / (S*C)][S][C]) and bank_apply folds
  * them itself when given `parts` (single-GPU write = stats -> apply, fixed summation order).  With acc, stats also reduces
- * into it (the data-parallel path all-reduces acc between the two calls) and apply is called with parts = NULL. */
+ * into it (the data-parallel path all-reduces acc between the two calls) and apply is called with parts = NULL.
+ * snap_k / snap_v (optional, float[S*C] each): the new rows are ALSO written there -- the copy the next attention branch's backward
+ * needs (the reference's torch.cat / Linear-on-expand copies, HQAViT_CIFAR100.py:398-399, :576-577) without a copy launch. */
 int qavit_bank_apply(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
                      int64_t* update_count, int S, int C, float inv_batch, int mode,
-                     const float* parts, int nparts, void* stream);
+                     const float* parts, int nparts, float* snap_k, float* snap_v, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * small helpers

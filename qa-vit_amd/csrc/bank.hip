@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void bank_reduce_kernel(const float* ws, float
 __global__ __launch_bounds__(1024) void bank_apply_kernel(float* __restrict__ acc, const float* __restrict__ Wc, const float* __restrict__ bc,
                                                           float* __restrict__ bank_k, float* __restrict__ bank_v,
                                                           int64_t* update_count, int S, int C, float inv_batch, int mode,
-                                                          const float* __restrict__ parts, int nparts) {
+                                                          const float* __restrict__ parts, int nparts, float* __restrict__ snap_k, float* __restrict__ snap_v) {
   extern __shared__ __attribute__((aligned(16))) float u[];   // [C] + fold scratch [groups][C]
   const int s = blockIdx.x;
   if (parts) {
@@ -205,9 +205,95 @@ __global__ __launch_bounds__(1024) void bank_apply_kernel(float* __restrict__ ac
         const float uv = fminf(fmaxf(u[c], -cu), cu);
         const float nk = bank_k[s * C + c] + rate * uk;
         const float nv = bank_v[s * C + c] + rate * uv;
-        bank_k[s * C + c] = fminf(fmaxf(nk, -cb), cb);
-        bank_v[s * C + c] = fminf(fmaxf(nv, -cb), cb);
+        const float ok_ = fminf(fmaxf(nk, -cb), cb), ov_ = fminf(fmaxf(nv, -cb), cb);
+        bank_k[s * C + c] = ok_;
+        bank_v[s * C + c] = ov_;
+        if (snap_k) { snap_k[s * C + c] = ok_; snap_v[s * C + c] = ov_; }
       }
+    }
+  }
+}
+
+// The same write for C <= 192 with 1024 threads, built around ONE memory round trip: a wave's weight rows (12 rows x 3 values per lane),
+// its old bank values and the thread's share of the partial sums are all requested before anything is consumed -- the kernel above is
+// a chain of dependent loads (fold -> u -> weight rows -> bank rows) on 16 workgroups, ~20 us for 0.3 MFLOP, and it sits on the
+// forward critical path three times per block (the next branch reads the bank this one writes).
+__global__ __launch_bounds__(1024) void bank_apply192_kernel(float* __restrict__ acc, const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                             float* __restrict__ bank_k, float* __restrict__ bank_v,
+                                                             int64_t* update_count, int S, int C, float inv_batch, int mode,
+                                                             const float* __restrict__ parts, int nparts, float* __restrict__ snap_k, float* __restrict__ snap_v) {
+  extern __shared__ __attribute__((aligned(16))) float u[];   // [C] + fold scratch [groups][C]
+  constexpr int RW = 12, KW = 3, NWV = 16, FMAX = 16;
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float w[RW][KW], bcr[RW], okr[RW], ovr[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int c = wv + NWV * i, cc = c < C ? c : 0;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      const int k = lane + 64 * j;
+      w[i][j] = Wc[(size_t)cc * C + (k < C ? k : 0)];
+    }
+    bcr[i] = bc[cc]; okr[i] = bank_k[s * C + cc]; ovr[i] = bank_v[s * C + cc];
+  }
+  const long cnt = (mode == 0 && update_count) ? update_count[0] : 0;
+  const int C4 = C >> 2, groups = 1024 / C4;
+  const int g = threadIdx.x / C4, c4 = threadIdx.x - g * C4;
+  float* fold = u + C;
+  if (parts) {
+    f32x4 v[FMAX];
+    const float* base = parts + (size_t)s * C + 4 * (g < groups ? c4 : 0);
+    const size_t stride = (size_t)S * C;
+#pragma unroll
+    for (int q = 0; q < FMAX; ++q) {
+      const int p_ = g + q * groups;
+      v[q] = *reinterpret_cast<const f32x4*>(base + (size_t)(p_ < nparts ? p_ : 0) * stride);
+    }
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < FMAX; ++q) {
+      if (g + q * groups < nparts) { a4[0] += v[q][0]; a4[1] += v[q][1]; a4[2] += v[q][2]; a4[3] += v[q][3]; }
+    }
+    for (int p_ = g + FMAX * groups; p_ < nparts; p_ += groups) {          // more partials than the unrolled window (not with <= 256 statistics workgroups)
+      const f32x4 t = *reinterpret_cast<const f32x4*>(base + (size_t)p_ * stride);
+      a4[0] += t[0]; a4[1] += t[1]; a4[2] += t[2]; a4[3] += t[3];
+    }
+    if (g < groups) *reinterpret_cast<f32x4*>(fold + g * C + 4 * c4) = a4;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 1024) {
+      float t = 0.f;
+      for (int q = 0; q < groups; ++q) t += fold[q * C + c];
+      u[c] = t * inv_batch;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 1024) { u[c] = acc[s * C + c] * inv_batch; acc[s * C + c] = 0.f; }   // consumed: zero for the next write
+  }
+  float rate, cu, cb;
+  if (mode == 1) { rate = 0.01f; cu = 0.1f; cb = 1.0f; }
+  else { rate = cnt >= 1000 ? 0.01f : 0.005f; cu = 0.05f; cb = 0.5f; }
+  __syncthreads();
+  if (mode == 0 && threadIdx.x == 0) {                       // once per write, by the last workgroup: every workgroup has read the counter by then
+    int* ticket = reinterpret_cast<int*>(acc + (size_t)S * C);
+    if (atomicAdd(ticket, 1) == S - 1) { update_count[0] += 1; *ticket = 0; }
+  }
+  float uk[KW];
+#pragma unroll
+  for (int j = 0; j < KW; ++j) { const int k = lane + 64 * j; uk[j] = k < C ? u[k] : 0.f; }
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) part += uk[j] * w[i][j];
+    part = wave_sum(part);
+    const int c = wv + NWV * i;
+    if (lane == 0 && c < C) {
+      const float dk = fminf(fmaxf(part + bcr[i], -cu), cu);
+      const float dv = fminf(fmaxf(u[c], -cu), cu);
+      const float nk = fminf(fmaxf(okr[i] + rate * dk, -cb), cb), nv = fminf(fmaxf(ovr[i] + rate * dv, -cb), cb);
+      bank_k[s * C + c] = nk;
+      bank_v[s * C + c] = nv;
+      if (snap_k) { snap_k[s * C + c] = nk; snap_v[s * C + c] = nv; }
     }
   }
 }
@@ -264,16 +350,22 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
 
 extern "C" int qavit_bank_apply(float* acc, const float* Wc, const float* bc, float* bank_k, float* bank_v,
                                 int64_t* update_count, int S, int C, float inv_batch, int mode,
-                                const float* parts, int nparts, void* stream) {
+                                const float* parts, int nparts, float* snap_k, float* snap_v, void* stream) {
   if (!acc || !Wc || !bc || !bank_k || !bank_v || S <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "bank_apply: bad arguments");
   if (mode == 0 && !update_count) return set_error(QAVIT_EINVAL, "bank_apply: mode 0 needs update_count");
+  if ((snap_k == nullptr) != (snap_v == nullptr)) return set_error(QAVIT_EINVAL, "bank_apply: snap_k and snap_v come together");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (parts) {
-    if (nparts <= 0 || C % 4 || C / 4 > 1024 || (reinterpret_cast<uintptr_t>(parts) & 15)) return set_error(QAVIT_EINVAL, "bank_apply: partials need C % 4 == 0, 16-byte alignment");
+  if (parts && (nparts <= 0 || C % 4 || C / 4 > 1024 || (reinterpret_cast<uintptr_t>(parts) & 15)))
+    return set_error(QAVIT_EINVAL, "bank_apply: partials need C % 4 == 0, 16-byte alignment");
+  if (C <= 192 && C % 4 == 0) {
     const int groups = 1024 / (C / 4);
-    hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(1024), (size_t)(1 + groups) * C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode, parts, nparts);
+    hipLaunchKernelGGL(bank_apply192_kernel, dim3(S), dim3(1024), (size_t)(1 + groups) * C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C,
+                       inv_batch, mode, parts, nparts, snap_k, snap_v);
+  } else if (parts) {
+    const int groups = 1024 / (C / 4);
+    hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(1024), (size_t)(1 + groups) * C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode, parts, nparts, snap_k, snap_v);
   } else {
-    hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(256), (size_t)C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode, (const float*)nullptr, 0);
+    hipLaunchKernelGGL(bank_apply_kernel, dim3(S), dim3(256), (size_t)C * sizeof(float), st, acc, Wc, bc, bank_k, bank_v, update_count, S, C, inv_batch, mode, (const float*)nullptr, 0, snap_k, snap_v);
   }
   return check_launch("bank_apply");
 }

@@ -655,7 +655,8 @@ class BranchFn(Function):
         # the values its forward used (torch.cat made a copy), so snapshot shared rows that alias a parameter (as AttnFn does).
         sk_s, sv_s = sh_k, sh_v
         if sh_k.is_leaf and sh_v.is_leaf:
-            sk_s, sv_s = K.copy2(sh_k, sh_v)
+            snap = meta.get("bank_snap")                    # the copy the previous bank write left (qavit_bank_apply snap_*), else copy now
+            sk_s, sv_s = snap if snap is not None else K.copy2(sh_k, sh_v)
         ctx.sh_alias = (sh_k, sh_v)
         ctx.meta = meta
         ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o, *saved)
@@ -756,7 +757,8 @@ class AttnFn(Function):
         need = any(ctx.needs_input_grad)
         sk_s, sv_s = sh_k, sh_v
         if need and sh_k.is_leaf and sh_v.is_leaf:
-            sk_s, sv_s = K.copy2(sh_k, sh_v)
+            snap = s.get("bank_snap")
+            sk_s, sv_s = snap if snap is not None else K.copy2(sh_k, sh_v)
         elif need and (sh_k.is_leaf or sh_v.is_leaf):
             sk_s = sh_k.detach().clone() if sh_k.is_leaf else sh_k
             sv_s = sh_v.detach().clone() if sh_v.is_leaf else sh_v
@@ -1443,15 +1445,29 @@ class _Snapshot2Fn(Function):
         return dk, dv
 
 
-def bank_snapshot(bank):
+class _SnapshotGivenFn(Function):
+    """_Snapshot2Fn whose copies already exist (written by the bank write that produced the current rows)."""
+
+    @staticmethod
+    def forward(ctx, k, v, k_copy, v_copy):
+        return k_copy.view_as(k), v_copy.view_as(v)
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        return dk, dv, None, None
+
+
+def bank_snapshot(bank, snap=None):
     """The bank rows as the reference's ``Linear`` on the EXPANDED bank sees them: a copy taken now, so the weight gradient
     is computed against the forward-time bank although ``GlobalTokenBank.write`` mutates the parameter in place later in
-    the same forward (HQAViT_CIFAR100.py:576-577)."""
+    the same forward (HQAViT_CIFAR100.py:576-577).  ``snap``: that copy, if the last bank write already made it."""
+    if snap is not None and torch.is_grad_enabled():
+        return _SnapshotGivenFn.apply(bank.global_k, bank.global_v, snap[0], snap[1])
     return _Snapshot2Fn.apply(bank.global_k, bank.global_v)
 
 
 @torch.no_grad()
-def bank_write(tokens, norm_g, norm_b, bank, mode, sync=None):
+def bank_write(tokens, norm_g, norm_b, bank, mode, sync=None, want_snap=False):
     """GlobalTokenBank.write(norm(tokens)) -- see csrc/bank.hip.  ``bank`` is the GlobalTokenBank module.
     ``sync(acc)`` (optional) all-reduces the [S,C] batch sum across data-parallel ranks and returns the
     global batch size divisor."""
@@ -1468,6 +1484,8 @@ def bank_write(tokens, norm_g, norm_b, bank, mode, sync=None):
     total = B
     if sync is not None:
         total = sync(acc[: S * Cc], B)
+    snap = (torch.empty_like(bank.global_k.data), torch.empty_like(bank.global_v.data)) if want_snap else None
     K.bank_apply(acc, bank.write_compression.weight, bank.write_compression.bias, bank.global_k.data, bank.global_v.data,
                  getattr(bank, "update_count", None), S, Cc, 1.0 / float(total), mode,
-                 ws if fold_in_apply else None, n_ws // (S * Cc) if fold_in_apply else 0)
+                 ws if fold_in_apply else None, n_ws // (S * Cc) if fold_in_apply else 0, snap=snap)
+    return snap

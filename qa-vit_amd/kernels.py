@@ -446,9 +446,10 @@ def bank_ws_floats(B, N, Cc, S) -> int:
     return int(L.load().qavit_bank_ws_floats(B, N, Cc, S))
 
 
-def bank_apply(acc, Wc, bc, bank_k, bank_v, update_count, S, Cc, inv_batch, mode, parts=None, nparts=0):
+def bank_apply(acc, Wc, bc, bank_k, bank_v, update_count, S, Cc, inv_batch, mode, parts=None, nparts=0, snap=None):
     L.check(L.load().qavit_bank_apply(acc.data_ptr(), Wc.data_ptr(), bc.data_ptr(), bank_k.data_ptr(), bank_v.data_ptr(), _p(update_count),
-                                      S, Cc, inv_batch, mode, _p(parts), int(nparts), stream()), "bank_apply")
+                                      S, Cc, inv_batch, mode, _p(parts), int(nparts), _p(snap[0]) if snap else None, _p(snap[1]) if snap else None,
+                                      stream()), "bank_apply")
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -108,7 +108,7 @@ _SIGS = {
     "qavit_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_bank_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]),
     "qavit_bank_ws_floats": (i64, [i32, i32, i32, i32]),
-    "qavit_bank_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp]),
+    "qavit_bank_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp, vp, vp]),
     "qavit_patchify": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_token_mean_fwd": (i32, [i32, vp, vp, i32, i32, i32, vp]),
     "qavit_token_mean_bwd": (i32, [i32, vp, vp, i32, i32, i32, vp]),

@@ -33,6 +33,10 @@ class _Ctx:
         self.bank_mode = 1 if variant == "v1" else 0
         self.bank_sync = None          # callable(acc, local_batch) -> global batch (set by parallel.DataParallel)
         self.bank_writes = True
+        # inside a QuadAttentionBlock.forward: the (k, v) copy the last bank write left beside the parameter (qavit_bank_apply snap_*),
+        # i.e. what the next branch's backward must see -- saves that branch its own snapshot launch
+        self.in_block = False
+        self.snap = None
 
 
 class GlobalTokenBank(nn.Module):
@@ -67,7 +71,13 @@ class _Branch(nn.Module):
     def _write(self, out):
         rt = self._rt
         if self.training and rt.bank_writes and hasattr(self, "norm"):
-            F.bank_write(out, self.norm.weight, self.norm.bias, self.global_bank, rt.bank_mode, rt.bank_sync)
+            rt.snap = F.bank_write(out, self.norm.weight, self.norm.bias, self.global_bank, rt.bank_mode, rt.bank_sync,
+                                   want_snap=rt.in_block and torch.is_grad_enabled())
+
+    def _snap(self):
+        """Forward-time copy of the bank rows if the previous branch of this block left one (else the consumer copies)."""
+        rt = self._rt
+        return rt.snap if rt.in_block else None
 
 
 class EfficientSpatialWindowAttention(_Branch):
@@ -109,7 +119,7 @@ class EfficientSpatialWindowAttention(_Branch):
             # one window = the image's tokens: the whole branch is one launch (csrc/branch_fwd.hip)
             out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
                                    self.global_bank.global_k, self.global_bank.global_v,
-                                   dict(kind=0, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+                                   dict(kind=0, attn_drop=(p, self._site_attn), proj_drop=(p, self._site), bank_snap=self._snap()))
             self._write(out)
             return out
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias).reshape(B * N, 3 * C)
@@ -118,6 +128,7 @@ class EfficientSpatialWindowAttention(_Branch):
                     q_rows_per_b=N, k_rows_per_b=N, q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=C, v_off=2 * C, q_rows=B * N)
         p = self.dropout.p if self.training else 0.0
         spec["drop"] = (p, self._site_attn)                    # efficient_attention(q, k, v, self.dropout.p, self.training), :461
+        spec["bank_snap"] = self._snap()
         o = F.AttnFn.apply(qkv, None, self.linformer.E_k, self.linformer.E_v,
                            self.global_bank.global_k, self.global_bank.global_v, spec)
         out = F.linear(o.reshape(B, N, C), self.proj.weight, self.proj.bias, drop=(p, self._site))
@@ -165,7 +176,8 @@ class EfficientMultiScaleDilatedAttention(_Branch):
         if same and NP <= 16 and F.branch_ok(1, x, NP, self.linformer.compressed_len, self.global_bank.bank_size, self.num_heads):
             out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
                                    self.global_bank.global_k, self.global_bank.global_v,
-                                   dict(kind=1, pool_idx=idx, pool_stride=stride, Lk=NP, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+                                   dict(kind=1, pool_idx=idx, pool_stride=stride, Lk=NP, attn_drop=(p, self._site_attn), proj_drop=(p, self._site),
+                                        bank_snap=self._snap()))
             self._write(out)
             return out
         pooled = F.GatherPoolFn.apply(x, idx, stride)
@@ -177,6 +189,7 @@ class EfficientMultiScaleDilatedAttention(_Branch):
                     q_off=0, k_off=0, v_off=C, q_rows=B * N)
         p = self.dropout.p if self.training else 0.0
         spec["drop"] = (p, self._site_attn)                    # :524
+        spec["bank_snap"] = self._snap()
         o = F.AttnFn.apply(q, kv, self.linformer.E_k, self.linformer.E_v,
                            self.global_bank.global_k, self.global_bank.global_v, spec)
         out = F.linear(o.reshape(B, N, C), self.proj.weight, self.proj.bias, drop=(p, self._site))
@@ -212,7 +225,7 @@ class EfficientChannelGroupAttention(_Branch):
         bank = self.global_bank
         # .clone(): the reference's Linear flattens the EXPANDED bank, which copies -- its weight gradient sees the
         # forward-time bank, not the in-place writes that follow (HQAViT_CIFAR100.py:576-577)
-        gk, gv = F.bank_snapshot(bank)
+        gk, gv = F.bank_snapshot(bank, self._snap())
         sh_k = F.linear(gk, self.bank_k_proj.weight, self.bank_k_proj.bias).reshape(bank.bank_size, ccg)
         sh_v = F.linear(gv, self.bank_v_proj.weight, self.bank_v_proj.bias).reshape(bank.bank_size, ccg)
         tbl = K.Runtime.get(x.device).table(("cga", N, G), lambda: [n * G + g for g in range(G) for n in range(N)])
@@ -242,7 +255,7 @@ class CrossAttentionBranch(_Branch):
     def forward(self, x):
         B, N, C = x.shape
         bank = self.global_bank
-        gk, gv = F.bank_snapshot(bank)                                                                         # see CGA
+        gk, gv = F.bank_snapshot(bank, self._snap())                                                           # see CGA
         sh_k = F.linear(gk, self.k_proj.weight, self.k_proj.bias).reshape(bank.bank_size, C)
         sh_v = F.linear(gv, self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
         p = self.dropout.p if self.training else 0.0
@@ -354,6 +367,14 @@ class QuadAttentionBlock(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         tr = self.training
+        rt = self._rt
+        rt.in_block, rt.snap = True, None
+        try:
+            return self._forward(x, B, N, C, tr)
+        finally:
+            rt.in_block, rt.snap = False, None
+
+    def _forward(self, x, B, N, C, tr):
         # xr = x again, for the residual: its gradient joins norm1's inside the LayerNorm-backward kernel
         xn, xr = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, alias=True)
         # norm1's output feeds four branches (MSDA twice): one k-way gradient sum instead of autograd's pairwise adds
