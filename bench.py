@@ -335,7 +335,9 @@ def main():
         mfma_bound = (tfl / peak_fl) >= (gbs / PEAK_HBM_GBS)
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        # the committed counter passes were taken on the default workload (C100, B = 1024, bf16): null for anything else
+        default_workload = args.config == "c100" and args.batch == 1024 and args.dtype == "bf16"
+        if os.path.exists(tp) and default_workload:
             try:
                 traffic = json.load(open(tp)).get(name)
                 if isinstance(traffic, dict):            # HBM bytes per launch from the rocprofv3 PMC passes (tools/pmc_traffic.py)
@@ -345,7 +347,7 @@ def main():
         # MFMA utilisation from hardware counters (rocprofv3 --pmc pass folded by tools/pmc_mfma.py into profiles/mfma_util.json)
         mfma_util = None
         mp = os.path.join(ROOT, "profiles", "mfma_util.json")
-        if os.path.exists(mp):
+        if os.path.exists(mp) and default_workload:
             try:
                 mj = json.load(open(mp))
                 mfma_util = {k: v["mfma_util_pct"] for k, v in mj.items() if isinstance(v, dict) and "mfma_util_pct" in v}

@@ -535,17 +535,15 @@ static int skinny_try(const qavit_gemm_args& g, hipStream_t st) {
 constexpr int TN_MC = 64;   // rows of M per staged chunk
 
 template <typename T>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(qavit_gemm_tn_args g, int rows_per_split) {
+__device__ __forceinline__ void gemm_tn_body(const qavit_gemm_tn_args& g, T* At, T* Bt, int bx, int by, int bz, int rows_per_split) {
   using M_ = Mma<T>;
   constexpr int VN = Vec<T>::N;
   constexpr int FK = M_::FK;
   constexpr int LDT = TN_MC + VN;                     // LDS row stride (elements); m is the contiguous axis
-  __shared__ __attribute__((aligned(16))) T At[64 * LDT];   // [n][m]
-  __shared__ __attribute__((aligned(16))) T Bt[64 * LDT];   // [k][m]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int mbeg = blockIdx.z * rows_per_split;
+  const int n0 = bx * 64, k0 = by * 64;
+  const int mbeg = bz * rows_per_split;
   const int mend = (mbeg + rows_per_split < g.M) ? mbeg + rows_per_split : g.M;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
@@ -587,7 +585,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(qavit_gemm_tn_arg
       }
     }
     __syncthreads();
-    if (g.colsum && blockIdx.y == 0 && tid < 64) {
+    if (g.colsum && by == 0 && tid < 64) {
       float s = 0.f;
 #pragma unroll 8
       for (int m = 0; m < TN_MC; ++m) s += to_f<T>(At[tid * LDT + m]);
@@ -611,7 +609,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(qavit_gemm_tn_arg
       const int n = n0 + wave * 16 + fq * 4 + r, k = k0 + j * 16 + fr;
       if (n < g.N && k < g.K) atomic_add_f(g.C + (size_t)n * g.ldc + k, acc[j][r]);
     }
-  if (g.colsum && blockIdx.y == 0 && tid < 64 && n0 + tid < g.N) atomic_add_f(g.colsum + n0 + tid, csum);
+  if (g.colsum && by == 0 && tid < 64 && n0 + tid < g.N) atomic_add_f(g.colsum + n0 + tid, csum);
+}
+
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(qavit_gemm_tn_args g, int rows_per_split) {
+  constexpr int LDT = TN_MC + Vec<T>::N;
+  __shared__ __attribute__((aligned(16))) T At[64 * LDT];   // [n][m]
+  __shared__ __attribute__((aligned(16))) T Bt[64 * LDT];   // [k][m]
+  gemm_tn_body<T>(g, At, Bt, blockIdx.x, blockIdx.y, blockIdx.z, rows_per_split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +771,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_bf16_grouped_kernel(TnGr
   gemm_tn_bf16_body(G.p[i], At, Bt, bx, by, bz, G.rows[i]);
 }
 
+// the fp32 problems of a flush (the M = 16 bank-projection weight gradients of the cross / channel-group branches: 32 per step,
+// each a 5 us launch of its own before) share a grid the same way
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_f32_grouped_kernel(TnGroup G) {
+  constexpr int LDT = TN_MC + Vec<float>::N;
+  __shared__ __attribute__((aligned(16))) float At[64 * LDT];
+  __shared__ __attribute__((aligned(16))) float Bt[64 * LDT];
+  const int bid = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < TN_GROUP; ++j) if (j < G.n && bid >= G.wg_start[j]) i = j;
+  const int local = bid - G.wg_start[i];
+  const int tiles = G.tn[i] * G.tk[i];
+  const int bz = local / tiles, t = local - bz * tiles;
+  const int by = t / G.tn[i], bx = t - by * G.tn[i];
+  gemm_tn_body<float>(G.p[i], At, Bt, bx, by, bz, G.rows[i]);
+}
+
 static void tn_split_plan(const qavit_gemm_tn_args& g, int budget, int& tn, int& tk, int& splits, int& rows) {
   tn = (g.N + 63) / 64; tk = (g.K + 63) / 64;
   splits = g.splits;
@@ -887,11 +910,30 @@ extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* s
     // the single-problem path.
     const int rc = gemm_tn_wide(a, n, st);
     if (rc) return rc;
+    TnGroup G;
+    G.n = 0;
+    int wg = 0;
+    auto flush_f32 = [&]() {
+      if (G.n == 0) return;
+      G.wg_start[G.n] = wg;
+      hipLaunchKernelGGL(gemm_tn_f32_grouped_kernel, dim3(wg), dim3(GEMM_THREADS), 0, st, G);
+      G.n = 0; wg = 0;
+    };
     for (int i = 0; i < n; ++i) {
       if (a[i].dtype == QAVIT_BF16 && gemm_tn_wide_ok(a[i])) continue;
-      const int rc2 = a[i].dtype == QAVIT_BF16 ? launch_gemm_tn<bf16>(a[i], st) : launch_gemm_tn<float>(a[i], st);
-      if (rc2) return rc2;
+      if (a[i].dtype == QAVIT_BF16) {
+        const int rc2 = launch_gemm_tn<bf16>(a[i], st);
+        if (rc2) return rc2;
+        continue;
+      }
+      int tn, tk, splits, rows;
+      tn_split_plan(a[i], 64, tn, tk, splits, rows);
+      G.p[G.n] = a[i]; G.tn[G.n] = tn; G.tk[G.n] = tk; G.rows[G.n] = rows; G.wg_start[G.n] = wg;
+      wg += tn * tk * splits;
+      if (++G.n == TN_GROUP) flush_f32();
     }
+    flush_f32();
+    if (int rc3 = check_launch("gemm_tn_grouped(f32)")) return rc3;
     return QAVIT_OK;
   }
   int done = 0;
