@@ -471,16 +471,17 @@ static int dispatch_gemm_nt(const qavit_gemm_args& g, hipStream_t st, const qavi
 // through LDS first: 12 us for 1.2 MFLOP).  Plain epilogue (bias) only.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KB>   // KB = K / FK fragment blocks (compile-time so the loads unroll)
-__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(qavit_gemm_args g) {
+__device__ __forceinline__ void gemm_nt_skinny_body(const qavit_gemm_args& g, int bx) {
   using M_ = Mma<T>;
   constexpr int FK = M_::FK, VN = Vec<T>::N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  const int n0 = (bx * 4 + wave) * 16;
   if (n0 >= g.N) return;                                 // whole wave
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
   T* C = reinterpret_cast<T*>(g.C);
+  const T* R = reinterpret_cast<const T*>(g.R);
   const int am = fr < g.M ? fr : g.M - 1;                // clamped rows: loads stay in bounds, extra rows/cols are not stored
   const int bn = n0 + fr < g.N ? n0 + fr : g.N - 1;
   typename M_::frag af[KB], bf_[KB];
@@ -498,22 +499,54 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(qavit_gemm_args g) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = fq * 4 + r;
-      if (m < g.M) C[(size_t)m * g.ldc + n] = from_f<T>(acc[r] + bv);
+      if (m < g.M) {
+        float v = acc[r] + bv;
+        if (R) v += to_f<T>(R[(size_t)m * g.ldr + n]);   // residual (may alias C: same element, same thread)
+        C[(size_t)m * g.ldc + n] = from_f<T>(v);
+      }
     }
   }
 }
 
+template <typename T, int KB>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(qavit_gemm_args g) { gemm_nt_skinny_body<T, KB>(g, blockIdx.x); }
+
+// up to 4 same-shape skinny problems in one grid (blockIdx.y = problem): the K and V projections of the bank, forward and backward
+struct SkinnyGroup { qavit_gemm_args p[4]; };
+template <typename T, int KB>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_group_kernel(SkinnyGroup G) { gemm_nt_skinny_body<T, KB>(G.p[blockIdx.y], blockIdx.x); }
+
 template <typename T>
-static int skinny_try(const qavit_gemm_args& g, hipStream_t st) {
+static bool skinny_ok(const qavit_gemm_args& g) {
   constexpr int FK = Mma<T>::FK, VN = Vec<T>::N;
+  if (g.M > 16 || g.a_mode != 0 || g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.scale != 1.f) return false;
+  if (g.K % FK || g.lda % VN || g.ldb % VN || ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15)) return false;
+  const int kb = g.K / FK;
+  return kb == 1 || kb == 2 || kb == 3 || kb == 4 || kb == 6 || kb == 8 || kb == 12;
+}
+
+template <typename T>
+static int skinny_try(const qavit_gemm_args& g, hipStream_t st, const qavit_gemm_args* grp = nullptr, int ng = 0) {
+  constexpr int FK = Mma<T>::FK;
   static int on = -1;
   if (on < 0) { const char* e = getenv("QAVIT_GEMM_SKINNY"); on = e ? atoi(e) : 1; }
   if (!on) return 0;
-  if (g.M > 16 || g.a_mode != 0 || g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f) return 0;
-  if (g.K % FK || g.lda % VN || g.ldb % VN || ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15)) return 0;
+  if (!skinny_ok<T>(g)) return 0;
+  SkinnyGroup G;
+  if (grp) {
+    if (ng > 4) return 0;
+    for (int i = 0; i < ng; ++i) {
+      if (!skinny_ok<T>(grp[i]) || grp[i].K != g.K || grp[i].N != g.N) return 0;
+      G.p[i] = grp[i];
+    }
+  }
   const int kb = g.K / FK;
   const int grid = (g.N + 63) / 64;
-#define SKINNY(KB_) hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, KB_>), dim3(grid), dim3(256), 0, st, g)
+#define SKINNY(KB_)                                                                                                   \
+  do {                                                                                                                \
+    if (grp) hipLaunchKernelGGL((gemm_nt_skinny_group_kernel<T, KB_>), dim3(grid, ng), dim3(256), 0, st, G);          \
+    else hipLaunchKernelGGL((gemm_nt_skinny_kernel<T, KB_>), dim3(grid), dim3(256), 0, st, g);                        \
+  } while (0)
   switch (kb) {
     case 1: SKINNY(1); break;
     case 2: SKINNY(2); break;
@@ -874,6 +907,15 @@ extern "C" int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stre
   for (int i = 1; i < n && same; ++i)
     same = a[i].dtype == a[0].dtype && a[i].M == a[0].M && a[i].N == a[0].N && a[i].K == a[0].K && a[i].a_mode == a[0].a_mode && kind(a[i]) == kind(a[0]);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n >= 2 && n <= 4 && a[0].M <= 16 && (a[0].dtype == QAVIT_F32 || a[0].dtype == QAVIT_BF16)) {
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) ok = a[i].A && a[i].B && a[i].C && a[i].M > 0 && a[i].dtype == a[0].dtype && a[i].lda >= a[i].K && a[i].ldb >= a[i].K && a[i].ldc >= a[i].N;
+    if (ok) {
+      const int took = a[0].dtype == QAVIT_F32 ? skinny_try<float>(a[0], st, a, n) : skinny_try<bf16>(a[0], st, a, n);
+      if (took < 0) return took;
+      if (took == 1) return QAVIT_OK;
+    }
+  }
   const bool big = a[0].dtype == QAVIT_BF16 && a[0].N >= 64 && a[0].K >= 96 && a[0].M >= 1024;     // K-loop kernel territory
   if (!same || n == 1 || big || a[0].M <= 16) {
     for (int i = 0; i < n; ++i) { const int rc = qavit_gemm_nt(a + i, stream); if (rc) return rc; }

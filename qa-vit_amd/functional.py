@@ -1445,6 +1445,72 @@ class _Snapshot2Fn(Function):
         return dk, dv
 
 
+class BankProj2Fn(Function):
+    """(sh_k, sh_v) = (Linear_k(bank_k), Linear_v(bank_v)): the batch-invariant K / V projections of the bank in the cross-attention
+    and channel-group branches (HQAViT_CIFAR100.py:576-577, :613-616; the reference applies the Linear to the EXPANDED bank).  One
+    grouped launch forward, one backward (two M = 16 GEMMs each were a launch of their own), the weight gradients see the
+    forward-time bank (``snap``: the copy the last bank write left, else taken here) and the bank rows' own gradient is accumulated
+    into the parameters' ``.grad`` by the input-gradient GEMM's residual epilogue -- no snapshot node, no AccumulateGrad adds."""
+
+    @staticmethod
+    def forward(ctx, gk, gv, snap_k, snap_v, wk, bk, wv, bv):
+        K._require_cuda(gk, wk)
+        S, Cc = gk.shape[-2], gk.shape[-1]
+        need = any(ctx.needs_input_grad)
+        if need and snap_k is None:
+            snap_k, snap_v = K.copy2(gk, gv)
+        xk, xv = gk.detach().reshape(S, Cc), gv.detach().reshape(S, Cc)
+        pk = pack_for(gk.device)
+        Wk, _ = pk.get(wk, gk.dtype)
+        Wv, _ = pk.get(wv, gk.dtype)
+        nk, nv = wk.shape[0], wv.shape[0]
+        yk = torch.empty(S, nk, dtype=gk.dtype, device=gk.device)
+        yv = torch.empty(S, nv, dtype=gk.dtype, device=gk.device)
+        K.gemm_nt_grouped([K.gemm_nt(xk, Wk, yk, S, nk, Cc, Cc, Cc, nk, None if bk is None else bk.detach(), build_only=True),
+                           K.gemm_nt(xv, Wv, yv, S, nv, Cc, Cc, Cc, nv, None if bv is None else bv.detach(), build_only=True)])
+        if need:
+            ctx.save_for_backward(gk, gv, snap_k, snap_v, wk, bk, wv, bv)
+        return yk, yv
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        gk, gv, snap_k, snap_v, wk, bk, wv, bv = ctx.saved_tensors
+        S, Cc = gk.shape[-2], gk.shape[-1]
+        nk, nv = wk.shape[0], wv.shape[0]
+        dk2 = dk.reshape(S, nk).contiguous()
+        dv2 = dv.reshape(S, nv).contiguous()
+        pk = pack_for(gk.device)
+        outs = [None, None]
+        probs = []
+        for i, (g_, d2, w, n) in enumerate(((gk, dk2, wk, nk), (gv, dv2, wv, nv))):
+            if not g_.requires_grad:
+                continue
+            _, Wt = pk.get(w, gk.dtype)
+            sink, ret = grad_sink(g_)
+            dst = sink.reshape(S, Cc)
+            # dst = d2 @ W + dst: the residual epilogue reads and writes the same element in one thread
+            probs.append(K.gemm_nt(d2, Wt, dst, S, Cc, n, n, Wt.shape[1], Cc, None, R=dst, ldr=Cc, build_only=True))
+            outs[i] = ret
+        if probs:
+            K.gemm_nt_grouped(probs)
+        DeferDW.arm()
+        for (x_s, d2, w, b, n) in ((snap_k, dk2, wk, bk, nk), (snap_v, dv2, wv, bv, nv)):
+            wbuf, _ = grad_sink(w)
+            bbuf, _ = grad_sink(b)
+            if wbuf is None and bbuf is None:
+                continue
+            if wbuf is None:
+                wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+            K.gemm_tn(d2, x_s.reshape(S, Cc), wbuf, S, n, Cc, n, Cc, Cc, bbuf)
+        return outs[0], outs[1], None, None, None, None, None, None
+
+
+def bank_proj2(bank, snap, lin_k, lin_v):
+    """-> (Linear_k(bank.global_k), Linear_v(bank.global_v)) as [S, n] matrices; see BankProj2Fn."""
+    sk, sv = snap if snap is not None else (None, None)
+    return BankProj2Fn.apply(bank.global_k, bank.global_v, sk, sv, lin_k.weight, lin_k.bias, lin_v.weight, lin_v.bias)
+
+
 class _SnapshotGivenFn(Function):
     """_Snapshot2Fn whose copies already exist (written by the bank write that produced the current rows)."""
 

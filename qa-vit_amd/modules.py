@@ -10,6 +10,8 @@ Reference: HQAViT_CIFAR100.py:256-1138 (HQA blocks), QAViT.py:161-651 (v1), QAVi
 import math
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as TF
@@ -20,6 +22,9 @@ from . import kernels as K
 
 def _hw(n: int) -> int:
     return int(math.sqrt(n))
+
+
+_BANK_PROJ2 = os.environ.get("QAVIT_BANK_PROJ2", "1") != "0"
 
 
 class _Ctx:
@@ -225,9 +230,12 @@ class EfficientChannelGroupAttention(_Branch):
         bank = self.global_bank
         # .clone(): the reference's Linear flattens the EXPANDED bank, which copies -- its weight gradient sees the
         # forward-time bank, not the in-place writes that follow (HQAViT_CIFAR100.py:576-577)
-        gk, gv = F.bank_snapshot(bank, self._snap())
-        sh_k = F.linear(gk, self.bank_k_proj.weight, self.bank_k_proj.bias).reshape(bank.bank_size, ccg)
-        sh_v = F.linear(gv, self.bank_v_proj.weight, self.bank_v_proj.bias).reshape(bank.bank_size, ccg)
+        if _BANK_PROJ2 and x.is_cuda and bank.global_k.dtype == torch.float32:
+            sh_k, sh_v = F.bank_proj2(bank, self._snap(), self.bank_k_proj, self.bank_v_proj)
+        else:
+            gk, gv = F.bank_snapshot(bank, self._snap())
+            sh_k = F.linear(gk, self.bank_k_proj.weight, self.bank_k_proj.bias).reshape(bank.bank_size, ccg)
+            sh_v = F.linear(gv, self.bank_v_proj.weight, self.bank_v_proj.bias).reshape(bank.bank_size, ccg)
         tbl = K.Runtime.get(x.device).table(("cga", N, G), lambda: [n * G + g for g in range(G) for n in range(N)])
         spec = dict(mode=1, G=B * G, Nq=N, L=N, H=H, D=ccg // H, S=bank.bank_size, groups_per_b=G,
                     q_rows_per_b=N * G, k_rows_per_b=N * G, q_tbl=tbl, k_tbl=tbl, q_off=0, k_off=ccg, v_off=2 * ccg,
@@ -255,9 +263,12 @@ class CrossAttentionBranch(_Branch):
     def forward(self, x):
         B, N, C = x.shape
         bank = self.global_bank
-        gk, gv = F.bank_snapshot(bank, self._snap())                                                           # see CGA
-        sh_k = F.linear(gk, self.k_proj.weight, self.k_proj.bias).reshape(bank.bank_size, C)
-        sh_v = F.linear(gv, self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
+        if _BANK_PROJ2 and x.is_cuda and bank.global_k.dtype == torch.float32:
+            sh_k, sh_v = F.bank_proj2(bank, self._snap(), self.k_proj, self.v_proj)                            # see CGA
+        else:
+            gk, gv = F.bank_snapshot(bank, self._snap())
+            sh_k = F.linear(gk, self.k_proj.weight, self.k_proj.bias).reshape(bank.bank_size, C)
+            sh_v = F.linear(gv, self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
         p = self.dropout.p if self.training else 0.0
         if F.branch_ok(2, x, 0, 0, bank.bank_size, self.num_heads):
             return F.BranchFn.apply(x, self.q_proj.weight, self.q_proj.bias, self.proj.weight, self.proj.bias, None, None, sh_k, sh_v,
