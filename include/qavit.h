@@ -130,8 +130,9 @@ int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
  * same-address float atomics this replaces were ~45 % of the kernel at 16k rows. */
 int qavit_layernorm_bwd_parts(int rows, int C);
 typedef struct qavit_ln_reduce_desc {
-  const float* parts; int nparts; int C;     /* [nparts][2][C] */
-  float* dgamma; float* dbeta;               /* += (either may be NULL) */
+  const float* parts; int nparts; int C;     /* nparts rows of [2][C] (C % 4 == 0, C <= 2048) ... */
+  float* dgamma; float* dbeta;               /* += the two halves of the summed row (either may be NULL) */
+  int64_t stride;                            /* ... `stride` floats apart (0: 2*C, dense; else a multiple of 4) */
 } qavit_ln_reduce_desc;
 int qavit_ln_param_reduce(const qavit_ln_reduce_desc* d, int n, void* stream);
 
@@ -297,6 +298,38 @@ int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream);
 int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Fused branch BACKWARD, first half (csrc/branch_bwd.hip): the proj input-gradient GEMM and the attention-core backward of a
+ * branch that went forward through qavit_branch_fwd with q_save / kv_save / o_save, in one launch (it replaces qavit_gemm_nt on
+ * Wproj^T, qavit_attn_bwd and its reduction).  Same fixed shapes as qavit_branch_args; bf16 only.
+ *   in : dout [B*T, C] (gradient of the branch output), wprojT_frag = the proj weight TRANSPOSED in fragment order
+ *        (qavit_pack_desc.pad = 3), q / k_tok / v_tok / o as saved by the forward (k_tok, v_tok: kv_rows rows per image, NULL for
+ *        kind 2), E_k / E_v / sh_k / sh_v with their FORWARD-TIME values, the two dropout (p, site) pairs and rng of the forward.
+ *   out: dz = dout * proj-dropout mask (operand of dW_proj; may be NULL when proj_drop_p == 0: dz == dout), dq [B*T, *],
+ *        dk_tok / dv_tok [B*kv_rows, *] (the caller runs the qkv input-gradient GEMM and the weight-gradient GEMMs on them),
+ *        parts: qavit_branch_bwd_parts(B) rows of parts_stride >= QAVIT_BRANCH_PARTS_FLOATS floats, one per workgroup:
+ *        [ dE_k 16x32 | dE_v 16x32 | d sh_k 16x192 | d sh_v 16x192 ] partial sums (plain stores; fold the rows with
+ *        qavit_ln_param_reduce, stride = parts_stride).  Kind 2 leaves the dE part unwritten.
+ * ------------------------------------------------------------------------------------------------- */
+#define QAVIT_BRANCH_PARTS_FLOATS 7168
+typedef struct qavit_branch_bwd_args {
+  int dtype; int kind;
+  int B, T, C, H, D, KC, S, L;
+  const void* dout; int64_t lddout;
+  const void* wprojT_frag;
+  const void* q; int64_t ldq;
+  const void* k_tok; const void* v_tok; int64_t ldkv; int kv_rows;
+  const void* o; int64_t ldo;
+  const float* E_k; const float* E_v; const float* sh_k; const float* sh_v;
+  float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
+  void* dz; int64_t lddz;
+  void* dq; int64_t lddq;
+  void* dk_tok; void* dv_tok; int64_t lddkv;
+  float* parts; int64_t parts_stride;
+} qavit_branch_bwd_args;
+int qavit_branch_bwd_parts(int B);
+int qavit_branch_bwd(const qavit_branch_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Depthwise k x k convolution, stride 1, pad k/2, on channel-last tokens x[B, H*W, C] (k in {3,5,7}):
  * ConvNeXtBlock.dwconv (HQAViT_CIFAR100.py:722, dw7x7), LMFAdapter.dwconv_3x3 / dwconv_5x5 (:811-812).
  * w is the nn.Conv2d weight [C,1,k,k] fp32; bias [C] or NULL.  bwd: dx, dw += , dbias += (fp32 atomics).
@@ -410,6 +443,8 @@ int qavit_chan_scale_add_bwd(int dtype, const void* dy, const void* u, const flo
 /* y = dropout(x) (pos_drop, HQAViT_CIFAR100.py:1251); bwd is the same call on dy */
 int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream);
 /* packed weights: dst = cast(src) and dstT = cast(src)^T for 2-D [rows, cols] fp32 params; descriptor table on device.
+ * pad = 3: as pad = 1 for the TRANSPOSE of src (fragment (t, s) = rows 16 t.. of src^T, i.e. columns of src; rows % 32 == 0,
+ * cols % 16 == 0): the operand image of a GEMM that contracts over src's rows (csrc/branch_bwd.hip).
  * pad = 1: dst is written in MFMA FRAGMENT order for v_mfma_f32_16x16x32_bf16 instead of row-major (rows % 16 == 0,
  * cols % 32 == 0): the 16-row x 32-column fragment (t, s) is 1 KB at ((t * (cols/32) + s) * 512) elements, and inside it
  * lane l's 8 elements are src[16 t + l % 16][32 s + 8 (l / 16) .. + 8] -- a wave reads it with one 16-byte load per lane,

@@ -1,0 +1,63 @@
+// Shared by the fused branch kernels (branch_fwd.hip, branch_bwd.hip): tile geometry, the weight-chunk ring (global_load_lds into
+// fragment order, counted vmcnt + raw barrier) and small register helpers.  See branch_fwd.hip for the design.
+#pragma once
+#include "common.cuh"
+#include "frag16.cuh"
+
+namespace qv {
+
+namespace {
+
+constexpr int BT = 16, BC = 192, BD = 48, BH = 4;          // tokens per image, channels, head dim, heads
+constexpr int NI = 4;                                      // images per workgroup tile
+constexpr int NW = 8;                                      // waves per workgroup
+constexpr int NIW = 2;                                     // images per wave in the QKV / attention phase
+constexpr int KST = BC / 32;                               // k-steps of 32
+constexpr int CT = BC / 16;                                // 16-row MFMA tiles of a 192-row weight block: fragments per chunk
+constexpr int CHUNK_BYTES = CT * 1024;                     // 12288
+constexpr int RING = 5, AHEAD = 4;                         // ring slots; chunks in flight incl. the one being consumed (the slot chunk c + AHEAD
+                                                           // lands in was consumed in iteration c - 1, behind this iteration's barrier)
+constexpr int GLDS_PER_CHUNK = 2;                          // LDS-DMA instructions per wave per chunk (12 fragments + 4 repeats over 8 waves)
+constexpr int LDB = BC + 8, LDO = BC + 8;                  // shared bank tiles [16][LDB]; per-image O / output tiles [16][LDO]
+constexpr int SM_BANK = RING * CHUNK_BYTES, SM_BIAS = SM_BANK + 2 * 16 * LDB * 2, SM_OUT = SM_BIAS + 4 * BC * 4,
+              OUT_BYTES = 16 * LDO * 2, SM_X = SM_OUT + NI * OUT_BYTES, SM_P = SM_X + NI * OUT_BYTES;
+// 61440 ring + 12800 bank + 3072 biases + 25600 O / output tiles + 25600 token tiles (+ 25600 landmark tiles, MSDA) = 128512 (154112) bytes
+constexpr int sm_total(int kind) { return kind == 1 ? SM_P + NI * OUT_BYTES : SM_P; }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ bf16x4 cvt4(const f32x4& acc) {
+  bf16x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (bf16)acc[r];
+  return v;
+}
+__device__ __forceinline__ bool nan4(const f32x4& v) { return (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]); }
+__device__ __forceinline__ f32x4 mma16b(bf16x4 a, bf16x4 b, f32x4 c) { return mma16(as_s16(a), as_s16(b), c); }
+
+// chunk = the 12 fragments {(tile t0 + j, k-step s)} of a fragment-packed [*, 192] weight (fragment (t, s) sits at (t * KST + s)
+// KB).  Wave w fetches j = w and j = w + 8 (waves 4..7: fragment 11 again, same bytes), so every wave issues exactly
+// GLDS_PER_CHUNK instructions and a counted `s_waitcnt vmcnt(2 k)` means "all but the k newest chunks have landed" for all.
+__device__ __forceinline__ void issue_chunk(const char* wpacked, int t0, int s, char* slot, int wave, int lane) {
+#pragma unroll
+  for (int f = 0; f < GLDS_PER_CHUNK; ++f) {
+    int j = wave + 8 * f;
+    j = j < CT ? j : CT - 1;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(wpacked + (size_t)((t0 + j) * KST + s) * 1024 + lane * 16), (lds_void_t*)(slot + j * 1024), 16, 0, 0);
+  }
+}
+// `newer` = chunks issued after the one about to be consumed (0 .. AHEAD-1).  This wave's share of it has landed once at most
+// those are outstanding; the barrier makes it true for all waves.
+__device__ __forceinline__ void ring_wait(int newer) {     // called with unrolled-loop constants: the chain folds
+  if (newer >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (newer == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (newer == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace
+
+}  // namespace qv

@@ -300,27 +300,32 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_multi_kernel(LnBwd4 
 // dgamma / dbeta += sum over the partial rows a layernorm_bwd launch left in ``parts`` ([nparts][2][C]): one workgroup per LayerNorm,
 // threads = (group, 4-float vector of the 2C-wide row), groups stride over the rows with four loads in flight, LDS fold, then ONE
 // atomic per channel (atomic because a shared parameter may collect from several LayerNorm calls).
-struct LnReduceGroup { int n; qavit_ln_reduce_desc d[64]; };
+struct LnReduceGroup { int n; qavit_ln_reduce_desc d[48]; };
+constexpr int LNR_SLICE = 32;                              // partial rows per workgroup (blockIdx.y = slice)
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnReduceGroup G) {
   __shared__ __attribute__((aligned(16))) float fold[4096];
   const qavit_ln_reduce_desc d = G.d[blockIdx.x];
+  const int p0 = blockIdx.y * LNR_SLICE;
+  if (p0 >= d.nparts) return;                              // uniform per workgroup
+  const int p1 = p0 + LNR_SLICE < d.nparts ? p0 + LNR_SLICE : d.nparts;
   const int W = 2 * d.C, V = W >> 2, groups = 1024 / V;
+  const size_t RS = d.stride > 0 ? (size_t)d.stride : (size_t)W;          // floats between partial rows
   const int g = threadIdx.x / V, v = threadIdx.x - g * V;
   if (g < groups) {
     f32x4 a[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* base = d.parts + 4 * v;
-    int p = g;
-    for (; p + 3 * groups < d.nparts; p += 4 * groups) {
+    int p = p0 + g;
+    for (; p + 3 * groups < p1; p += 4 * groups) {
       f32x4 t[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const f32x4*>(base + (size_t)(p + q * groups) * W);
+      for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const f32x4*>(base + (size_t)(p + q * groups) * RS);
 #pragma unroll
       for (int q = 0; q < 4; ++q) { a[q][0] += t[q][0]; a[q][1] += t[q][1]; a[q][2] += t[q][2]; a[q][3] += t[q][3]; }
     }
-    for (; p < d.nparts; p += groups) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(base + (size_t)p * W);
+    for (; p < p1; p += groups) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(base + (size_t)p * RS);
       a[0][0] += t[0]; a[0][1] += t[1]; a[0][2] += t[2]; a[0][3] += t[3];
     }
     f32x4 o;
@@ -497,15 +502,17 @@ extern "C" int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy
 extern "C" int qavit_ln_param_reduce(const qavit_ln_reduce_desc* d, int n, void* stream) {
   if (!d || n <= 0) return set_error(QAVIT_EINVAL, "ln_param_reduce: empty list");
   for (int i = 0; i < n; ++i) {
-    if (!d[i].parts || d[i].nparts <= 0 || d[i].C <= 0 || d[i].C % 4 || d[i].C > 1024 || (reinterpret_cast<uintptr_t>(d[i].parts) & 15))
-      return set_error(QAVIT_EINVAL, "ln_param_reduce: bad descriptor (C % 4 == 0, C <= 1024, 16-byte aligned partial sums)");
+    if (!d[i].parts || d[i].nparts <= 0 || d[i].C <= 0 || d[i].C % 4 || d[i].C > 2048 || (reinterpret_cast<uintptr_t>(d[i].parts) & 15) ||
+        d[i].stride < 0 || d[i].stride % 4 || (d[i].stride > 0 && d[i].stride < 2 * d[i].C))
+      return set_error(QAVIT_EINVAL, "ln_param_reduce: bad descriptor (C % 4 == 0, C <= 2048, 16-byte aligned partial sums, stride % 4 == 0)");
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  for (int done = 0; done < n; done += 64) {
+  for (int done = 0; done < n; done += 48) {
     LnReduceGroup G;
-    G.n = n - done < 64 ? n - done : 64;
-    for (int i = 0; i < G.n; ++i) G.d[i] = d[done + i];
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(G.n), dim3(1024), 0, st, G);
+    G.n = n - done < 48 ? n - done : 48;
+    int maxp = 1;
+    for (int i = 0; i < G.n; ++i) { G.d[i] = d[done + i]; if (d[done + i].nparts > maxp) maxp = d[done + i].nparts; }
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(G.n, (maxp + LNR_SLICE - 1) / LNR_SLICE), dim3(1024), 0, st, G);
   }
   return check_launch("ln_param_reduce");
 }

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const qavit_pack_desc* descs,
         size_t o = (size_t)r * d.cols + c;
         if (d.pad == 1)                                    // MFMA fragment order (include/qavit.h, qavit_pack_desc)
           o = ((size_t)((r >> 4) * (d.cols >> 5) + (c >> 5)) * 64 + (size_t)(((c & 31) >> 3) * 16 + (r & 15))) * 8 + (c & 7);
+        else if (d.pad == 3)                               // fragment order of the transpose: row of src^T = c, k index = r
+          o = ((size_t)((c >> 4) * (d.rows >> 5) + (r >> 5)) * 64 + (size_t)(((r & 31) >> 3) * 16 + (c & 15))) * 8 + (r & 7);
         reinterpret_cast<T*>(d.dst)[o] = from_f<T>(v);
       }
     }

@@ -673,6 +673,8 @@ class BranchFn(Function):
         H, D = 4, Cc // 4
         S = sk_s.reshape(-1, Cc).shape[0]
         x2 = x.reshape(B * T, Cc)
+        if _BRANCH_BWD and dout.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
+            return _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o, saved, sh_k_in, sh_v_in, m, B, T, Cc, S)
         # ---- proj backward: dO = (dout * mask) Wproj ; dWproj += (dout * mask)^T O ; dbproj
         d_o = _linear_bwd(o, wproj, bproj, dout.reshape(B * T, Cc), 0, Cc, True, drop=m["proj_drop"])
         # ---- the attention-core backward on the saved projections, then the projections' own backward
@@ -706,6 +708,120 @@ class BranchFn(Function):
         gE_v = _ret(ev_ret, E_v) if ev_ret is not None else None
         return (dx.reshape(B, T, Cc) if dx is not None else None), None, None, None, None, gE_k, gE_v, \
             _ret(sk_ret, sh_k_in), _ret(sv_ret, sh_v_in), None
+
+
+_BRANCH_BWD = os.environ.get("QAVIT_FUSED_BRANCH_BWD", "1") != "0"
+
+
+def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o, saved, sh_k_in, sh_v_in, m, B, T, Cc, S):
+    """BranchFn.backward through csrc/branch_bwd.hip: ONE launch for the proj input gradient + the attention-core backward, then
+    the qkv input-gradient GEMM(s); weight gradients deferred as everywhere, the sums over images (dE_k, dE_v, shared rows) left as
+    per-workgroup partial rows for the end-of-backward reduce launch (at once where a consumer waits: cross-attention's projected bank)."""
+    kind = m["kind"]
+    rt = _rt(x)
+    M = B * T
+    g2 = dout.reshape(M, Cc)
+    if not g2.is_contiguous():
+        g2 = g2.contiguous()
+    pd, ad = m["proj_drop"], m["attn_drop"]
+    dz = torch.empty_like(g2) if pd[0] > 0.0 else g2
+    a = L.BranchBwdArgs()
+    a.dtype, a.kind = K.dt_code(x.dtype), kind
+    a.B, a.T, a.C, a.H, a.D, a.S = B, T, Cc, 4, Cc // 4, S
+    a.dout, a.lddout = g2.data_ptr(), Cc
+    a.wprojT_frag = pack_for(x.device).get_frag(wproj, x.dtype, order=3).data_ptr()
+    a.o, a.ldo = o.data_ptr(), Cc
+    a.sh_k, a.sh_v = sk_s.data_ptr(), sv_s.data_ptr()
+    a.attn_drop_p, a.attn_drop_site = float(ad[0]), int(ad[1])
+    a.proj_drop_p, a.proj_drop_site = float(pd[0]), int(pd[1])
+    a.rng = rt.rng.data_ptr()
+    if pd[0] > 0.0:
+        a.dz, a.lddz = dz.data_ptr(), Cc
+    esz = 2
+    dkv = None
+    if kind == 0:
+        qkv = saved[0]
+        dq = torch.empty_like(qkv)
+        a.q, a.ldq = qkv.data_ptr(), 3 * Cc
+        a.k_tok, a.v_tok, a.ldkv, a.kv_rows = qkv.data_ptr() + Cc * esz, qkv.data_ptr() + 2 * Cc * esz, 3 * Cc, T
+        a.dq, a.lddq = dq.data_ptr(), 3 * Cc
+        a.dk_tok, a.dv_tok, a.lddkv = dq.data_ptr() + Cc * esz, dq.data_ptr() + 2 * Cc * esz, 3 * Cc
+        a.KC, a.L = E_k.shape[1], T
+    elif kind == 1:
+        q, kv, p2 = saved
+        Lk = m["Lk"]
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        a.q, a.ldq = q.data_ptr(), Cc
+        a.k_tok, a.v_tok, a.ldkv, a.kv_rows = kv.data_ptr(), kv.data_ptr() + Cc * esz, 2 * Cc, Lk
+        a.dq, a.lddq = dq.data_ptr(), Cc
+        a.dk_tok, a.dv_tok, a.lddkv = dkv.data_ptr(), dkv.data_ptr() + Cc * esz, 2 * Cc
+        a.KC, a.L = E_k.shape[1], Lk
+    else:
+        q = saved[0]
+        dq = torch.empty_like(q)
+        a.q, a.ldq = q.data_ptr(), Cc
+        a.dq, a.lddq = dq.data_ptr(), Cc
+    if kind != 2:
+        a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
+    nparts = K.branch_bwd_parts(B)
+    PF = K.BRANCH_PARTS_FLOATS
+    parts = torch.empty(nparts * PF, dtype=torch.float32, device=x.device)
+    a.parts, a.parts_stride = parts.data_ptr(), PF
+    DeferDW.arm()
+    K.branch_bwd(a)
+    # ---- dW_proj += dz^T O, db_proj += colsum(dz)
+    wbuf, _ = grad_sink(wproj)
+    bbuf, _ = grad_sink(bproj)
+    if wbuf is not None or bbuf is not None:
+        if wbuf is None:
+            wbuf = torch.zeros(wproj.shape, dtype=torch.float32, device=x.device)
+        K.gemm_tn(dz, o, wbuf, M, Cc, Cc, Cc, Cc, Cc, bbuf)
+    # ---- the partial rows: [dE_k | dE_v | d sh_k | d sh_v]
+    ek_ret = ev_ret = None
+    if kind != 2:
+        ek_buf, ek_ret = grad_sink(E_k)
+        ev_buf, ev_ret = grad_sink(E_v)
+        if ek_buf is not None or ev_buf is not None:
+            K.DeferredLN.push_raw(parts.data_ptr(), nparts, 512, K._p(ek_buf), K._p(ev_buf), PF, (parts, ek_buf, ev_buf))
+    leaf = sh_k_in.is_leaf and sh_v_in.is_leaf
+    if leaf:
+        sk_buf, sk_ret = grad_sink(sh_k_in)
+        sv_buf, sv_ret = grad_sink(sh_v_in)
+    else:                                                  # a consumer waits for these (the bank projections' backward): reduce now
+        both = torch.zeros((2,) + tuple(sh_k_in.shape), dtype=torch.float32, device=x.device)
+        sk_buf = sk_ret = both[0] if sh_k_in.requires_grad else None
+        sv_buf = sv_ret = both[1] if sh_v_in.requires_grad else None
+    half = (S * Cc) // 2
+    descs = []
+    for buf, off in ((sk_buf, 1024), (sv_buf, 1024 + S * Cc)):
+        if buf is not None:
+            descs.append((parts.data_ptr() + off * 4, nparts, half, buf.data_ptr(), buf.data_ptr() + half * 4, PF))
+    if descs:
+        if leaf:
+            for d_ in descs:
+                K.DeferredLN.push_raw(*d_, (parts, sk_buf, sv_buf))
+        else:
+            K.reduce_now([K.DeferredLN.desc(*d_) for d_ in descs])
+    # ---- the projections' own backward
+    need_dx = ctx.needs_input_grad[0]
+    with torch.no_grad():
+        if kind == 0:
+            dx = _linear_bwd(x2, wqkv, bqkv, dq, 0, 3 * Cc, need_dx)
+        elif kind == 1:
+            idx, stride = m["pool_idx"], m["pool_stride"]
+            NP = idx.numel() // stride
+            dpool = _linear_bwd(saved[2], wqkv, bqkv, dkv, Cc, 2 * Cc, need_dx)
+            dxp = None
+            if need_dx:
+                dxp = torch.empty(M, Cc, dtype=x.dtype, device=x.device)
+                K.gather_pool_bwd(dpool.reshape(B, NP, Cc).contiguous(), idx, dxp, B, T, NP, stride, Cc)
+            dx = _linear_bwd(x2, wqkv, bqkv, dq, 0, Cc, need_dx, dx_add=dxp)
+        else:
+            dx = _linear_bwd(x2, wqkv, bqkv, dq, 0, Cc, need_dx)
+    gE_k = _ret(ek_ret, E_k) if ek_ret is not None else None
+    gE_v = _ret(ev_ret, E_v) if ev_ret is not None else None
+    return (dx.reshape(B, T, Cc) if dx is not None else None), None, None, None, None, gE_k, gE_v, \
+        _ret(sk_ret, sh_k_in) if sk_ret is not None else None, _ret(sv_ret, sh_v_in) if sv_ret is not None else None, None
 
 
 def branch_ok(kind, x, Lk, KC, S, heads) -> bool:
@@ -812,8 +928,14 @@ def _attn_bwd(q_t, kv_t, E_k, E_v, sh_k, sh_v, sh_k_in, sh_v_in, s, d_o):
         a.dv_tok, a.lddv = dst.data_ptr() + s["v_off"] * esz, dst.shape[1]
     ek_buf, ek_ret = grad_sink(E_k) if s["mode"] == 0 else (None, None)
     ev_buf, ev_ret = grad_sink(E_v) if s["mode"] == 0 else (None, None)
-    sk_buf, sk_ret = grad_sink(sh_k_in)
-    sv_buf, sv_ret = grad_sink(sh_v_in)
+    if (sh_k_in is not None and sh_v_in is not None and sh_k_in.requires_grad and sh_v_in.requires_grad and not sh_k_in.is_leaf
+            and not sh_v_in.is_leaf and sh_k_in.shape == sh_v_in.shape):
+        both = torch.zeros((2,) + tuple(sh_k_in.shape), dtype=torch.float32, device=sh_k_in.device)     # one fill for the two sinks
+        sk_buf = sk_ret = both[0]
+        sv_buf = sv_ret = both[1]
+    else:
+        sk_buf, sk_ret = grad_sink(sh_k_in)
+        sv_buf, sv_ret = grad_sink(sh_v_in)
     a.dE_k, a.dE_v = K._p(ek_buf), K._p(ev_buf)
     a.dsh_k, a.dsh_v = K._p(sk_buf), K._p(sv_buf)
     nws = K.attn_ws_floats(a)

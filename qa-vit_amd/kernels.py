@@ -280,11 +280,24 @@ class DeferredLN:
 
     @classmethod
     def push(cls, ws, n, Cc, dgamma, dbeta, keep=()):
+        cls.push_raw(ws.data_ptr(), n, Cc, _p(dgamma), _p(dbeta), 0, (ws, dgamma, dbeta) + tuple(keep))
+
+    @staticmethod
+    def desc(parts_ptr, n, Cc, dg_ptr, db_ptr, stride=0):
         d = L.LnReduceDesc()
-        d.parts, d.nparts, d.C = ws.data_ptr(), n, Cc
-        d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)
+        d.parts, d.nparts, d.C = parts_ptr, n, Cc
+        d.dgamma, d.dbeta, d.stride = dg_ptr, db_ptr, stride
+        return d
+
+    @classmethod
+    def push_raw(cls, parts_ptr, n, Cc, dg_ptr, db_ptr, stride, keep):
+        """Queue ``dst halves += column sums of n partial rows`` (qavit_ln_reduce_desc); reduced now when no backward pass has armed the queue."""
+        d = cls.desc(parts_ptr, n, Cc, dg_ptr, db_ptr, stride)
+        if not (cls.enabled and cls.ON):
+            reduce_now([d])
+            return
         foreign = DeferredTN.home_stream is not None and DeferredTN.home_stream != stream()
-        cls.queue.append((d, (ws, dgamma, dbeta) + tuple(keep), torch.cuda.current_stream() if foreign else None))
+        cls.queue.append((d, tuple(keep), torch.cuda.current_stream() if foreign else None))
 
     @classmethod
     def flush(cls):
@@ -294,6 +307,11 @@ class DeferredLN:
         DeferredTN._adopt_foreign(q)
         arr = (L.LnReduceDesc * len(q))(*[d for d, _, _ in q])
         L.check(L.load().qavit_ln_param_reduce(arr, len(q), stream()), "ln_param_reduce")
+
+
+def reduce_now(descs):
+    arr = (L.LnReduceDesc * len(descs))(*descs)
+    L.check(L.load().qavit_ln_param_reduce(arr, len(descs), stream()), "ln_param_reduce")
 
 
 def layernorm_bwd_multi(dys, xs, gammas, means, rstds, dxs, dgammas, dbetas, rows, Cc):
@@ -355,6 +373,17 @@ def branch_supported(kind, T, Cc, H, D, KC, S, Lk) -> bool:
 
 def branch_fwd(a):
     L.check(L.load().qavit_branch_fwd(C.byref(a), stream()), "branch_fwd")
+
+
+def branch_bwd(a):
+    L.check(L.load().qavit_branch_bwd(C.byref(a), stream()), "branch_bwd")
+
+
+def branch_bwd_parts(B) -> int:
+    return int(L.load().qavit_branch_bwd_parts(int(B)))
+
+
+BRANCH_PARTS_FLOATS = 7168
 
 
 def nan_guard(x, flag):

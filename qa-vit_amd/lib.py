@@ -24,7 +24,19 @@ class GemmArgs(C.Structure):
 
 
 class LnReduceDesc(C.Structure):
-    _fields_ = [("parts", vp), ("nparts", i32), ("C", i32), ("dgamma", vp), ("dbeta", vp)]
+    _fields_ = [("parts", vp), ("nparts", i32), ("C", i32), ("dgamma", vp), ("dbeta", vp), ("stride", i64)]
+
+
+class BranchBwdArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("kind", i32), ("B", i32), ("T", i32), ("C", i32), ("H", i32), ("D", i32), ("KC", i32), ("S", i32), ("L", i32),
+        ("dout", vp), ("lddout", i64), ("wprojT_frag", vp), ("q", vp), ("ldq", i64),
+        ("k_tok", vp), ("v_tok", vp), ("ldkv", i64), ("kv_rows", i32), ("o", vp), ("ldo", i64),
+        ("E_k", vp), ("E_v", vp), ("sh_k", vp), ("sh_v", vp),
+        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
+        ("dz", vp), ("lddz", i64), ("dq", vp), ("lddq", i64), ("dk_tok", vp), ("dv_tok", vp), ("lddkv", i64),
+        ("parts", vp), ("parts_stride", i64),
+    ]
 
 
 class GemmTnArgs(C.Structure):
@@ -87,6 +99,8 @@ _SIGS = {
     "qavit_layernorm_bwd_multi": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_parts": (i32, [i32, i32]),
+    "qavit_branch_bwd_parts": (i32, [i32]),
+    "qavit_branch_bwd": (i32, [vp, vp]),
     "qavit_ln_param_reduce": (i32, [vp, i32, vp]),
     "qavit_attn_fwd": (i32, [C.POINTER(AttnArgs), vp]),
     "qavit_attn_bwd": (i32, [C.POINTER(AttnArgs), vp]),

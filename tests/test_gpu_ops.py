@@ -855,6 +855,64 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
         assert rel(out, out2) <= 2e-2
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+@pytest.mark.parametrize("B", [5, 64, 1030])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_fused_branch_backward(F, Q, kind, B, drop):
+    """BranchFn's backward through the fused kernel (proj input gradient + attention-core backward in one launch, csrc/branch_bwd.hip)
+    against its backward through the unfused kernels: same forward launch, same dropout masks (pure functions of seed / step / site),
+    same saved projections -- the two differ only in where bf16 roundings fall.  Every gradient of the branch is compared: x, both
+    weights and biases, the Linformer matrices and the shared (bank) rows -- the latter two are sums over all images and heads."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    T, C, H, S, KC = 16, 192, 4, 16, 32
+    n_qkv = C if kind == 2 else 3 * C
+    idx, stride, Lk = None, 0, 0
+    if kind == 1:
+        t = [y * 4 + xx for d in (1, 2) for y in range(0, 4, d) for xx in range(0, 4, d)]
+        stride = 2
+        t = t[: (len(t) // stride) * stride]
+        idx = torch.tensor(t, dtype=torch.int32, device=DEV)
+        Lk = len(t) // stride
+    sa, sp = K.new_site(), K.new_site()
+    gout = leaf(B, T, C, seed=399).detach().to(torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        x = leaf(B, T, C, seed=300).detach().to(torch.bfloat16).requires_grad_(True)
+        wqkv, bqkv = leaf(n_qkv, C, scale=0.08, seed=301), leaf(n_qkv, scale=0.1, seed=302)
+        wproj, bproj = leaf(C, C, scale=0.08, seed=303), leaf(C, scale=0.1, seed=304)
+        Ek = Ev = None
+        if kind != 2:
+            rows = 16 if kind == 0 else 128
+            Ek, Ev = leaf(rows, KC, scale=0.3, seed=305), leaf(rows, KC, scale=0.3, seed=306)
+        bk, bv = leaf(1, S, C, scale=0.5, seed=307), leaf(1, S, C, scale=0.5, seed=308)
+        if kind == 2:       # cross: the shared rows are activations (projections of the bank), their gradient is returned to autograd
+            sk, sv = (bk * 1.0).reshape(S, C), (bv * 1.0).reshape(S, C)
+        else:
+            sk, sv = bk, bv
+        meta = dict(kind=kind, attn_drop=(drop, sa), proj_drop=(drop, sp))
+        if kind == 1:
+            meta.update(pool_idx=idx, pool_stride=stride, Lk=Lk)
+        old = F._BRANCH_BWD
+        F._BRANCH_BWD = fused
+        try:
+            out = F.BranchFn.apply(x, wqkv, bqkv, wproj, bproj, Ek, Ev, sk, sv, meta)
+            out.backward(gout)
+        finally:
+            F._BRANCH_BWD = old
+        torch.cuda.synchronize()
+        g = dict(x=x.grad.float(), wqkv=wqkv.grad, bqkv=bqkv.grad, wproj=wproj.grad, bproj=bproj.grad, bk=bk.grad, bv=bv.grad)
+        if kind != 2:
+            g.update(Ek=Ek.grad, Ev=Ev.grad)
+        res.append((out.detach().float(), g))
+    (o1, g1), (o2, g2) = res
+    assert torch.equal(o1, o2)
+    for k_ in g1:
+        assert g1[k_] is not None and g2[k_] is not None, k_
+        assert torch.isfinite(g1[k_]).all(), k_
+        assert rel(g1[k_], g2[k_]) <= 3e-2, (k_, rel(g1[k_], g2[k_]))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C", [(4, 100), (37, 10), (1024, 100), (1500, 200)])
 def test_cross_entropy_label_smoothing(F, dtype, B, C):
