@@ -117,6 +117,15 @@ class KernelTimer:
             g = self._obj(a[0])
             by = g.B * g.T * g.C * 2 * (3 if g.o_save else 2) + (4 if g.kind != 2 else 2) * g.C * g.C * 2
             return BRANCH_MFLOP_PER_IMG[g.kind] * 1e6 * g.B, float(by)
+        if name == "qavit_branch_bwd":
+            # proj input gradient (2 T C C) + attention-core backward (~2.5x the forward core, as for qavit_attn_bwd); operands read / written once:
+            # dout, q, o in; dz, dq out; k, v in and dk, dv out for SWA / MSDA
+            g = self._obj(a[0])
+            nk = (g.KC if g.kind != 2 else 0) + g.S
+            core = 4.0 * g.H * g.T * nk * g.D + (4.0 * g.H * g.KC * g.L * g.D if g.kind != 2 else 0.0)
+            fl = g.B * (2.0 * g.T * g.C * g.C + 2.5 * core)
+            by = g.B * g.T * g.C * 2 * 5 + (4 * g.B * g.kv_rows * g.C * 2 if g.kind != 2 else 0) + g.C * g.C * 2
+            return fl, float(by)
         if name in ("qavit_layernorm_fwd", "qavit_layernorm_bwd", "qavit_row_stats"):
             e = esz[a[0]]
             if name == "qavit_layernorm_fwd": rows, Cc, k = a[6], a[7], 2
@@ -144,7 +153,8 @@ class KernelTimer:
         import importlib
         L = importlib.import_module("qa-vit_amd.lib")
         for name in L.EXPORTS:
-            if name in ("qavit_version", "qavit_last_error", "qavit_attn_ws_floats", "qavit_bank_ws_floats"):
+            if name in ("qavit_version", "qavit_last_error", "qavit_attn_ws_floats", "qavit_bank_ws_floats", "qavit_branch_supported",
+                        "qavit_layernorm_bwd_parts", "qavit_branch_bwd_parts"):      # host-side queries: nothing is launched
                 continue
             self._wrap(name)
         return self

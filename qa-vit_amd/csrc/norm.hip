@@ -186,6 +186,112 @@ template <typename T> struct V4;
 template <> struct V4<float> { typedef f32x4 type; };
 template <> struct V4<bf16> { typedef bf16x4 type; };
 
+// forward / statistics, vector form: lane owns channels 4 lane .. + 3 (+ 256 per extra pass), RB rows of a wave are loaded before the
+// first reduction.  STATS: mean / rstd only (qavit_row_stats).  Same two-pass arithmetic as the scalar kernels above.
+template <typename T, int NP, int RB, int NW, bool STATS>
+__device__ __forceinline__ void layernorm_fwd_v4_body(const T* x, T* y, const float* gamma, const float* beta, float eps, int rows, int C,
+                                                      float* mean_o, float* rstd_o, const float* add, int add_rows, int act) {
+  typedef typename V4<T>::type v4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  float gm[NP][4], bt[NP][4];
+  if (!STATS) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int c = 4 * lane + 256 * i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gm[i][j] = (c + j < C) ? gamma[c + j] : 0.f; bt[i][j] = (c + j < C) ? beta[c + j] : 0.f; }
+    }
+  }
+  for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
+    v4 xv[RB][NP];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int row = row0 + r < rows ? row0 + r : rows - 1;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < C) xv[r][i] = *reinterpret_cast<const v4*>(x + (size_t)row * C + c);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const bool live = row0 + r < rows;
+      float v[NP][4];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c = 4 * lane + 256 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[i][j] = (c < C) ? to_f<T>(xv[r][i][j]) : 0.f; s += v[i][j]; }
+      }
+      const float mean = wave_sum(s) * invC;
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c = 4 * lane + 256 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float dlt = (c < C) ? v[i][j] - mean : 0.f; s2 += dlt * dlt; }
+      }
+      const float rstd = rsqrtf(wave_sum(s2) * invC + eps);
+      if (!live) continue;                                  // uniform per wave
+      if (lane == 0) {
+        if (mean_o) mean_o[row0 + r] = mean;
+        if (rstd_o) rstd_o[row0 + r] = rstd;
+      }
+      if (!STATS) {
+        const float* ar = add ? add + (size_t)((row0 + r) % add_rows) * C : nullptr;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int c = 4 * lane + 256 * i;
+          if (c < C) {
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (ar) av = *reinterpret_cast<const f32x4*>(ar + c);
+            v4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float t = (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j];
+              if (act) t = gelu_f(t);
+              o[j] = from_f<T>(t + av[j]);
+            }
+            *reinterpret_cast<v4*>(y + (size_t)(row0 + r) * C + c) = o;
+          }
+        }
+      }
+    }
+  }
+}
+template <typename T, int NP, int RB, int NW, bool STATS>
+__global__ __launch_bounds__(64 * NW) void layernorm_fwd_v4_kernel(const T* x, T* y, const float* gamma, const float* beta, float eps, int rows, int C,
+                                                                   float* mean_o, float* rstd_o, const float* add, int add_rows, int act) {
+  layernorm_fwd_v4_body<T, NP, RB, NW, STATS>(x, y, gamma, beta, eps, rows, C, mean_o, rstd_o, add, add_rows, act);
+}
+struct Ptr4v { const void* x[4]; float* mean[4]; float* rstd[4]; };
+template <typename T, int NP, int RB, int NW>
+__global__ __launch_bounds__(64 * NW) void row_stats_v4_multi_kernel(Ptr4v P, float eps, int rows, int C) {
+  layernorm_fwd_v4_body<T, NP, RB, NW, true>(reinterpret_cast<const T*>(P.x[blockIdx.y]), nullptr, nullptr, nullptr, eps, rows, C, P.mean[blockIdx.y],
+                                             P.rstd[blockIdx.y], nullptr, 0, 0);
+}
+
+// launch helper: -> true when the vector form applies (C % 4 == 0, C <= 1024, vector-aligned rows)
+template <bool STATS>
+static bool ln_fwd_v4_launch(int dtype, const void* x, void* y, const float* gamma, const float* beta, float eps, int rows, int C, float* mean, float* rstd,
+                             const float* add, int add_rows, int act, hipStream_t st) {
+  static const int on = getenv("QAVIT_LNF_V4") ? atoi(getenv("QAVIT_LNF_V4")) : 1;
+  if (!on || C % 4 || C > 1024 || (dtype != QAVIT_F32 && dtype != QAVIT_BF16)) return false;
+  const size_t vec = dtype == QAVIT_F32 ? 16 : 8;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % vec || (add && (reinterpret_cast<uintptr_t>(add) & 15))) return false;
+  constexpr int NW = 4, RB = 4;
+  int grid = (rows + NW * RB - 1) / (NW * RB);
+  if (grid > 2048) grid = 2048;
+  const int np = (C + 255) / 256;
+#define LNF(T_, NP_) hipLaunchKernelGGL((layernorm_fwd_v4_kernel<T_, NP_, (NP_ <= 2 ? RB : 2), NW, STATS>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)x, (T_*)y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows, act)
+  if (dtype == QAVIT_F32) { if (np == 1) LNF(float, 1); else if (np == 2) LNF(float, 2); else LNF(float, 4); }
+  else { if (np == 1) LNF(bf16, 1); else if (np == 2) LNF(bf16, 2); else LNF(bf16, 4); }
+#undef LNF
+  return true;
+}
+
 template <typename T, int NP, int RB, int NW>
 __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, const float* gamma, const float* mean,
                                                       const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act,
@@ -361,6 +467,7 @@ extern "C" int qavit_layernorm_fwd(int dtype, const void* x, void* y, const floa
   if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "layernorm_fwd: C > 1024 unsupported");
   if (add && add_rows <= 0) return set_error(QAVIT_EINVAL, "layernorm_fwd: add_rows must be positive");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ln_fwd_v4_launch<false>(dtype, x, y, gamma, beta, eps, rows, C, mean, rstd, add, add_rows, act, st)) return check_launch("layernorm_fwd");
   int grid = (rows + 3) / 4;
   if (grid > 4096) grid = 4096;
   const int pl = ln_pl(C);
@@ -376,6 +483,7 @@ extern "C" int qavit_row_stats(int dtype, const void* x, float eps, int rows, in
   if (!x || !mean || !rstd || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "row_stats: bad arguments");
   if (C > LN_MAX_C) return set_error(QAVIT_EINVAL, "row_stats: C > 1024 unsupported");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ln_fwd_v4_launch<true>(dtype, x, const_cast<void*>(x), nullptr, nullptr, eps, rows, C, mean, rstd, nullptr, 0, 0, st)) return check_launch("row_stats");
   int grid = (rows + 3) / 4;
   if (grid > 4096) grid = 4096;
   const int pl = ln_pl(C);
@@ -458,6 +566,24 @@ extern "C" int qavit_row_stats_multi(int dtype, int n, const void* const* x, flo
     ptrs.x[i] = x[i]; ptrs.mean[i] = mean[i]; ptrs.rstd[i] = rstd[i];
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    const size_t vec = dtype == QAVIT_F32 ? 16 : 8;
+    bool v4ok = C % 4 == 0 && C <= 512 && (dtype == QAVIT_F32 || dtype == QAVIT_BF16);
+    for (int i = 0; i < n && v4ok; ++i) v4ok = reinterpret_cast<uintptr_t>(x[i]) % vec == 0;
+    if (v4ok) {
+      Ptr4v P;
+      for (int i = 0; i < n; ++i) { P.x[i] = x[i]; P.mean[i] = mean[i]; P.rstd[i] = rstd[i]; }
+      constexpr int NW = 4, RB = 4;
+      int g = (rows + NW * RB - 1) / (NW * RB);
+      if (g > 2048 / n) g = 2048 / n;
+      const int np = (C + 255) / 256;
+      if (dtype == QAVIT_F32) { if (np == 1) hipLaunchKernelGGL((row_stats_v4_multi_kernel<float, 1, RB, NW>), dim3(g, n), dim3(64 * NW), 0, st, P, eps, rows, C);
+                                else hipLaunchKernelGGL((row_stats_v4_multi_kernel<float, 2, RB, NW>), dim3(g, n), dim3(64 * NW), 0, st, P, eps, rows, C); }
+      else { if (np == 1) hipLaunchKernelGGL((row_stats_v4_multi_kernel<bf16, 1, RB, NW>), dim3(g, n), dim3(64 * NW), 0, st, P, eps, rows, C);
+             else hipLaunchKernelGGL((row_stats_v4_multi_kernel<bf16, 2, RB, NW>), dim3(g, n), dim3(64 * NW), 0, st, P, eps, rows, C); }
+      return check_launch("row_stats_multi");
+    }
+  }
   int grid = (rows + 3) / 4;
   if (grid > 4096 / n) grid = 4096 / n;
   const int pl = ln_pl(C);
