@@ -349,10 +349,11 @@ int big_modes(const qavit_gemm_args& g, hipStream_t st) {
 
 // returns 1 = launched, 0 = not applicable (caller falls back to the resident-slice kernel), < 0 error
 int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st) {
-  static long thresh = -1, force_bn = 0;
+  static long thresh = -1, force_bn = 0, wide_n = 0;
   if (thresh < 0) {
     const char* e = getenv("QAVIT_GEMM_BIG"); thresh = e ? atol(e) : 64L * 128L;
     e = getenv("QAVIT_BIG_BN"); force_bn = e ? atol(e) : 0;
+    e = getenv("QAVIT_BIG_WIDE_N"); wide_n = e ? atol(e) : 0;
   }
   if (thresh == 0 || (long)g.N * g.K < thresh || g.N < 64 || g.K < 96 || g.M < 1024) return 0;
   if (g.K % 32) return 0;
@@ -366,6 +367,7 @@ int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st) {
   // 128-wide blocks (64 accumulator registers -> two workgroups per CU) unless N is a multiple of 192 only
   int bn;
   if (g.a_mode == 2 && g.N <= 256) bn = g.N > 192 ? 256 : (g.N > 128 ? 192 : 128);
+  else if (wide_n > 0 && g.N >= wide_n && g.N % 256 == 0) bn = 256;   // fat FFN layers (N = 1024): half the column blocks, so half the A re-reads and prologue repeats
   else if (g.N % 128 == 0) bn = 128;
   else if (g.N % 192 == 0) bn = 192;
   else bn = g.N > 192 ? 256 : (g.N > 128 ? 192 : 128);

@@ -1591,12 +1591,14 @@ class BankProj2Fn(Function):
         K.gemm_nt_grouped([K.gemm_nt(xk, Wk, yk, S, nk, Cc, Cc, Cc, nk, None if bk is None else bk.detach(), build_only=True),
                            K.gemm_nt(xv, Wv, yv, S, nv, Cc, Cc, Cc, nv, None if bv is None else bv.detach(), build_only=True)])
         if need:
-            ctx.save_for_backward(gk, gv, snap_k, snap_v, wk, bk, wv, bv)
+            ctx.save_for_backward(snap_k, snap_v, wk, bk, wv, bv)
+            ctx.bank = (gk, gv)                             # the parameters themselves (their values are mutated in place later: not "saved")
         return yk, yv
 
     @staticmethod
     def backward(ctx, dk, dv):
-        gk, gv, snap_k, snap_v, wk, bk, wv, bv = ctx.saved_tensors
+        snap_k, snap_v, wk, bk, wv, bv = ctx.saved_tensors
+        gk, gv = ctx.bank
         S, Cc = gk.shape[-2], gk.shape[-1]
         nk, nv = wk.shape[0], wv.shape[0]
         dk2 = dk.reshape(S, nk).contiguous()

@@ -24,6 +24,15 @@ def _hw(n: int) -> int:
     return int(math.sqrt(n))
 
 
+def _drive(gen):
+    """Run a step generator to its end -> its return value."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
 _BANK_PROJ2 = os.environ.get("QAVIT_BANK_PROJ2", "1") != "0"
 
 
@@ -564,14 +573,23 @@ class CNNStemModel(nn.Module):
 
     def forward_tokens(self, x, cdt):
         """-> (F2, F3, F4) as channel-last tokens [B, h*w, c] in the compute dtype, and (h, w)."""
+        return _drive(self.forward_tokens_steps(x, cdt))
+
+    def forward_tokens_steps(self, x, cdt):
+        """``forward_tokens`` as a generator that yields between its stages (the model interleaves this chain's launches with the
+        token path's: models.HQAViT.forward); the result is the generator's return value."""
         B, Cin, H, W = x.shape
         with torch.autocast("cuda", enabled=False):
             t = self._conv3x3s2_tokens(x, self.stem[0], self.stem[1], (B, Cin, H, W, 3, 2, 1), cdt)
+            yield
             H1, W1 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
             t = self._conv3x3s2_tokens(t, self.stage1[0], self.stage1[1], (B, self.stem[0].out_channels, H1, W1, 3, 2, 1), cdt)
+            yield
             h, w = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
             f2 = self.stage1[3].forward_tokens(t, h, w)
+            yield
             f3 = self.stage2[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f2, self.stage2[0]), self.stage2[1], self.training), h, w)
+            yield
             f4 = self.stage3[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f3, self.stage3[0]), self.stage3[1], self.training), h, w)
         return (f2, f3, f4), (h, w)
 
@@ -613,6 +631,9 @@ class CNNStemModelV2(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward_tokens(self, x, cdt):
+        return _drive(self.forward_tokens_steps(x, cdt))
+
+    def forward_tokens_steps(self, x, cdt):
         B, Cin, H, W = x.shape
         with torch.autocast("cuda", enabled=False):
             conv = self.stem[0]
@@ -622,14 +643,17 @@ class CNNStemModelV2(nn.Module):
             t = _spatial_ln_tokens(t, self.stem[1])
             for blk in self.stage2:
                 t = blk.forward_tokens(t, h, w)
+                yield
             f2 = t
             t = _conv1x1_tokens(_spatial_ln_tokens(f2, self.downsample2[0]), self.downsample2[1])
             for blk in self.stage3:
                 t = blk.forward_tokens(t, h, w)
+                yield
             f3 = t
             t = _conv1x1_tokens(_spatial_ln_tokens(f3, self.downsample3[0]), self.downsample3[1])
             for blk in self.stage4:
                 t = blk.forward_tokens(t, h, w)
+                yield
         return (f2, f3, t), (h, w)
 
     def forward(self, x):                                   # NCHW surface of the reference class

@@ -913,6 +913,66 @@ def test_fused_branch_backward(F, Q, kind, B, drop):
         assert rel(g1[k_], g2[k_]) <= 3e-2, (k_, rel(g1[k_], g2[k_]))
 
 
+def test_partial_row_reduce(F, Q):
+    """qavit_ln_param_reduce: dst halves += column sums of n partial rows, dense rows and rows embedded in a wider record (stride) --
+    the end-of-backward fold of the LayerNorm dgamma/dbeta partials and of the fused branch backward's dE / shared-row partials."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    g = torch.Generator().manual_seed(7)
+    for n, C, stride, off in ((256, 192, 0, 0), (3, 64, 0, 0), (258, 512, 7168, 0), (77, 1536, 7168, 1024), (40, 1536, 7168, 4096)):
+        width = stride if stride else 2 * C
+        parts = torch.randn(n, width, generator=g).to(DEV)
+        dg = torch.randn(C, generator=g).to(DEV)
+        db = torch.randn(C, generator=g).to(DEV)
+        ref_g = dg + parts[:, off:off + C].sum(0)
+        ref_b = db + parts[:, off + C:off + 2 * C].sum(0)
+        K.reduce_now([K.DeferredLN.desc(parts.data_ptr() + off * 4, n, C, dg.data_ptr(), db.data_ptr(), stride)])
+        torch.cuda.synchronize()
+        assert rel(dg, ref_g) <= 1e-5 and rel(db, ref_b) <= 1e-5, (n, C, stride)
+    # one half only
+    parts = torch.randn(9, 384, generator=g).to(DEV)
+    dg = torch.zeros(192, device=DEV)
+    K.reduce_now([K.DeferredLN.desc(parts.data_ptr(), 9, 192, dg.data_ptr(), None, 0)])
+    assert rel(dg, parts[:, :192].sum(0)) <= 1e-5
+
+
+def test_bank_proj2(F, Q):
+    """The bank projections of the cross / channel-group branches as one grouped skinny launch each way against two F.linear calls:
+    values, weight / bias gradients (which must see the SNAPSHOT of the bank, not its later in-place update) and the bank rows' own
+    gradient, accumulated in place by the GEMM's residual epilogue on top of what .grad already holds."""
+    S, C, n = 16, 192, 192
+    res = []
+    for fused in (True, False):
+        gk, gv = leaf(1, S, C, scale=0.5, seed=500), leaf(1, S, C, scale=0.5, seed=501)
+        lk, lv = torch.nn.Linear(C, n).to(DEV), torch.nn.Linear(C, n).to(DEV)
+        with torch.no_grad():
+            for i, lin in enumerate((lk, lv)):
+                lin.weight.copy_(leaf(n, C, scale=0.1, seed=502 + i).detach())
+                lin.bias.copy_(leaf(n, scale=0.1, seed=504 + i).detach())
+        gk.grad = torch.full_like(gk, 0.25)                  # something to accumulate onto
+        bank = type("B", (), {})()
+        bank.global_k, bank.global_v = gk, gv
+        snap = (gk.detach().clone(), gv.detach().clone())
+        if fused:
+            yk, yv = F.bank_proj2(bank, snap, lk, lv)
+        else:
+            a, b = F.bank_snapshot(bank, snap)
+            yk = F.linear(a, lk.weight, lk.bias).reshape(S, n)
+            yv = F.linear(b, lv.weight, lv.bias).reshape(S, n)
+        with torch.no_grad():                                # the in-place bank write that follows in the model
+            gk.mul_(3.0)
+        go = leaf(S, n, seed=506).detach()
+        (yk * go).sum().backward(retain_graph=True)
+        (yv * go * 0.5).sum().backward()
+        torch.cuda.synchronize()
+        res.append(dict(yk=yk.detach(), yv=yv.detach(), gk=gk.grad.clone(), gv=gv.grad.clone(), wk=lk.weight.grad.clone(), bk=lk.bias.grad.clone(),
+                        wv=lv.weight.grad.clone(), bv=lv.bias.grad.clone()))
+    for k_ in res[0]:
+        assert rel(res[0][k_], res[1][k_]) <= 2e-5, k_
+    x0 = leaf(1, S, C, scale=0.5, seed=500).detach().reshape(S, C)
+    assert rel(res[0]["wk"], leaf(S, n, seed=506).detach().t() @ x0) <= 2e-5      # forward-time bank, not 3x
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C", [(4, 100), (37, 10), (1024, 100), (1500, 200)])
 def test_cross_entropy_label_smoothing(F, dtype, B, C):
