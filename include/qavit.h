@@ -278,7 +278,7 @@ int qavit_gather_pool_bwd(int dtype, const void* dy, const int32_t* idx, void* d
 /* ---------------------------------------------------------------------------------------------------
  * CCF-FFN middle (HQAViT_CIFAR100.py:706-708, :670-675): h2 = LN2( scale * dwconv3x3( LN1(h) ) (+bias) )
  * on [B, Hs*Ws, C] channel-last tokens.  flags bit0: LN1/LN2 present (v1 has none), bit1: conv bias,
- * bit2: per-channel scale.  bwd accumulates all parameter grads with fp32 atomics.
+ * bit2: per-channel scale.  bwd accumulates all parameter grads with fp32 atomics, or leaves per-workgroup partial rows (parts).
  * ------------------------------------------------------------------------------------------------- */
 typedef struct qavit_ccf_args {
   int dtype; int flags;
@@ -292,7 +292,11 @@ typedef struct qavit_ccf_args {
   /* backward */
   const void* d_out; void* d_h;
   float* dg1; float* db1; float* dg2; float* db2; float* dw; float* dcbias; float* dcscale;
+  float* parts;        /* optional (bwd, C <= 256, >= 15 tokens, C % 8 == 0): qavit_ccf_bwd_parts(B) rows of 15*C floats
+                        * [dg1 | db1 | dg2 | db2 | dcbias | dcscale | dw (9C)], one per workgroup, written with plain stores INSTEAD of the
+                        * atomics into the seven gradient buffers; fold them with qavit_ln_param_reduce (stride 15*C) */
 } qavit_ccf_args;
+int qavit_ccf_bwd_parts(int B);
 
 int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream);
 int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream);

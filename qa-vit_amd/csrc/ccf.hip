@@ -69,6 +69,91 @@ __global__ __launch_bounds__(512) void ccf_fwd_kernel(qavit_ccf_args p) {
   }
 }
 
+// Forward on the (wave = rows, lane = channels) mapping with the parameters in registers (C <= 64 * CP): the generic kernel above
+// fetches every tap weight and LayerNorm parameter from global memory inside its loops and divides to find (row, channel).
+template <typename T, int CP, int NW, int HS, int WS>
+__global__ __launch_bounds__(64 * NW) void ccf_fwd2_kernel(qavit_ccf_args p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Hs = HS ? HS : p.Hs, Ws = WS ? WS : p.Ws;      // HS / WS != 0: the map size is a compile-time constant (4 x 4 learned tokens)
+  const int N = Hs * Ws, C = p.C;
+  float* a = sm;               // [N][C] input, then LN1 output
+  float* t = sm + N * C;       // [N][C] conv output
+  const T* h = reinterpret_cast<const T*>(p.h);
+  T* out = reinterpret_cast<T*>(p.out);
+  const bool ln = p.flags & F_LN, hb = p.flags & F_BIAS, hs = p.flags & F_SCALE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  float g1v[CP], b1v[CP], g2v[CP], b2v[CP], csv[CP], cbv[CP], wt[CP][9];
+#pragma unroll
+  for (int k = 0; k < CP; ++k) {
+    const int c = lane + 64 * k;
+    const bool ok = c < C;
+    g1v[k] = (ok && ln) ? p.g1[c] : 0.f; b1v[k] = (ok && ln) ? p.b1[c] : 0.f;
+    g2v[k] = (ok && ln) ? p.g2[c] : 0.f; b2v[k] = (ok && ln) ? p.b2[c] : 0.f;
+    cbv[k] = (ok && hb) ? p.cbias[c] : 0.f;
+    csv[k] = (ok && hs) ? p.cscale[c] : 1.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wt[k][q] = ok ? p.w[c * 9 + q] : 0.f;
+  }
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * C; i += 64 * NW) a[i] = to_f<T>(h[(size_t)b * N * C + i]);
+    __syncthreads();
+    if (ln) {
+      for (int r = wave; r < N; r += NW) {
+        float v[CP], s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CP; ++k) { const int c = lane + 64 * k; v[k] = c < C ? a[r * C + c] : 0.f; s1 += v[k]; }
+        const float mean = wave_sum(s1) * invC;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CP; ++k) { const int c = lane + 64 * k; const float d = c < C ? v[k] - mean : 0.f; s2 += d * d; }
+        const float rstd = rsqrtf(wave_sum(s2) * invC + p.eps);
+#pragma unroll
+        for (int k = 0; k < CP; ++k) { const int c = lane + 64 * k; if (c < C) a[r * C + c] = (v[k] - mean) * rstd * g1v[k] + b1v[k]; }
+        if (lane == 0) { p.mean1[(size_t)b * N + r] = mean; p.rstd1[(size_t)b * N + r] = rstd; }
+      }
+      __syncthreads();
+    }
+    for (int r = wave; r < N; r += NW) {
+      const int y = r / Ws, x = r - y * Ws;
+      float v[CP], s1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = 0.f;
+        if (c < C) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int yy = y + dy - 1, xx = x + dx - 1;
+              if (yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) sacc += wt[k][dy * 3 + dx] * a[(yy * Ws + xx) * C + c];
+            }
+          v[k] = (sacc + cbv[k]) * csv[k];
+        }
+        s1 += v[k];
+      }
+      T* orow = out + ((size_t)b * N + r) * C;
+      if (ln) {                                              // LN2 on the row this wave just produced
+        const float mean = wave_sum(s1) * invC;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CP; ++k) { const int c = lane + 64 * k; const float d = c < C ? v[k] - mean : 0.f; s2 += d * d; }
+        const float rstd = rsqrtf(wave_sum(s2) * invC + p.eps);
+#pragma unroll
+        for (int k = 0; k < CP; ++k) { const int c = lane + 64 * k; if (c < C) orow[c] = from_f<T>((v[k] - mean) * rstd * g2v[k] + b2v[k]); }
+        if (lane == 0) { p.mean2[(size_t)b * N + r] = mean; p.rstd2[(size_t)b * N + r] = rstd; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < CP; ++k) { const int c = lane + 64 * k; if (c < C) orow[c] = from_f<T>(v[k]); }
+      }
+    }
+  }
+  (void)t;
+}
+
 // LN backward over rows of LDS buffers: xin holds the LN INPUT rows, gy the output gradient (overwritten by dx).
 // pg/pb: [C] LDS partial sums (LDS atomics across the 4 waves)
 __device__ __forceinline__ void ln_rows_bwd(const float* xin, float* gy, int N, int C, const float* g, const float* mean, const float* rstd,
@@ -198,10 +283,11 @@ __global__ __launch_bounds__(256) void ccf_bwd_kernel(qavit_ccf_args p) {
 // l, l+64, ... (CP of them) -- so each parameter-gradient partial (LN gammas/betas, conv bias/scale, the 9 taps) is a
 // register of the thread that owns the channel, summed over the rows and images the thread visits, and folded across
 // the 4 waves through LDS once at the end.  (The first version issued 13 same-address LDS atomics per element.)
-template <typename T, int CP, int NW>
+template <typename T, int CP, int NW, int HS, int WS>
 __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int N = p.Hs * p.Ws, C = p.C;
+  const int Hs = HS ? HS : p.Hs, Ws = WS ? WS : p.Ws;      // HS / WS != 0: the map size is a compile-time constant (4 x 4 learned tokens)
+  const int N = Hs * Ws, C = p.C;
   float* hin = sm;                 // [N][C] raw input h (LN1 input)
   float* a = hin + N * C;          // [N][C] LN1 output
   float* raw = a + N * C;          // [N][C] conv (+bias) before scale; later d(LN1 output), then dh
@@ -212,7 +298,7 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
   const bool ln = p.flags & F_LN, hb = p.flags & F_BIAS, hs = p.flags & F_SCALE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invC = 1.f / (float)C;
-  float rg1[CP], rb1[CP], rg2[CP], rb2[CP], rcb[CP], rcs[CP], rw[CP][9], wt[CP][9], g1v[CP], g2v[CP], csv[CP];
+  float rg1[CP], rb1[CP], rg2[CP], rb2[CP], rcb[CP], rcs[CP], rw[CP][9], wt[CP][9], g1v[CP], g2v[CP], csv[CP], b1v[CP], cbv[CP];
 #pragma unroll
   for (int k = 0; k < CP; ++k) {
     const int c = lane + 64 * k;
@@ -220,17 +306,50 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
     rg1[k] = rb1[k] = rg2[k] = rb2[k] = rcb[k] = rcs[k] = 0.f;
     g1v[k] = (ok && ln) ? p.g1[c] : 0.f;
     g2v[k] = (ok && ln) ? p.g2[c] : 0.f;
+    b1v[k] = (ok && ln) ? p.b1[c] : 0.f;
+    cbv[k] = (ok && hb) ? p.cbias[c] : 0.f;
     csv[k] = (ok && hs) ? p.cscale[c] : 1.f;
 #pragma unroll
     for (int q = 0; q < 9; ++q) { rw[k][q] = 0.f; wt[k][q] = ok ? p.w[c * 9 + q] : 0.f; }
   }
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     __syncthreads();
-    for (int i = threadIdx.x; i < N * C; i += 64 * NW) { const float v = to_f<T>(h[(size_t)b * N * C + i]); hin[i] = v; a[i] = v; }
+    for (int i = threadIdx.x; i < N * C; i += 64 * NW) hin[i] = to_f<T>(h[(size_t)b * N * C + i]);
     __syncthreads();
-    if (ln) { ln_rows(a, N, C, p.g1, p.b1, p.eps, nullptr, nullptr); __syncthreads(); }
-    dwconv_rows(a, t, p.w, hb ? p.cbias : nullptr, hs ? p.cscale : nullptr, p.Hs, p.Ws, C, raw);
+    // recompute of the forward on the same (wave = rows, lane = channels) mapping with the parameters in registers: the saved
+    // statistics make LN1 elementwise, and the stencil reads one channel of the neighbour rows.  (The generic helpers above
+    // fetch every tap weight from global memory inside the tap loop and divide to find (row, channel): 3/4 of this kernel's time.)
+    for (int r = wave; r < N; r += NW) {
+      float mu = 0.f, rs = 1.f;
+      if (ln) { mu = p.mean1[(size_t)b * N + r]; rs = p.rstd1[(size_t)b * N + r]; }
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) { const float v = hin[r * C + c]; a[r * C + c] = ln ? (v - mu) * rs * g1v[k] + b1v[k] : v; }
+      }
+    }
     __syncthreads();
+    for (int r = wave; r < N; r += NW) {
+      const int y = r / Ws, x = r - y * Ws;
+#pragma unroll
+      for (int k = 0; k < CP; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int yy = y + dy - 1, xx = x + dx - 1;
+              if (yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) sacc += wt[k][dy * 3 + dx] * a[(yy * Ws + xx) * C + c];
+            }
+          sacc += cbv[k];
+          raw[r * C + c] = sacc;
+          t[r * C + c] = sacc * csv[k];
+        }
+      }
+    }
+    wave_sync();                                        // LN2 backward below reads only the rows this wave just wrote
     // LN2 backward, then d(conv output) = dt * scale, with dscale / dbias partials -- one pass over the owned elements
     for (int r = wave; r < N; r += NW) {
       const T* gr = dout + ((size_t)b * N + r) * C;
@@ -271,7 +390,7 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
     __syncthreads();
     // conv backward: tap partials in registers, d(LN1 output) into raw
     for (int r = wave; r < N; r += NW) {
-      const int y = r / p.Ws, x = r - y * p.Ws;
+      const int y = r / Ws, x = r - y * Ws;
 #pragma unroll
       for (int k = 0; k < CP; ++k) {
         const int c = lane + 64 * k;
@@ -283,9 +402,9 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
               const int yy = y + dy - 1, xx = x + dx - 1;           // forward tap read by output (y,x)
-              if (yy >= 0 && yy < p.Hs && xx >= 0 && xx < p.Ws) rw[k][dy * 3 + dx] += dc * a[(yy * p.Ws + xx) * C + c];
+              if (yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) rw[k][dy * 3 + dx] += dc * a[(yy * Ws + xx) * C + c];
               const int yo = y - dy + 1, xo = x - dx + 1;           // outputs that read input (y,x) through tap (dy,dx)
-              if (yo >= 0 && yo < p.Hs && xo >= 0 && xo < p.Ws) da += wt[k][dy * 3 + dx] * t[(yo * p.Ws + xo) * C + c];
+              if (yo >= 0 && yo < Hs && xo >= 0 && xo < Ws) da += wt[k][dy * 3 + dx] * t[(yo * Ws + xo) * C + c];
             }
           raw[r * C + c] = da;
         }
@@ -344,6 +463,13 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
     float v = 0.f;
 #pragma unroll
     for (int w_ = 0; w_ < NW; ++w_) v += part[w_ * 15 * C + i];
+    if (p.parts) {                                    // one row of partial sums per workgroup; 512-way same-address atomics otherwise
+      const int which = i / C;
+      float keep = v;
+      if (which < 4 && !ln) keep = 0.f;
+      p.parts[(size_t)blockIdx.x * 15 * C + i] = keep;
+      continue;
+    }
     const int which = i / C;
     if (which >= 6) { atomic_add_f(p.dw + (i - 6 * C), v); continue; }
     const int c = i - which * C;
@@ -380,6 +506,22 @@ extern "C" int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = a->B < 2048 ? a->B : 2048;
   const int threads = a->Hs * a->Ws >= 64 ? 512 : 256;    // 64-token maps fill one CU per image: 8 waves share the rows
+  static const int fwd2 = getenv("QAVIT_CCF_FWD2") ? atoi(getenv("QAVIT_CCF_FWD2")) : 1;
+  if (fwd2 && a->C <= 256 && (a->dtype == QAVIT_F32 || a->dtype == QAVIT_BF16)) {
+    const int cp = (a->C + 63) / 64;
+#define CCFF(T_, CP_) { if (threads == 512) { \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd2_kernel<T_, CP_, 8, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                          hipLaunchKernelGGL((ccf_fwd2_kernel<T_, CP_, 8, 0, 0>), dim3(grid), dim3(512), smem, st, *a); \
+                        } else if (a->Hs == 4 && a->Ws == 4 && smem <= 48 * 1024) { \
+                          hipLaunchKernelGGL((ccf_fwd2_kernel<T_, CP_, 4, 4, 4>), dim3(grid), dim3(256), smem, st, *a); \
+                        } else { \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd2_kernel<T_, CP_, 4, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                          hipLaunchKernelGGL((ccf_fwd2_kernel<T_, CP_, 4, 0, 0>), dim3(grid), dim3(256), smem, st, *a); } }
+    if (a->dtype == QAVIT_F32) { if (cp == 1) CCFF(float, 1) else if (cp == 2) CCFF(float, 2) else if (cp == 3) CCFF(float, 3) else CCFF(float, 4) }
+    else { if (cp == 1) CCFF(bf16, 1) else if (cp == 2) CCFF(bf16, 2) else if (cp == 3) CCFF(bf16, 3) else CCFF(bf16, 4) }
+#undef CCFF
+    return check_launch("ccf_mid_fwd");
+  }
   if (a->dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((ccf_fwd_kernel<float>), dim3(grid), dim3(threads), smem, st, *a);
@@ -390,22 +532,30 @@ extern "C" int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream) {
   return check_launch("ccf_mid_fwd");
 }
 
+extern "C" int qavit_ccf_bwd_parts(int B) {
+  static const int cgrid = getenv("QAVIT_CCF_BWD_GRID") ? atoi(getenv("QAVIT_CCF_BWD_GRID")) : 512;
+  return B < cgrid ? B : cgrid;
+}
+
 extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
   int rc = ccf_validate(a, true);
   if (rc) return rc;
   const size_t smem = ((size_t)4 * a->Hs * a->Ws * a->C + 15 * (size_t)a->C) * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_bwd: image tile too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static const int cgrid = getenv("QAVIT_CCF_BWD_GRID") ? atoi(getenv("QAVIT_CCF_BWD_GRID")) : 512;
-  const int grid = a->B < cgrid ? a->B : cgrid;
+  const int grid = qavit_ccf_bwd_parts(a->B);
+  if (a->parts && !(a->C <= 256 && a->Hs * a->Ws >= 15 && a->C % 8 == 0 && (reinterpret_cast<uintptr_t>(a->parts) & 15) == 0))
+    return set_error(QAVIT_EINVAL, "ccf_mid_bwd: parts needs C <= 256, C % 8 == 0, >= 15 tokens and a 16-byte aligned workspace");
   if (a->C <= 256 && a->Hs * a->Ws >= 15) {             // register-partial kernel (its wave fold needs 60*C floats of the image buffers)
     const int cp = (a->C + 63) / 64;
 #define CCF2(T_, CP_) { if (a->Hs * a->Ws >= 64) { \
-                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                          hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_, 8>), dim3(grid), dim3(512), smem, st, *a); \
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_, 8, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                          hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_, 8, 0, 0>), dim3(grid), dim3(512), smem, st, *a); \
+                        } else if (a->Hs == 4 && a->Ws == 4 && smem <= 48 * 1024) { \
+                          hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_, 4, 4, 4>), dim3(grid), dim3(256), smem, st, *a); \
                         } else { \
-                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                          hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_, 4>), dim3(grid), dim3(256), smem, st, *a); } }
+                          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_, 4, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                          hipLaunchKernelGGL((ccf_bwd2_kernel<T_, CP_, 4, 0, 0>), dim3(grid), dim3(256), smem, st, *a); } }
     if (a->dtype == QAVIT_F32) { if (cp == 1) CCF2(float, 1) else if (cp == 2) CCF2(float, 2) else if (cp == 3) CCF2(float, 3) else CCF2(float, 4) }
     else if (a->dtype == QAVIT_BF16) { if (cp == 1) CCF2(bf16, 1) else if (cp == 2) CCF2(bf16, 2) else if (cp == 3) CCF2(bf16, 3) else CCF2(bf16, 4) }
     else return set_error(QAVIT_EINVAL, "ccf_mid_bwd: unknown dtype");

@@ -1080,7 +1080,26 @@ class CcfMidFn(Function):
         if a.dw is None:
             scratch = torch.zeros_like(w, dtype=torch.float32)
             a.dw = scratch.data_ptr()
+        parts = None
+        DeferDW.arm()
+        if K.DeferredLN.enabled and K.DeferredLN.ON and Cc <= 256 and Cc % 8 == 0 and Hs * Ws >= 15:
+            # per-workgroup partial rows [dg1 | db1 | dg2 | db2 | dcbias | dcscale | dw(9C)], folded when backward ends
+            npart = int(L.load().qavit_ccf_bwd_parts(B))
+            parts = torch.empty(npart * 15 * Cc, dtype=torch.float32, device=h.device)
+            a.parts = parts.data_ptr()
         K.ccf_bwd(a)
+        if parts is not None:
+            base, st = parts.data_ptr(), 15 * Cc
+            sg1, sb1, sg2, sb2, sw, scb, scs = sinks
+            keep = (parts,) + tuple(sinks)
+            if flags & 1:
+                K.DeferredLN.push_raw(base, npart, Cc, K._p(sg1), K._p(sb1), st, keep)
+                K.DeferredLN.push_raw(base + 2 * Cc * 4, npart, Cc, K._p(sg2), K._p(sb2), st, keep)
+            if scb is not None or scs is not None:
+                K.DeferredLN.push_raw(base + 4 * Cc * 4, npart, Cc, K._p(scb), K._p(scs), st, keep)
+            if sw is not None:
+                half = (9 * Cc) // 2
+                K.DeferredLN.push_raw(base + 6 * Cc * 4, npart, half, sw.data_ptr(), sw.data_ptr() + half * 4, st, keep)
         return (d_h,) + (None,) * 10
 
 

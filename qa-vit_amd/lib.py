@@ -79,6 +79,7 @@ class CcfArgs(C.Structure):
         ("h", vp), ("out", vp), ("g1", vp), ("b1", vp), ("g2", vp), ("b2", vp), ("eps", f32),
         ("w", vp), ("cbias", vp), ("cscale", vp), ("mean1", vp), ("rstd1", vp), ("mean2", vp), ("rstd2", vp),
         ("d_out", vp), ("d_h", vp), ("dg1", vp), ("db1", vp), ("dg2", vp), ("db2", vp), ("dw", vp), ("dcbias", vp), ("dcscale", vp),
+        ("parts", vp),
     ]
 
 
@@ -100,6 +101,7 @@ _SIGS = {
     "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_parts": (i32, [i32, i32]),
     "qavit_branch_bwd_parts": (i32, [i32]),
+    "qavit_ccf_bwd_parts": (i32, [i32]),
     "qavit_branch_bwd": (i32, [vp, vp]),
     "qavit_ln_param_reduce": (i32, [vp, i32, vp]),
     "qavit_attn_fwd": (i32, [C.POINTER(AttnArgs), vp]),
