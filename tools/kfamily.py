@@ -3,9 +3,14 @@ usage: kfamily.py <kernel_stats.csv> <steps-profiled>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+# every training step ends with ONE fused AdamW launch: its call count is the number of steps the trace holds (warm-up, capture and
+# instrumented eager steps included), a better divisor than the caller's guess
+_adamw = [int(r["Calls"]) for r in rows if "adamw_kernel" in r["Name"]]
+if _adamw:
+    n = float(sum(_adamw))
 FAM = [("branch_fwd", ("branch_fwd_kernel", "branch_nan_fix")), ("branch_bwd", ("branch_bwd_kernel",)), ("gemm_nt", ("gemm_nt_",)), ("gemm_tn", ("gemm_tn_",)), ("attn_bwd", ("attn2_kernel<", "attn3_kernel<", "attn4_kernel<", "attn_bwd_kernel", "attn_reduce")),
        ("layernorm_bwd", ("layernorm_bwd",)), ("layernorm_fwd", ("layernorm_fwd",)), ("row_stats", ("row_stats",)), ("dwconv", ("dwconv",)),
-       ("ccf", ("ccf_",)), ("bank", ("bank_",)), ("bn", ("bn_",)), ("tokmix/upmix", ("tokmix", "upmix")), ("elementwise (own)", ("hybrid_", "scale_add", "mix2_", "dropout_kernel", "gather_pool", "token_mean", "patchify", "im2col", "col2im", "nan_", "zero_f32", "pack_kernel", "adamw", "l2_", "rng_", "ce_ls_kernel", "sum_k_kernel", "copy2_kernel", "gate_mix", "local_clip", "chan_scale", "sln_", "ln_param_reduce", "ln_dadd")), ("torch/other", ("",))]
+       ("ccf", ("ccf_",)), ("bank", ("bank_",)), ("bn", ("bn_",)), ("tokmix/upmix", ("tokmix", "upmix")), ("elementwise (own)", ("hybrid_", "scale_add", "mix2_", "dropout_kernel", "gather_pool", "token_mean", "patchify", "im2col", "col2im", "nan_", "zero_f32", "pack_kernel", "adamw", "l2_", "rng_", "ce_ls_kernel", "sum_k_kernel", "copy2_kernel", "gate_mix", "local_clip", "chan_scale", "sln_", "ln_param_reduce", "ln_dadd")), ("bench harness", ("spin_kernel",)), ("torch/other", ("",))]
 agg = {}
 for r in rows:
     nm = r["Name"]
