@@ -288,7 +288,10 @@ void launch_class(const qavit_gemm_tn_args* const* probs, int n, hipStream_t st)
     const int cnt = (n - done < TNW_GROUP) ? (n - done) : TNW_GROUP;
     TnwGroup G;
     G.n = cnt;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QAVIT_TN_DBG"); dbg = e ? atoi(e) : 0; } G.dbg = dbg; }
+    G.dbg = 0;
+#ifdef QAVIT_TN_FLUSH_EXPERIMENT   // diagnostic build only (QAVIT_EXTRA_HIPCC_FLAGS=-DQAVIT_TN_FLUSH_EXPERIMENT): QAVIT_TN_DBG bit 0 skips the tile flush,
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QAVIT_TN_DBG"); dbg = e ? atoi(e) : 0; } G.dbg = dbg; }   // bit 1 the column-sum flush -- WRONG results, timing only
+#endif
     int units = 0;
     for (int i = 0; i < cnt; ++i) {
       const qavit_gemm_tn_args& g = *probs[done + i];
