@@ -334,6 +334,31 @@ int qavit_branch_bwd_parts(int B);
 int qavit_branch_bwd(const qavit_branch_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Fused CHANNEL-GROUP attention branch (EfficientChannelGroupAttention, HQAViT_CIFAR100.py:535-595) on the 16-learned-token
+ * problems: per image, for each of the G = 6 channel groups (32 channels) q / k / v = Linear(32 -> 16) of the group's slice of x,
+ * 4 heads of D = 4 over [16 token keys ; 16 projected bank rows], softmax (+ attention dropout), P.V, then proj(96 -> 192) + bias
+ * (+ dropout) over the concatenated groups -- ONE launch instead of qkv GEMM, attention kernel, NaN guard and proj GEMM.
+ * Fixed shapes: T = 16, C = 192, G = 6, H = 4, D = 4, S = 16; bf16.  wqkv_rm = [Wq; Wk; Wv] stacked [48, 32] bf16 row-major,
+ * wproj_rm = [192, 96] bf16 row-major (both from qavit_pack_weights), biases fp32, sh_k / sh_v = the bank projections [16, 16] fp32.
+ * Dropout contracts as the unfused chain (attention: problem id = (image * 6 + group) * 4 + head; proj: row * C + col);
+ * nan_flag as in qavit_branch_args.  o_save (optional) [B*16, 96]: the attention output, operand of backward's dW_proj.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_cga_args {
+  int dtype;
+  int B, T, C, G, H, D, S;
+  const void* x; int64_t ldx;
+  const void* wqkv_rm; const float* bqkv;
+  const void* wproj_rm; const float* bproj;
+  const float* sh_k; const float* sh_v;
+  void* out; int64_t ldo;
+  void* o_save;
+  float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
+  int* nan_flag;
+} qavit_cga_args;
+int qavit_cga_supported(int T, int C, int G, int H, int S);
+int qavit_cga_fwd(const qavit_cga_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Depthwise k x k convolution, stride 1, pad k/2, on channel-last tokens x[B, H*W, C] (k in {3,5,7}):
  * ConvNeXtBlock.dwconv (HQAViT_CIFAR100.py:722, dw7x7), LMFAdapter.dwconv_3x3 / dwconv_5x5 (:811-812).
  * w is the nn.Conv2d weight [C,1,k,k] fp32; bias [C] or NULL.  bwd: dx, dw += , dbias += (fp32 atomics).

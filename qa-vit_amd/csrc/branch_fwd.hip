@@ -523,6 +523,14 @@ int branch_validate(const qavit_branch_args* a) {
 
 }  // namespace
 
+// the NaN -> zeros rule's rewrite launch, shared with the fused channel-group branch (cga.hip)
+void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag, hipStream_t st) {
+  const int64_t n = (int64_t)rows * C;
+  int nb = (int)((n + 2047) / 2048);
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(branch_nan_fix_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<bf16*>(out), ldo, rows, C, bias, p, site, rng, flag);
+}
+
 }  // namespace qv
 
 using namespace qv;

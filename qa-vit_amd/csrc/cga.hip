@@ -1,0 +1,225 @@
+// Fused CHANNEL-GROUP attention branch, forward (EfficientChannelGroupAttention, HQAViT_CIFAR100.py:535-595) for the 16-learned-token
+// problems of the CIFAR configuration:  out = dropout( proj( concat_g SDPA_g ) ),  SDPA_g over 4 heads of D = 4 on
+// q / k / v = Linear(32 -> 16) of channel group g, keys = [16 tokens ; 16 projected bank rows].  One launch replaces the stacked
+// q/k/v GEMM (98304 x 32 -> 48), the attention kernel (24576 problems of 16 x 32 x 4), its NaN guard and the proj GEMM.
+//
+// The problems are far too small to tile: everything about an image fits one WAVE.  A workgroup of 4 waves takes 4 images (grid =
+// B / 4 = one workgroup per CU at B = 1024); the proj weight sits in LDS as 16x16x16 MFMA fragments, the q/k/v weights (shared by
+// all groups) in registers.  Per (image, group), with acc[r] = C[4 q4 + r][col] and operand quads = 4 consecutive k of row col:
+//   q^T = Wq x_g^T          acc = q[token = col][d = 4 q4 + r]  -> B operand of S^T;  lane group q4 holds exactly head q4's 4 dims
+//   k^T = Wk x_g^T          acc = k[token = col][d ..]          -> A operand of S^T
+//   v   = x_g Wv^T          acc = v[token = 4 q4 + r][d = col]  -> A operand of O^T
+//   S_h^T = K (Q masked to lane group h)^T   (the mask makes one 16-deep MFMA contract over head h's 4 dims only)
+//   softmax over the 32 keys on the accumulator registers (+ dropout), P_h^T as B operand of
+//   O_h^T = V^T P_h^T       valid in lane group h (d in head h): the four heads' results are merged by lane group
+// then the 6 groups' O quads meet in the image's LDS tile and out^T = Wp O^T runs on the LDS fragments.
+#include "common.cuh"
+#include "../../include/qavit.h"
+#include "launch.h"
+#include "attn_shared.h"
+#include "frag16.cuh"
+
+namespace qv {
+
+void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag, hipStream_t st);
+
+namespace {
+
+constexpr int CT = 16, CC = 192, CG = 6, CPG = 32, CCG = 16, CH = 4, CD = 4, CS = 16, CO = CG * CCG;   // tokens, channels, groups, ch/group, q dims/group, heads, head dim, bank rows, 96
+constexpr int CNI = 4;                                     // images (= waves) per workgroup
+constexpr int LDX = CC + 8, LDOO = CO + 8;
+constexpr int WP_FRAGS = (CC / 16) * (CO / 16);            // 12 x 6 fragments of 512 B
+constexpr int SM_WP = 0, SM_XT = WP_FRAGS * 512, SM_OT = SM_XT + CNI * CT * LDX * 2, SM_CGA = SM_OT + CNI * CT * LDOO * 2;   // 36864 + 25600 + 13312 = 75776 bytes
+
+__device__ __forceinline__ bf16x4 cvt4c(const f32x4& acc) {
+  bf16x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (bf16)acc[r];
+  return v;
+}
+
+__global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
+  bf16* swp = reinterpret_cast<bf16*>(smraw + SM_WP);
+  bf16* xt = reinterpret_cast<bf16*>(smraw + SM_XT) + wave * (CT * LDX);
+  bf16* ot = reinterpret_cast<bf16*>(smraw + SM_OT) + wave * (CT * LDOO);
+  const int img_raw = blockIdx.x * CNI + wave;
+  const bool valid = img_raw < a.B;
+  const int img = valid ? img_raw : a.B - 1;
+  const bf16* xg = reinterpret_cast<const bf16*>(a.x);
+  const bf16* wq = reinterpret_cast<const bf16*>(a.wqkv_rm);
+  const bf16* wp = reinterpret_cast<const bf16*>(a.wproj_rm);
+  bf16* og = reinterpret_cast<bf16*>(a.out);
+  bf16* osv = reinterpret_cast<bf16*>(a.o_save);
+
+  // ---- loads: the image's token tile, the proj weight as fragments, q/k/v weights, biases, bank rows ----
+  bf16x8 xr[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+    xr[it] = *reinterpret_cast<const bf16x8*>(xg + ((size_t)img * CT + row) * a.ldx + 8 * c8);
+  }
+  bf16x4 wpr[WP_FRAGS * 64 / (64 * CNI)];                  // 18 quads per thread
+#pragma unroll
+  for (int it = 0; it < WP_FRAGS / CNI; ++it) {
+    const int f = it * CNI + wave, ctile = f / (CO / 16), otile = f - ctile * (CO / 16);
+    wpr[it] = *reinterpret_cast<const bf16x4*>(wp + (size_t)(16 * ctile + col) * CO + 16 * otile + 4 * q4);
+  }
+  s16x4 wqf[3][2];                                         // [part][k-step]: lane = output dim d (col), 4 consecutive input channels
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wqf[p][ks] = as_s16(*reinterpret_cast<const bf16x4*>(wq + (size_t)(16 * p + col) * CPG + 16 * ks + 4 * q4));
+  f32x4 bq, bk;
+  float bv;
+  bq = *reinterpret_cast<const f32x4*>(a.bqkv + 4 * q4);
+  bk = *reinterpret_cast<const f32x4*>(a.bqkv + CCG + 4 * q4);
+  bv = a.bqkv[2 * CCG + col];
+  const f32x4 shk4 = *reinterpret_cast<const f32x4*>(a.sh_k + (size_t)col * CCG + 4 * q4);      // bank key s = col, dims 4 q4 ..
+  float shv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) shv[i] = a.sh_v[(size_t)(4 * q4 + i) * CCG + col];               // bank value rows 4 q4 + i, dim col
+  // ---- consumers ----
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+    *reinterpret_cast<bf16x8*>(xt + row * LDX + 8 * c8) = xr[it];
+  }
+#pragma unroll
+  for (int it = 0; it < WP_FRAGS / CNI; ++it) {
+    const int f = it * CNI + wave;
+    *reinterpret_cast<bf16x4*>(swp + ((size_t)f * 64 + lane) * 4) = wpr[it];
+  }
+  bool bad = false;
+  s16x4 bkA, bvP;
+  {
+    bf16x4 t1, t2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bad |= (shk4[i] != shk4[i]) | (shv[i] != shv[i]); t1[i] = (bf16)shk4[i]; t2[i] = (bf16)shv[i]; }
+    bkA = as_s16(t1); bvP = as_s16(t2);
+  }
+  const bool adrop = a.attn_drop_p > 0.f && a.rng != nullptr;
+  AttnDrop drop;
+  drop.on = adrop;
+  drop.p = adrop ? a.attn_drop_p : 0.f;
+  drop.inv_keep = adrop ? 1.f / (1.f - a.attn_drop_p) : 1.f;
+  drop.key = adrop ? rng_key(a.rng, a.attn_drop_site) : 0u;
+  const bool pdrop = a.proj_drop_p > 0.f && a.rng != nullptr;
+  const uint32_t pkey_proj = pdrop ? rng_key(a.rng, a.proj_drop_site) : 0u;
+  const float pp = pdrop ? a.proj_drop_p : 0.f, pinv = pdrop ? 1.f / (1.f - a.proj_drop_p) : 1.f;
+  const float scale = 0.5f;                                // 1 / sqrt(D = 4)
+  const s16x4 zero_s = {0, 0, 0, 0};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                         // the proj fragments are complete (the token tile is this wave's own)
+
+  for (int g = 0; g < CG; ++g) {
+    const s16x4 xf0 = rowfrag(xt, LDX, 0, CPG * g), xf1 = rowfrag(xt, LDX, 0, CPG * g + 16);   // lane = token, 4 consecutive channels
+    f32x4 aq = bq, ak = bk, av = f32x4{bv, bv, bv, bv};
+    aq = mma16(wqf[0][0], xf0, aq); aq = mma16(wqf[0][1], xf1, aq);      // q[token = col][d = 4 q4 + r]
+    ak = mma16(wqf[1][0], xf0, ak); ak = mma16(wqf[1][1], xf1, ak);      // k[token = col][d = 4 q4 + r]
+    av = mma16(xf0, wqf[2][0], av); av = mma16(xf1, wqf[2][1], av);      // v[token = 4 q4 + r][d = col]
+    const s16x4 qb = as_s16(cvt4c(aq)), ka = as_s16(cvt4c(ak)), vp = as_s16(cvt4c(av));
+    f32x4 oacc = zero4;
+#pragma unroll
+    for (int h = 0; h < CH; ++h) {
+      const s16x4 qm = (q4 == h) ? qb : zero_s;            // head h's dims only
+      f32x4 s0 = mma16(ka, qm, zero4);                     // S^T[key = 4 q4 + r (tokens)][query = col]
+      f32x4 s1 = mma16(bkA, qm, zero4);                    // bank keys
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s0[r] *= scale; s1[r] *= scale; mx = fmaxf(mx, fmaxf(s0[r], s1[r])); }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mx); s1[r] = __expf(s1[r] - mx); sum += s0[r] + s1[r]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      if (adrop) {
+        const uint32_t pkey = attn_drop_pkey(drop, (img * CG + g) * CH + h);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s0[r] *= inv * attn_drop_factor(drop, pkey, col, 4 * q4 + r);
+          s1[r] *= inv * attn_drop_factor(drop, pkey, col, CT + 4 * q4 + r);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[r] *= inv; s1[r] *= inv; }
+      }
+      f32x4 oh = mma16(vp, as_s16(cvt4c(s0)), zero4);      // O_h^T[d = 4 q4 + r][query = col]: meaningful where d is in head h = lane group h
+      oh = mma16(bvP, as_s16(cvt4c(s1)), oh);
+      if (q4 == h) oacc = oh;
+    }
+    bad |= (oacc[0] != oacc[0]) | (oacc[1] != oacc[1]) | (oacc[2] != oacc[2]) | (oacc[3] != oacc[3]);
+    const bf16x4 o4 = cvt4c(oacc);                         // O[query = col][16 g + 4 q4 ..]
+    *reinterpret_cast<bf16x4*>(ot + col * LDOO + CCG * g + 4 * q4) = o4;
+    if (osv && valid) *reinterpret_cast<bf16x4*>(osv + ((size_t)img * CT + col) * CO + CCG * g + 4 * q4) = o4;
+  }
+  wave_sync();                                             // the O tile is this wave's own
+
+  // ---- out = dropout(O Wp^T + b): out^T[c][t] = Wp[c][:] . O[t][:], 12 output tiles x 6 k-steps from the LDS fragments ----
+  s16x4 of[CO / 16];
+#pragma unroll
+  for (int o16 = 0; o16 < CO / 16; ++o16) of[o16] = rowfrag(ot, LDOO, 0, 16 * o16);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {                   // six output tiles at a time: 24 accumulator registers
+    f32x4 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] = *reinterpret_cast<const f32x4*>(a.bproj + (6 * half + j) * 16 + 4 * q4);
+#pragma unroll
+    for (int o16 = 0; o16 < CO / 16; ++o16)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const s16x4 wf = as_s16(*reinterpret_cast<const bf16x4*>(swp + ((size_t)((6 * half + j) * (CO / 16) + o16) * 64 + lane) * 4));
+        acc[j] = mma16(wf, of[o16], acc[j]);
+      }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int c0 = (6 * half + j) * 16 + 4 * q4;
+      if (pdrop) {
+        const uint32_t base = (uint32_t)(img * CT + col) * (uint32_t)CC + (uint32_t)c0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] *= drop_factor(pkey_proj, base + r, pp, pinv);
+      }
+      if (valid) *reinterpret_cast<bf16x4*>(og + ((size_t)img * CT + col) * a.ldo + c0) = cvt4c(acc[j]);
+    }
+  }
+  if (a.nan_flag && __any(bad && valid) && lane == 0) atomicOr(a.nan_flag, 1);
+}
+
+int cga_validate(const qavit_cga_args* a) {
+  if (!a) return set_error(QAVIT_EINVAL, "cga: null args");
+  if (a->dtype != QAVIT_BF16) return set_error(QAVIT_EINVAL, "cga: the fused channel-group kernel is bf16 only");
+  if (a->T != CT || a->C != CC || a->G != CG || a->H != CH || a->D != CD || a->S != CS)
+    return set_error(QAVIT_EINVAL, "cga: built for 16 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
+  if (a->B <= 0 || !a->x || !a->out || !a->wqkv_rm || !a->wproj_rm || !a->bqkv || !a->bproj || !a->sh_k || !a->sh_v) return set_error(QAVIT_EINVAL, "cga: null operand");
+  auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+  if (!al(a->x, 15) || !al(a->out, 7) || !al(a->wqkv_rm, 7) || !al(a->wproj_rm, 7) || !al(a->bqkv, 15) || !al(a->bproj, 15) || !al(a->sh_k, 15) || !al(a->sh_v, 3) ||
+      (a->o_save && !al(a->o_save, 7)) || a->ldx % 8 || a->ldo % 4)
+    return set_error(QAVIT_EINVAL, "cga: alignment (x 16 bytes / ld % 8; out, weights, o_save 8 bytes / ld % 4; biases and sh_k 16 bytes)");
+  return QAVIT_OK;
+}
+
+}  // namespace
+
+}  // namespace qv
+
+using namespace qv;
+
+extern "C" int qavit_cga_supported(int T, int C, int G, int H, int S) { return (T == CT && C == CC && G == CG && H == CH && S == CS) ? 1 : 0; }
+
+extern "C" int qavit_cga_fwd(const qavit_cga_args* a, void* stream) {
+  int rc = cga_validate(a);
+  if (rc) return rc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cga_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_CGA);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(cga_fwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNI), SM_CGA, st, *a);
+  if (a->nan_flag) branch_nan_fix_launch(a->out, a->ldo, a->B * CT, CC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, st);
+  return check_launch("cga_fwd");
+}

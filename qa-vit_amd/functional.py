@@ -834,6 +834,95 @@ def branch_ok(kind, x, Lk, KC, S, heads) -> bool:
     return K.branch_supported(kind, T, Cc, heads, Cc // heads, KC, S, Lk)
 
 
+_CGA_FUSED = os.environ.get("QAVIT_FUSED_CGA", "1") != "0"
+
+
+def cga_ok(x, G, heads, S) -> bool:
+    if not _CGA_FUSED or x.dtype != torch.bfloat16 or x.dim() != 3 or not x.is_cuda:
+        return False
+    B, T, Cc = x.shape
+    return bool(L.load().qavit_cga_supported(T, Cc, G, heads, S))
+
+
+class CGABranchFn(Function):
+    """The whole channel-group branch (HQAViT_CIFAR100.py:535-595) in one forward launch (csrc/cga.hip): q/k/v projections of the six
+    channel groups, 4 heads of D = 4 over [tokens ; projected bank rows], softmax + dropout, P.V, proj + dropout.  Backward: the
+    unfused kernels on q/k/v recomputed by one GEMM (they are 9 MB the forward does not store) and the saved attention output."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wproj, bproj, sh_k, sh_v, meta):
+        K._require_cuda(x, wq)
+        rt = _rt(x)
+        B, T, Cc = x.shape
+        G, H, S = meta["G"], meta["H"], sh_k.shape[0]
+        x = x.contiguous()
+        pk = pack_for(x.device)
+        Wqkv, _ = pk.get([wq, wk, wv], x.dtype)
+        bqkv = pk.get([bq, bk, bv], torch.float32)[0].reshape(-1)
+        Wp, _ = pk.get(wproj, x.dtype)
+        need = any(ctx.needs_input_grad)
+        out = torch.empty(B, T, Cc, dtype=x.dtype, device=x.device)
+        o = torch.empty(B * T, wproj.shape[1], dtype=x.dtype, device=x.device) if need else None
+        a = L.CgaArgs()
+        a.dtype = K.dt_code(x.dtype)
+        a.B, a.T, a.C, a.G, a.H, a.D, a.S = B, T, Cc, G, H, (wq.shape[0] // H), S
+        a.x, a.ldx = x.data_ptr(), Cc
+        a.wqkv_rm, a.bqkv = Wqkv.data_ptr(), bqkv.data_ptr()
+        a.wproj_rm, a.bproj = Wp.data_ptr(), bproj.data_ptr()
+        shk, shv = sh_k.detach().contiguous(), sh_v.detach().contiguous()
+        a.sh_k, a.sh_v = shk.data_ptr(), shv.data_ptr()
+        a.out, a.ldo = out.data_ptr(), Cc
+        a.o_save = K._p(o)
+        ad, pd = meta["attn_drop"], meta["proj_drop"]
+        a.attn_drop_p, a.attn_drop_site = float(ad[0]), int(ad[1])
+        a.proj_drop_p, a.proj_drop_site = float(pd[0]), int(pd[1])
+        a.rng = rt.rng.data_ptr()
+        if rt.nan_guard:
+            a.nan_flag = rt.nan_flag.data_ptr()
+        L.check(L.load().qavit_cga_fwd(C.byref(a), K.stream()), "cga_fwd")
+        if need:
+            ctx.meta = meta
+            ctx.save_for_backward(x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk, shv, o)
+            ctx.sh_in = (sh_k, sh_v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk, shv, o = ctx.saved_tensors
+        sh_k_in, sh_v_in = ctx.sh_in
+        m = ctx.meta
+        B, T, Cc = x.shape
+        G, H = m["G"], m["H"]
+        cpg, ccg = Cc // G, wq.shape[0]
+        M = B * T * G
+        # ---- proj backward: dO = (dout * mask) Wproj ; dWproj, dbproj deferred
+        d_o = _linear_bwd(o, wproj, bproj, dout.reshape(B * T, Cc), 0, Cc, True, drop=m["proj_drop"])
+        with torch.no_grad():
+            # ---- q / k / v again (one GEMM), the attention-core backward, the stacked projection's backward
+            x2 = x.reshape(M, cpg)
+            pk = pack_for(x.device)
+            Wc, Wt = pk.get([wq, wk, wv], x.dtype)
+            bias = pk.get([bq, bk, bv], torch.float32)[0].reshape(-1)
+            qkv = torch.empty(M, 3 * ccg, dtype=x.dtype, device=x.device)
+            K.gemm_nt(x2, Wc, qkv, M, 3 * ccg, cpg, cpg, cpg, 3 * ccg, bias)
+            spec = dict(m["spec"])
+            dqkv, _, _, _, sk_ret, sv_ret = _attn_bwd(qkv, None, None, None, shk, shv, sh_k_in, sh_v_in, spec, d_o.reshape(M, ccg))
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(M, cpg, dtype=x.dtype, device=x.device)
+                K.gemm_nt(dqkv, Wt, dx, M, cpg, 3 * ccg, 3 * ccg, 3 * ccg, cpg, None)
+            off, esz = 0, dqkv.element_size()
+            DeferDW.arm()
+            for w, b in ((wq, bq), (wk, bk), (wv, bv)):
+                wbuf, _ = grad_sink(w)
+                bbuf, _ = grad_sink(b)
+                if wbuf is not None:
+                    K.gemm_tn(dqkv, x2, wbuf, M, ccg, cpg, 3 * ccg, cpg, cpg, bbuf, A_ptr=dqkv.data_ptr() + off * esz)
+                off += ccg
+        return (dx.reshape(B, T, Cc) if dx is not None else None), None, None, None, None, None, None, None, None, \
+            _ret(sk_ret, sh_k_in) if sk_ret is not None else None, _ret(sv_ret, sh_v_in) if sv_ret is not None else None, None
+
+
 class AttnFn(Function):
     """See include/qavit.h (qavit_attn_args).  ``q_t`` is a 2-D row matrix holding q (and, when ``kv_t`` is
     None and L > 0, also k and v) at column offsets; gradients come back as whole matrices.

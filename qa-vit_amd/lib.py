@@ -27,6 +27,15 @@ class LnReduceDesc(C.Structure):
     _fields_ = [("parts", vp), ("nparts", i32), ("C", i32), ("dgamma", vp), ("dbeta", vp), ("stride", i64)]
 
 
+class CgaArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("G", i32), ("H", i32), ("D", i32), ("S", i32),
+        ("x", vp), ("ldx", i64), ("wqkv_rm", vp), ("bqkv", vp), ("wproj_rm", vp), ("bproj", vp), ("sh_k", vp), ("sh_v", vp),
+        ("out", vp), ("ldo", i64), ("o_save", vp),
+        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp), ("nan_flag", vp),
+    ]
+
+
 class BranchBwdArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("kind", i32), ("B", i32), ("T", i32), ("C", i32), ("H", i32), ("D", i32), ("KC", i32), ("S", i32), ("L", i32),
@@ -101,6 +110,8 @@ _SIGS = {
     "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_parts": (i32, [i32, i32]),
     "qavit_branch_bwd_parts": (i32, [i32]),
+    "qavit_cga_supported": (i32, [i32, i32, i32, i32, i32]),
+    "qavit_cga_fwd": (i32, [vp, vp]),
     "qavit_ccf_bwd_parts": (i32, [i32]),
     "qavit_branch_bwd": (i32, [vp, vp]),
     "qavit_ln_param_reduce": (i32, [vp, i32, vp]),

@@ -234,9 +234,8 @@ class EfficientChannelGroupAttention(_Branch):
     def forward(self, x):
         B, N, C = x.shape
         G, cpg, ccg, H = self.num_groups, self.channels_per_group, self.compress_per_group, self.num_heads
-        qkv = F.LinearStack3Fn.apply(x.reshape(B * N * G, cpg), self.q_proj.weight, self.q_proj.bias,
-                                     self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias)
         bank = self.global_bank
+        fused = F.cga_ok(x, G, H, bank.bank_size) and ccg == 16 and cpg == 32
         # .clone(): the reference's Linear flattens the EXPANDED bank, which copies -- its weight gradient sees the
         # forward-time bank, not the in-place writes that follow (HQAViT_CIFAR100.py:576-577)
         if _BANK_PROJ2 and x.is_cuda and bank.global_k.dtype == torch.float32:
@@ -251,6 +250,14 @@ class EfficientChannelGroupAttention(_Branch):
                     q_rows=B * N * G)
         p = self.dropout.p if self.training else 0.0
         spec["drop"] = (p, self._site_attn)                    # :587
+        if fused:
+            out = F.CGABranchFn.apply(x, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias,
+                                      self.proj.weight, self.proj.bias, sh_k, sh_v,
+                                      dict(G=G, H=H, spec=spec, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+            self._write(out)
+            return out
+        qkv = F.LinearStack3Fn.apply(x.reshape(B * N * G, cpg), self.q_proj.weight, self.q_proj.bias,
+                                     self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias)
         o = F.AttnFn.apply(qkv, None, None, None, sh_k, sh_v, spec)
         out = F.linear(o.reshape(B, N, self.compress_c), self.proj.weight, self.proj.bias, drop=(p, self._site))
         self._write(out)

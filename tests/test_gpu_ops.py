@@ -913,6 +913,50 @@ def test_fused_branch_backward(F, Q, kind, B, drop):
         assert rel(g1[k_], g2[k_]) <= 3e-2, (k_, rel(g1[k_], g2[k_]))
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+@pytest.mark.parametrize("B", [3, 64, 1030])
+def test_fused_cga_branch(F, Q, B, drop):
+    """The channel-group branch through the fused kernel (csrc/cga.hip: q/k/v projections of the six groups, 4 heads of D = 4 over
+    tokens + projected bank rows, softmax + dropout, P.V, proj + dropout in one launch) against the unfused chain of the same module:
+    identical dropout masks (same sites / counters), so outputs and every gradient agree to bf16 rounding."""
+    import importlib
+    M = importlib.import_module("qa-vit_amd.modules")
+    K = importlib.import_module("qa-vit_amd.kernels")
+    cfg = Q.HQAViTConfig()
+    cfg.dropout = drop
+    res = []
+    x0 = leaf(B, 16, cfg.embed_dim, seed=600).detach().to(torch.bfloat16)
+    g0 = leaf(B, 16, cfg.embed_dim, seed=601).detach().to(torch.bfloat16)
+    for fused in (True, False):
+        torch.manual_seed(1)
+        bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+        rt = M._Ctx("hqa")
+        rt.bank_writes = False
+        mod = M.EfficientChannelGroupAttention(cfg, bank, rt).to(DEV).train()
+        mod._site, mod._site_attn = 9001, 9002                  # same dropout sites in both runs
+        x = x0.clone().requires_grad_(True)
+        old = F._CGA_FUSED
+        F._CGA_FUSED = fused
+        try:
+            out = mod(x)
+            out.backward(g0)
+        finally:
+            F._CGA_FUSED = old
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+        grads.update({"bank." + n: p.grad.clone() for n, p in bank.named_parameters() if p.grad is not None})
+        res.append((out.detach().float(), x.grad.float(), grads))
+    (o1, dx1, g1), (o2, dx2, g2) = res
+    assert rel(o1, o2) <= 3e-2
+    if drop > 0:
+        assert torch.equal(o1 == 0, o2 == 0)                     # same proj-dropout mask
+    assert rel(dx1, dx2) <= 4e-2
+    assert set(g1) == set(g2) and len(g1) >= 10
+    for k_ in g1:
+        assert torch.isfinite(g1[k_]).all(), k_
+        assert rel(g1[k_], g2[k_]) <= 4e-2, (k_, rel(g1[k_], g2[k_]))
+
+
 def test_partial_row_reduce(F, Q):
     """qavit_ln_param_reduce: dst halves += column sums of n partial rows, dense rows and rows embedded in a wider record (stride) --
     the end-of-backward fold of the LayerNorm dgamma/dbeta partials and of the fused branch backward's dE / shared-row partials."""
