@@ -357,6 +357,29 @@ typedef struct qavit_cga_args {
 } qavit_cga_args;
 int qavit_cga_supported(int T, int C, int G, int H, int S);
 int qavit_cga_fwd(const qavit_cga_args* a, void* stream);
+/* Backward of the same branch in one launch (it replaces the proj dX GEMM, a q/k/v recompute GEMM, qavit_attn_bwd + its reduction and
+ * the q/k/v dX GEMM): everything is recomputed from x.  in: dout [B*16, 192]; x; wqkv_rm and its transpose wqkvT_rm [32, 48];
+ * wprojT_rm = the proj weight transposed [96, 192] (row-major bf16, the W^T copies qavit_pack_weights makes); bqkv; sh_k / sh_v with
+ * their forward-time values; the forward's dropout (p, site) pairs and rng.  out: dz = dout * proj mask (operand of dW_proj; may be
+ * NULL without proj dropout), dqkv [B*16*6, 48] (rows = (image, token, group); operand of the q/k/v weight gradients), dx [B*16, 192],
+ * parts: qavit_cga_bwd_parts(B) rows of QAVIT_CGA_PARTS_FLOATS = [d sh_k 16x16 | d sh_v 16x16] (fold with qavit_ln_param_reduce). */
+#define QAVIT_CGA_PARTS_FLOATS 512
+typedef struct qavit_cga_bwd_args {
+  int dtype;
+  int B, T, C, G, H, D, S;
+  const void* dout; int64_t lddout;
+  const void* x; int64_t ldx;
+  const void* wqkv_rm; const void* wqkvT_rm; const float* bqkv;
+  const void* wprojT_rm;
+  const float* sh_k; const float* sh_v;
+  float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
+  void* dz; int64_t lddz;
+  void* dqkv;
+  void* dx; int64_t lddx;
+  float* parts;
+} qavit_cga_bwd_args;
+int qavit_cga_bwd_parts(int B);
+int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Depthwise k x k convolution, stride 1, pad k/2, on channel-last tokens x[B, H*W, C] (k in {3,5,7}):

@@ -189,6 +189,232 @@ __global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
   if (a.nan_flag && __any(bad && valid) && lane == 0) atomicOr(a.nan_flag, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward, one launch: the proj input gradient, the recomputed attention cores' backward, the q/k/v projections' input gradient.
+//   dO = (dout * mask) Wp ;  per (group, head): P recomputed, dP = dO V^T, D = rowsum(P m * dP), dS = P (dP m - D) / 2,
+//   dQ = dS K, dK = dS^T Q, dV = (P m)^T dO ;  dx_g = dq Wq + dk Wk + dv Wv
+// Contractions over queries (dK, dV) and over keys (dQ) need S-shaped matrices in both orientations: S and dP are formed twice from
+// the same operand registers with A and B swapped, the second orientation's statistics arrive by lane permute (as in branch_bwd.hip).
+// dq / dk / dv leave as rows of [B*16*6, 48] (operand of the deferred weight-gradient GEMMs), the masked dout as dz (operand of
+// dW_proj with the O the forward saved); the bank rows' gradients as one row of 512 partial sums per workgroup.
+constexpr int CGA_PART = 2 * CS * CCG;                     // [d sh_k 16 x 16 | d sh_v 16 x 16]
+constexpr int SMB_WP = 0, SMB_GT = WP_FRAGS * 512, SMB_XT = SMB_GT + CNI * CT * LDX * 2, SMB_RED = SMB_XT + CNI * CT * LDX * 2,
+              SM_CGA_BWD = SMB_RED + CNI * CGA_PART * 4;   // 36864 + 25600 + 25600 + 8192 = 96256 bytes
+
+__global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
+  bf16* swp = reinterpret_cast<bf16*>(smraw + SMB_WP);      // Wp^T fragments: (o tile, c tile): lane = o, 4 consecutive c
+  bf16* gt = reinterpret_cast<bf16*>(smraw + SMB_GT) + wave * (CT * LDX);
+  bf16* xt = reinterpret_cast<bf16*>(smraw + SMB_XT) + wave * (CT * LDX);
+  float* red = reinterpret_cast<float*>(smraw + SMB_RED);
+  const int img_raw = blockIdx.x * CNI + wave;
+  const bool valid = img_raw < a.B;
+  const int img = valid ? img_raw : a.B - 1;
+  const bf16* xg = reinterpret_cast<const bf16*>(a.x);
+  const bf16* gg = reinterpret_cast<const bf16*>(a.dout);
+  const bf16* wq = reinterpret_cast<const bf16*>(a.wqkv_rm);
+  const bf16* wqT = reinterpret_cast<const bf16*>(a.wqkvT_rm);
+  const bf16* wpT = reinterpret_cast<const bf16*>(a.wprojT_rm);
+  bf16* dzg = reinterpret_cast<bf16*>(a.dz);
+  bf16* dqg = reinterpret_cast<bf16*>(a.dqkv);
+  bf16* dxg = reinterpret_cast<bf16*>(a.dx);
+
+  bf16x8 xr[6], gr[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+    xr[it] = *reinterpret_cast<const bf16x8*>(xg + ((size_t)img * CT + row) * a.ldx + 8 * c8);
+    gr[it] = *reinterpret_cast<const bf16x8*>(gg + ((size_t)img * CT + row) * a.lddout + 8 * c8);
+  }
+  bf16x4 wpr[WP_FRAGS / CNI];
+#pragma unroll
+  for (int it = 0; it < WP_FRAGS / CNI; ++it) {
+    const int f = it * CNI + wave, otile = f / (CC / 16), ctile = f - otile * (CC / 16);
+    wpr[it] = *reinterpret_cast<const bf16x4*>(wpT + (size_t)(16 * otile + col) * CC + 16 * ctile + 4 * q4);
+  }
+  s16x4 wqf[3][2], wtf[3][2];                              // forward operand (lane = d, 4 channels) and its transpose (lane = channel, 4 dims)
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      wqf[p][ks] = as_s16(*reinterpret_cast<const bf16x4*>(wq + (size_t)(16 * p + col) * CPG + 16 * ks + 4 * q4));
+      wtf[p][ks] = as_s16(*reinterpret_cast<const bf16x4*>(wqT + (size_t)(16 * ks + col) * (3 * CCG) + 16 * p + 4 * q4));
+    }
+  const f32x4 bq = *reinterpret_cast<const f32x4*>(a.bqkv + 4 * q4);
+  const f32x4 bk = *reinterpret_cast<const f32x4*>(a.bqkv + CCG + 4 * q4);
+  const float bqp = a.bqkv[col], bkp = a.bqkv[CCG + col];
+  const f32x4 shk4 = *reinterpret_cast<const f32x4*>(a.sh_k + (size_t)col * CCG + 4 * q4);      // lane = bank row, 4 dims
+  const f32x4 shv4 = *reinterpret_cast<const f32x4*>(a.sh_v + (size_t)col * CCG + 4 * q4);
+  float shkp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) shkp[i] = a.sh_k[(size_t)(4 * q4 + i) * CCG + col];              // lane = dim, 4 bank rows
+  const bool pdrop = a.proj_drop_p > 0.f && a.rng != nullptr;
+  const uint32_t pkey_proj = pdrop ? rng_key(a.rng, a.proj_drop_site) : 0u;
+  const float pp = pdrop ? a.proj_drop_p : 0.f, pinv = pdrop ? 1.f / (1.f - a.proj_drop_p) : 1.f;
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+    bf16x8 g8 = gr[it];
+    if (pdrop) {
+      const uint32_t base = (uint32_t)(img * CT + row) * (uint32_t)CC + (uint32_t)(8 * c8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g8[e] = (bf16)((float)g8[e] * drop_factor(pkey_proj, base + e, pp, pinv));
+      if (dzg && valid) *reinterpret_cast<bf16x8*>(dzg + ((size_t)img * CT + row) * a.lddz + 8 * c8) = g8;
+    }
+    *reinterpret_cast<bf16x8*>(gt + row * LDX + 8 * c8) = g8;
+    *reinterpret_cast<bf16x8*>(xt + row * LDX + 8 * c8) = xr[it];
+  }
+#pragma unroll
+  for (int it = 0; it < WP_FRAGS / CNI; ++it) *reinterpret_cast<bf16x4*>(swp + ((size_t)(it * CNI + wave) * 64 + lane) * 4) = wpr[it];
+  s16x4 bkA, bvA, bkP;
+  {
+    bf16x4 t1, t2, t3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { t1[i] = (bf16)shk4[i]; t2[i] = (bf16)shv4[i]; t3[i] = (bf16)shkp[i]; }
+    bkA = as_s16(t1); bvA = as_s16(t2); bkP = as_s16(t3);
+  }
+  const bool adrop = a.attn_drop_p > 0.f && a.rng != nullptr;
+  AttnDrop drop;
+  drop.on = adrop;
+  drop.p = adrop ? a.attn_drop_p : 0.f;
+  drop.inv_keep = adrop ? 1.f / (1.f - a.attn_drop_p) : 1.f;
+  drop.key = adrop ? rng_key(a.rng, a.attn_drop_site) : 0u;
+  const float scale = 0.5f;
+  const s16x4 zero_s = {0, 0, 0, 0};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  // ---- dO = gm Wp in both layouts: dob[g] lane = query, 4 dims (B operand);  dop[g] lane = dim, 4 queries ----
+  s16x4 dob[CG], dop[CG];
+  {
+    s16x4 gf[CC / 16];
+#pragma unroll
+    for (int ct = 0; ct < CC / 16; ++ct) gf[ct] = rowfrag(gt, LDX, 0, 16 * ct);
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+      f32x4 c1 = zero4, c2 = zero4;
+#pragma unroll
+      for (int ct = 0; ct < CC / 16; ++ct) {
+        const s16x4 wf = as_s16(*reinterpret_cast<const bf16x4*>(swp + ((size_t)(g * (CC / 16) + ct) * 64 + lane) * 4));
+        c1 = mma16(wf, gf[ct], c1);                        // dO^T[o = 4 q4 + r][t = col]
+        c2 = mma16(gf[ct], wf, c2);                        // dO  [t = 4 q4 + r][o = col]
+      }
+      dob[g] = as_s16(cvt4c(c1));
+      dop[g] = as_s16(cvt4c(c2));
+    }
+  }
+  f32x4 dshk = zero4, dshv = zero4;                        // acc[r] = d sh^T[d = 4 q4 + r][s = col], summed over groups
+
+  if (valid)
+  for (int g = 0; g < CG; ++g) {
+    const s16x4 xf0 = rowfrag(xt, LDX, 0, CPG * g), xf1 = rowfrag(xt, LDX, 0, CPG * g + 16);
+    f32x4 aq = bq, ak = bk, av = zero4, aqp = f32x4{bqp, bqp, bqp, bqp}, akp = f32x4{bkp, bkp, bkp, bkp};
+    {
+      const f32x4 bvv = *reinterpret_cast<const f32x4*>(a.bqkv + 2 * CCG + 4 * q4);
+      av = bvv;
+    }
+    aq = mma16(wqf[0][0], xf0, aq); aq = mma16(wqf[0][1], xf1, aq);          // q[token = col][4 dims]
+    ak = mma16(wqf[1][0], xf0, ak); ak = mma16(wqf[1][1], xf1, ak);          // k[token = col][4 dims]
+    av = mma16(wqf[2][0], xf0, av); av = mma16(wqf[2][1], xf1, av);          // v[token = col][4 dims]
+    aqp = mma16(xf0, wqf[0][0], aqp); aqp = mma16(xf1, wqf[0][1], aqp);      // q[token = 4 q4 + r][dim = col]
+    akp = mma16(xf0, wqf[1][0], akp); akp = mma16(xf1, wqf[1][1], akp);      // k[token = 4 q4 + r][dim = col]
+    const s16x4 qb = as_s16(cvt4c(aq)), ka = as_s16(cvt4c(ak)), va = as_s16(cvt4c(av)), qp = as_s16(cvt4c(aqp)), kp = as_s16(cvt4c(akp));
+    f32x4 dq = zero4, dk = zero4, dv = zero4;
+#pragma unroll
+    for (int h = 0; h < CH; ++h) {
+      const bool mine = q4 == h;
+      const s16x4 qm = mine ? qb : zero_s, dom = mine ? dob[g] : zero_s;
+      f32x4 sT0 = mma16(ka, qm, zero4), sT1 = mma16(bkA, qm, zero4);        // S^T[key][query = col]
+      f32x4 s20 = mma16(qm, ka, zero4), s21 = mma16(qm, bkA, zero4);        // S  [query = 4 q4 + r][key = col]
+      const f32x4 dT0 = mma16(va, dom, zero4), dT1 = mma16(bvA, dom, zero4);  // dP^T
+      const f32x4 d20 = mma16(dom, va, zero4), d21 = mma16(dom, bvA, zero4);  // dP
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sT0[r] *= scale; sT1[r] *= scale; mx = fmaxf(mx, fmaxf(sT0[r], sT1[r])); }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sT0[r] = __expf(sT0[r] - mx); sT1[r] = __expf(sT1[r] - mx); sum += sT0[r] + sT1[r]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      const uint32_t pkey = adrop ? attn_drop_pkey(drop, (img * CG + g) * CH + h) : 0u;
+      float m0[4], m1[4], dsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        m0[r] = adrop ? attn_drop_factor(drop, pkey, col, 4 * q4 + r) : 1.f;
+        m1[r] = adrop ? attn_drop_factor(drop, pkey, col, CT + 4 * q4 + r) : 1.f;
+        sT0[r] *= inv; sT1[r] *= inv;                      // P^T
+        dsum += sT0[r] * m0[r] * dT0[r] + sT1[r] * m1[r] * dT1[r];
+      }
+      dsum += __shfl_xor(dsum, 16, 64);
+      dsum += __shfl_xor(dsum, 32, 64);                    // D[query = col] = sum_keys (P m) dP
+      f32x4 e0, e1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e0[r] = sT0[r] * (dT0[r] * m0[r] - dsum) * scale;  // dS^T
+        e1[r] = sT1[r] * (dT1[r] * m1[r] - dsum) * scale;
+      }
+      const s16x4 dsT0 = as_s16(cvt4c(e0)), dsT1 = as_s16(cvt4c(e1));
+      // second orientation: lane = key (col), registers = queries 4 q4 + r
+      f32x4 f0, f1, p0, p1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float mxq = __shfl(mx, 4 * q4 + r, 64), invq = __shfl(inv, 4 * q4 + r, 64), dq_ = __shfl(dsum, 4 * q4 + r, 64);
+        const float pa = __expf(s20[r] * scale - mxq) * invq, pb = __expf(s21[r] * scale - mxq) * invq;
+        const float ma = adrop ? attn_drop_factor(drop, pkey, 4 * q4 + r, col) : 1.f;
+        const float mb = adrop ? attn_drop_factor(drop, pkey, 4 * q4 + r, CT + col) : 1.f;
+        p0[r] = pa * ma; p1[r] = pb * mb;
+        f0[r] = pa * (d20[r] * ma - dq_) * scale;
+        f1[r] = pb * (d21[r] * mb - dq_) * scale;
+      }
+      const s16x4 ds20 = as_s16(cvt4c(f0)), ds21 = as_s16(cvt4c(f1)), pd20 = as_s16(cvt4c(p0)), pd21 = as_s16(cvt4c(p1));
+      // dQ^T[d][query] = sum_key K[key][d] dS^T[key][query]  (tokens + bank rows); valid where d is in head h = this lane group
+      f32x4 t = mma16(kp, dsT0, zero4);
+      t = mma16(bkP, dsT1, t);
+      if (mine) dq = t;
+      // dK^T[d][key] = sum_query Q[query][d] dS[query][key];  dV^T[d][key] = sum_query dO[query][d] (P m)[query][key]
+      t = mma16(qp, ds20, zero4);
+      if (mine) dk = t;
+      t = mma16(dop[g], pd20, zero4);
+      if (mine) dv = t;
+      t = mma16(qp, ds21, zero4);                           // bank rows: d sh_k^T[d][s]
+      if (mine) { dshk[0] += t[0]; dshk[1] += t[1]; dshk[2] += t[2]; dshk[3] += t[3]; }
+      t = mma16(dop[g], pd21, zero4);
+      if (mine) { dshv[0] += t[0]; dshv[1] += t[1]; dshv[2] += t[2]; dshv[3] += t[3]; }
+    }
+    // dq / dk / dv: value[token = col][d = 4 q4 + r] -> the (image, token, group) row of dqkv
+    const bf16x4 dq4 = cvt4c(dq), dk4 = cvt4c(dk), dv4 = cvt4c(dv);
+    bf16* drow = dqg + (((size_t)img * CT + col) * CG + g) * (3 * CCG);
+    *reinterpret_cast<bf16x4*>(drow + 4 * q4) = dq4;
+    *reinterpret_cast<bf16x4*>(drow + CCG + 4 * q4) = dk4;
+    *reinterpret_cast<bf16x4*>(drow + 2 * CCG + 4 * q4) = dv4;
+    // dx_g^T[c][token] = sum_d Wq[d][c] dq[token][d] + Wk .. + Wv ..
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 c = mma16(wtf[0][ks], as_s16(dq4), zero4);
+      c = mma16(wtf[1][ks], as_s16(dk4), c);
+      c = mma16(wtf[2][ks], as_s16(dv4), c);
+      *reinterpret_cast<bf16x4*>(dxg + ((size_t)img * CT + col) * a.lddx + CPG * g + 16 * ks + 4 * q4) = cvt4c(c);
+    }
+  }
+  // ---- bank-row gradients: the four waves' sums -> one row of partials ----
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[wave * CGA_PART + col * CCG + 4 * q4 + r] = dshk[r];                 // [s][d]
+    red[wave * CGA_PART + CS * CCG + col * CCG + 4 * q4 + r] = dshv[r];
+  }
+  __syncthreads();
+  for (int e = tid; e < CGA_PART; e += 64 * CNI) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int w = 0; w < CNI; ++w) sacc += red[w * CGA_PART + e];
+    a.parts[(size_t)blockIdx.x * CGA_PART + e] = sacc;
+  }
+}
+
 int cga_validate(const qavit_cga_args* a) {
   if (!a) return set_error(QAVIT_EINVAL, "cga: null args");
   if (a->dtype != QAVIT_BF16) return set_error(QAVIT_EINVAL, "cga: the fused channel-group kernel is bf16 only");
@@ -207,6 +433,31 @@ int cga_validate(const qavit_cga_args* a) {
 }  // namespace qv
 
 using namespace qv;
+
+extern "C" int qavit_cga_bwd_parts(int B) { return B > 0 ? (B + CNI - 1) / CNI : 0; }
+
+extern "C" int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream) {
+  if (!a) return set_error(QAVIT_EINVAL, "cga_bwd: null args");
+  if (a->dtype != QAVIT_BF16) return set_error(QAVIT_EINVAL, "cga_bwd: bf16 only");
+  if (a->T != CT || a->C != CC || a->G != CG || a->H != CH || a->D != CD || a->S != CS)
+    return set_error(QAVIT_EINVAL, "cga_bwd: built for 16 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
+  if (a->B <= 0 || !a->x || !a->dout || !a->wqkv_rm || !a->wqkvT_rm || !a->wprojT_rm || !a->bqkv || !a->sh_k || !a->sh_v || !a->dqkv || !a->dx || !a->parts)
+    return set_error(QAVIT_EINVAL, "cga_bwd: null operand");
+  if (a->proj_drop_p > 0.f && a->rng && !a->dz) return set_error(QAVIT_EINVAL, "cga_bwd: proj dropout needs dz");
+  auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+  if (!al(a->x, 15) || !al(a->dout, 15) || (a->dz && !al(a->dz, 15)) || !al(a->wqkv_rm, 7) || !al(a->wqkvT_rm, 7) || !al(a->wprojT_rm, 7) || !al(a->bqkv, 15) ||
+      !al(a->sh_k, 15) || !al(a->sh_v, 15) || !al(a->dqkv, 7) || !al(a->dx, 7) || !al(a->parts, 15) || a->ldx % 8 || a->lddout % 8 || (a->dz && a->lddz % 8) || a->lddx % 4)
+    return set_error(QAVIT_EINVAL, "cga_bwd: alignment (activations 16 bytes / ld % 8; weights, dqkv, dx 8 bytes; biases, bank rows, parts 16 bytes)");
+  static_assert(CGA_PART == QAVIT_CGA_PARTS_FLOATS, "header constant out of date");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cga_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_CGA_BWD);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(cga_bwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNI), SM_CGA_BWD, st, *a);
+  return check_launch("cga_bwd");
+}
 
 extern "C" int qavit_cga_supported(int T, int C, int G, int H, int S) { return (T == CT && C == CC && G == CG && H == CH && S == CS) ? 1 : 0; }
 

@@ -835,6 +835,7 @@ def branch_ok(kind, x, Lk, KC, S, heads) -> bool:
 
 
 _CGA_FUSED = os.environ.get("QAVIT_FUSED_CGA", "1") != "0"
+_CGA_FUSED_BWD = os.environ.get("QAVIT_FUSED_CGA_BWD", "1") != "0"
 
 
 def cga_ok(x, G, heads, S) -> bool:
@@ -895,6 +896,8 @@ class CGABranchFn(Function):
         G, H = m["G"], m["H"]
         cpg, ccg = Cc // G, wq.shape[0]
         M = B * T * G
+        if _CGA_FUSED_BWD and dout.dtype == torch.bfloat16:
+            return CGABranchFn._backward_fused(ctx, dout, x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk, shv, o, sh_k_in, sh_v_in, m, B, T, Cc, G, H, cpg, ccg, M)
         # ---- proj backward: dO = (dout * mask) Wproj ; dWproj, dbproj deferred
         d_o = _linear_bwd(o, wproj, bproj, dout.reshape(B * T, Cc), 0, Cc, True, drop=m["proj_drop"])
         with torch.no_grad():
@@ -921,6 +924,72 @@ class CGABranchFn(Function):
                 off += ccg
         return (dx.reshape(B, T, Cc) if dx is not None else None), None, None, None, None, None, None, None, None, \
             _ret(sk_ret, sh_k_in) if sk_ret is not None else None, _ret(sv_ret, sh_v_in) if sv_ret is not None else None, None
+
+
+def _cga_backward_fused(ctx, dout, x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk, shv, o, sh_k_in, sh_v_in, m, B, T, Cc, G, H, cpg, ccg, M):
+    """CGABranchFn.backward through csrc/cga.hip's backward kernel: one launch from dout to dx / dqkv / dz; weight gradients deferred
+    as everywhere; the bank rows' gradients (sums over images and groups) reduced at once -- BankProj2Fn.backward is waiting for them."""
+    rt = _rt(x)
+    g2 = dout.reshape(B * T, Cc)
+    if not g2.is_contiguous():
+        g2 = g2.contiguous()
+    pd, ad = m["proj_drop"], m["attn_drop"]
+    dz = torch.empty_like(g2) if pd[0] > 0.0 else g2
+    pk = pack_for(x.device)
+    Wqkv, WqkvT = pk.get([wq, wk, wv], x.dtype)
+    bqkv = pk.get([bq, bk, bv], torch.float32)[0].reshape(-1)
+    _, WpT = pk.get(wproj, x.dtype)
+    dqkv = torch.empty(M, 3 * ccg, dtype=x.dtype, device=x.device)
+    dx = torch.empty(B * T, Cc, dtype=x.dtype, device=x.device)
+    nparts = int(L.load().qavit_cga_bwd_parts(B))
+    parts = torch.empty(nparts * 512, dtype=torch.float32, device=x.device)
+    a = L.CgaBwdArgs()
+    a.dtype = K.dt_code(x.dtype)
+    a.B, a.T, a.C, a.G, a.H, a.D, a.S = B, T, Cc, G, H, ccg // H, shk.shape[0]
+    a.dout, a.lddout = g2.data_ptr(), Cc
+    a.x, a.ldx = x.data_ptr(), Cc
+    a.wqkv_rm, a.wqkvT_rm, a.bqkv = Wqkv.data_ptr(), WqkvT.data_ptr(), bqkv.data_ptr()
+    a.wprojT_rm = WpT.data_ptr()
+    a.sh_k, a.sh_v = shk.data_ptr(), shv.data_ptr()
+    a.attn_drop_p, a.attn_drop_site = float(ad[0]), int(ad[1])
+    a.proj_drop_p, a.proj_drop_site = float(pd[0]), int(pd[1])
+    a.rng = rt.rng.data_ptr()
+    if pd[0] > 0.0:
+        a.dz, a.lddz = dz.data_ptr(), Cc
+    a.dqkv = dqkv.data_ptr()
+    a.dx, a.lddx = dx.data_ptr(), Cc
+    a.parts = parts.data_ptr()
+    DeferDW.arm()
+    L.check(L.load().qavit_cga_bwd(C.byref(a), K.stream()), "cga_bwd")
+    # dW_proj += dz^T O, db_proj += colsum(dz)
+    wbuf, _ = grad_sink(wproj)
+    bbuf, _ = grad_sink(bproj)
+    if wbuf is not None or bbuf is not None:
+        if wbuf is None:
+            wbuf = torch.zeros(wproj.shape, dtype=torch.float32, device=x.device)
+        K.gemm_tn(dz, o, wbuf, B * T, Cc, wproj.shape[1], Cc, wproj.shape[1], wproj.shape[1], bbuf)
+    # q / k / v weight gradients from the rows of dqkv and the [B*T*G, 32] view of x
+    x2 = x.reshape(M, cpg)
+    off, esz = 0, dqkv.element_size()
+    for w, b in ((wq, bq), (wk, bk), (wv, bv)):
+        wb_, _ = grad_sink(w)
+        bb_, _ = grad_sink(b)
+        if wb_ is not None:
+            K.gemm_tn(dqkv, x2, wb_, M, ccg, cpg, 3 * ccg, cpg, cpg, bb_, A_ptr=dqkv.data_ptr() + off * esz)
+        off += ccg
+    # bank-row gradients: [d sh_k | d sh_v] partial rows -> the (non-leaf) projected bank rows' gradient buffers
+    sk_ret = sv_ret = None
+    need_k, need_v = sh_k_in.requires_grad, sh_v_in.requires_grad
+    if need_k or need_v:
+        both = torch.zeros((2,) + tuple(shk.shape), dtype=torch.float32, device=x.device)
+        K.reduce_now([K.DeferredLN.desc(parts.data_ptr(), nparts, 256, both[0].data_ptr() if need_k else None, both[1].data_ptr() if need_v else None, 512)])
+        sk_ret = both[0] if need_k else None
+        sv_ret = both[1] if need_v else None
+    return (dx.reshape(B, T, Cc) if ctx.needs_input_grad[0] else None), None, None, None, None, None, None, None, None, \
+        _ret(sk_ret, sh_k_in) if sk_ret is not None else None, _ret(sv_ret, sh_v_in) if sv_ret is not None else None, None
+
+
+CGABranchFn._backward_fused = staticmethod(_cga_backward_fused)
 
 
 class AttnFn(Function):

@@ -36,6 +36,16 @@ class CgaArgs(C.Structure):
     ]
 
 
+class CgaBwdArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("G", i32), ("H", i32), ("D", i32), ("S", i32),
+        ("dout", vp), ("lddout", i64), ("x", vp), ("ldx", i64), ("wqkv_rm", vp), ("wqkvT_rm", vp), ("bqkv", vp), ("wprojT_rm", vp),
+        ("sh_k", vp), ("sh_v", vp),
+        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
+        ("dz", vp), ("lddz", i64), ("dqkv", vp), ("dx", vp), ("lddx", i64), ("parts", vp),
+    ]
+
+
 class BranchBwdArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("kind", i32), ("B", i32), ("T", i32), ("C", i32), ("H", i32), ("D", i32), ("KC", i32), ("S", i32), ("L", i32),
@@ -112,6 +122,8 @@ _SIGS = {
     "qavit_branch_bwd_parts": (i32, [i32]),
     "qavit_cga_supported": (i32, [i32, i32, i32, i32, i32]),
     "qavit_cga_fwd": (i32, [vp, vp]),
+    "qavit_cga_bwd_parts": (i32, [i32]),
+    "qavit_cga_bwd": (i32, [vp, vp]),
     "qavit_ccf_bwd_parts": (i32, [i32]),
     "qavit_branch_bwd": (i32, [vp, vp]),
     "qavit_ln_param_reduce": (i32, [vp, i32, vp]),

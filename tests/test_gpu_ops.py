@@ -927,7 +927,7 @@ def test_fused_cga_branch(F, Q, B, drop):
     res = []
     x0 = leaf(B, 16, cfg.embed_dim, seed=600).detach().to(torch.bfloat16)
     g0 = leaf(B, 16, cfg.embed_dim, seed=601).detach().to(torch.bfloat16)
-    for fused in (True, False):
+    for fused in (True, "fwd", False):                         # fused forward + fused backward / fused forward only / unfused chain
         torch.manual_seed(1)
         bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
         rt = M._Ctx("hqa")
@@ -935,26 +935,27 @@ def test_fused_cga_branch(F, Q, B, drop):
         mod = M.EfficientChannelGroupAttention(cfg, bank, rt).to(DEV).train()
         mod._site, mod._site_attn = 9001, 9002                  # same dropout sites in both runs
         x = x0.clone().requires_grad_(True)
-        old = F._CGA_FUSED
-        F._CGA_FUSED = fused
+        old = (F._CGA_FUSED, F._CGA_FUSED_BWD)
+        F._CGA_FUSED, F._CGA_FUSED_BWD = bool(fused), fused is True
         try:
             out = mod(x)
             out.backward(g0)
         finally:
-            F._CGA_FUSED = old
+            F._CGA_FUSED, F._CGA_FUSED_BWD = old
         torch.cuda.synchronize()
         grads = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
         grads.update({"bank." + n: p.grad.clone() for n, p in bank.named_parameters() if p.grad is not None})
         res.append((out.detach().float(), x.grad.float(), grads))
-    (o1, dx1, g1), (o2, dx2, g2) = res
-    assert rel(o1, o2) <= 3e-2
-    if drop > 0:
-        assert torch.equal(o1 == 0, o2 == 0)                     # same proj-dropout mask
-    assert rel(dx1, dx2) <= 4e-2
-    assert set(g1) == set(g2) and len(g1) >= 10
-    for k_ in g1:
-        assert torch.isfinite(g1[k_]).all(), k_
-        assert rel(g1[k_], g2[k_]) <= 4e-2, (k_, rel(g1[k_], g2[k_]))
+    o2, dx2, g2 = res[2]
+    for (o1, dx1, g1) in res[:2]:
+        assert rel(o1, o2) <= 3e-2
+        if drop > 0:
+            assert torch.equal(o1 == 0, o2 == 0)                 # same proj-dropout mask
+        assert rel(dx1, dx2) <= 4e-2
+        assert set(g1) == set(g2) and len(g1) >= 10
+        for k_ in g1:
+            assert torch.isfinite(g1[k_]).all(), k_
+            assert rel(g1[k_], g2[k_]) <= 4e-2, (k_, rel(g1[k_], g2[k_]))
 
 
 def test_partial_row_reduce(F, Q):
