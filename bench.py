@@ -117,6 +117,14 @@ class KernelTimer:
             g = self._obj(a[0])
             by = g.B * g.T * g.C * 2 * (3 if g.o_save else 2) + (4 if g.kind != 2 else 2) * g.C * g.C * 2
             return BRANCH_MFLOP_PER_IMG[g.kind] * 1e6 * g.B, float(by)
+        if name in ("qavit_cga_fwd", "qavit_cga_bwd"):
+            # per image: 6 groups x (q/k/v projections 2*16*32*48 + 4 heads x (QK^T + PV over 32 keys, D = 4)) + proj 2*16*96*192; x in, out (+ o) out;
+            # backward ~2.5x the forward's flops, dout + x in, dz + dqkv + dx out
+            g = self._obj(a[0])
+            fwd = g.B * (g.G * (2.0 * g.T * 32 * 48 + g.H * 4.0 * g.T * 32 * g.D) + 2.0 * g.T * 96 * g.C)
+            if name == "qavit_cga_fwd":
+                return fwd, float(g.B * g.T * (2 * g.C + 96) * 2)
+            return 2.5 * fwd, float(g.B * g.T * (4 * g.C + 6 * 48) * 2)
         if name == "qavit_branch_bwd":
             # proj input gradient (2 T C C) + attention-core backward (~2.5x the forward core, as for qavit_attn_bwd); operands read / written once:
             # dout, q, o in; dz, dq out; k, v in and dk, dv out for SWA / MSDA
@@ -154,7 +162,7 @@ class KernelTimer:
         L = importlib.import_module("qa-vit_amd.lib")
         for name in L.EXPORTS:
             if name in ("qavit_version", "qavit_last_error", "qavit_attn_ws_floats", "qavit_bank_ws_floats", "qavit_branch_supported",
-                        "qavit_layernorm_bwd_parts", "qavit_branch_bwd_parts"):      # host-side queries: nothing is launched
+                        "qavit_layernorm_bwd_parts", "qavit_branch_bwd_parts", "qavit_cga_supported", "qavit_cga_bwd_parts", "qavit_ccf_bwd_parts"):      # host-side queries: nothing is launched
                 continue
             self._wrap(name)
         return self
