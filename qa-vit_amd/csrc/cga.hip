@@ -26,7 +26,10 @@ void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float*
 namespace {
 
 constexpr int CT = 16, CC = 192, CG = 6, CPG = 32, CCG = 16, CH = 4, CD = 4, CS = 16, CO = CG * CCG;   // tokens, channels, groups, ch/group, q dims/group, heads, head dim, bank rows, 96
-constexpr int CNI = 4;                                     // images (= waves) per workgroup
+constexpr int CNI = 4;                                     // images per workgroup
+constexpr int CNW = 8;                                     // waves per workgroup: TWO per image (three channel groups each) -- the chain of one
+                                                           // image is long and serial (softmax, dropout hashes, lane permutes between small MFMAs),
+                                                           // a second wave per SIMD hides its latencies
 constexpr int LDX = CC + 8, LDOO = CO + 8;
 constexpr int WP_FRAGS = (CC / 16) * (CO / 16);            // 12 x 6 fragments of 512 B
 constexpr int SM_WP = 0, SM_XT = WP_FRAGS * 512, SM_OT = SM_XT + CNI * CT * LDX * 2, SM_CGA = SM_OT + CNI * CT * LDOO * 2;   // 36864 + 25600 + 13312 = 75776 bytes
@@ -38,13 +41,14 @@ __device__ __forceinline__ bf16x4 cvt4c(const f32x4& acc) {
   return v;
 }
 
-__global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
+__global__ __launch_bounds__(64 * CNW) void cga_fwd_kernel(qavit_cga_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
   bf16* swp = reinterpret_cast<bf16*>(smraw + SM_WP);
-  bf16* xt = reinterpret_cast<bf16*>(smraw + SM_XT) + wave * (CT * LDX);
-  bf16* ot = reinterpret_cast<bf16*>(smraw + SM_OT) + wave * (CT * LDOO);
-  const int img_raw = blockIdx.x * CNI + wave;
+  const int wimg = wave >> 1, half = wave & 1;             // this wave: image wimg of the tile, channel groups 3 half .. 3 half + 2
+  bf16* xt = reinterpret_cast<bf16*>(smraw + SM_XT) + wimg * (CT * LDX);
+  bf16* ot = reinterpret_cast<bf16*>(smraw + SM_OT) + wimg * (CT * LDOO);
+  const int img_raw = blockIdx.x * CNI + wimg;
   const bool valid = img_raw < a.B;
   const int img = valid ? img_raw : a.B - 1;
   const bf16* xg = reinterpret_cast<const bf16*>(a.x);
@@ -54,16 +58,16 @@ __global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
   bf16* osv = reinterpret_cast<bf16*>(a.o_save);
 
   // ---- loads: the image's token tile, the proj weight as fragments, q/k/v weights, biases, bank rows ----
-  bf16x8 xr[6];
+  bf16x8 xr[3];                                            // rows 8 half .. + 8 of the image's token tile
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+  for (int it = 0; it < 3; ++it) {
+    const int p = lane + 64 * it, row = 8 * half + p / 24, c8 = p % 24;
     xr[it] = *reinterpret_cast<const bf16x8*>(xg + ((size_t)img * CT + row) * a.ldx + 8 * c8);
   }
-  bf16x4 wpr[WP_FRAGS * 64 / (64 * CNI)];                  // 18 quads per thread
+  bf16x4 wpr[WP_FRAGS / CNW];                              // 9 quads per thread
 #pragma unroll
-  for (int it = 0; it < WP_FRAGS / CNI; ++it) {
-    const int f = it * CNI + wave, ctile = f / (CO / 16), otile = f - ctile * (CO / 16);
+  for (int it = 0; it < WP_FRAGS / CNW; ++it) {
+    const int f = it * CNW + wave, ctile = f / (CO / 16), otile = f - ctile * (CO / 16);
     wpr[it] = *reinterpret_cast<const bf16x4*>(wp + (size_t)(16 * ctile + col) * CO + 16 * otile + 4 * q4);
   }
   s16x4 wqf[3][2];                                         // [part][k-step]: lane = output dim d (col), 4 consecutive input channels
@@ -82,13 +86,13 @@ __global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
   for (int i = 0; i < 4; ++i) shv[i] = a.sh_v[(size_t)(4 * q4 + i) * CCG + col];               // bank value rows 4 q4 + i, dim col
   // ---- consumers ----
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+  for (int it = 0; it < 3; ++it) {
+    const int p = lane + 64 * it, row = 8 * half + p / 24, c8 = p % 24;
     *reinterpret_cast<bf16x8*>(xt + row * LDX + 8 * c8) = xr[it];
   }
 #pragma unroll
-  for (int it = 0; it < WP_FRAGS / CNI; ++it) {
-    const int f = it * CNI + wave;
+  for (int it = 0; it < WP_FRAGS / CNW; ++it) {
+    const int f = it * CNW + wave;
     *reinterpret_cast<bf16x4*>(swp + ((size_t)f * 64 + lane) * 4) = wpr[it];
   }
   bool bad = false;
@@ -111,9 +115,9 @@ __global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
   const float scale = 0.5f;                                // 1 / sqrt(D = 4)
   const s16x4 zero_s = {0, 0, 0, 0};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();                                         // the proj fragments are complete (the token tile is this wave's own)
+  __syncthreads();                                         // the proj fragments and the token tiles are complete
 
-  for (int g = 0; g < CG; ++g) {
+  for (int g = 3 * half; g < 3 * half + 3; ++g) {
     const s16x4 xf0 = rowfrag(xt, LDX, 0, CPG * g), xf1 = rowfrag(xt, LDX, 0, CPG * g + 16);   // lane = token, 4 consecutive channels
     f32x4 aq = bq, ak = bk, av = f32x4{bv, bv, bv, bv};
     aq = mma16(wqf[0][0], xf0, aq); aq = mma16(wqf[0][1], xf1, aq);      // q[token = col][d = 4 q4 + r]
@@ -157,14 +161,13 @@ __global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
     *reinterpret_cast<bf16x4*>(ot + col * LDOO + CCG * g + 4 * q4) = o4;
     if (osv && valid) *reinterpret_cast<bf16x4*>(osv + ((size_t)img * CT + col) * CO + CCG * g + 4 * q4) = o4;
   }
-  wave_sync();                                             // the O tile is this wave's own
+  __syncthreads();                                         // both waves of the image have written their groups' O quads
 
-  // ---- out = dropout(O Wp^T + b): out^T[c][t] = Wp[c][:] . O[t][:], 12 output tiles x 6 k-steps from the LDS fragments ----
+  // ---- out = dropout(O Wp^T + b): out^T[c][t] = Wp[c][:] . O[t][:]; this wave: output tiles 6 half .. + 6, 6 k-steps from the LDS fragments ----
   s16x4 of[CO / 16];
 #pragma unroll
   for (int o16 = 0; o16 < CO / 16; ++o16) of[o16] = rowfrag(ot, LDOO, 0, 16 * o16);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {                   // six output tiles at a time: 24 accumulator registers
+  {
     f32x4 acc[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc[j] = *reinterpret_cast<const f32x4*>(a.bproj + (6 * half + j) * 16 + 4 * q4);
@@ -199,16 +202,17 @@ __global__ __launch_bounds__(64 * CNI) void cga_fwd_kernel(qavit_cga_args a) {
 // dW_proj with the O the forward saved); the bank rows' gradients as one row of 512 partial sums per workgroup.
 constexpr int CGA_PART = 2 * CS * CCG;                     // [d sh_k 16 x 16 | d sh_v 16 x 16]
 constexpr int SMB_WP = 0, SMB_GT = WP_FRAGS * 512, SMB_XT = SMB_GT + CNI * CT * LDX * 2, SMB_RED = SMB_XT + CNI * CT * LDX * 2,
-              SM_CGA_BWD = SMB_RED + CNI * CGA_PART * 4;   // 36864 + 25600 + 25600 + 8192 = 96256 bytes
+              SM_CGA_BWD = SMB_RED + CNW * CGA_PART * 4;   // 36864 + 25600 + 25600 + 16384 = 104448 bytes
 
-__global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a) {
+__global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
   bf16* swp = reinterpret_cast<bf16*>(smraw + SMB_WP);      // Wp^T fragments: (o tile, c tile): lane = o, 4 consecutive c
-  bf16* gt = reinterpret_cast<bf16*>(smraw + SMB_GT) + wave * (CT * LDX);
-  bf16* xt = reinterpret_cast<bf16*>(smraw + SMB_XT) + wave * (CT * LDX);
+  const int wimg = wave >> 1, half = wave & 1;             // image wimg of the tile, channel groups 3 half .. 3 half + 2
+  bf16* gt = reinterpret_cast<bf16*>(smraw + SMB_GT) + wimg * (CT * LDX);
+  bf16* xt = reinterpret_cast<bf16*>(smraw + SMB_XT) + wimg * (CT * LDX);
   float* red = reinterpret_cast<float*>(smraw + SMB_RED);
-  const int img_raw = blockIdx.x * CNI + wave;
+  const int img_raw = blockIdx.x * CNI + wimg;
   const bool valid = img_raw < a.B;
   const int img = valid ? img_raw : a.B - 1;
   const bf16* xg = reinterpret_cast<const bf16*>(a.x);
@@ -220,17 +224,17 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
   bf16* dqg = reinterpret_cast<bf16*>(a.dqkv);
   bf16* dxg = reinterpret_cast<bf16*>(a.dx);
 
-  bf16x8 xr[6], gr[6];
+  bf16x8 xr[3], gr[3];
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+  for (int it = 0; it < 3; ++it) {
+    const int p = lane + 64 * it, row = 8 * half + p / 24, c8 = p % 24;
     xr[it] = *reinterpret_cast<const bf16x8*>(xg + ((size_t)img * CT + row) * a.ldx + 8 * c8);
     gr[it] = *reinterpret_cast<const bf16x8*>(gg + ((size_t)img * CT + row) * a.lddout + 8 * c8);
   }
-  bf16x4 wpr[WP_FRAGS / CNI];
+  bf16x4 wpr[WP_FRAGS / CNW];
 #pragma unroll
-  for (int it = 0; it < WP_FRAGS / CNI; ++it) {
-    const int f = it * CNI + wave, otile = f / (CC / 16), ctile = f - otile * (CC / 16);
+  for (int it = 0; it < WP_FRAGS / CNW; ++it) {
+    const int f = it * CNW + wave, otile = f / (CC / 16), ctile = f - otile * (CC / 16);
     wpr[it] = *reinterpret_cast<const bf16x4*>(wpT + (size_t)(16 * otile + col) * CC + 16 * ctile + 4 * q4);
   }
   s16x4 wqf[3][2], wtf[3][2];                              // forward operand (lane = d, 4 channels) and its transpose (lane = channel, 4 dims)
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
   const uint32_t pkey_proj = pdrop ? rng_key(a.rng, a.proj_drop_site) : 0u;
   const float pp = pdrop ? a.proj_drop_p : 0.f, pinv = pdrop ? 1.f / (1.f - a.proj_drop_p) : 1.f;
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+  for (int it = 0; it < 3; ++it) {
+    const int p = lane + 64 * it, row = 8 * half + p / 24, c8 = p % 24;
     bf16x8 g8 = gr[it];
     if (pdrop) {
       const uint32_t base = (uint32_t)(img * CT + row) * (uint32_t)CC + (uint32_t)(8 * c8);
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
     *reinterpret_cast<bf16x8*>(xt + row * LDX + 8 * c8) = xr[it];
   }
 #pragma unroll
-  for (int it = 0; it < WP_FRAGS / CNI; ++it) *reinterpret_cast<bf16x4*>(swp + ((size_t)(it * CNI + wave) * 64 + lane) * 4) = wpr[it];
+  for (int it = 0; it < WP_FRAGS / CNW; ++it) *reinterpret_cast<bf16x4*>(swp + ((size_t)(it * CNW + wave) * 64 + lane) * 4) = wpr[it];
   s16x4 bkA, bvA, bkP;
   {
     bf16x4 t1, t2, t3;
@@ -286,17 +290,17 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
   __syncthreads();
 
   // ---- dO = gm Wp in both layouts: dob[g] lane = query, 4 dims (B operand);  dop[g] lane = dim, 4 queries ----
-  s16x4 dob[CG], dop[CG];
+  s16x4 dob[CG / 2], dop[CG / 2];                          // this wave's three groups
   {
     s16x4 gf[CC / 16];
 #pragma unroll
     for (int ct = 0; ct < CC / 16; ++ct) gf[ct] = rowfrag(gt, LDX, 0, 16 * ct);
 #pragma unroll
-    for (int g = 0; g < CG; ++g) {
+    for (int g = 0; g < CG / 2; ++g) {
       f32x4 c1 = zero4, c2 = zero4;
 #pragma unroll
       for (int ct = 0; ct < CC / 16; ++ct) {
-        const s16x4 wf = as_s16(*reinterpret_cast<const bf16x4*>(swp + ((size_t)(g * (CC / 16) + ct) * 64 + lane) * 4));
+        const s16x4 wf = as_s16(*reinterpret_cast<const bf16x4*>(swp + ((size_t)((3 * half + g) * (CC / 16) + ct) * 64 + lane) * 4));
         c1 = mma16(wf, gf[ct], c1);                        // dO^T[o = 4 q4 + r][t = col]
         c2 = mma16(gf[ct], wf, c2);                        // dO  [t = 4 q4 + r][o = col]
       }
@@ -307,7 +311,9 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
   f32x4 dshk = zero4, dshv = zero4;                        // acc[r] = d sh^T[d = 4 q4 + r][s = col], summed over groups
 
   if (valid)
-  for (int g = 0; g < CG; ++g) {
+#pragma unroll
+  for (int gl = 0; gl < CG / 2; ++gl) {
+    const int g = 3 * half + gl;
     const s16x4 xf0 = rowfrag(xt, LDX, 0, CPG * g), xf1 = rowfrag(xt, LDX, 0, CPG * g + 16);
     f32x4 aq = bq, ak = bk, av = zero4, aqp = f32x4{bqp, bqp, bqp, bqp}, akp = f32x4{bkp, bkp, bkp, bkp};
     {
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
 #pragma unroll
     for (int h = 0; h < CH; ++h) {
       const bool mine = q4 == h;
-      const s16x4 qm = mine ? qb : zero_s, dom = mine ? dob[g] : zero_s;
+      const s16x4 qm = mine ? qb : zero_s, dom = mine ? dob[gl] : zero_s;
       f32x4 sT0 = mma16(ka, qm, zero4), sT1 = mma16(bkA, qm, zero4);        // S^T[key][query = col]
       f32x4 s20 = mma16(qm, ka, zero4), s21 = mma16(qm, bkA, zero4);        // S  [query = 4 q4 + r][key = col]
       const f32x4 dT0 = mma16(va, dom, zero4), dT1 = mma16(bvA, dom, zero4);  // dP^T
@@ -378,11 +384,11 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
       // dK^T[d][key] = sum_query Q[query][d] dS[query][key];  dV^T[d][key] = sum_query dO[query][d] (P m)[query][key]
       t = mma16(qp, ds20, zero4);
       if (mine) dk = t;
-      t = mma16(dop[g], pd20, zero4);
+      t = mma16(dop[gl], pd20, zero4);
       if (mine) dv = t;
       t = mma16(qp, ds21, zero4);                           // bank rows: d sh_k^T[d][s]
       if (mine) { dshk[0] += t[0]; dshk[1] += t[1]; dshk[2] += t[2]; dshk[3] += t[3]; }
-      t = mma16(dop[g], pd21, zero4);
+      t = mma16(dop[gl], pd21, zero4);
       if (mine) { dshv[0] += t[0]; dshv[1] += t[1]; dshv[2] += t[2]; dshv[3] += t[3]; }
     }
     // dq / dk / dv: value[token = col][d = 4 q4 + r] -> the (image, token, group) row of dqkv
@@ -407,10 +413,10 @@ __global__ __launch_bounds__(64 * CNI) void cga_bwd_kernel(qavit_cga_bwd_args a)
     red[wave * CGA_PART + CS * CCG + col * CCG + 4 * q4 + r] = dshv[r];
   }
   __syncthreads();
-  for (int e = tid; e < CGA_PART; e += 64 * CNI) {
+  for (int e = tid; e < CGA_PART; e += 64 * CNW) {
     float sacc = 0.f;
 #pragma unroll
-    for (int w = 0; w < CNI; ++w) sacc += red[w * CGA_PART + e];
+    for (int w = 0; w < CNW; ++w) sacc += red[w * CGA_PART + e];
     a.parts[(size_t)blockIdx.x * CGA_PART + e] = sacc;
   }
 }
@@ -455,7 +461,7 @@ extern "C" int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cga_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_CGA_BWD);
     attr_done = true;
   }
-  hipLaunchKernelGGL(cga_bwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNI), SM_CGA_BWD, st, *a);
+  hipLaunchKernelGGL(cga_bwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNW), SM_CGA_BWD, st, *a);
   return check_launch("cga_bwd");
 }
 
@@ -470,7 +476,7 @@ extern "C" int qavit_cga_fwd(const qavit_cga_args* a, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cga_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_CGA);
     attr_done = true;
   }
-  hipLaunchKernelGGL(cga_fwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNI), SM_CGA, st, *a);
+  hipLaunchKernelGGL(cga_fwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNW), SM_CGA, st, *a);
   if (a->nan_flag) branch_nan_fix_launch(a->out, a->ldo, a->B * CT, CC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, st);
   return check_launch("cga_fwd");
 }
