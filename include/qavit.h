@@ -382,6 +382,26 @@ int qavit_cga_bwd_parts(int B);
 int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * QuadAttentionBlock's HybridFusion(concat_i compress_i(norm_i(branch_i))) (HQAViT_CIFAR100.py:904-925, :1075-1081), forward, in one
+ * launch for 16 tokens x 192 channels, 4 branches of Linear(192 -> 48): x[i] [B*16, 192] bf16 (contiguous rows), w_rm[i] [48, 192]
+ * bf16 row-major, bias[i] fp32 or NULL, fw = the 4 fusion logits.  Writes cat [B*16, 192] (unscaled concat), y = cat * softmax(fw)
+ * per branch slice, and the norms' mean[i] / rstd[i] [B*16] -- what the unfused forward (qavit_row_stats_multi, the LayerNorm-prologue
+ * qavit_gemm_nt_grouped, qavit_hybrid_fuse_fwd) leaves for the backward.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_cfuse_args {
+  int dtype;
+  int B, T, C, NB, CB;
+  const void* x[4];
+  const float* gamma[4]; const float* beta[4];
+  const void* w_rm[4]; const float* bias[4];
+  const float* fw; float eps;
+  void* cat; void* y;
+  float* mean[4]; float* rstd[4];
+} qavit_cfuse_args;
+int qavit_compress_fuse_supported(int T, int C, int nb, int Cb);
+int qavit_compress_fuse_fwd(const qavit_cfuse_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Depthwise k x k convolution, stride 1, pad k/2, on channel-last tokens x[B, H*W, C] (k in {3,5,7}):
  * ConvNeXtBlock.dwconv (HQAViT_CIFAR100.py:722, dw7x7), LMFAdapter.dwconv_3x3 / dwconv_5x5 (:811-812).
  * w is the nn.Conv2d weight [C,1,k,k] fp32; bias [C] or NULL.  bwd: dx, dw += , dbias += (fp32 atomics).

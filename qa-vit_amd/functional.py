@@ -835,6 +835,7 @@ def branch_ok(kind, x, Lk, KC, S, heads) -> bool:
 
 
 _CGA_FUSED = os.environ.get("QAVIT_FUSED_CGA", "1") != "0"
+_CFUSE = os.environ.get("QAVIT_FUSED_COMPRESS", "1") != "0"
 _CGA_FUSED_BWD = os.environ.get("QAVIT_FUSED_CGA_BWD", "1") != "0"
 
 
@@ -1416,6 +1417,26 @@ class CompressFuseFn(Function):
         esz = cat.element_size()
         means = [torch.empty(M, dtype=torch.float32, device=dev) for _ in range(nb)]
         rstds = [torch.empty(M, dtype=torch.float32, device=dev) for _ in range(nb)]
+        T_ = args[0].shape[-2] if args[0].dim() >= 2 else 0
+        if (_CFUSE and dt == torch.bfloat16 and nb == 4 and M % max(T_, 1) == 0 and all(a_ is not None for a_ in args[:20])
+                and L.load().qavit_compress_fuse_supported(T_, Kd, nb, Cb)):
+            # norms, compress Linears, concat and fusion scaling in ONE launch (csrc/cfuse.hip)
+            a = L.CfuseArgs()
+            a.dtype, a.B, a.T, a.C, a.NB, a.CB = K.dt_code(dt), M // T_, T_, Kd, nb, Cb
+            pk = pack_for(dev)
+            for i in range(nb):
+                g, b, W, bias = args[5 * i + 1: 5 * i + 5]
+                a.x[i], a.gamma[i], a.beta[i] = xs[i].data_ptr(), g.data_ptr(), b.data_ptr()
+                a.w_rm[i] = pk.get(W, dt)[0].data_ptr()
+                a.bias[i] = None if bias is None else bias.data_ptr()
+                a.mean[i], a.rstd[i] = means[i].data_ptr(), rstds[i].data_ptr()
+            y = torch.empty_like(cat)
+            a.fw, a.eps, a.cat, a.y = fw.data_ptr(), float(eps), cat.data_ptr(), y.data_ptr()
+            L.check(L.load().qavit_compress_fuse_fwd(C.byref(a), K.stream()), "compress_fuse_fwd")
+            stats = [t for i in range(nb) for t in (means[i], rstds[i])]
+            ctx.meta = (nb, M, Kd, Cb, eps, args[0].shape)
+            ctx.save_for_backward(fw, cat, *xs, *[a_ for i in range(nb) for a_ in args[5 * i + 1: 5 * i + 5]], *stats)
+            return y.reshape(*args[0].shape[:-1], nb * Cb)
         K.row_stats_multi(xs, eps, M, Kd, means, rstds)                      # the four branch norms: one grid
         probs, stats = [], []
         for i in range(nb):

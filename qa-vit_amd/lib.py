@@ -36,6 +36,14 @@ class CgaArgs(C.Structure):
     ]
 
 
+class CfuseArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("NB", i32), ("CB", i32),
+        ("x", vp * 4), ("gamma", vp * 4), ("beta", vp * 4), ("w_rm", vp * 4), ("bias", vp * 4),
+        ("fw", vp), ("eps", f32), ("cat", vp), ("y", vp), ("mean", vp * 4), ("rstd", vp * 4),
+    ]
+
+
 class CgaBwdArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("G", i32), ("H", i32), ("D", i32), ("S", i32),
@@ -123,6 +131,8 @@ _SIGS = {
     "qavit_cga_supported": (i32, [i32, i32, i32, i32, i32]),
     "qavit_cga_fwd": (i32, [vp, vp]),
     "qavit_cga_bwd_parts": (i32, [i32]),
+    "qavit_compress_fuse_supported": (i32, [i32, i32, i32, i32]),
+    "qavit_compress_fuse_fwd": (i32, [vp, vp]),
     "qavit_cga_bwd": (i32, [vp, vp]),
     "qavit_ccf_bwd_parts": (i32, [i32]),
     "qavit_branch_bwd": (i32, [vp, vp]),
