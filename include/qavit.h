@@ -400,6 +400,26 @@ typedef struct qavit_cfuse_args {
 } qavit_cfuse_args;
 int qavit_compress_fuse_supported(int T, int C, int nb, int Cb);
 int qavit_compress_fuse_fwd(const qavit_cfuse_args* a, void* stream);
+/* Backward of the same node in one launch (it replaces qavit_hybrid_fuse_bwd, the grouped input-gradient qavit_gemm_nt and
+ * qavit_layernorm_bwd_multi): dcat = dy * softmax(fw) per slice (written: operand of the compress weight gradients, which stay deferred
+ * qavit_gemm_tn problems with LayerNorm-on-load), dx[i] = LayerNorm_i'(dcat_i W_i), and one row of QAVIT_CFUSE_PARTS_FLOATS partial
+ * sums per workgroup (qavit_compress_fuse_bwd_parts(B) rows): [4 x (dgamma_i 192 | dbeta_i 192) | dfw 4 | 4 zeros]. */
+#define QAVIT_CFUSE_PARTS_FLOATS 1544
+typedef struct qavit_cfuse_bwd_args {
+  int dtype;
+  int B, T, C, NB, CB;
+  const void* dy; const void* cat;
+  const void* x[4];
+  const float* gamma[4];
+  const void* w_rm[4];
+  const float* mean[4]; const float* rstd[4];
+  const float* fw;
+  void* dcat;
+  void* dx[4];
+  float* parts;
+} qavit_cfuse_bwd_args;
+int qavit_compress_fuse_bwd_parts(int B);
+int qavit_compress_fuse_bwd(const qavit_cfuse_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Depthwise k x k convolution, stride 1, pad k/2, on channel-last tokens x[B, H*W, C] (k in {3,5,7}):

@@ -233,8 +233,7 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
 #pragma unroll
       for (int r = 0; r < 4; ++r) dpart += (float)o4[r] * (float)d4[r];
     }
-    dpart += __shfl_xor(dpart, 16, 64);
-    dpart += __shfl_xor(dpart, 32, 64);                    // D[query = col] = sum_d dO O over this head
+    dpart = rows4_sum(dpart);                    // D[query = col] = sum_d dO O over this head
     // K_f, V_f of the token / landmark rows in both layouts
     s16x4 kfa[KT0a][DT], kfb[KT0a][DT], vfa[KT0a][DT], vfb[KT0a][DT], kR[DT], vR[DT];
     if (MODE0) {
@@ -279,15 +278,13 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
         sT[nt][r] = ok ? sT[nt][r] * scale : -INFINITY;
         mx = fmaxf(mx, sT[nt][r]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows4_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float e = __expf(sT[nt][r] - mx); sT[nt][r] = e; sum += e; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows4_sum(sum);
     const float inv = 1.f / sum;
     const uint32_t pkey = adrop ? attn_drop_pkey(drop, img * BH + h) : 0u;
     // first orientation: P^T, dS^T (lane = query)

@@ -315,15 +315,13 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
           sc[nt][r] = ok ? sc[nt][r] * scale : -INFINITY;
           mx = fmaxf(mx, sc[nt][r]);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows4_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float e = __expf(sc[nt][r] - mx); sc[nt][r] = e; sum += e; }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows4_sum(sum);
       const float inv = 1.f / sum;
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt)

@@ -133,13 +133,11 @@ __global__ __launch_bounds__(64 * CNW) void cga_fwd_kernel(qavit_cga_args a) {
       float mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s0[r] *= scale; s1[r] *= scale; mx = fmaxf(mx, fmaxf(s0[r], s1[r])); }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows4_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mx); s1[r] = __expf(s1[r] - mx); sum += s0[r] + s1[r]; }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows4_sum(sum);
       const float inv = 1.f / sum;
       if (adrop) {
         const uint32_t pkey = attn_drop_pkey(drop, (img * CG + g) * CH + h);
@@ -338,13 +336,11 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
       float mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { sT0[r] *= scale; sT1[r] *= scale; mx = fmaxf(mx, fmaxf(sT0[r], sT1[r])); }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows4_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { sT0[r] = __expf(sT0[r] - mx); sT1[r] = __expf(sT1[r] - mx); sum += sT0[r] + sT1[r]; }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows4_sum(sum);
       const float inv = 1.f / sum;
       const uint32_t pkey = adrop ? attn_drop_pkey(drop, (img * CG + g) * CH + h) : 0u;
       float m0[4], m1[4], dsum = 0.f;
@@ -355,8 +351,7 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
         sT0[r] *= inv; sT1[r] *= inv;                      // P^T
         dsum += sT0[r] * m0[r] * dT0[r] + sT1[r] * m1[r] * dT1[r];
       }
-      dsum += __shfl_xor(dsum, 16, 64);
-      dsum += __shfl_xor(dsum, 32, 64);                    // D[query = col] = sum_keys (P m) dP
+      dsum = rows4_sum(dsum);                    // D[query = col] = sum_keys (P m) dP
       f32x4 e0, e1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

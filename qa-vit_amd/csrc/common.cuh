@@ -41,6 +41,36 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane, on the VALU's data-parallel-primitive paths
+// (quad permutes, then the half-row and row mirrors): no LDS-pipe permute instructions, which all the waves of a CU share
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]: lane ^ 1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: lane ^ 2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror: the other quad of the half row
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror: the other half row
+  return v;
+}
+// lane ^ 16 and lane ^ 32 exchanges by gfx950's v_permlane16_swap / v_permlane32_swap (VALU; with both operands = v the two results
+// are {even rows' values in both rows of a pair, odd rows' values ...} resp. {low half, high half}): sums / maxima over the four
+// 16-lane rows without ds_bpermute, which goes through the LDS pipe all the waves of a CU share
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float rows4_sum(float v) { return xor32_sum(xor16_sum(v)); }     // over the 4 lanes {col, col+16, col+32, col+48}
+__device__ __forceinline__ float rows4_max(float v) { return xor32_max(xor16_max(v)); }
 // reduce over a power-of-two group of `W` adjacent lanes (W <= 64)
 template <int W> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll

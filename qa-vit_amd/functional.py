@@ -836,6 +836,7 @@ def branch_ok(kind, x, Lk, KC, S, heads) -> bool:
 
 _CGA_FUSED = os.environ.get("QAVIT_FUSED_CGA", "1") != "0"
 _CFUSE = os.environ.get("QAVIT_FUSED_COMPRESS", "1") != "0"
+_CFUSE_BWD = os.environ.get("QAVIT_FUSED_COMPRESS_BWD", "1") != "0"
 _CGA_FUSED_BWD = os.environ.get("QAVIT_FUSED_CGA_BWD", "1") != "0"
 
 
@@ -1470,6 +1471,43 @@ class CompressFuseFn(Function):
         fbuf, fret = grad_sink(fw)
         if fbuf is None:
             fbuf = torch.zeros(nb, dtype=torch.float32, device=dev)
+        T_ = xshape[-2] if len(xshape) >= 2 else 0
+        gs_all = [grad_sink(prm[4 * i]) for i in range(nb)]
+        bs_all = [grad_sink(prm[4 * i + 1]) for i in range(nb)]
+        if (_CFUSE_BWD and dt == torch.bfloat16 and nb == 4 and T_ > 0 and all(g_[0] is not None for g_ in gs_all) and all(b_[0] is not None for b_ in bs_all)
+                and K.DeferredLN.ON and L.load().qavit_compress_fuse_supported(T_, Kd, nb, Cb)):
+            # scaling backward, the four input-gradient GEMMs and the four LayerNorm backwards in ONE launch (csrc/cfuse.hip)
+            DeferDW.arm()
+            a = L.CfuseBwdArgs()
+            a.dtype, a.B, a.T, a.C, a.NB, a.CB = K.dt_code(dt), M // T_, T_, Kd, nb, Cb
+            pk = pack_for(dev)
+            dxs = [torch.empty(M, Kd, dtype=dt, device=dev) for _ in range(nb)]
+            for i in range(nb):
+                a.x[i], a.gamma[i] = xs[i].data_ptr(), prm[4 * i].data_ptr()
+                a.w_rm[i] = pk.get(prm[4 * i + 2], dt)[0].data_ptr()
+                a.mean[i], a.rstd[i] = stats[2 * i].data_ptr(), stats[2 * i + 1].data_ptr()
+                a.dx[i] = dxs[i].data_ptr()
+            npart = int(L.load().qavit_compress_fuse_bwd_parts(M // T_))
+            PF = 1544
+            parts = torch.empty(npart * PF, dtype=torch.float32, device=dev)
+            a.dy, a.cat, a.fw, a.dcat, a.parts = dy.data_ptr(), cat.data_ptr(), fw.data_ptr(), dcat.data_ptr(), parts.data_ptr()
+            L.check(L.load().qavit_compress_fuse_bwd(C.byref(a), K.stream()), "compress_fuse_bwd")
+            keep = (parts, fbuf) + tuple(g_[0] for g_ in gs_all) + tuple(b_[0] for b_ in bs_all)
+            for i in range(nb):
+                K.DeferredLN.push_raw(parts.data_ptr() + i * 2 * Kd * 4, npart, Kd, gs_all[i][0].data_ptr(), bs_all[i][0].data_ptr(), PF, keep)
+            K.DeferredLN.push_raw(parts.data_ptr() + nb * 2 * Kd * 4, npart, 4, fbuf.data_ptr(), None, PF, keep)
+            esz = dcat.element_size()
+            grads = []
+            for i in range(nb):
+                g, b, W, bias = prm[4 * i: 4 * i + 4]
+                mean, rstd = stats[2 * i], stats[2 * i + 1]
+                wbuf, wret = grad_sink(W)
+                bbuf2, b2ret = grad_sink(bias)
+                if wbuf is None:
+                    wbuf = torch.zeros(W.shape, dtype=torch.float32, device=dev)
+                K.gemm_tn(dcat, xs[i], wbuf, M, Cb, Kd, nb * Cb, Kd, Kd, bbuf2, ln=(g, b, mean, rstd), A_ptr=dcat.data_ptr() + i * Cb * esz)
+                grads += [dxs[i].reshape(xshape), _ret(gs_all[i][1], g), _ret(bs_all[i][1], b), _ret(wret, W), None if bias is None else _ret(b2ret, bias)]
+            return (fret, None, *grads)
         K.hybrid_fuse_bwd(dy, cat, fw.detach(), dcat, fbuf, M, nb, Cb)
         esz = dcat.element_size()
         DeferDW.arm()

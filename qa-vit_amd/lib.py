@@ -44,6 +44,14 @@ class CfuseArgs(C.Structure):
     ]
 
 
+class CfuseBwdArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("NB", i32), ("CB", i32),
+        ("dy", vp), ("cat", vp), ("x", vp * 4), ("gamma", vp * 4), ("w_rm", vp * 4), ("mean", vp * 4), ("rstd", vp * 4),
+        ("fw", vp), ("dcat", vp), ("dx", vp * 4), ("parts", vp),
+    ]
+
+
 class CgaBwdArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("G", i32), ("H", i32), ("D", i32), ("S", i32),
@@ -133,6 +141,8 @@ _SIGS = {
     "qavit_cga_bwd_parts": (i32, [i32]),
     "qavit_compress_fuse_supported": (i32, [i32, i32, i32, i32]),
     "qavit_compress_fuse_fwd": (i32, [vp, vp]),
+    "qavit_compress_fuse_bwd_parts": (i32, [i32]),
+    "qavit_compress_fuse_bwd": (i32, [vp, vp]),
     "qavit_cga_bwd": (i32, [vp, vp]),
     "qavit_ccf_bwd_parts": (i32, [i32]),
     "qavit_branch_bwd": (i32, [vp, vp]),

@@ -959,12 +959,12 @@ def test_fused_cga_branch(F, Q, B, drop):
 
 
 @pytest.mark.parametrize("B", [3, 64, 1030])
-def test_fused_compress_fuse_forward(F, Q, B):
+def test_fused_compress_fuse(F, Q, B):
     """CompressFuseFn through the one-launch forward (csrc/cfuse.hip: four LayerNorms, four Linear(192 -> 48), concat, softmax-weighted
     scaling) against the three-launch forward, and both against torch; the backward (shared) runs on what each forward saved."""
     T, C, Cb, nb = 16, 192, 48, 4
     outs = []
-    for fused in (True, False):
+    for fused in (True, "fwd", False):                         # fused forward + backward / fused forward only / unfused
         xs = [leaf(B, T, C, seed=700 + i).detach().to(torch.bfloat16).requires_grad_(True) for i in range(nb)]
         gs = [leaf(C, scale=0.2, seed=710 + i) for i in range(nb)]
         bs = [leaf(C, scale=0.2, seed=720 + i) for i in range(nb)]
@@ -977,25 +977,26 @@ def test_fused_compress_fuse_forward(F, Q, B):
         args = []
         for i in range(nb):
             args += [xs[i], gs[i], bs[i], Ws[i], bi[i]]
-        old = F._CFUSE
-        F._CFUSE = fused
+        old = (F._CFUSE, F._CFUSE_BWD)
+        F._CFUSE, F._CFUSE_BWD = bool(fused), fused is True
         try:
             y = F.CompressFuseFn.apply(fw, 1e-5, *args)
+            go = leaf(B, T, nb * Cb, seed=760).detach().to(torch.bfloat16)
+            y.backward(go)
         finally:
-            F._CFUSE = old
-        go = leaf(B, T, nb * Cb, seed=760).detach().to(torch.bfloat16)
-        y.backward(go)
+            F._CFUSE, F._CFUSE_BWD = old
         torch.cuda.synchronize()
         outs.append((y.detach().float(), [x.grad.float() for x in xs], [t.grad.clone() for t in gs + bs + Ws + bi + [fw]]))
-        if fused:                                            # torch reference on the same (bf16-rounded) inputs
+        if fused is True:                                    # torch reference on the same (bf16-rounded) inputs
             w = torch.softmax(fw.detach(), 0)
             ref = torch.cat([TF.linear(TF.layer_norm(xs[i].detach().float(), (C,), gs[i].detach(), bs[i].detach()).to(torch.bfloat16).float(),
                                        Ws[i].detach().to(torch.bfloat16).float(), bi[i].detach()) * w[i] for i in range(nb)], -1)
             assert rel(y, ref) <= 3e-2
-    (y1, dx1, g1), (y2, dx2, g2) = outs
-    assert rel(y1, y2) <= 1e-2
-    for a_, b_ in zip(dx1 + g1, dx2 + g2):
-        assert rel(a_, b_) <= 3e-2
+    y2, dx2, g2 = outs[2]
+    for (y1, dx1, g1) in outs[:2]:
+        assert rel(y1, y2) <= 1e-2
+        for a_, b_ in zip(dx1 + g1, dx2 + g2):
+            assert rel(a_, b_) <= 3e-2
 
 
 def test_partial_row_reduce(F, Q):
