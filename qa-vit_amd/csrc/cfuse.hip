@@ -292,7 +292,13 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_arg
       bf16x4 o4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o4[j] = (bf16)(rs * (acc[ks][j] - c2 - ((float)x4[j] - mu) * rs * c1));
-      *reinterpret_cast<bf16x4*>(dxg + ((size_t)img * FT + col) * FC + 16 * ks + 4 * q4) = o4;
+      *reinterpret_cast<bf16x4*>(xt + col * FLD + 16 * ks + 4 * q4) = o4;          // in place: the tile becomes dx (each lane rewrites what it read)
+    }
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {                        // whole rows out: 16-byte pieces, 384 contiguous bytes per row
+      const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+      *reinterpret_cast<bf16x8*>(dxg + ((size_t)img * FT + row) * FC + 8 * c8) = *reinterpret_cast<const bf16x8*>(xt + row * FLD + 8 * c8);
     }
   }
   // ---- fold the 16 token lanes, then the two waves of a branch; one row of partials per workgroup ----

@@ -184,7 +184,15 @@ __global__ __launch_bounds__(64 * CNW) void cga_fwd_kernel(qavit_cga_args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[j][r] *= drop_factor(pkey_proj, base + r, pp, pinv);
       }
-      if (valid) *reinterpret_cast<bf16x4*>(og + ((size_t)img * CT + col) * a.ldo + c0) = cvt4c(acc[j]);
+      *reinterpret_cast<bf16x4*>(xt + col * LDX + c0) = cvt4c(acc[j]);      // the token tile is dead: it collects the output rows
+    }
+  }
+  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {                        // whole rows out: 16-byte pieces
+      const int p = lane + 64 * it, row = 8 * half + p / 24, c8 = p % 24;
+      *reinterpret_cast<bf16x8*>(og + ((size_t)img * CT + row) * a.ldo + 8 * c8) = *reinterpret_cast<const bf16x8*>(xt + row * LDX + 8 * c8);
     }
   }
   if (a.nan_flag && __any(bad && valid) && lane == 0) atomicOr(a.nan_flag, 1);
@@ -398,7 +406,15 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
       f32x4 c = mma16(wtf[0][ks], as_s16(dq4), zero4);
       c = mma16(wtf[1][ks], as_s16(dk4), c);
       c = mma16(wtf[2][ks], as_s16(dv4), c);
-      *reinterpret_cast<bf16x4*>(dxg + ((size_t)img * CT + col) * a.lddx + CPG * g + 16 * ks + 4 * q4) = cvt4c(c);
+      *reinterpret_cast<bf16x4*>(xt + col * LDX + CPG * g + 16 * ks + 4 * q4) = cvt4c(c);      // in place: group g's columns of the tile (only this wave reads them) become dx
+    }
+  }
+  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {                        // whole dx rows out: 16-byte pieces
+      const int p = lane + 64 * it, row = 8 * half + p / 24, c8 = p % 24;
+      *reinterpret_cast<bf16x8*>(dxg + ((size_t)img * CT + row) * a.lddx + 8 * c8) = *reinterpret_cast<const bf16x8*>(xt + row * LDX + 8 * c8);
     }
   }
   // ---- bank-row gradients: the four waves' sums -> one row of partials ----
@@ -423,8 +439,8 @@ int cga_validate(const qavit_cga_args* a) {
     return set_error(QAVIT_EINVAL, "cga: built for 16 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
   if (a->B <= 0 || !a->x || !a->out || !a->wqkv_rm || !a->wproj_rm || !a->bqkv || !a->bproj || !a->sh_k || !a->sh_v) return set_error(QAVIT_EINVAL, "cga: null operand");
   auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
-  if (!al(a->x, 15) || !al(a->out, 7) || !al(a->wqkv_rm, 7) || !al(a->wproj_rm, 7) || !al(a->bqkv, 15) || !al(a->bproj, 15) || !al(a->sh_k, 15) || !al(a->sh_v, 3) ||
-      (a->o_save && !al(a->o_save, 7)) || a->ldx % 8 || a->ldo % 4)
+  if (!al(a->x, 15) || !al(a->out, 15) || !al(a->wqkv_rm, 7) || !al(a->wproj_rm, 7) || !al(a->bqkv, 15) || !al(a->bproj, 15) || !al(a->sh_k, 15) || !al(a->sh_v, 3) ||
+      (a->o_save && !al(a->o_save, 7)) || a->ldx % 8 || a->ldo % 8)
     return set_error(QAVIT_EINVAL, "cga: alignment (x 16 bytes / ld % 8; out, weights, o_save 8 bytes / ld % 4; biases and sh_k 16 bytes)");
   return QAVIT_OK;
 }
@@ -447,7 +463,7 @@ extern "C" int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream) {
   if (a->proj_drop_p > 0.f && a->rng && !a->dz) return set_error(QAVIT_EINVAL, "cga_bwd: proj dropout needs dz");
   auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
   if (!al(a->x, 15) || !al(a->dout, 15) || (a->dz && !al(a->dz, 15)) || !al(a->wqkv_rm, 7) || !al(a->wqkvT_rm, 7) || !al(a->wprojT_rm, 7) || !al(a->bqkv, 15) ||
-      !al(a->sh_k, 15) || !al(a->sh_v, 15) || !al(a->dqkv, 7) || !al(a->dx, 7) || !al(a->parts, 15) || a->ldx % 8 || a->lddout % 8 || (a->dz && a->lddz % 8) || a->lddx % 4)
+      !al(a->sh_k, 15) || !al(a->sh_v, 15) || !al(a->dqkv, 7) || !al(a->dx, 15) || !al(a->parts, 15) || a->ldx % 8 || a->lddout % 8 || (a->dz && a->lddz % 8) || a->lddx % 8)
     return set_error(QAVIT_EINVAL, "cga_bwd: alignment (activations 16 bytes / ld % 8; weights, dqkv, dx 8 bytes; biases, bank rows, parts 16 bytes)");
   static_assert(CGA_PART == QAVIT_CGA_PARTS_FLOATS, "header constant out of date");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
