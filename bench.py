@@ -117,6 +117,14 @@ class KernelTimer:
             g = self._obj(a[0])
             by = g.B * g.T * g.C * 2 * (3 if g.o_save else 2) + (4 if g.kind != 2 else 2) * g.C * g.C * 2
             return BRANCH_MFLOP_PER_IMG[g.kind] * 1e6 * g.B, float(by)
+        if name in ("qavit_compress_fuse_fwd", "qavit_compress_fuse_bwd"):
+            # four Linear(192 -> 48) per token row (+ their input-gradient GEMMs backward); fwd: 4 x in, cat + y out; bwd: dy, cat, 4 x in, dcat + 4 dx out
+            g = self._obj(a[0])
+            rows = g.B * g.T
+            fl = 2.0 * rows * g.NB * g.CB * g.C
+            if name == "qavit_compress_fuse_fwd":
+                return fl, float(rows * (g.NB * g.C + 2 * g.NB * g.CB) * 2)
+            return fl, float(rows * (2 * g.NB * g.C + 3 * g.NB * g.CB) * 2)
         if name in ("qavit_cga_fwd", "qavit_cga_bwd"):
             # per image: 6 groups x (q/k/v projections 2*16*32*48 + 4 heads x (QK^T + PV over 32 keys, D = 4)) + proj 2*16*96*192; x in, out (+ o) out;
             # backward ~2.5x the forward's flops, dout + x in, dz + dqkv + dx out
@@ -162,7 +170,7 @@ class KernelTimer:
         L = importlib.import_module("qa-vit_amd.lib")
         for name in L.EXPORTS:
             if name in ("qavit_version", "qavit_last_error", "qavit_attn_ws_floats", "qavit_bank_ws_floats", "qavit_branch_supported",
-                        "qavit_layernorm_bwd_parts", "qavit_branch_bwd_parts", "qavit_cga_supported", "qavit_cga_bwd_parts", "qavit_ccf_bwd_parts"):      # host-side queries: nothing is launched
+                        "qavit_layernorm_bwd_parts", "qavit_branch_bwd_parts", "qavit_cga_supported", "qavit_cga_bwd_parts", "qavit_ccf_bwd_parts", "qavit_compress_fuse_supported", "qavit_compress_fuse_bwd_parts"):      # host-side queries: nothing is launched
                 continue
             self._wrap(name)
         return self
