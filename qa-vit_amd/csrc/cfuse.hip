@@ -153,7 +153,8 @@ constexpr int SMB_W = 0, SMB_G = FNB * FCB * FLD * 2, SMB_X2 = SMB_G + FNB * FC 
 
 __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, q4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every per-wave base pointer below lives in SGPRs
   const int br = wave & 3, slot = wave >> 2;
   bf16* sw = reinterpret_cast<bf16*>(smraw + SMB_W);
   float* sgam = reinterpret_cast<float*>(smraw + SMB_G);    // [4][192]
@@ -167,10 +168,8 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_arg
 
   auto load_x = [&](int img, bf16x8* r) {
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
-      const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
-      r[it] = *reinterpret_cast<const bf16x8*>(xg + ((size_t)img * FT + row) * FC + 8 * c8);
-    }
+    for (int it = 0; it < 6; ++it)                          // an image's 16 x 192 tile is contiguous: piece p at 8 p elements
+      r[it] = *reinterpret_cast<const bf16x8*>(xg + (size_t)img * (FT * FC) + 8 * (lane + 64 * it));
   };
   const int img0 = blockIdx.x * FIMG + 2 * slot;
   // every global operand of an image is requested in one go (x rows, its slices of dy and cat, the row statistics); the second
@@ -226,11 +225,17 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_arg
   const bf16* swb = sw + (size_t)br * FCB * FLD;
   const float* gam = sgam + br * FC;
   const float invC = 1.f / (float)FC;
-  float pg[FC / 16][4], pb[FC / 16][4], dsum = 0.f;
+  // dgamma needs the per-element products, 48 running sums per lane.  dbeta = sum_t dxn[t][c] = sum_n W[n][c] (sum_t dz[t][n]): only
+  // the 12 column sums of dz per lane are kept, and the 48 x 192 matrix-vector product is done once per workgroup at the end.
+  float pg[FC / 16][4], sdz[3][4], dsum = 0.f;
 #pragma unroll
   for (int ks = 0; ks < FC / 16; ++ks)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { pg[ks][j] = 0.f; pb[ks][j] = 0.f; }
+    for (int j = 0; j < 4; ++j) pg[ks][j] = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sdz[nt][j] = 0.f;
 
 #pragma unroll 1
   for (int ii = 0; ii < 2; ++ii) {
@@ -249,7 +254,12 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_arg
     for (int nt = 0; nt < 3; ++nt) {
       bf16x4 z4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float g = (float)dyr[nt][j]; z4[j] = (bf16)(g * wsc); dsum += g * (float)ctr[nt][j]; }
+      for (int j = 0; j < 4; ++j) {
+        const float g = (float)dyr[nt][j];
+        z4[j] = (bf16)(g * wsc);
+        sdz[nt][j] += (float)z4[j];                          // the rounded value: what the product below multiplies
+        dsum += g * (float)ctr[nt][j];
+      }
       *reinterpret_cast<bf16x4*>(dcg + rowo + 16 * nt) = z4;
       dzf[nt] = as_s16(z4);
     }
@@ -277,7 +287,6 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_arg
         const float d = acc[ks][j];
         const float gg = d * g4[j];
         pg[ks][j] += d * xh;
-        pb[ks][j] += d;
         c1 += gg * xh;
         c2 += gg;
         acc[ks][j] = gg;
@@ -298,31 +307,48 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_arg
 #pragma unroll
     for (int it = 0; it < 6; ++it) {                        // whole rows out: 16-byte pieces, 384 contiguous bytes per row
       const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
-      *reinterpret_cast<bf16x8*>(dxg + ((size_t)img * FT + row) * FC + 8 * c8) = *reinterpret_cast<const bf16x8*>(xt + row * FLD + 8 * c8);
+      *reinterpret_cast<bf16x8*>(dxg + (size_t)img * (FT * FC) + 8 * p) = *reinterpret_cast<const bf16x8*>(xt + row * FLD + 8 * c8);
     }
   }
   // ---- fold the 16 token lanes, then the two waves of a branch; one row of partials per workgroup ----
 #pragma unroll
   for (int ks = 0; ks < FC / 16; ++ks)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { pg[ks][j] = row16_sum(pg[ks][j]); pb[ks][j] = row16_sum(pb[ks][j]); }   // the 16 token lanes = one DPP row
+    for (int j = 0; j < 4; ++j) pg[ks][j] = row16_sum(pg[ks][j]);      // the 16 token lanes = one DPP row
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sdz[nt][j] = row16_sum(sdz[nt][j]);
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) dsum += __shfl_xor(dsum, o, 64);
   if (col == 0) {
 #pragma unroll
     for (int ks = 0; ks < FC / 16; ++ks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        red[(wave * 2 + 0) * FC + 16 * ks + 4 * q4 + j] = pg[ks][j];
-        red[(wave * 2 + 1) * FC + 16 * ks + 4 * q4 + j] = pb[ks][j];
-      }
+      for (int j = 0; j < 4; ++j) red[(wave * 2 + 0) * FC + 16 * ks + 4 * q4 + j] = pg[ks][j];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wave * 2 + 1) * FC + 16 * nt + 4 * q4 + j] = sdz[nt][j];     // the wave's second row: 48 column sums of dz
   }
   if (lane == 0) red[FNW * 2 * FC + wave] = dsum;
   __syncthreads();
   float* out = a.parts + (size_t)blockIdx.x * CF_PART;
   for (int e = tid; e < FNB * 2 * FC; e += 64 * FNW) {
     const int b = e / (2 * FC), rem = e - b * (2 * FC);      // branch b: waves b and b + 4
-    out[e] = red[(b * 2) * FC + rem] + red[((b + 4) * 2) * FC + rem];
+    float v;
+    if (rem < FC) {
+      v = red[(b * 2) * FC + rem] + red[((b + 4) * 2) * FC + rem];
+    } else {
+      const int c = rem - FC;
+      const float* s0 = red + (b * 2 + 1) * FC;
+      const float* s1 = red + ((b + 4) * 2 + 1) * FC;
+      const bf16* wc = sw + (size_t)b * FCB * FLD + c;
+      v = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < FCB; ++n) v += (float)wc[n * FLD] * (s0[n] + s1[n]);
+    }
+    out[e] = v;
   }
   if (tid == 0) {
     float ds[FNB], dot = 0.f;
@@ -374,7 +400,7 @@ extern "C" int qavit_compress_fuse_bwd(const qavit_cfuse_bwd_args* a, void* stre
   for (int i = 0; i < FNB; ++i) {
     if (!a->x[i] || !a->gamma[i] || !a->w_rm[i] || !a->mean[i] || !a->rstd[i] || !a->dx[i]) return set_error(QAVIT_EINVAL, "compress_fuse_bwd: null branch operand");
     if ((reinterpret_cast<uintptr_t>(a->x[i]) | reinterpret_cast<uintptr_t>(a->w_rm[i])) & 15) return set_error(QAVIT_EINVAL, "compress_fuse_bwd: x and weights must be 16-byte aligned");
-    if (reinterpret_cast<uintptr_t>(a->dx[i]) & 7) return set_error(QAVIT_EINVAL, "compress_fuse_bwd: dx must be 8-byte aligned");
+    if (reinterpret_cast<uintptr_t>(a->dx[i]) & 15) return set_error(QAVIT_EINVAL, "compress_fuse_bwd: dx must be 16-byte aligned");
   }
   if ((reinterpret_cast<uintptr_t>(a->dy) | reinterpret_cast<uintptr_t>(a->cat) | reinterpret_cast<uintptr_t>(a->dcat)) & 7) return set_error(QAVIT_EINVAL, "compress_fuse_bwd: dy / cat / dcat must be 8-byte aligned");
   if (reinterpret_cast<uintptr_t>(a->parts) & 15) return set_error(QAVIT_EINVAL, "compress_fuse_bwd: parts must be 16-byte aligned");
