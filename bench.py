@@ -390,7 +390,7 @@ def main():
                            "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                             "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                                             "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
-                                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+                                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("QAVIT_BENCH_FAMILIES", "12"))]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(tin=args.config == "tin")
     if rank == 0:

@@ -430,6 +430,13 @@ int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias
                      int B, int H, int W, int C, int ks, void* stream);
 int qavit_dwconv_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
                      int B, int H, int W, int C, int ks, void* stream);
+/* The same kernels on column slices of wider buffers (LMFAdapter's cat([dw3(x), dw5(x), x]) and its gradient, :830-834, without the
+ * cat / slice copies): y rows are ldy elements apart; dy rows lddy apart; dadd (NULL, or rows lddadd apart; may be dx itself) is another
+ * gradient that meets this one at x and is added into dx.  Strides in elements, >= C; needs H and W multiples of 8 when they differ from C. */
+int qavit_dwconv_fwd_ld(int dtype, const void* x, const float* w, const float* bias, void* y, int ldy,
+                        int B, int H, int W, int C, int ks, void* stream);
+int qavit_dwconv_bwd_ld(int dtype, const void* dy, int lddy, const void* x, const float* w, void* dx, const void* dadd, int lddadd,
+                        float* dw, float* dbias, int B, int H, int W, int C, int ks, void* stream);
 
 /* im2col / col2im for the strided 3x3 stem convolutions (HQAViT_CIFAR100.py:752, :759) so that they run on
  * qavit_gemm_nt: cols[(b,oy,ox), c*k*k+dy*k+dx] = src[b, c, oy*s+dy-p, ox*s+dx-p].  src is the fp32 NCHW image

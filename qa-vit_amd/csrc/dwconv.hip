@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd8_kernel(const T* dy, const T* 
 // map are clamped loads zeroed by a wave-uniform select.  FLIP correlates with the flipped taps (dx of the forward).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int HR>
-__device__ __forceinline__ void dw_halo_row(const T* src, float (&xr)[HR], int b, int gy, int x0, int H, int W, int C, int cc) {
+__device__ __forceinline__ void dw_halo_row(const T* src, float (&xr)[HR], int b, int gy, int x0, int H, int W, int ld, int cc) {
   const bool rok = gy >= 0 && gy < H;
   const int gyc = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
 #pragma unroll
@@ -268,7 +268,7 @@ __device__ __forceinline__ void dw_halo_row(const T* src, float (&xr)[HR], int b
     const int gx = x0 + ci;
     const bool ok = rok && gx >= 0 && gx < W;
     const int gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-    const float v = to_f<T>(src[(((size_t)b * H + gyc) * W + gxc) * C + cc]);
+    const float v = to_f<T>(src[(((size_t)b * H + gyc) * W + gxc) * ld + cc]);
     xr[ci] = ok ? v : 0.f;
   }
 }
@@ -291,17 +291,38 @@ struct RowPairs {
   __device__ __forceinline__ f32x2 at(int k) const { return (k & 1) ? o[k >> 1] : e[k >> 1]; }     // (x[k], x[k+1]), k constant
 };
 
-template <typename T, int KS, bool FLIP>
-__device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS * KS], f32x2 (&o)[8][4], int b, int y0, int x0, int H, int W, int C, int cc) {
+// One halo row of a map that IS the 8x8 tile, from the tile held in registers (everything outside is zero; indices are constants)
+template <int HR, int R>
+__device__ __forceinline__ void dw_reg_row(const float (*pre)[8], float (&xr)[HR], int r) {
+  const int rr = r - R;
+#pragma unroll
+  for (int ci = 0; ci < HR; ++ci) xr[ci] = (rr >= 0 && rr < 8 && ci >= R && ci < R + 8) ? pre[rr < 0 ? 0 : (rr > 7 ? 7 : rr)][ci >= R && ci < R + 8 ? ci - R : 0] : 0.f;
+}
+
+// PRE: the map is one 8x8 tile already in registers (``pre``): no loads here at all -- the caller requested the whole tile at once,
+// one memory round trip per tile instead of one per streamed row.
+template <typename T, int KS, bool FLIP, bool CAP = false, bool PRE = false>
+__device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS * KS], f32x2 (&o)[8][4], int b, int y0, int x0, int H, int W, int ld, int cc,
+                                             f32x2 (*cap)[4] = nullptr, const float (*pre)[8] = nullptr) {
   constexpr int TS = 8, R = KS / 2, HR = TS + 2 * R;
   float xr[HR], xn[HR];
-  dw_halo_row<T, HR>(src, xr, b, y0, x0, H, W, C, cc);
+  if constexpr (!PRE) dw_halo_row<T, HR>(src, xr, b, y0, x0, H, W, ld, cc);
 #pragma unroll
   for (int r = 0; r < HR; ++r) {
-    if (r + 1 < HR) dw_halo_row<T, HR>(src, xn, b, y0 + r + 1, x0, H, W, C, cc);     // one row ahead, no further
-    asm volatile("" ::: "memory");
+    if constexpr (PRE) {
+      dw_reg_row<HR, R>(pre, xr, r);
+    } else {
+      if (r + 1 < HR) dw_halo_row<T, HR>(src, xn, b, y0 + r + 1, x0, H, W, ld, cc);     // one row ahead, no further
+      asm volatile("" ::: "memory");
+    }
     RowPairs<HR> rp;
     rp.set(xr);
+    if constexpr (CAP) {                                     // the tile's own cells pass by once: keep them (the caller's second use of src)
+      if (r >= R && r < R + TS) {
+#pragma unroll
+        for (int p = 0; p < TS / 2; ++p) cap[r - R][p] = f32x2{xr[R + 2 * p], xr[R + 2 * p + 1]};
+      }
+    }
     const bool row_in = (y0 + r >= 0) && (y0 + r < H);       // rows outside the map are all zero: nothing to add
 #pragma unroll
     for (int yy = 0; yy < TS; ++yy) {
@@ -315,14 +336,28 @@ __device__ __forceinline__ void dw_tile_rows(const T* src, const float (&wt)[KS 
         for (int p = 0; p < TS / 2; ++p) o[yy][p] = __builtin_elementwise_fma(w2, rp.at(2 * p + dxx), o[yy][p]);
       }
     }
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int ci = 0; ci < HR; ++ci) xr[ci] = xn[ci];
+      for (int ci = 0; ci < HR; ++ci) xr[ci] = xn[ci];
+    } else {
+      __builtin_amdgcn_sched_barrier(0);                     // rows in order: with every operand in registers the scheduler would interleave them all
+    }
   }
+}
+
+// the 8x8 tile of channel cc of image b (rows ld elements apart): 64 loads in flight together
+template <typename T>
+__device__ __forceinline__ void dw_load_tile8(const T* src, float (&tl)[8][8], int b, int ld, int cc) {
+  T raw[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) raw[i] = src[((size_t)b * 64 + i) * ld + cc];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) tl[i >> 3][i & 7] = to_f<T>(raw[i]);
 }
 
 // ONE8: the map IS one 8x8 tile (H = W = 8 known at compile time: out-of-map rows / columns and their loads fold away)
 template <typename T, int KS, bool ONE8>
-__global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H_, int W_, int C) {
+__global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H_, int W_, int C, int ldy) {
   constexpr int TS = 8, R = KS / 2, KK = KS * KS;
   const int H = ONE8 ? 8 : H_, W = ONE8 ? 8 : W_;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -341,19 +376,27 @@ __global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const floa
     for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
       for (int p = 0; p < TS / 2; ++p) o[yy][p] = f32x2{bv, bv};
-    dw_tile_rows<T, KS, false>(x, wt, o, b, ty * TS - R, tx * TS - R, H, W, C, cc);
+    if constexpr (ONE8) {
+      float xt[8][8];
+      dw_load_tile8<T>(x, xt, b, C, cc);
+      dw_tile_rows<T, KS, false, false, true>(x, wt, o, b, -R, -R, 8, 8, C, cc, nullptr, xt);
+    } else {
+      dw_tile_rows<T, KS, false>(x, wt, o, b, ty * TS - R, tx * TS - R, H, W, C, cc);
+    }
     if (cok) {
 #pragma unroll
       for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
-        for (int xx = 0; xx < TS; ++xx) y[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx >> 1][xx & 1]);
+        for (int xx = 0; xx < TS; ++xx) y[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * ldy + c] = from_f<T>(o[yy][xx >> 1][xx & 1]);
     }
   }
 }
 
 template <typename T, int KS, bool ONE8>
-__global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int H_, int W_, int C) {
+__global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int H_, int W_, int C,
+                                                          int lddy, const T* dadd, int lddadd) {
   constexpr int TS = 8, R = KS / 2, KK = KS * KS, HR = TS + 2 * R;
+  constexpr bool RT = ONE8 && KS <= 5;                      // both tiles of a unit in registers (7x7: 49 taps + 49 tap sums leave no room; rows are streamed)
   const int H = ONE8 ? 8 : H_, W = ONE8 ? 8 : W_;
   __shared__ float red[4][64 * KK + 64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -367,7 +410,22 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
   const int TX = W / TS, TPI = (H / TS) * TX, units = B * TPI;
   for (int u = blockIdx.y * 4 + wave; u < units; u += gridDim.y * 4) {
     const int b = ONE8 ? u : u / TPI, t = u - b * TPI, ty = ONE8 ? 0 : t / TX, tx = ONE8 ? 0 : t - ty * TX;
+    f32x2 g[TS][TS / 2];
+    float gt[RT ? 8 : 1][8], xt[RT ? 8 : 1][8];            // RT: the dy and x tiles, every load of the unit requested up front
+    if constexpr (RT) {
+      dw_load_tile8<T>(dy, gt, b, lddy, cc);
+      dw_load_tile8<T>(x, xt, b, C, cc);
+    }
     {
+      // the addend's 64 cells are requested before the tap arithmetic when the registers allow (k <= 5), after it otherwise
+      constexpr bool EARLY = KS <= 5;
+      T da[EARLY ? TS * TS : 1];
+      if (EARLY && dadd && cok) {
+#pragma unroll
+        for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+          for (int xx = 0; xx < TS; ++xx) da[EARLY ? yy * TS + xx : 0] = dadd[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * lddadd + c];
+      }
       float wt[KK];
 #pragma unroll
       for (int i = 0; i < KK; ++i) wt[i] = w[(size_t)cc * KK + i];
@@ -376,29 +434,44 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
       for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
         for (int p = 0; p < TS / 2; ++p) o[yy][p] = f32x2{0.f, 0.f};
-      dw_tile_rows<T, KS, true>(dy, wt, o, b, ty * TS - R, tx * TS - R, H, W, C, cc);
+      if constexpr (RT) {
+        dw_tile_rows<T, KS, true, false, true>(dy, wt, o, b, -R, -R, 8, 8, lddy, cc, nullptr, gt);
+#pragma unroll
+        for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+          for (int p = 0; p < TS / 2; ++p) g[yy][p] = f32x2{gt[yy][2 * p], gt[yy][2 * p + 1]};
+      } else {
+        dw_tile_rows<T, KS, true, true>(dy, wt, o, b, ty * TS - R, tx * TS - R, H, W, lddy, cc, g);
+      }
       if (cok) {
+        if (dadd) {       // another gradient that meets this one at x (may be dx itself: every lane reads exactly the cells it then writes)
+#pragma unroll
+          for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < TS; ++xx)
+              o[yy][xx >> 1][xx & 1] += to_f<T>(EARLY ? da[EARLY ? yy * TS + xx : 0] : dadd[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * lddadd + c]);
+        }
 #pragma unroll
         for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
           for (int xx = 0; xx < TS; ++xx) dx[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + c] = from_f<T>(o[yy][xx >> 1][xx & 1]);
       }
     }
-    f32x2 g[TS][TS / 2];
 #pragma unroll
-    for (int yy = 0; yy < TS; ++yy)
+    for (int yy = 0; yy < TS; ++yy)                          // g: the dy tile, kept from the stream above
 #pragma unroll
-      for (int xx = 0; xx < TS; ++xx) {
-        const float v = to_f<T>(dy[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * C + cc]);
-        g[yy][xx >> 1][xx & 1] = v; ab += v;
-      }
+      for (int p = 0; p < TS / 2; ++p) ab += g[yy][p][0] + g[yy][p][1];
     // dw[dyy][dxx] += sum_{yy,xx} dy[yy][xx] * x[yy+dyy-R][xx+dxx-R]: halo rows of x streamed against the dy tile
     float xr[HR], xn[HR];
-    dw_halo_row<T, HR>(x, xr, b, ty * TS - R, tx * TS - R, H, W, C, cc);
+    if constexpr (!RT) dw_halo_row<T, HR>(x, xr, b, ty * TS - R, tx * TS - R, H, W, C, cc);
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
-      if (r + 1 < HR) dw_halo_row<T, HR>(x, xn, b, ty * TS - R + r + 1, tx * TS - R, H, W, C, cc);
-      asm volatile("" ::: "memory");
+      if constexpr (RT) {
+        dw_reg_row<HR, R>(xt, xr, r);
+      } else {
+        if (r + 1 < HR) dw_halo_row<T, HR>(x, xn, b, ty * TS - R + r + 1, tx * TS - R, H, W, C, cc);
+        asm volatile("" ::: "memory");
+      }
       RowPairs<HR> rp;
       rp.set(xr);
       const bool row_in = (ty * TS - R + r >= 0) && (ty * TS - R + r < H);
@@ -414,8 +487,12 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
           aw[dyy * KS + dxx] += s2[0] + s2[1];
         }
       }
+      if constexpr (!RT) {
 #pragma unroll
-      for (int ci = 0; ci < HR; ++ci) xr[ci] = xn[ci];
+        for (int ci = 0; ci < HR; ++ci) xr[ci] = xn[ci];
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 #pragma unroll
@@ -431,21 +508,29 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
   }
 }
 
+// Row strides (in elements) of the operands that may be column slices of a wider buffer: y forward, dy and the addend backward.
+struct DwStrides { int ldy; int lddy; const void* dadd; int lddadd; };
+static inline bool tiled_ok(int H, int W) { return H % 8 == 0 && W % 8 == 0; }
+
 template <typename T, int KS>
 static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, const float* bias, void* o0, float* dw, float* dbias,
-                     int B, int H, int W, int C, hipStream_t st) {
+                     int B, int H, int W, int C, hipStream_t st, const DwStrides& S) {
   const int N = H * W;
+  const int ld0 = bwd ? S.lddy : S.ldy;                      // the strided operand: y forward, dy backward
+  const bool plain = ld0 == C && !S.dadd;
   const int chunks = (C + DW_CH - 1) / DW_CH;
   static const int pk8 = getenv("QAVIT_DW8_PK") ? atoi(getenv("QAVIT_DW8_PK")) : 1;      // 8x8 maps on the packed-FMA tile kernels (0: the scalar-FMA dwconv_fwd8 / bwd8)
-  if (pk8 && H == 8 && W == 8) {
+  if ((pk8 || !plain) && H == 8 && W == 8) {
     int gy = (B + 3) / 4;
-    static const int w8 = getenv("QAVIT_DWT8_BWD_WGS") ? atoi(getenv("QAVIT_DWT8_BWD_WGS")) : 256;
+    static const int w8 = getenv("QAVIT_DWT8_BWD_WGS") ? atoi(getenv("QAVIT_DWT8_BWD_WGS")) : 512;
     const int cap = (bwd ? w8 : 1024) / chunks > 0 ? (bwd ? w8 : 1024) / chunks : 1;
     if (gy > cap) gy = cap;
-    if (!bwd) hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
-    else hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
+    if (!bwd) hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C, S.ldy);
+    else hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C,
+                            S.lddy, (const T*)S.dadd, S.lddadd);
     return check_launch("dwconv8(pk)");
   }
+  if (!plain && !(tiled_ok(H, W))) return set_error(QAVIT_EINVAL, "dwconv: row strides / addend need the tile kernels (sides multiples of 8)");
   if (!bwd && H == 8 && W == 8) {
     int gy8 = (B + 3) / 4;
     const int cap = 1024 / chunks > 0 ? 1024 / chunks : 1;
@@ -454,17 +539,18 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
     return check_launch("dwconv_fwd8");
   }
   static const bool tiled = !(getenv("QAVIT_DW_TILED") && atoi(getenv("QAVIT_DW_TILED")) == 0);
-  if (tiled && H % 8 == 0 && W % 8 == 0 && H * W > 64) {
+  if ((tiled || !plain) && H % 8 == 0 && W % 8 == 0 && H * W > 64) {
     const int units = B * (H / 8) * (W / 8);
     int gy = (units + 3) / 4;
     static const int wt_ = getenv("QAVIT_DWT_BWD_WGS") ? atoi(getenv("QAVIT_DWT_BWD_WGS")) : 256;
     const int cap = (bwd ? wt_ : 2048) / chunks > 0 ? (bwd ? wt_ : 2048) / chunks : 1;
     if (gy > cap) gy = cap;
     if (!bwd) {
-      hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C);
+      hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C, S.ldy);
       return check_launch("dwconv_fwdt");
     }
-    hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C);
+    hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C,
+                       S.lddy, (const T*)S.dadd, S.lddadd);
     return check_launch("dwconv_bwdt");
   }
   if (!bwd) {
@@ -495,11 +581,11 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
 
 template <typename T>
 static int dispatch_dw(int ks, bool bwd, const void* a0, const void* a1, const float* w, const float* bias, void* o0, float* dw, float* dbias,
-                       int B, int H, int W, int C, hipStream_t st) {
+                       int B, int H, int W, int C, hipStream_t st, const DwStrides& S) {
   switch (ks) {
-    case 3: return launch_dw<T, 3>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st);
-    case 5: return launch_dw<T, 5>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st);
-    case 7: return launch_dw<T, 7>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st);
+    case 3: return launch_dw<T, 3>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st, S);
+    case 5: return launch_dw<T, 5>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st, S);
+    case 7: return launch_dw<T, 7>(bwd, a0, a1, w, bias, o0, dw, dbias, B, H, W, C, st, S);
     default: return set_error(QAVIT_EINVAL, "dwconv: kernel size must be 3, 5 or 7");
   }
 }
@@ -593,19 +679,31 @@ extern "C" int qavit_col2im(int dtype, const void* dcols, void* dx, int B, int C
   return check_launch("col2im");
 }
 
-extern "C" int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int ks, void* stream) {
-  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "dwconv_fwd: bad arguments");
+extern "C" int qavit_dwconv_fwd_ld(int dtype, const void* x, const float* w, const float* bias, void* y, int ldy, int B, int H, int W, int C, int ks, void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldy < C) return set_error(QAVIT_EINVAL, "dwconv_fwd: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st);
-  if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st);
+  const DwStrides S{ldy, C, nullptr, 0};
+  if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st, S);
+  if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st, S);
   return set_error(QAVIT_EINVAL, "dwconv_fwd: unknown dtype");
+}
+
+extern "C" int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int ks, void* stream) {
+  return qavit_dwconv_fwd_ld(dtype, x, w, bias, y, C, B, H, W, C, ks, stream);
+}
+
+extern "C" int qavit_dwconv_bwd_ld(int dtype, const void* dy, int lddy, const void* x, const float* w, void* dx, const void* dadd, int lddadd,
+                                   float* dw, float* dbias, int B, int H, int W, int C, int ks, void* stream) {
+  if (!dy || !x || !w || !dx || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0 || lddy < C || (dadd && lddadd < C))
+    return set_error(QAVIT_EINVAL, "dwconv_bwd: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const DwStrides S{C, lddy, dadd, dadd ? lddadd : 0};
+  if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, true, dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, st, S);
+  if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, true, dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, st, S);
+  return set_error(QAVIT_EINVAL, "dwconv_bwd: unknown dtype");
 }
 
 extern "C" int qavit_dwconv_bwd(int dtype, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
                                 int B, int H, int W, int C, int ks, void* stream) {
-  if (!dy || !x || !w || !dx || !dw || B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "dwconv_bwd: bad arguments");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, true, dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, st);
-  if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, true, dy, x, w, nullptr, dx, dw, dbias, B, H, W, C, st);
-  return set_error(QAVIT_EINVAL, "dwconv_bwd: unknown dtype");
+  return qavit_dwconv_bwd_ld(dtype, dy, C, x, w, dx, nullptr, 0, dw, dbias, B, H, W, C, ks, stream);
 }

@@ -1366,6 +1366,41 @@ class DwConvFn(Function):
         return dx, _ret(wret, w), _ret(bret, bias), None, None
 
 
+class LmfGatherFn(Function):
+    """LMFAdapter's  cat([dwconv_3x3(x), dwconv_5x5(x), x], channel)  (HQAViT_CIFAR100.py:830-834) on channel-last tokens as one autograd
+    node: the two depthwise convolutions write their column slices of the [B, N, 3C] buffer themselves, and backward reads the gradient's
+    slices in place -- dx = dw3^T(d0) + dw5^T(d1) + d2 leaves the second convolution's kernel complete (no cat, no slice copies, no adds)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, b3, w5, b5, H, W):
+        B, N, Cc = x.shape
+        x = x.contiguous()
+        cat = torch.empty(B, N, 3 * Cc, dtype=x.dtype, device=x.device)
+        K.dwconv_fwd_ld(x, w3.detach(), None if b3 is None else b3.detach(), cat, 3 * Cc, B, H, W, Cc, w3.shape[-1])
+        K.dwconv_fwd_ld(x, w5.detach(), None if b5 is None else b5.detach(), cat[:, :, Cc:], 3 * Cc, B, H, W, Cc, w5.shape[-1])
+        cat[:, :, 2 * Cc:].copy_(x)
+        ctx.save_for_backward(x, w3, b3, w5, b5)
+        ctx.dims = (B, H, W, Cc)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x, w3, b3, w5, b5 = ctx.saved_tensors
+        B, H, W, Cc = ctx.dims
+        dcat = dcat.contiguous()
+        dx = torch.empty_like(x)
+        sinks = []
+        for p, needed in ((w3, True), (b3, False), (w5, True), (b5, False)):
+            buf, ret = grad_sink(p)
+            if buf is None and needed:                       # the kernel always accumulates a weight gradient
+                buf = torch.zeros_like(p, dtype=torch.float32)
+            sinks.append((buf, ret))
+        ld = 3 * Cc
+        K.dwconv_bwd_ld(dcat, ld, x, w3.detach(), dx, dcat[:, :, 2 * Cc:], ld, sinks[0][0], sinks[1][0], B, H, W, Cc, w3.shape[-1])
+        K.dwconv_bwd_ld(dcat[:, :, Cc:], ld, x, w5.detach(), dx, dx, Cc, sinks[2][0], sinks[3][0], B, H, W, Cc, w5.shape[-1])
+        return dx, _ret(sinks[0][1], w3), _ret(sinks[1][1], b3), _ret(sinks[2][1], w5), _ret(sinks[3][1], b5), None, None
+
+
 # ---------------------------------------------------------------------------------------------------
 # elementwise helpers
 # ---------------------------------------------------------------------------------------------------

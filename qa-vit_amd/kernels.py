@@ -457,6 +457,17 @@ def dwconv_fwd(x, w, bias, y, B, H, W, Cc, ks):
     L.check(L.load().qavit_dwconv_fwd(dt_code(x.dtype), x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cc, ks, stream()), "dwconv_fwd")
 
 
+def dwconv_fwd_ld(x, w, bias, y, ldy, B, H, W, Cc, ks):
+    """``y`` is a column slice (row stride ``ldy`` elements) of a wider buffer."""
+    L.check(L.load().qavit_dwconv_fwd_ld(dt_code(x.dtype), x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), ldy, B, H, W, Cc, ks, stream()), "dwconv_fwd_ld")
+
+
+def dwconv_bwd_ld(dy, lddy, x, w, dx, dadd, lddadd, dw, dbias, B, H, W, Cc, ks):
+    """``dy`` is a column slice (row stride ``lddy``); ``dadd`` (None, or row stride ``lddadd``; may be ``dx``) is added into ``dx``."""
+    L.check(L.load().qavit_dwconv_bwd_ld(dt_code(x.dtype), dy.data_ptr(), lddy, x.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dadd), lddadd,
+                                         dw.data_ptr(), _p(dbias), B, H, W, Cc, ks, stream()), "dwconv_bwd_ld")
+
+
 def dwconv_bwd(dy, x, w, dx, dw, dbias, B, H, W, Cc, ks):
     L.check(L.load().qavit_dwconv_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), w.data_ptr(), dx.data_ptr(), dw.data_ptr(), _p(dbias),
                                       B, H, W, Cc, ks, stream()), "dwconv_bwd")

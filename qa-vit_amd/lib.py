@@ -163,6 +163,8 @@ _SIGS = {
     "qavit_ccf_mid_bwd": (i32, [C.POINTER(CcfArgs), vp]),
     "qavit_dwconv_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_dwconv_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "qavit_dwconv_fwd_ld": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "qavit_dwconv_bwd_ld": (i32, [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_im2col": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_bank_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]),

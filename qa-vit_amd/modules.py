@@ -669,6 +669,9 @@ class CNNStemModelV2(nn.Module):
         return tuple(f.transpose(1, 2).reshape(B, -1, h, w) for f in (f2, f3, f4))
 
 
+_LMF_GATHER = os.environ.get("QAVIT_LMF_GATHER", "1") != "0"      # 0: separate depthwise convolutions + torch.cat
+
+
 class LMFAdapter(nn.Module):
     """HQAViT_CIFAR100.py:799-849 on channel-last tokens."""
 
@@ -682,9 +685,13 @@ class LMFAdapter(nn.Module):
         self.act = nn.GELU()
 
     def forward_tokens(self, t, H, W):
-        f1 = F.DwConvFn.apply(t, self.dwconv_3x3.weight, self.dwconv_3x3.bias, H, W)
-        f2 = F.DwConvFn.apply(t, self.dwconv_5x5.weight, self.dwconv_5x5.bias, H, W)
-        h = _conv1x1_tokens(torch.cat([f1, f2, t], -1), self.proj)
+        if _LMF_GATHER and H % 8 == 0 and W % 8 == 0:
+            cat = F.LmfGatherFn.apply(t, self.dwconv_3x3.weight, self.dwconv_3x3.bias, self.dwconv_5x5.weight, self.dwconv_5x5.bias, H, W)
+        else:
+            f1 = F.DwConvFn.apply(t, self.dwconv_3x3.weight, self.dwconv_3x3.bias, H, W)
+            f2 = F.DwConvFn.apply(t, self.dwconv_5x5.weight, self.dwconv_5x5.bias, H, W)
+            cat = torch.cat([f1, f2, t], -1)
+        h = _conv1x1_tokens(cat, self.proj)
         if H != self.target_hw or W != self.target_hw:      # :840-842 (not hit by the in-scope configs)
             B = h.shape[0]
             img = TF.interpolate(h.transpose(1, 2).reshape(B, -1, H, W).float(), size=(self.target_hw, self.target_hw),

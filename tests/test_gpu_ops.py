@@ -486,6 +486,29 @@ def test_dwconv_tokens(F, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(64, 8, 21), (256, 8, 70), (40, 16, 5)])
+def test_lmf_gather(F, dtype, case):
+    """LMFAdapter's cat([dw3(x), dw5(x), x]) (HQAViT_CIFAR100.py:830-834) as one node: the convolutions write / read column slices of the
+    3C-wide buffer (row strides), the pass-through gradient and the first convolution's dx are added inside the kernels."""
+    C, H, B = case
+    x = leaf(B, H * H, C, seed=150).detach().to(dtype).requires_grad_(True)
+    w3, b3 = leaf(C, 1, 3, 3, scale=0.2, seed=151), leaf(C, scale=0.2, seed=152)
+    w5, b5 = leaf(C, 1, 5, 5, scale=0.2, seed=153), leaf(C, scale=0.2, seed=154)
+    y = F.LmfGatherFn.apply(x, w3, b3, w5, b5, H, H)
+    xr, w3r, b3r, w5r, b5r = [t.detach().clone().float().requires_grad_(True) for t in (x, w3, b3, w5, b5)]
+    img = xr.transpose(1, 2).reshape(B, C, H, H)
+    ref = torch.cat([TF.conv2d(img, w3r, b3r, padding=1, groups=C), TF.conv2d(img, w5r, b5r, padding=2, groups=C), img], 1).flatten(2).transpose(1, 2)
+    assert y.shape == ref.shape
+    assert rel(y, ref) <= tol(dtype)
+    go = torch.randn_like(ref)
+    y.backward(go.to(dtype))
+    ref.backward(go)
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+    for g, r in ((w3, w3r), (b3, b3r), (w5, w5r), (b5, b5r)):
+        assert rel(g.grad, r.grad) <= tol(dtype, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv3x3_s2_as_im2col_gemm(F, dtype):
     """Both stem convolutions: NCHW fp32 image source (no input grad) and channel-last token source (col2im grad)."""
     B = 9
