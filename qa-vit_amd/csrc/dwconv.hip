@@ -396,7 +396,8 @@ template <typename T, int KS, bool ONE8>
 __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* x, const float* w, T* dx, float* dw, float* dbias, int B, int H_, int W_, int C,
                                                           int lddy, const T* dadd, int lddadd) {
   constexpr int TS = 8, R = KS / 2, KK = KS * KS, HR = TS + 2 * R;
-  constexpr bool RT = ONE8 && KS <= 5;                      // both tiles of a unit in registers (7x7: 49 taps + 49 tap sums leave no room; rows are streamed)
+  constexpr bool RT = ONE8 && KS <= 5;                      // both tiles of a unit in registers (7x7: 49 taps + 49 tap sums leave no room for
+  constexpr bool RT1 = ONE8;                                //  the x tile: its rows are streamed; the dy tile is in registers for every k)
   const int H = ONE8 ? 8 : H_, W = ONE8 ? 8 : W_;
   __shared__ float red[4][64 * KK + 64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -411,11 +412,9 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
   for (int u = blockIdx.y * 4 + wave; u < units; u += gridDim.y * 4) {
     const int b = ONE8 ? u : u / TPI, t = u - b * TPI, ty = ONE8 ? 0 : t / TX, tx = ONE8 ? 0 : t - ty * TX;
     f32x2 g[TS][TS / 2];
-    float gt[RT ? 8 : 1][8], xt[RT ? 8 : 1][8];            // RT: the dy and x tiles, every load of the unit requested up front
-    if constexpr (RT) {
-      dw_load_tile8<T>(dy, gt, b, lddy, cc);
-      dw_load_tile8<T>(x, xt, b, C, cc);
-    }
+    float gt[RT1 ? 8 : 1][8], xt[RT ? 8 : 1][8];           // the dy and x tiles, every load of the unit requested up front
+    if constexpr (RT1) dw_load_tile8<T>(dy, gt, b, lddy, cc);
+    if constexpr (RT) dw_load_tile8<T>(x, xt, b, C, cc);
     {
       // the addend's 64 cells are requested before the tap arithmetic when the registers allow (k <= 5), after it otherwise
       constexpr bool EARLY = KS <= 5;
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
       for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
         for (int p = 0; p < TS / 2; ++p) o[yy][p] = f32x2{0.f, 0.f};
-      if constexpr (RT) {
+      if constexpr (RT1) {
         dw_tile_rows<T, KS, true, false, true>(dy, wt, o, b, -R, -R, 8, 8, lddy, cc, nullptr, gt);
 #pragma unroll
         for (int yy = 0; yy < TS; ++yy)
