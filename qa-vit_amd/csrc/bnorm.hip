@@ -19,6 +19,7 @@ template <> struct BV<bf16> { static constexpr int N = 8; typedef bf16x8 type; }
 template <> struct BV<float> { static constexpr int N = 4; typedef f32x4 type; };
 
 constexpr int BN_MAXC = 2048;
+constexpr int BN_U = 4, BN_US = 8;                         // rows a thread has in flight: apply passes (thousands of workgroups), statistics passes (<= 256)
 
 // ws[0..C) = sum (x - pivot), ws[C..2C) = sum (x - pivot)^2, ws[2C..3C) = the pivot used (the running mean BEFORE this
 // step's update: any pivot is exact, one near the mean avoids the E[x^2] - mean^2 cancellation)
@@ -36,10 +37,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, const float* 
   for (int j = 0; j < VEC; ++j) { pv[j] = pivot ? pivot[cg * VEC + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
   const int mb = blockIdx.x * rows_per_wg;
   const int me = (mb + rows_per_wg < M) ? mb + rows_per_wg : M;
-  for (int m = mb + r0; m < me; m += rpp) {
-    const vec_t v = *reinterpret_cast<const vec_t*>(x + (size_t)m * C + cg * VEC);
+  // BN_US row loads in flight per thread: with one, a workgroup keeps 4 KB on the wire and the pass runs at a quarter of the memory rate
+  for (int m0 = mb + r0; m0 < me; m0 += rpp * BN_US) {
+    vec_t v[BN_US];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { const float d = to_f<T>(v[j]) - pv[j]; s1[j] += d; s2[j] += d * d; }
+    for (int u = 0; u < BN_US; ++u) {
+      const int m = m0 + u * rpp;
+      v[u] = *reinterpret_cast<const vec_t*>(x + (size_t)(m < me ? m : m0) * C + cg * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_US; ++u) {
+      if (m0 + u * rpp < me) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float d = to_f<T>(v[u][j]) - pv[j]; s1[j] += d; s2[j] += d * d; }
+      }
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -80,16 +92,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, T* y, const f
       }
     }
   }
-  for (int m = blockIdx.x * rpp + r0; m < M; m += gridDim.x * rpp) {
-    const vec_t v = *reinterpret_cast<const vec_t*>(x + (size_t)m * C + cg * VEC);
-    vec_t o;
+  for (int m0 = blockIdx.x * rpp * BN_U + r0; m0 < M; m0 += gridDim.x * rpp * BN_U) {
+    vec_t v[BN_U];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float z = (to_f<T>(v[j]) - mu[j]) * sc[j] + sh[j];
-      if (act) z = gelu_f(z);
-      o[j] = from_f<T>(z);
+    for (int u = 0; u < BN_U; ++u) {
+      const int m = m0 + u * rpp;
+      v[u] = *reinterpret_cast<const vec_t*>(x + (size_t)(m < M ? m : m0) * C + cg * VEC);
     }
-    *reinterpret_cast<vec_t*>(y + (size_t)m * C + cg * VEC) = o;
+#pragma unroll
+    for (int u = 0; u < BN_U; ++u) {
+      const int m = m0 + u * rpp;
+      if (m >= M) break;
+      vec_t o;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z = (to_f<T>(v[u][j]) - mu[j]) * sc[j] + sh[j];
+        if (act) z = gelu_f(z);
+        o[j] = from_f<T>(z);
+      }
+      *reinterpret_cast<vec_t*>(y + (size_t)m * C + cg * VEC) = o;
+    }
   }
 }
 
@@ -111,15 +133,26 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* dy, const T*
   }
   const int mb = blockIdx.x * rows_per_wg;
   const int me = (mb + rows_per_wg < M) ? mb + rows_per_wg : M;
-  for (int m = mb + r0; m < me; m += rpp) {
-    const vec_t xv = *reinterpret_cast<const vec_t*>(x + (size_t)m * C + cg * VEC);
-    const vec_t gv = *reinterpret_cast<const vec_t*>(dy + (size_t)m * C + cg * VEC);
+  for (int m0 = mb + r0; m0 < me; m0 += rpp * BN_US) {
+    vec_t xv[BN_US], gv[BN_US];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const float xh = (to_f<T>(xv[j]) - mu[j]) * rs[j];
-      float g = to_f<T>(gv[j]);
-      if (act) g *= gelu_grad_f(xh * ga[j] + be[j]);
-      s1[j] += g; s2[j] += g * xh;
+    for (int u = 0; u < BN_US; ++u) {
+      const int m = m0 + u * rpp;
+      const size_t off = (size_t)(m < me ? m : m0) * C + cg * VEC;
+      xv[u] = *reinterpret_cast<const vec_t*>(x + off);
+      gv[u] = *reinterpret_cast<const vec_t*>(dy + off);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_US; ++u) {
+      if (m0 + u * rpp < me) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float xh = (to_f<T>(xv[u][j]) - mu[j]) * rs[j];
+          float g = to_f<T>(gv[u][j]);
+          if (act) g *= gelu_grad_f(xh * ga[j] + be[j]);
+          s1[j] += g; s2[j] += g * xh;
+        }
+      }
     }
   }
   __syncthreads();
@@ -150,18 +183,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T*
       if (dgamma) atomic_add_f(dgamma + c, ws_param[C + c]);
     }
   }
-  for (int m = blockIdx.x * rpp + r0; m < M; m += gridDim.x * rpp) {
-    const vec_t xv = *reinterpret_cast<const vec_t*>(x + (size_t)m * C + cg * VEC);
-    const vec_t gv = *reinterpret_cast<const vec_t*>(dy + (size_t)m * C + cg * VEC);
-    vec_t o;
+  for (int m0 = blockIdx.x * rpp * BN_U + r0; m0 < M; m0 += gridDim.x * rpp * BN_U) {
+    vec_t xv[BN_U], gv[BN_U];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const float xh = (to_f<T>(xv[j]) - mu[j]) * rs[j];
-      float g = to_f<T>(gv[j]);
-      if (act) g *= gelu_grad_f(xh * ga[j] + be[j]);
-      o[j] = from_f<T>(ga[j] * rs[j] * (g - k1[j] - xh * k2[j]));
+    for (int u = 0; u < BN_U; ++u) {
+      const int m = m0 + u * rpp;
+      const size_t off = (size_t)(m < M ? m : m0) * C + cg * VEC;
+      xv[u] = *reinterpret_cast<const vec_t*>(x + off);
+      gv[u] = *reinterpret_cast<const vec_t*>(dy + off);
     }
-    *reinterpret_cast<vec_t*>(dx + (size_t)m * C + cg * VEC) = o;
+#pragma unroll
+    for (int u = 0; u < BN_U; ++u) {
+      const int m = m0 + u * rpp;
+      if (m >= M) break;
+      vec_t o;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float xh = (to_f<T>(xv[u][j]) - mu[j]) * rs[j];
+        float g = to_f<T>(gv[u][j]);
+        if (act) g *= gelu_grad_f(xh * ga[j] + be[j]);
+        o[j] = from_f<T>(ga[j] * rs[j] * (g - k1[j] - xh * k2[j]));
+      }
+      *reinterpret_cast<vec_t*>(dx + (size_t)m * C + cg * VEC) = o;
+    }
   }
 }
 
@@ -198,7 +242,7 @@ int bn_fwd_t(const void* x, void* y, int M, int C, const float* gamma, const flo
   }
   if (phase == 1) return check_launch("bn_fwd(stats)");
   const int rpp = 256 / (C / VEC);
-  int g2 = (M + rpp - 1) / rpp;
+  int g2 = (M + rpp * BN_U - 1) / (rpp * BN_U);
   if (g2 > 2048) g2 = 2048;
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(g2), dim3(256), 0, st, (const T*)x, (T*)y, gamma, beta, ws, rm, rv, save_mean, save_rstd,
                      momentum, eps, act, training, M, C, Mtot);
@@ -221,7 +265,7 @@ int bn_bwd_t(const void* dy, const void* x, int M, int C, const float* gamma, co
   }
   if (phase == 1) return check_launch("bn_bwd(stats)");
   const int rpp = 256 / (C / VEC);
-  int g2 = (M + rpp - 1) / rpp;
+  int g2 = (M + rpp * BN_U - 1) / (rpp * BN_U);
   if (g2 > 2048) g2 = 2048;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g2), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd, ws, (T*)dx, dgamma, dbeta, act, training, M, C, Mtot, ws_param);
   return check_launch("bn_bwd");
