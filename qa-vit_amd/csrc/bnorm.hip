@@ -7,6 +7,7 @@
 // partials are registers; a workgroup folds them through LDS and leaves 2*C fp32 atomics.  Grids are capped at 256
 // workgroups: the flush, not the streaming, was what bounded the LayerNorm backward (norm.hip).
 #include "common.cuh"
+#include <stdlib.h>
 #include "../../include/qavit.h"
 #include "launch.h"
 
@@ -218,10 +219,16 @@ bool bn_shape_ok(const void* p0, const void* p1, const void* p2, int C) {
   return ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
 }
 
+inline int bn_apply_cap() {
+  static const int cap = getenv("QAVIT_BN_APPLY_WGS") ? atoi(getenv("QAVIT_BN_APPLY_WGS")) : 1024;
+  return cap;
+}
+
 inline void stats_grid(int M, int C, int vec, int& grid, int& rows_per_wg) {
   const int rpp = 256 / (C / vec);
   grid = (M + 4 * rpp - 1) / (4 * rpp);                 // >= 4 passes per workgroup
-  if (grid > 256) grid = 256;
+  static const int cap = getenv("QAVIT_BN_STATS_WGS") ? atoi(getenv("QAVIT_BN_STATS_WGS")) : 256;
+  if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   rows_per_wg = (M + grid - 1) / grid;
   rows_per_wg = (rows_per_wg + rpp - 1) / rpp * rpp;
@@ -243,7 +250,7 @@ int bn_fwd_t(const void* x, void* y, int M, int C, const float* gamma, const flo
   if (phase == 1) return check_launch("bn_fwd(stats)");
   const int rpp = 256 / (C / VEC);
   int g2 = (M + rpp * BN_U - 1) / (rpp * BN_U);
-  if (g2 > 2048) g2 = 2048;
+  if (g2 > bn_apply_cap()) g2 = bn_apply_cap();
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(g2), dim3(256), 0, st, (const T*)x, (T*)y, gamma, beta, ws, rm, rv, save_mean, save_rstd,
                      momentum, eps, act, training, M, C, Mtot);
   return check_launch("bn_fwd");
@@ -266,7 +273,7 @@ int bn_bwd_t(const void* dy, const void* x, int M, int C, const float* gamma, co
   if (phase == 1) return check_launch("bn_bwd(stats)");
   const int rpp = 256 / (C / VEC);
   int g2 = (M + rpp * BN_U - 1) / (rpp * BN_U);
-  if (g2 > 2048) g2 = 2048;
+  if (g2 > bn_apply_cap()) g2 = bn_apply_cap();
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g2), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, rstd, ws, (T*)dx, dgamma, dbeta, act, training, M, C, Mtot, ws_param);
   return check_launch("bn_bwd");
 }
