@@ -249,17 +249,22 @@ class DeferDW:
         return True
 
     @classmethod
-    def flush(cls):
-        """Launch what is queued and wait for it (data-parallel sync points: the bucket about to be reduced must be complete)."""
+    def _launch(cls):
+        if DeferredBank.queue:
+            K.DeferredLN.flush()                             # the projected bank rows' gradients are among the partial rows
+            DeferredBank.run()                               # queues the projections' weight gradients
         K.DeferredTN.flush()
         K.DeferredLN.flush()
         K.DeferredTN.join()
 
     @classmethod
+    def flush(cls):
+        """Launch what is queued and wait for it (data-parallel sync points: the bucket about to be reduced must be complete)."""
+        cls._launch()
+
+    @classmethod
     def finish(cls):
-        K.DeferredTN.flush()
-        K.DeferredLN.flush()
-        K.DeferredTN.join()
+        cls._launch()
         K.DeferredTN.enabled = False
         K.DeferredLN.enabled = False
         cls._armed = False
@@ -784,9 +789,14 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
         if ek_buf is not None or ev_buf is not None:
             K.DeferredLN.push_raw(parts.data_ptr(), nparts, 512, K._p(ek_buf), K._p(ev_buf), PF, (parts, ek_buf, ev_buf))
     leaf = sh_k_in.is_leaf and sh_v_in.is_leaf
+    rec = None if leaf else DeferredBank.record_of(sh_k_in, sh_v_in)
     if leaf:
         sk_buf, sk_ret = grad_sink(sh_k_in)
         sv_buf, sv_ret = grad_sink(sh_v_in)
+    elif rec is not None:                                  # BankProj2Fn's rows: their projection's backward runs once, when the pass ends
+        both = DeferredBank.slot(sh_k_in.shape, x.device)
+        sk_buf, sv_buf = both[0], both[1]
+        sk_ret = sv_ret = None
     else:                                                  # a consumer waits for these (the bank projections' backward): reduce now
         both = torch.zeros((2,) + tuple(sh_k_in.shape), dtype=torch.float32, device=x.device)
         sk_buf = sk_ret = both[0] if sh_k_in.requires_grad else None
@@ -797,9 +807,11 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
         if buf is not None:
             descs.append((parts.data_ptr() + off * 4, nparts, half, buf.data_ptr(), buf.data_ptr() + half * 4, PF))
     if descs:
-        if leaf:
+        if leaf or rec is not None:
             for d_ in descs:
                 K.DeferredLN.push_raw(*d_, (parts, sk_buf, sv_buf))
+            if rec is not None:
+                DeferredBank.queue.append((rec, both))
         else:
             K.reduce_now([K.DeferredLN.desc(*d_) for d_ in descs])
     # ---- the projections' own backward
@@ -982,7 +994,12 @@ def _cga_backward_fused(ctx, dout, x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk,
     # bank-row gradients: [d sh_k | d sh_v] partial rows -> the (non-leaf) projected bank rows' gradient buffers
     sk_ret = sv_ret = None
     need_k, need_v = sh_k_in.requires_grad, sh_v_in.requires_grad
-    if need_k or need_v:
+    rec = DeferredBank.record_of(sh_k_in, sh_v_in)
+    if rec is not None:
+        both = DeferredBank.slot(shk.shape, x.device)
+        K.DeferredLN.push_raw(parts.data_ptr(), nparts, 256, both[0].data_ptr(), both[1].data_ptr(), 512, (parts, both))
+        DeferredBank.queue.append((rec, both))
+    elif need_k or need_v:
         both = torch.zeros((2,) + tuple(shk.shape), dtype=torch.float32, device=x.device)
         K.reduce_now([K.DeferredLN.desc(parts.data_ptr(), nparts, 256, both[0].data_ptr() if need_k else None, both[1].data_ptr() if need_v else None, 512)])
         sk_ret = both[0] if need_k else None
@@ -1864,19 +1881,37 @@ class BankProj2Fn(Function):
         if need:
             ctx.save_for_backward(snap_k, snap_v, wk, bk, wv, bv)
             ctx.bank = (gk, gv)                             # the parameters themselves (their values are mutated in place later: not "saved")
+            ctx.set_materialize_grads(False)                # a branch that defers this backward (DeferredBank) sends no gradient here
+            ctx.rec = (gk, gv, snap_k, snap_v, wk, bk, wv, bv)
         return yk, yv
 
     @staticmethod
     def backward(ctx, dk, dv):
+        if dk is None and dv is None:
+            return (None,) * 8
         snap_k, snap_v, wk, bk, wv, bv = ctx.saved_tensors
         gk, gv = ctx.bank
+        S = gk.shape[-2]
+        nk, nv = wk.shape[0], wv.shape[0]
+        dk2 = torch.zeros(S, nk, dtype=gk.dtype, device=gk.device) if dk is None else dk.reshape(S, nk).contiguous()
+        dv2 = torch.zeros(S, nv, dtype=gk.dtype, device=gk.device) if dv is None else dv.reshape(S, nv).contiguous()
+        DeferDW.arm()
+        outs = _bank_proj2_backward([((gk, gv, snap_k, snap_v, wk, bk, wv, bv), dk2, dv2)])
+        return outs[0], outs[1], None, None, None, None, None, None
+
+
+def _bank_proj2_backward(items):
+    """Backward of BankProj2Fn for a list of (record, d sh_k [S, nk], d sh_v [S, nv]): ONE grouped launch for all the bank-row
+    gradients (residual epilogue: they accumulate into the parameters' ``.grad``), the weight gradients join the deferred queue.
+    -> the autograd returns for (bank_k, bank_v) of the LAST item (None where the gradient went into ``.grad``)."""
+    probs = []
+    outs = [None, None]
+    tn = []
+    for (gk, gv, snap_k, snap_v, wk, bk, wv, bv), dk2, dv2 in items:
         S, Cc = gk.shape[-2], gk.shape[-1]
         nk, nv = wk.shape[0], wv.shape[0]
-        dk2 = dk.reshape(S, nk).contiguous()
-        dv2 = dv.reshape(S, nv).contiguous()
         pk = pack_for(gk.device)
         outs = [None, None]
-        probs = []
         for i, (g_, d2, w, n) in enumerate(((gk, dk2, wk, nk), (gv, dv2, wv, nv))):
             if not g_.requires_grad:
                 continue
@@ -1886,9 +1921,6 @@ class BankProj2Fn(Function):
             # dst = d2 @ W + dst: the residual epilogue reads and writes the same element in one thread
             probs.append(K.gemm_nt(d2, Wt, dst, S, Cc, n, n, Wt.shape[1], Cc, None, R=dst, ldr=Cc, build_only=True))
             outs[i] = ret
-        if probs:
-            K.gemm_nt_grouped(probs)
-        DeferDW.arm()
         for (x_s, d2, w, b, n) in ((snap_k, dk2, wk, bk, nk), (snap_v, dv2, wv, bv, nv)):
             wbuf, _ = grad_sink(w)
             bbuf, _ = grad_sink(b)
@@ -1896,14 +1928,80 @@ class BankProj2Fn(Function):
                 continue
             if wbuf is None:
                 wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
-            K.gemm_tn(d2, x_s.reshape(S, Cc), wbuf, S, n, Cc, n, Cc, Cc, bbuf)
-        return outs[0], outs[1], None, None, None, None, None, None
+            tn.append((d2, x_s.reshape(S, Cc), wbuf, S, n, Cc, n, Cc, Cc, bbuf))
+    if probs:
+        _grouped_by_destination(probs)                       # several projections accumulate into the same bank parameter
+    for a in tn:
+        K.gemm_tn(*a)
+    return outs
+
+
+def _grouped_by_destination(probs):
+    """gemm_nt_grouped over problems whose residual epilogue accumulates into a shared destination: problems with the same output
+    pointer must not run in the same launch (read-modify-write without atomics), so they are dealt into successive launches."""
+    rounds = []
+    for pr in probs:
+        key = int(pr.C)
+        for r in rounds:
+            if key not in r[0]:
+                r[0].add(key); r[1].append(pr)
+                break
+        else:
+            rounds.append(({key}, [pr]))
+    for _, plist in rounds:
+        K.gemm_nt_grouped(plist)
+
+
+_BANK_DEFER = os.environ.get("QAVIT_BANK_DEFER", "1") != "0"
+
+
+class DeferredBank:
+    """The backward of every BankProj2Fn of a pass, run once when the pass ends (DeferDW._launch).  The fused branch kernels leave
+    the projected rows' gradient as partial rows; nothing but the bank parameters' and the projection weights' ``.grad`` depends on
+    them, so instead of (zero fill, reduce, grouped dX launch) on the critical path of each of the 16 cross-attention and
+    channel-group branches, the partial rows are folded by the pass's single reduce launch into slots of one zeroed pool and the 32
+    bank-row GEMMs run as a handful of grouped launches (problems that accumulate into the same parameter in successive ones)."""
+    queue = []          # (record, both[2, S, n] fp32)
+    _pools = {}         # shape -> [pool tensor, used]
+
+    @staticmethod
+    def record_of(sh_k, sh_v):
+        if not (_BANK_DEFER and K.DeferredLN.enabled and K.DeferredLN.ON):
+            return None
+        rec = getattr(sh_k, "_qavit_bank_rec", None)
+        if rec is None or rec is not getattr(sh_v, "_qavit_bank_rec", None):
+            return None
+        if not (sh_k.requires_grad and sh_v.requires_grad and sh_k.shape == sh_v.shape and rec[0].is_leaf and rec[1].is_leaf):
+            return None
+        return rec
+
+    @classmethod
+    def slot(cls, shape, device):
+        key = (tuple(shape), str(device))
+        ent = cls._pools.get(key)
+        if ent is None or ent[1] >= ent[0].shape[0]:
+            ent = [torch.zeros((32, 2) + tuple(shape), dtype=torch.float32, device=device), 0]
+            cls._pools[key] = ent
+        ent[1] += 1
+        return ent[0][ent[1] - 1]
+
+    @classmethod
+    def run(cls):
+        q, cls.queue = cls.queue, []
+        cls._pools = {}
+        _bank_proj2_backward([(rec, both[0], both[1]) for rec, both in q])
 
 
 def bank_proj2(bank, snap, lin_k, lin_v):
     """-> (Linear_k(bank.global_k), Linear_v(bank.global_v)) as [S, n] matrices; see BankProj2Fn."""
     sk, sv = snap if snap is not None else (None, None)
-    return BankProj2Fn.apply(bank.global_k, bank.global_v, sk, sv, lin_k.weight, lin_k.bias, lin_v.weight, lin_v.bias)
+    yk, yv = BankProj2Fn.apply(bank.global_k, bank.global_v, sk, sv, lin_k.weight, lin_k.bias, lin_v.weight, lin_v.bias)
+    fn = yk.grad_fn
+    rec = getattr(fn, "rec", None) if fn is not None else None
+    if rec is not None:                                     # lets a fused branch backward defer this node's backward (DeferredBank)
+        yk._qavit_bank_rec = rec
+        yv._qavit_bank_rec = rec
+    return yk, yv
 
 
 class _SnapshotGivenFn(Function):
