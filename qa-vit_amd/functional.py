@@ -377,8 +377,14 @@ class LinearFn(Function):
         M, n, Kd, off, act, drop, dp, xshape, has_res, koff = ctx.meta
         if dy is None:                                      # only the alias was differentiated through
             return dalias, None, None, None, None, None, None
+        dx_add = None
+        if dalias is not None and ln_g is None and dalias.dtype == x2.dtype:
+            dx_add = dalias.reshape(M, Kd)
+            if not dx_add.is_contiguous():
+                dx_add = dx_add.contiguous()
+            dalias = None
         dx = _linear_bwd(x2, w, b, dy.reshape(M, n), off, n, ctx.needs_input_grad[0], ln_g, ln_b, Z, mean, rstd, act, drop, dp, koff,
-                         dres=dalias)
+                         dres=dalias, dx_add=dx_add)
         dres = dy if has_res else None
         return (dx.reshape(xshape) if (dx is not None and ctx.needs_input_grad[0]) else None), None, None, None, None, dres, None
 
@@ -444,9 +450,9 @@ def linear(x, w, b=None, *, ln=None, act=None, drop=None, dp=None, resid=None, r
     """``rows=(off, n)``: output rows off..off+n of ``w``; ``cols=(k_off, k_len)``: the K-slice w[:, k_off:k_off+k_len] (x has k_len
     columns) -- with ``resid`` it turns a Linear on a concatenation into accumulating GEMMs, no ``cat`` buffer."""
     ln_g, ln_b = ln if ln is not None else (None, None)
-    # alias=True (LayerNorm-prologue Linears): -> (y, x_alias); the gradient that arrives on x_alias (x's other consumer) is added
-    # inside the LayerNorm-backward kernel instead of by an elementwise add of autograd's
-    want_alias = bool(alias) and ln is not None and torch.is_grad_enabled() and x.requires_grad
+    # alias=True: -> (y, x_alias); the gradient that arrives on x_alias (x's other consumer) is added inside the LayerNorm-backward
+    # kernel (LayerNorm-prologue Linears) or by the input-gradient GEMM's residual epilogue, instead of by an elementwise add of autograd's
+    want_alias = bool(alias) and torch.is_grad_enabled() and x.requires_grad
     opts = dict(act=act, drop=drop, dp=dp, rows=rows, cols=cols, eps=eps, train=train, alias=want_alias)
     out = LinearFn.apply(x, w, b, ln_g, ln_b, resid, opts)
     if alias and not want_alias:
@@ -1356,10 +1362,12 @@ def ccf_mid(h, g1, b1, g2, b2, w, cbias, cscale, Hs, Ws, eps=1e-5):
 
 
 class DwConvFn(Function):
-    """Depthwise k x k conv on channel-last tokens [B, H*W, C] (csrc/dwconv.hip)."""
+    """Depthwise k x k conv on channel-last tokens [B, H*W, C] (csrc/dwconv.hip).  ``alias=True`` -> (y, x_alias): use ``x_alias`` for
+    the residual connection around the block this convolution opens (ConvNeXtBlock); the gradient arriving on it is added inside
+    the backward kernel (qavit_dwconv_bwd_ld's addend) instead of by an elementwise add of autograd's."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, H, W):
+    def forward(ctx, x, w, bias, H, W, alias=False):
         B, N, Cc = x.shape
         ks = w.shape[-1]
         x = x.contiguous()
@@ -1367,20 +1375,31 @@ class DwConvFn(Function):
         K.dwconv_fwd(x, w.detach(), None if bias is None else bias.detach(), y, B, H, W, Cc, ks)
         ctx.save_for_backward(x, w, bias)
         ctx.dims = (B, H, W, Cc, ks)
+        if alias:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         x, w, bias = ctx.saved_tensors
         B, H, W, Cc, ks = ctx.dims
+        if dy is None:                                      # only the alias was differentiated through
+            return dalias, None, None, None, None, None
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         wbuf, wret = grad_sink(w)
         bbuf, bret = grad_sink(bias)
         if wbuf is None:
             wbuf = torch.zeros_like(w, dtype=torch.float32)
-        K.dwconv_bwd(dy, x, w.detach(), dx, wbuf, bbuf, B, H, W, Cc, ks)
-        return dx, _ret(wret, w), _ret(bret, bias), None, None
+        fold = dalias is not None and H % 8 == 0 and W % 8 == 0 and dalias.dtype == dy.dtype
+        if fold:
+            K.dwconv_bwd_ld(dy, Cc, x, w.detach(), dx, dalias.contiguous(), Cc, wbuf, bbuf, B, H, W, Cc, ks)
+        else:
+            K.dwconv_bwd(dy, x, w.detach(), dx, wbuf, bbuf, B, H, W, Cc, ks)
+            if dalias is not None:
+                dx = dx + dalias
+        return dx, _ret(wret, w), _ret(bret, bias), None, None, None
 
 
 class LmfGatherFn(Function):

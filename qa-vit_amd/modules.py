@@ -509,9 +509,10 @@ def _to_tokens(x):
     return x.flatten(2).transpose(1, 2).contiguous()
 
 
-def _conv1x1_tokens(t, conv: nn.Conv2d):
-    """A 1x1 nn.Conv2d applied to channel-last tokens is a GEMM over the channel axis (weight [Cout,Cin,1,1])."""
-    return F.linear(t, conv.weight, conv.bias)
+def _conv1x1_tokens(t, conv: nn.Conv2d, alias: bool = False):
+    """A 1x1 nn.Conv2d applied to channel-last tokens is a GEMM over the channel axis (weight [Cout,Cin,1,1]).
+    ``alias`` -> (y, t_alias): hand ``t_alias`` to t's other consumer (its gradient is added in this GEMM's backward epilogue)."""
+    return F.linear(t, conv.weight, conv.bias, alias=alias)
 
 
 def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool, gelu: bool = False):
@@ -547,7 +548,10 @@ class ConvNeXtBlock(nn.Module):
         self._site = K.new_site()
 
     def forward_tokens(self, t, H, W):
-        h = F.DwConvFn.apply(t, self.dwconv.weight, self.dwconv.bias, H, W)
+        if torch.is_grad_enabled() and t.requires_grad:      # t also feeds the residual: its gradient is added inside the dwconv backward
+            h, t = F.DwConvFn.apply(t, self.dwconv.weight, self.dwconv.bias, H, W, True)
+        else:
+            h = F.DwConvFn.apply(t, self.dwconv.weight, self.dwconv.bias, H, W)
         h = F.linear(h, self.pwconv1.weight, self.pwconv1.bias, ln=(self.norm.weight, self.norm.bias), eps=self.norm.eps, act="gelu")
         p = self.drop_path.drop_prob if (self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob) else 0.0
         if self.layer_scale and self.gamma is not None:
@@ -595,9 +599,12 @@ class CNNStemModel(nn.Module):
             h, w = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
             f2 = self.stage1[3].forward_tokens(t, h, w)
             yield
-            f3 = self.stage2[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f2, self.stage2[0]), self.stage2[1], self.training), h, w)
+            # f2 / f3 also leave as lateral features: the aliases carry those consumers' gradients into the 1x1 convs' backward GEMMs
+            t, f2 = _conv1x1_tokens(f2, self.stage2[0], alias=True)
+            f3 = self.stage2[2].forward_tokens(_bn_tokens(t, self.stage2[1], self.training), h, w)
             yield
-            f4 = self.stage3[2].forward_tokens(_bn_tokens(_conv1x1_tokens(f3, self.stage3[0]), self.stage3[1], self.training), h, w)
+            t, f3 = _conv1x1_tokens(f3, self.stage3[0], alias=True)
+            f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training), h, w)
         return (f2, f3, f4), (h, w)
 
     def forward(self, x):                                   # NCHW surface of the reference class
@@ -717,7 +724,7 @@ class RRCV(nn.Module):
         self.beta = nn.Parameter(torch.tensor(0.1))
 
     def forward(self, A, H: int, W: int):
-        h = _conv1x1_tokens(A, self.reverse_proj)
+        h, A = _conv1x1_tokens(A, self.reverse_proj, alias=True)     # A also feeds the residual below
         for blk in self.blocks:
             h = blk.forward_tokens(h, H, W)
         t = _conv1x1_tokens(h, self.reembed_proj)
