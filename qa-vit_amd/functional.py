@@ -263,11 +263,37 @@ class DeferDW:
         cls._launch()
 
     @classmethod
+    def flush_home(cls):
+        """Launch what the arming stream has queued so far and leave the other streams' entries for the end of the pass: called where
+        this stream's backward is (almost) over while another stream's chain still runs (HQAViT: the CNN lateral path's backward
+        tail), so the weight-gradient GEMMs run beside that chain instead of after it."""
+        if not cls._armed:
+            return
+        if DeferredBank.queue:
+            K.DeferredLN.flush(home_only=True)
+            DeferredBank.run()
+        K.DeferredTN.flush(home_only=True)
+        K.DeferredLN.flush(home_only=True)
+
+    @classmethod
     def finish(cls):
         cls._launch()
         K.DeferredTN.enabled = False
         K.DeferredLN.enabled = False
         cls._armed = False
+
+
+class FlushMarkFn(Function):
+    """Identity whose backward launches the deferred weight-gradient work queued so far on this stream (DeferDW.flush_home)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        DeferDW.flush_home()
+        return dy
 
 
 class SideStream:

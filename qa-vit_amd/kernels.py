@@ -172,10 +172,17 @@ class DeferredTN:
                         u.record_stream(cur)
 
     @classmethod
-    def flush(cls):
+    def flush(cls, home_only=False):
+        """``home_only``: launch only what the arming stream queued and keep the other streams' problems for the final flush (an early
+        flush must not make this stream wait for a chain that is still running beside it)."""
         if not cls.queue:
             return
         q, cls.queue = cls.queue, []
+        if home_only:
+            cls.queue = [e for e in q if e[2] is not None]
+            q = [e for e in q if e[2] is None]
+            if not q:
+                return
         if not cls.ASYNC:
             # this stream's problems first: the launch that has to wait for the other stream should not hold them back
             parts = ([e for e in q if e[2] is None], [e for e in q if e[2] is not None]) if cls.SPLIT_FOREIGN else (q,)
@@ -300,10 +307,15 @@ class DeferredLN:
         cls.queue.append((d, tuple(keep), torch.cuda.current_stream() if foreign else None))
 
     @classmethod
-    def flush(cls):
+    def flush(cls, home_only=False):
         if not cls.queue:
             return
         q, cls.queue = cls.queue, []
+        if home_only:                                       # see DeferredTN.flush
+            cls.queue = [e for e in q if e[2] is not None]
+            q = [e for e in q if e[2] is None]
+            if not q:
+                return
         DeferredTN._adopt_foreign(q)
         arr = (L.LnReduceDesc * len(q))(*[d for d, _, _ in q])
         L.check(L.load().qavit_ln_param_reduce(arr, len(q), stream()), "ln_param_reduce")

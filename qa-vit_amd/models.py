@@ -66,6 +66,7 @@ class _Base(nn.Module):
 
 _LATERAL_STREAM = os.environ.get("QAVIT_LATERAL_STREAM", "1") != "0"
 _LATERAL_ORDER = int(os.environ.get("QAVIT_LATERAL_ORDER", "0"))
+_EARLY_FLUSH = os.environ.get("QAVIT_EARLY_FLUSH", "0") != "0"   # deferred weight-gradient work of the token path launched when ITS backward ends
 _DONE = object()
 _SIDE = {}
 
@@ -145,6 +146,8 @@ class HQAViT(_Base):
             def stage1():
                 T_ = self.patch_embed(x, self.pos_embed)
                 T_ = F.dropout(T_, self.pos_drop.p, self._pos_site, self.training)
+                if _EARLY_FLUSH and side is not None and torch.is_grad_enabled() and T_.requires_grad:
+                    T_ = F.FlushMarkFn.apply(T_)            # backward: the token path ends here while the lateral path's tail still runs
                 T_ = self._sync(T_, "stage1_blocks")
                 for blk in self.stage1_blocks:
                     T_ = blk(T_)
@@ -161,6 +164,8 @@ class HQAViT(_Base):
             def stage1_steps(out):
                 T_ = self.patch_embed(x, self.pos_embed)
                 T_ = F.dropout(T_, self.pos_drop.p, self._pos_site, self.training)
+                if _EARLY_FLUSH and side is not None and torch.is_grad_enabled() and T_.requires_grad:
+                    T_ = F.FlushMarkFn.apply(T_)            # backward: the token path ends here while the lateral path's tail still runs
                 T_ = self._sync(T_, "stage1_blocks")
                 yield
                 for blk in self.stage1_blocks:
