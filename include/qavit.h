@@ -502,6 +502,13 @@ int qavit_gate_mix_bwd(int dtype, const void* dy, const void* r, const void* g, 
 int qavit_mix2_fwd(int dtype, const void* a, const void* b, const float* fw, void* y, int64_t n, void* stream);
 int qavit_mix2_bwd(int dtype, const void* dy, const void* a, const void* b, const float* fw, void* da, void* db, float* dfw,
                    int64_t n, void* stream);
+/* The blend with its second operand built in place (HQAViT_CIFAR100.py:953-963): y = s0*a + s1*(t + dropout(h)) -- dropout with
+ * the library's counter-based mask (drop_p, drop_site, rng as qavit_dropout; element index = flat index).  bwd: da = s0*dy,
+ * dt = s1*dy, dh = dt * mask, dfw[2] += (may be NULL).  Same size / alignment rules as qavit_mix2_*; n < 2^32. */
+int qavit_mix3_fwd(int dtype, const void* a, const void* t, const void* h, const float* fw, void* y, int64_t n,
+                   float drop_p, int drop_site, const int64_t* rng, void* stream);
+int qavit_mix3_bwd(int dtype, const void* dy, const void* a, const void* t, const void* h, const float* fw, void* da, void* dt, void* dh,
+                   float* dfw, int64_t n, float drop_p, int drop_site, const int64_t* rng, void* stream);
 /* y = x + droppath( gamma[0] * u )  (CCF-FFN gamma + residual, HQAViT_CIFAR100.py:712,1083); gamma may be NULL (=1) */
 int qavit_scale_add_fwd(int dtype, const void* x, const void* u, const float* gamma, void* y, int rows, int C,
                         float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);

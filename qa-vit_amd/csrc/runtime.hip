@@ -293,6 +293,65 @@ __global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, c
   }
 }
 
+// The same blend with SplitFusion's second operand built in place (HQAViT_CIFAR100.py:953-963): y = s0*a + s1*(t + dropout(h)).
+// One launch instead of dropout + add + blend forward, and instead of blend-backward + dropout-backward.
+// bwd: da = s0*dy, dt = s1*dy, dh = dt * mask, dfw through the softmax from (sum dy*a, sum dy*(t + dropout(h))).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void mix3_vec_kernel(const T* a, const T* t, const T* h, const T* dy, const float* fw, T* o0, T* o1, T* o2, float* dfw,
+                                                       uint32_t nvec, float p, int site, const int64_t* rng) {
+  constexpr int VEC = Vec<T>::N;
+  typedef typename Vec<T>::type vec_t;
+  float w[8];
+  softmax_small(fw, 2, w);
+  const uint32_t key = p > 0.f ? rng_key(rng, site) : 0u;
+  const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float p0 = 0.f, p1 = 0.f;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+    const vec_t av = *reinterpret_cast<const vec_t*>(a + (size_t)v * VEC);
+    const vec_t tv = *reinterpret_cast<const vec_t*>(t + (size_t)v * VEC);
+    const vec_t hv = *reinterpret_cast<const vec_t*>(h + (size_t)v * VEC);
+    float f[VEC], b[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      f[j] = p > 0.f ? drop_factor(key, v * (uint32_t)VEC + (uint32_t)j, p, inv) : 1.f;
+      // the unfused chain rounds dropout(h) and the sum to T before the blend: keep its values
+      b[j] = to_f<T>(from_f<T>(to_f<T>(tv[j]) + to_f<T>(from_f<T>(to_f<T>(hv[j]) * f[j]))));
+    }
+    vec_t x0, x1, x2;
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) x0[j] = from_f<T>(w[0] * to_f<T>(av[j]) + w[1] * b[j]);
+      *reinterpret_cast<vec_t*>(o0 + (size_t)v * VEC) = x0;
+    } else {
+      const vec_t gv = *reinterpret_cast<const vec_t*>(dy + (size_t)v * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float g = to_f<T>(gv[j]);
+        x0[j] = from_f<T>(g * w[0]);
+        x1[j] = from_f<T>(g * w[1]);
+        x2[j] = from_f<T>(to_f<T>(x1[j]) * f[j]);
+        p0 += g * to_f<T>(av[j]); p1 += g * b[j];
+      }
+      *reinterpret_cast<vec_t*>(o0 + (size_t)v * VEC) = x0;
+      *reinterpret_cast<vec_t*>(o1 + (size_t)v * VEC) = x1;
+      *reinterpret_cast<vec_t*>(o2 + (size_t)v * VEC) = x2;
+    }
+  }
+  if (BWD && dfw) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float s0 = wave_sum(p0), s1 = wave_sum(p1);
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float d0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], d1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      const float dot = d0 * w[0] + d1 * w[1];
+      atomic_add_f(dfw + 0, w[0] * (d0 - dot));
+      atomic_add_f(dfw + 1, w[1] * (d1 - dot));
+    }
+  }
+}
+
 // Device-side CutMix / MixUp of the input batch (train_epoch, HQAViT_CIFAR100.py:1381-1399).  plan[6] (device):
 // mode (0 none, 1 cutmix, 2 mixup), lambda, x1, y1, x2, y2.  out[b] = in[b] with the box pasted from in[perm[b]]
 // (cutmix) or lam*in[b] + (1-lam)*in[perm[b]] (mixup).  One thread per 4 pixels of a row (W % 4 == 0).
@@ -682,6 +741,44 @@ extern "C" int qavit_mix2_fwd(int dtype, const void* a, const void* b, const flo
   } else return set_error(QAVIT_EINVAL, "mix2_fwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
   return check_launch("mix2_fwd");
 }
+extern "C" int qavit_mix3_fwd(int dtype, const void* a, const void* t, const void* h, const float* fw, void* y, int64_t n,
+                              float drop_p, int drop_site, const int64_t* rng, void* stream) {
+  if (!a || !t || !h || !fw || !y || n <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !rng)) return set_error(QAVIT_EINVAL, "mix3_fwd: bad arguments");
+  if (n > 0xffffffffll) return set_error(QAVIT_EINVAL, "mix3_fwd: the dropout index is 32 bits");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (dtype == QAVIT_BF16 && al && n % 8 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((mix3_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)a, (const bf16*)t, (const bf16*)h, (const bf16*)nullptr, fw,
+                       (bf16*)y, (bf16*)nullptr, (bf16*)nullptr, (float*)nullptr, nvec, drop_p, drop_site, rng);
+  } else if (dtype == QAVIT_F32 && al && n % 4 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((mix3_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)a, (const float*)t, (const float*)h, (const float*)nullptr, fw,
+                       (float*)y, (float*)nullptr, (float*)nullptr, (float*)nullptr, nvec, drop_p, drop_site, rng);
+  } else return set_error(QAVIT_EINVAL, "mix3_fwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
+  return check_launch("mix3_fwd");
+}
+
+extern "C" int qavit_mix3_bwd(int dtype, const void* dy, const void* a, const void* t, const void* h, const float* fw, void* da, void* dt, void* dh,
+                              float* dfw, int64_t n, float drop_p, int drop_site, const int64_t* rng, void* stream) {
+  if (!dy || !a || !t || !h || !fw || !da || !dt || !dh || n <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !rng))
+    return set_error(QAVIT_EINVAL, "mix3_bwd: bad arguments");
+  if (n > 0xffffffffll) return set_error(QAVIT_EINVAL, "mix3_bwd: the dropout index is 32 bits");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool al = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(h) |
+                    reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(dt) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
+  if (dtype == QAVIT_BF16 && al && n % 8 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 8);
+    hipLaunchKernelGGL((mix3_vec_kernel<bf16, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)a, (const bf16*)t, (const bf16*)h, (const bf16*)dy, fw,
+                       (bf16*)da, (bf16*)dt, (bf16*)dh, dfw, nvec, drop_p, drop_site, rng);
+  } else if (dtype == QAVIT_F32 && al && n % 4 == 0) {
+    const uint32_t nvec = (uint32_t)(n / 4);
+    hipLaunchKernelGGL((mix3_vec_kernel<float, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)a, (const float*)t, (const float*)h, (const float*)dy, fw,
+                       (float*)da, (float*)dt, (float*)dh, dfw, nvec, drop_p, drop_site, rng);
+  } else return set_error(QAVIT_EINVAL, "mix3_bwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
+  return check_launch("mix3_bwd");
+}
+
 extern "C" int qavit_mix2_bwd(int dtype, const void* dy, const void* a, const void* b, const float* fw, void* da, void* db, float* dfw, int64_t n, void* stream) {
   if (!dy || !a || !b || !fw || !da || !db || n <= 0) return set_error(QAVIT_EINVAL, "mix2_bwd: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

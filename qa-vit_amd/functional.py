@@ -1712,6 +1712,32 @@ class Mix2Fn(Function):
         return da, db, fret
 
 
+class Mix3Fn(Function):
+    """y = s0*a + s1*(t + dropout(h)), s = softmax(fw) -- SplitFusion's blend with its second operand built in the kernel
+    (csrc/runtime.hip: mix3): no dropout / add launches, backward writes (da, dt, dh) in one pass."""
+
+    @staticmethod
+    def forward(ctx, a, t, h, fw, drop):
+        K._require_cuda(a, fw)
+        rt = _rt(a)
+        a, t, h = a.contiguous(), t.contiguous(), h.contiguous()
+        y = torch.empty_like(a)
+        K.mix3_fwd(a, t, h, fw.detach(), y, drop, rt.rng)
+        ctx.save_for_backward(a, t, h, fw)
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, t, h, fw = ctx.saved_tensors
+        rt = _rt(a)
+        dy = dy.contiguous()
+        da, dt, dh = torch.empty_like(a), torch.empty_like(t), torch.empty_like(h)
+        fbuf, fret = grad_sink(fw)
+        K.mix3_bwd(dy, a, t, h, fw.detach(), da, dt, dh, fbuf, ctx.drop, rt.rng)
+        return da, dt, dh, fret, None
+
+
 class ScaleAddFn(Function):
     """y = x + droppath(gamma * u)"""
 

@@ -544,6 +544,16 @@ def mix2_fwd(a, b, fw, y):
     L.check(L.load().qavit_mix2_fwd(dt_code(a.dtype), a.data_ptr(), b.data_ptr(), fw.data_ptr(), y.data_ptr(), a.numel(), stream()), "mix2_fwd")
 
 
+def mix3_fwd(a, t, h, fw, y, drop, rng):
+    L.check(L.load().qavit_mix3_fwd(dt_code(a.dtype), a.data_ptr(), t.data_ptr(), h.data_ptr(), fw.data_ptr(), y.data_ptr(), a.numel(),
+                                    drop[0], drop[1], rng.data_ptr(), stream()), "mix3_fwd")
+
+
+def mix3_bwd(dy, a, t, h, fw, da, dt, dh, dfw, drop, rng):
+    L.check(L.load().qavit_mix3_bwd(dt_code(a.dtype), dy.data_ptr(), a.data_ptr(), t.data_ptr(), h.data_ptr(), fw.data_ptr(), da.data_ptr(), dt.data_ptr(),
+                                    dh.data_ptr(), _p(dfw), a.numel(), drop[0], drop[1], rng.data_ptr(), stream()), "mix3_bwd")
+
+
 def mix2_bwd(dy, a, b, fw, da, db, dfw):
     L.check(L.load().qavit_mix2_bwd(dt_code(a.dtype), dy.data_ptr(), a.data_ptr(), b.data_ptr(), fw.data_ptr(), da.data_ptr(), db.data_ptr(),
                                     _p(dfw), a.numel(), stream()), "mix2_bwd")

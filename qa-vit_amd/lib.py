@@ -182,6 +182,8 @@ _SIGS = {
     "qavit_gate_mix_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
     "qavit_mix2_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
     "qavit_mix2_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "qavit_mix3_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, f32, i32, vp, vp]),
+    "qavit_mix3_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, i32, vp, vp]),
     "qavit_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_chan_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),

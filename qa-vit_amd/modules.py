@@ -732,6 +732,9 @@ class RRCV(nn.Module):
         return F.ScaleAddFn.apply(A, F.layer_norm(t, self.norm.weight, self.norm.bias, self.norm.eps), self.beta, (0.0, 0, 1))
 
 
+_MIX3 = os.environ.get("QAVIT_MIX3", "1") != "0"              # 0: SplitFusion's dropout, add and blend as three launches
+
+
 class SplitFusion(nn.Module):
     """HQAViT_CIFAR100.py:913-965."""
 
@@ -766,9 +769,14 @@ class SplitFusion(nn.Module):
         h = F.linear(T2, c0.weight, c0.bias, cols=(0, Cc))
         h = F.linear(R2, c0.weight, None, cols=(Cc, Cc), resid=h)
         h = F.layer_norm(h, c1.weight, c1.bias, c1.eps, act="gelu")
-        h = F.dropout(h, self.cat_mlp[3].p, self._site, self.training)
         fn = self.final_norm
-        if isinstance(self.fusion_weights, nn.Parameter) and self.fusion_weights.numel() == 2 and (t_add.numel() * t_add.element_size()) % 16 == 0:
+        own = isinstance(self.fusion_weights, nn.Parameter) and self.fusion_weights.numel() == 2 and (t_add.numel() * t_add.element_size()) % 16 == 0
+        if own and _MIX3 and T3.dtype == h.dtype == t_add.dtype and t_add.numel() < 2 ** 32:
+            # dropout, the add and the blend in one kernel each way
+            mixed = F.Mix3Fn.apply(t_add, T3, h, self.fusion_weights, (self.cat_mlp[3].p if self.training else 0.0, self._site))
+            return F.layer_norm(mixed, fn.weight, fn.bias, fn.eps)
+        h = F.dropout(h, self.cat_mlp[3].p, self._site, self.training)
+        if own:
             mixed = F.Mix2Fn.apply(t_add, T3 + h, self.fusion_weights)
         else:
             w = torch.softmax(self.fusion_weights, 0).to(T.dtype)
