@@ -348,9 +348,11 @@ int big_modes(const qavit_gemm_args& g, hipStream_t st) {
 }  // namespace
 
 // returns 1 = launched, 0 = not applicable (caller falls back to the resident-slice kernel), < 0 error
-int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st) {
-  static long thresh = -1, force_bn = 0, wide_n = 0;
+int gemm_nt_big_try(const qavit_gemm_args& g_in, hipStream_t st) {
+  qavit_gemm_args g = g_in;
+  static long thresh = -1, force_bn = 0, wide_n = 0, stats_ncb = 3;
   if (thresh < 0) {
+    const char* e0 = getenv("QAVIT_BIG_STATS_NCB"); stats_ncb = e0 ? atol(e0) : 3;
     const char* e = getenv("QAVIT_GEMM_BIG"); thresh = e ? atol(e) : 64L * 128L;
     e = getenv("QAVIT_BIG_BN"); force_bn = e ? atol(e) : 0;
     e = getenv("QAVIT_BIG_WIDE_N"); wide_n = e ? atol(e) : 0;
@@ -373,6 +375,13 @@ int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st) {
   else bn = g.N > 192 ? 256 : (g.N > 128 ? 192 : 128);
   if (force_bn) bn = (int)force_bn;
   const int ncb = (g.N + bn - 1) / bn;
+  if (g.a_mode == 3 && stats_ncb > 0 && ncb >= stats_ncb && g.lda == g.K) {
+    // every column block of a row tile would recompute that tile's LayerNorm statistics in its prologue (two dependent passes
+    // over its A rows before the first MFMA): with several column blocks one row_stats launch in front is cheaper
+    const int rc0 = qavit_row_stats(g.dtype, g.A, g.ln_eps, g.M, g.K, g.ln_mean, g.ln_rstd, reinterpret_cast<void*>(st));
+    if (rc0) return rc0;
+    g.a_mode = 1;
+  }
   const bool bm128 = (long)((g.M + 127) / 128) * ncb >= 448;
   int rc;
   // fewer than ~1.75 workgroups per CU at 64-row tiles (rows = B*16 learned tokens): 32-row tiles put two workgroups on a
