@@ -25,6 +25,17 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _seed_per_test(request):
+    """Every test starts from the same generator state (a function of its own name), so a comparison that draws random upstream
+    gradients does not depend on which tests ran before it."""
+    import zlib
+    seed = zlib.crc32(request.node.name.encode()) & 0x7FFFFFFF
+    torch.manual_seed(seed)
+    np.random.seed(seed & 0xFFFF)
+    yield
+
+
 class _Golden:
     """golden_v1.npz (make_golden.py) + golden_v2.npz (make_golden_v2.py) behind one mapping; tags do not collide."""
 
