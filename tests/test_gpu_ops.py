@@ -1010,6 +1010,63 @@ def test_fused_cga_branch(F, Q, B, drop):
             assert rel(g1[k_], g2[k_]) <= 4e-2, (k_, rel(g1[k_], g2[k_]))
 
 
+@pytest.mark.parametrize("B", [5, 1030])
+@pytest.mark.parametrize("kind", [0, 1, 2, "cga"])
+def test_fused_branch_nan_rule(F, Q, kind, B):
+    """efficient_attention's NaN rule (HQAViT_CIFAR100.py:356-357, :394-395) inside the fused branch kernels: one NaN in the input zeroes
+    the whole attention output, so every output row is the proj bias (dropout off); the flag words are reset by the launch itself
+    (last workgroup), so the next, clean launch is untouched.  B = 1030: more workgroups than one round."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    rt = K.Runtime.get(0)
+    assert rt.nan_guard
+    T, C, S, KC = 16, 192, 16, 32
+    x = leaf(B, T, C, seed=700).detach().to(torch.bfloat16)
+    bad = x.clone()
+    bad[B // 2, 7, 11] = float("nan")
+    if kind == "cga":
+        M = importlib.import_module("qa-vit_amd.modules")
+        cfg = Q.HQAViTConfig()
+        cfg.dropout = 0.0
+        bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+        ctx = M._Ctx("hqa")
+        ctx.bank_writes = False
+        mod = M.EfficientChannelGroupAttention(cfg, bank, ctx).to(DEV).eval()
+        with torch.no_grad():
+            mod.proj.bias.copy_(leaf(C, scale=0.3, seed=701).detach())
+        assert F._CGA_FUSED
+        run = lambda inp: mod(inp).detach()
+        bias = mod.proj.bias.detach()
+    else:
+        n_qkv = C if kind == 2 else 3 * C
+        wqkv, bqkv = leaf(n_qkv, C, scale=0.08, seed=301).detach(), leaf(n_qkv, scale=0.1, seed=302).detach()
+        wproj, bproj = leaf(C, C, scale=0.08, seed=303).detach(), leaf(C, scale=0.3, seed=304).detach()
+        Ek = Ev = idx = None
+        stride, Lk = 0, 0
+        if kind != 2:
+            rows = 16 if kind == 0 else 128
+            Ek, Ev = leaf(rows, KC, scale=0.3, seed=305).detach(), leaf(rows, KC, scale=0.3, seed=306).detach()
+            Lk = 16
+        if kind == 1:
+            t = [y * 4 + xx for d in (1, 2) for y in range(0, 4, d) for xx in range(0, 4, d)]
+            stride = 2
+            t = t[: (len(t) // stride) * stride]
+            idx = torch.tensor(t, dtype=torch.int32, device=DEV)
+            Lk = len(t) // stride
+        bk, bv = leaf(S, C, scale=0.5, seed=307).detach(), leaf(S, C, scale=0.5, seed=308).detach()
+        run = lambda inp: F.branch_forward(kind, inp, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, idx, stride, Lk,
+                                           attn_drop=(0.0, 0), proj_drop=(0.0, 0))
+        bias = bproj
+    clean0 = run(x).clone()
+    assert torch.isfinite(clean0).all()
+    poisoned = run(bad)
+    torch.cuda.synchronize()
+    assert rt.nan_flag.tolist() == [0, 0]                    # reset by the launch that used it
+    assert torch.equal(poisoned.reshape(-1, C), bias.to(torch.bfloat16).expand(B * T, C))
+    clean1 = run(x)
+    assert torch.equal(clean1, clean0)
+
+
 @pytest.mark.parametrize("B", [3, 64, 1030])
 def test_fused_compress_fuse(F, Q, B):
     """CompressFuseFn through the one-launch forward (csrc/cfuse.hip: four LayerNorms, four Linear(192 -> 48), concat, softmax-weighted
