@@ -122,6 +122,16 @@ class HQAViT(_Base):
         self.apply(_init_weights)
 
     def forward(self, x):
+        # one model pass: the bank copy a branch's write leaves stays valid for the next BLOCK's first branch too (nothing but
+        # the branches writes the bank inside a forward), so only the first block takes its own snapshot
+        rt = self._rt
+        rt.in_model, rt.snap = True, None
+        try:
+            return self._forward_impl(x)
+        finally:
+            rt.in_model, rt.snap = False, None
+
+    def _forward_impl(self, x):
         self._check(x)
         cdt = self._dtype(x)
         self.patch_embed.proj.compute_dtype = cdt
@@ -238,6 +248,16 @@ class QAViT(_Base):
         self.apply(_init_weights)
 
     def forward(self, x):
+        # one model pass: the bank copy a branch's write leaves stays valid for the next BLOCK's first branch too (nothing but
+        # the branches writes the bank inside a forward), so only the first block takes its own snapshot
+        rt = self._rt
+        rt.in_model, rt.snap = True, None
+        try:
+            return self._forward_impl(x)
+        finally:
+            rt.in_model, rt.snap = False, None
+
+    def _forward_impl(self, x):
         self._check(x)
         cdt = self._dtype(x)
         self.patch_embed.proj.compute_dtype = cdt

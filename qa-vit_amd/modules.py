@@ -50,6 +50,7 @@ class _Ctx:
         # inside a QuadAttentionBlock.forward: the (k, v) copy the last bank write left beside the parameter (qavit_bank_apply snap_*),
         # i.e. what the next branch's backward must see -- saves that branch its own snapshot launch
         self.in_block = False
+        self.in_model = False          # inside a model's forward (models.py): the copy survives from one block to the next
         self.snap = None
 
 
@@ -395,11 +396,15 @@ class QuadAttentionBlock(nn.Module):
         B, N, C = x.shape
         tr = self.training
         rt = self._rt
-        rt.in_block, rt.snap = True, None
+        rt.in_block = True
+        if not rt.in_model:
+            rt.snap = None
         try:
             return self._forward(x, B, N, C, tr)
         finally:
-            rt.in_block, rt.snap = False, None
+            rt.in_block = False
+            if not rt.in_model:
+                rt.snap = None
 
     def _forward(self, x, B, N, C, tr):
         # xr = x again, for the residual: its gradient joins norm1's inside the LayerNorm-backward kernel
