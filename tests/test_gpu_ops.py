@@ -907,15 +907,23 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
         assert rel(out, out2) <= 2e-2
 
 
+def _proj_keep(seed, step, site, rows, C, p):
+    """bool [rows, C] on DEV: the proj-dropout mask of a GEMM epilogue / fused branch kernel (drop_factor(key(site), row * C + col))."""
+    from conftest import rng_key, drop_keep
+    return torch.from_numpy(drop_keep(rng_key(seed, step, site), np.arange(rows * C, dtype=np.uint64), p).reshape(rows, C)).to(DEV)
+
+
 @pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("B", [5, 64, 1030])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_fused_branch_backward(F, Q, kind, B, drop):
     """BranchFn's backward through the fused kernel (proj input gradient + attention-core backward in one launch, csrc/branch_bwd.hip)
-    against its backward through the unfused kernels: same forward launch, same dropout masks (pure functions of seed / step / site),
-    same saved projections -- the two differ only in where bf16 roundings fall.  Every gradient of the branch is compared: x, both
-    weights and biases, the Linformer matrices and the shared (bank) rows -- the latter two are sums over all images and heads."""
+    (1) against fp32 torch autograd of the reference chain (HQAViT_CIFAR100.py:441-469 / :496-532 / :613-626) on the same bf16-rounded
+    operands with the EXACT dropout masks the kernels drew (attention mask and proj mask from the host RNG replica), every gradient
+    compared directly: x, both weights and biases, the Linformer matrices, the shared (bank) rows; and (2) against its backward through
+    the unfused kernels (same forward launch, same masks, same saved projections: the two differ only in where bf16 roundings fall)."""
     import importlib
+    from conftest import attn_keep_mask
     K = importlib.import_module("qa-vit_amd.kernels")
     T, C, H, S, KC = 16, 192, 4, 16, 32
     n_qkv = C if kind == 2 else 3 * C
@@ -927,6 +935,7 @@ def test_fused_branch_backward(F, Q, kind, B, drop):
         idx = torch.tensor(t, dtype=torch.int32, device=DEV)
         Lk = len(t) // stride
     sa, sp = K.new_site(), K.new_site()
+    seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
     gout = leaf(B, T, C, seed=399).detach().to(torch.bfloat16)
     res = []
     for fused in (True, False):
@@ -963,6 +972,45 @@ def test_fused_branch_backward(F, Q, kind, B, drop):
         assert g1[k_] is not None and g2[k_] is not None, k_
         assert torch.isfinite(g1[k_]).all(), k_
         assert rel(g1[k_], g2[k_]) <= 3e-2, (k_, rel(g1[k_], g2[k_]))
+    # ---- (1) fp32 torch autograd of the reference chain, exact masks ----
+    NK = S if kind == 2 else KC + S
+    keep = torch.from_numpy(attn_keep_mask(seed, step, sa, B, H, T, NK, drop)).to(DEV) if drop > 0 else None
+    r = dict(x=leaf(B, T, C, seed=300).detach().to(torch.bfloat16).float(),
+             wqkv=leaf(n_qkv, C, scale=0.08, seed=301).detach().to(torch.bfloat16).float(), bqkv=leaf(n_qkv, scale=0.1, seed=302).detach(),
+             wproj=leaf(C, C, scale=0.08, seed=303).detach().to(torch.bfloat16).float(), bproj=leaf(C, scale=0.1, seed=304).detach(),
+             bk=leaf(1, S, C, scale=0.5, seed=307).detach(), bv=leaf(1, S, C, scale=0.5, seed=308).detach())
+    if kind != 2:
+        rows = 16 if kind == 0 else 128
+        r.update(Ek=leaf(rows, KC, scale=0.3, seed=305).detach(), Ev=leaf(rows, KC, scale=0.3, seed=306).detach())
+    for v in r.values():
+        v.requires_grad_(True)
+    ref, _ = _branch_reference(kind, r["x"], r["wqkv"], r["bqkv"], r["wproj"], r["bproj"], r.get("Ek"), r.get("Ev"), r["bk"], r["bv"], idx, stride, keep, drop)
+    if drop > 0:
+        ref = ref * _proj_keep(seed, step, sp, B * T, C, drop).reshape(B, T, C).float() / (1.0 - drop)
+    assert rel(o1, ref) <= 3e-2
+    ref.backward(gout.float())
+    for k_ in g1:
+        assert rel(g1[k_], r[k_].grad) <= 4e-2, (k_, rel(g1[k_], r[k_].grad))
+
+
+def _cga_reference(x, P, G, H, keep, p_attn):
+    """EfficientChannelGroupAttention.forward (HQAViT_CIFAR100.py:559-590, up to ``proj``) as fp32 torch on a name -> tensor dict."""
+    B, N, C = x.shape
+    cpg = C // G
+    xf = x.view(B, N, G, cpg).permute(0, 2, 1, 3).reshape(B * G, N, cpg)
+    q = TF.linear(xf, P["q_proj.weight"], P["q_proj.bias"])
+    k = TF.linear(xf, P["k_proj.weight"], P["k_proj.bias"])
+    v = TF.linear(xf, P["v_proj.weight"], P["v_proj.bias"])
+    ccg = q.shape[-1]
+    d = ccg // H
+    q, k, v = [t.reshape(B * G, N, H, d).transpose(1, 2) for t in (q, k, v)]
+    kb = TF.linear(P["bank.global_k"].expand(B, -1, -1), P["bank_k_proj.weight"], P["bank_k_proj.bias"]).unsqueeze(1).expand(-1, G, -1, -1)
+    vb = TF.linear(P["bank.global_v"].expand(B, -1, -1), P["bank_v_proj.weight"], P["bank_v_proj.bias"]).unsqueeze(1).expand(-1, G, -1, -1)
+    kb = kb.reshape(B * G, -1, H, d).transpose(1, 2)
+    vb = vb.reshape(B * G, -1, H, d).transpose(1, 2)
+    o = _ref_attn(q, torch.cat([k, kb], 2), torch.cat([v, vb], 2), keep, p_attn)
+    o = o.transpose(1, 2).reshape(B * G, N, -1).view(B, G, N, -1).permute(0, 2, 1, 3).reshape(B, N, G * ccg)
+    return TF.linear(o, P["proj.weight"], P["proj.bias"])
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.1])
@@ -1008,6 +1056,36 @@ def test_fused_cga_branch(F, Q, B, drop):
         for k_ in g1:
             assert torch.isfinite(g1[k_]).all(), k_
             assert rel(g1[k_], g2[k_]) <= 4e-2, (k_, rel(g1[k_], g2[k_]))
+    # ---- fp32 torch autograd of the reference module (HQAViT_CIFAR100.py:559-595) on the bf16-rounded operands, exact masks ----
+    from conftest import attn_keep_mask
+    seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
+    T, C, G, H, S = 16, cfg.embed_dim, cfg.num_channel_groups, cfg.num_heads, cfg.global_bank_size
+    keep = torch.from_numpy(attn_keep_mask(seed, step, 9002, B * G, H, T, T + S, drop)).to(DEV) if drop > 0 else None
+    keep_p = _proj_keep(seed, step, 9001, B * T, C, drop).reshape(B, T, C).float() if drop > 0 else None
+    torch.manual_seed(1)
+    bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+    rt = M._Ctx("hqa")
+    mod = M.EfficientChannelGroupAttention(cfg, bank, rt).to(DEV)
+    P = {n: p.detach().clone() for n, p in mod.named_parameters() if not n.startswith("global_bank.")}
+    P.update({"bank." + n: p.detach().clone() for n, p in bank.named_parameters()})
+    for n in ("q_proj.weight", "k_proj.weight", "v_proj.weight", "proj.weight"):     # the kernels read bf16 copies of these
+        P[n] = P[n].to(torch.bfloat16).float()
+    for v in P.values():
+        v.requires_grad_(True)
+    xr = x0.float().requires_grad_(True)
+    ref = _cga_reference(xr, P, G, H, keep, drop)
+    if drop > 0:
+        ref = ref * keep_p / (1.0 - drop)
+    ref.backward(g0.float())
+    for (o1, dx1, g1) in res[:2]:
+        assert rel(o1, ref) <= 3e-2
+        assert rel(dx1, xr.grad) <= 4e-2, rel(dx1, xr.grad)
+        for k_ in g1:
+            if k_ in P and P[k_].grad is not None:
+                assert rel(g1[k_], P[k_].grad) <= 4e-2, (k_, rel(g1[k_], P[k_].grad))
+        for k_ in ("q_proj.weight", "k_proj.weight", "v_proj.weight", "proj.weight", "proj.bias", "bank_k_proj.weight", "bank_v_proj.weight",
+                   "bank.global_k", "bank.global_v"):
+            assert k_ in g1, k_
 
 
 @pytest.mark.parametrize("B", [5, 1030])
@@ -1101,11 +1179,24 @@ def test_fused_compress_fuse(F, Q, B):
             ref = torch.cat([TF.linear(TF.layer_norm(xs[i].detach().float(), (C,), gs[i].detach(), bs[i].detach()).to(torch.bfloat16).float(),
                                        Ws[i].detach().to(torch.bfloat16).float(), bi[i].detach()) * w[i] for i in range(nb)], -1)
             assert rel(y, ref) <= 3e-2
+            # ... and fp32 torch autograd of HybridFusion(concat_i compress_i(norm_i(.))) (HQAViT_CIFAR100.py:1075-1081) for EVERY gradient
+            xr = [x.detach().float().requires_grad_(True) for x in xs]
+            pr = [t.detach().clone().requires_grad_(True) for t in gs + bs] + [t.detach().to(torch.bfloat16).float().requires_grad_(True) for t in Ws] + \
+                 [t.detach().clone().requires_grad_(True) for t in bi + [fw]]
+            gr, br_, Wr, bir, fwr = pr[:nb], pr[nb:2 * nb], pr[2 * nb:3 * nb], pr[3 * nb:4 * nb], pr[4 * nb]
+            wr_ = torch.softmax(fwr, 0)
+            ref2 = torch.cat([TF.linear(TF.layer_norm(xr[i], (C,), gr[i], br_[i]), Wr[i], bir[i]) * wr_[i] for i in range(nb)], -1)
+            ref2.backward(go.float())
+            ref_grads = ([t.grad for t in xr], [t.grad for t in pr])
     y2, dx2, g2 = outs[2]
     for (y1, dx1, g1) in outs[:2]:
         assert rel(y1, y2) <= 1e-2
         for a_, b_ in zip(dx1 + g1, dx2 + g2):
             assert rel(a_, b_) <= 3e-2
+    names = [f"x{i}" for i in range(nb)] + [f"{n}{i}" for n in ("gamma", "beta", "W", "bias") for i in range(nb)] + ["fusion_weights"]
+    for (y1, dx1, g1) in outs:                               # all three paths against fp32 torch autograd
+        for nm, a_, b_ in zip(names, dx1 + g1, ref_grads[0] + ref_grads[1]):
+            assert rel(a_, b_) <= 4e-2, (nm, rel(a_, b_))
 
 
 def test_partial_row_reduce(F, Q):
