@@ -60,24 +60,57 @@ def _lin(P: Dict[str, Tensor], pre: str, x: Tensor) -> Tensor:
     return F.linear(x, P[pre + ".weight"], P.get(pre + ".bias"))
 
 
-def _drop(x: Tensor, p: float, train: bool) -> Tensor:
-    return F.dropout(x, p, train) if (train and p > 0.0) else x
+# Optional mask injection (tests only): ``set_masks(fn)`` installs ``fn(name, kind, shape, p) -> bool keep tensor or None``; every
+# stochastic site below then multiplies by keep / (1 - p) -- the documented math of nn.Dropout, drop_path (:256-263) and SDPA's
+# ``dropout_p`` -- with the caller's mask instead of torch's RNG.  ``name`` = the module path of the site's owner + a suffix
+# (".proj" / ".attn" / ".dp1" ...), ``kind`` in {"drop", "path", "attn"}.  With no provider installed nothing changes.
+_MASKS = None
 
 
-def _drop_path(x: Tensor, p: float, train: bool) -> Tensor:
+def set_masks(fn) -> None:
+    global _MASKS
+    _MASKS = fn
+
+
+def _given(name: Optional[str], kind: str, shape, p: float):
+    if _MASKS is None or name is None:
+        return None
+    m = _MASKS(name, kind, tuple(shape), p)
+    return None if m is None else torch.as_tensor(m)
+
+
+def _drop(x: Tensor, p: float, train: bool, name: Optional[str] = None) -> Tensor:
+    if not (train and p > 0.0):
+        return x
+    keep = _given(name, "drop", x.shape, p)
+    if keep is not None:
+        return x * keep.reshape(x.shape).to(x.dtype) / (1.0 - p)
+    return F.dropout(x, p, train)
+
+
+def _drop_path(x: Tensor, p: float, train: bool, name: Optional[str] = None) -> Tensor:
     """HQAViT_CIFAR100.py:256-263 -- per-sample Bernoulli keep, scaled by 1/keep."""
     if p == 0.0 or not train:
         return x
     keep = 1.0 - p
-    mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype)).floor_()
+    given = _given(name, "path", (x.shape[0],), p)
+    if given is not None:
+        mask = given.reshape((x.shape[0],) + (1,) * (x.ndim - 1)).to(x.dtype)
+    else:
+        mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype)).floor_()
     return x.div(keep) * mask
 
 
-def _sdpa(q: Tensor, k: Tensor, v: Tensor, p: float, train: bool) -> Tensor:
+def _sdpa(q: Tensor, k: Tensor, v: Tensor, p: float, train: bool, name: Optional[str] = None) -> Tensor:
     """efficient_attention, HQAViT_CIFAR100.py:355-397: NaN in -> zeros, SDPA, NaN out -> zeros."""
     if torch.isnan(q).any() or torch.isnan(k).any() or torch.isnan(v).any():
         return torch.zeros_like(q)
-    o = F.scaled_dot_product_attention(q, k, v, dropout_p=p if train else 0.0)
+    keep = _given(name, "attn", (q.shape[0], q.shape[1], q.shape[2], k.shape[2]), p) if (train and p > 0.0) else None
+    if keep is not None:            # softmax(QK^T / sqrt(D)) * keep / (1 - p) @ V: scaled_dot_product_attention's dropout_p branch
+        pr = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(q.shape[-1]), -1)
+        o = (pr * keep.to(pr.dtype) / (1.0 - p)) @ v
+    else:
+        o = F.scaled_dot_product_attention(q, k, v, dropout_p=p if train else 0.0)
     if torch.isnan(o).any():
         return torch.zeros_like(o)
     return o
@@ -162,9 +195,9 @@ def swa(P, pre: str, x: Tensor, cfg, var: Variant, train: bool, sync=None) -> Te
     q, k, v = qkv[0], qkv[1], qkv[2]
     kc, vc = _linformer(P, pre + ".linformer", k, v)
     bk, bv = _bank_heads(P, BW, heads)
-    o = _sdpa(q, torch.cat([kc, bk], 2), torch.cat([vc, bv], 2), cfg.dropout, train)
+    o = _sdpa(q, torch.cat([kc, bk], 2), torch.cat([vc, bv], 2), cfg.dropout, train, pre + ".attn")
     o = o.transpose(1, 2).reshape(BW, NW, C)
-    o = _drop(_lin(P, pre + ".proj", o), cfg.dropout, train)
+    o = _drop(_lin(P, pre + ".proj", o), cfg.dropout, train, pre + ".proj")
     # window_reverse is called with the UNPADDED H, W (:466); identical when no padding happened
     o = o.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H * W, C)
     bank_write(P, _ln(P, pre + ".norm", o), var, train, sync)
@@ -186,9 +219,9 @@ def msda(P, pre: str, x: Tensor, cfg, var: Variant, train: bool, sync=None) -> T
     kc, vc = _linformer(P, pre + ".linformer", kv[1], kv[2])                   # pad/trunc to 128 inside
     bk, bv = _bank_heads(P, B, heads)
     q = _lin(P, pre + ".qkv", x).reshape(B, N, 3, heads, D)[:, :, 0].permute(0, 2, 1, 3)   # :523
-    o = _sdpa(q, torch.cat([kc, bk], 2), torch.cat([vc, bv], 2), cfg.dropout, train)
+    o = _sdpa(q, torch.cat([kc, bk], 2), torch.cat([vc, bv], 2), cfg.dropout, train, pre + ".attn")
     o = o.transpose(1, 2).reshape(B, N, C)
-    o = _drop(_lin(P, pre + ".proj", o), cfg.dropout, train)
+    o = _drop(_lin(P, pre + ".proj", o), cfg.dropout, train, pre + ".proj")
     bank_write(P, _ln(P, pre + ".norm", o), var, train, sync)
     return o
 
@@ -211,9 +244,9 @@ def cga(P, pre: str, x: Tensor, cfg, var: Variant, train: bool, sync=None) -> Te
     # stride-0 view copies, so the saved input holds the forward-time bank, not the later in-place writes.
     bk = _lin(P, pre + ".bank_k_proj", gk.expand(B, -1, -1)).unsqueeze(1).expand(-1, G, -1, -1).reshape(B * G, S, heads, dh).transpose(1, 2)
     bv = _lin(P, pre + ".bank_v_proj", gv.expand(B, -1, -1)).unsqueeze(1).expand(-1, G, -1, -1).reshape(B * G, S, heads, dh).transpose(1, 2)
-    o = _sdpa(q, torch.cat([k, bk], 2), torch.cat([v, bv], 2), cfg.dropout, train)
+    o = _sdpa(q, torch.cat([k, bk], 2), torch.cat([v, bv], 2), cfg.dropout, train, pre + ".attn")
     o = o.transpose(1, 2).reshape(B, G, N, ccg).permute(0, 2, 1, 3).reshape(B, N, cc)
-    o = _drop(_lin(P, pre + ".proj", o), cfg.dropout, train)
+    o = _drop(_lin(P, pre + ".proj", o), cfg.dropout, train, pre + ".proj")
     bank_write(P, _ln(P, pre + ".norm", o), var, train, sync)
     return o
 
@@ -229,9 +262,9 @@ def cross(P, pre: str, x: Tensor, cfg, train: bool) -> Tensor:
     # projected AFTER expansion, as the reference does (:617-619) -- see the note in cga()
     k = _lin(P, pre + ".k_proj", gk.expand(B, -1, -1)).reshape(B, S, heads, D).transpose(1, 2)
     v = _lin(P, pre + ".v_proj", gv.expand(B, -1, -1)).reshape(B, S, heads, D).transpose(1, 2)
-    o = _sdpa(q, k, v, cfg.dropout, train)
+    o = _sdpa(q, k, v, cfg.dropout, train, pre + ".attn")
     o = o.transpose(1, 2).reshape(B, N, C)
-    return _drop(_lin(P, pre + ".proj", o), cfg.dropout, train)
+    return _drop(_lin(P, pre + ".proj", o), cfg.dropout, train, pre + ".proj")
 
 
 # --------------------------------------------------------------------------------------------------
@@ -253,7 +286,7 @@ def ccf_ffn(P, pre: str, x: Tensor, cfg, var: Variant, train: bool) -> Tensor:
     h = img.flatten(2).transpose(1, 2)
     if var.ccf_norm:
         h = _ln(P, pre + ".post_dwconv_norm", h)
-    h = _drop(_lin(P, pre + ".fc2", h), cfg.dropout, train)
+    h = _drop(_lin(P, pre + ".fc2", h), cfg.dropout, train, pre + ".fc2")
     if var.ccf_norm:
         h = h * P[pre + ".gamma"]
     return h
@@ -275,10 +308,10 @@ def quad_block(P, pre: str, x: Tensor, cfg, var: Variant, train: bool, dp: float
         outs.append(_lin(P, f"{pre}.compress_{name}", _ln(P, f"{pre}.norm_{name}", t)))
     fw = F.softmax(P[pre + ".fusion.fusion_weights"], dim=0)                   # HybridFusion :637-640
     fused = torch.cat([o * fw[i] for i, o in enumerate(outs)], -1)
-    h = _drop(F.gelu(_lin(P, pre + ".bottleneck_mlp.fc1", fused)), cfg.dropout, train)   # :651-656
-    h = _drop(_lin(P, pre + ".bottleneck_mlp.fc2", h), cfg.dropout, train)
-    x = x + _drop_path(h, dp, train)
-    x = x + _drop_path(ccf_ffn(P, pre + ".ccf_ffn", _ln(P, pre + ".norm2", x), cfg, var, train), dp, train)
+    h = _drop(F.gelu(_lin(P, pre + ".bottleneck_mlp.fc1", fused)), cfg.dropout, train, pre + ".bottleneck_mlp.fc1")   # :651-656
+    h = _drop(_lin(P, pre + ".bottleneck_mlp.fc2", h), cfg.dropout, train, pre + ".bottleneck_mlp.fc2")
+    x = x + _drop_path(h, dp, train, pre + ".dp1")
+    x = x + _drop_path(ccf_ffn(P, pre + ".ccf_ffn", _ln(P, pre + ".norm2", x), cfg, var, train), dp, train, pre + ".dp2")
     return x
 
 
@@ -395,7 +428,7 @@ def split_fusion(P, pre: str, T: Tensor, R: Tensor, train: bool) -> Tensor:
     gate = torch.sigmoid(_lin(P, pre + ".gate_fc", _ln(P, pre + ".gate_norm", T + R)))
     t_add = T + gate * R
     h = F.gelu(_ln(P, pre + ".cat_mlp.1", _lin(P, pre + ".cat_mlp.0", torch.cat([T, R], -1))))
-    t_cat = T + _drop(h, 0.1 if train else 0.0, train)
+    t_cat = T + _drop(h, 0.1 if train else 0.0, train, pre + ".cat_mlp")
     w = F.softmax(P[pre + ".fusion_weights"], dim=0)
     return _ln(P, pre + ".final_norm", w[0] * t_add + w[1] * t_cat)
 
@@ -424,7 +457,7 @@ def hqavit_forward(P, x: Tensor, cfg, train: bool = False, variant: str = "hqa",
     for i, f in ((2, f2), (3, f3), (4, f4)):
         R[i] = rrcv(P, f"rrcv{i}", lmfa(P, f"lmfa{i}", f, Hh), Hh, Hh)
     T = patch_embed(P, x, cfg) + P["pos_embed"]
-    T = _drop(T, cfg.dropout, train)
+    T = _drop(T, cfg.dropout, train, "pos_drop")
     if taps is not None:
         taps["embed"] = T
     dpr = torch.linspace(0, cfg.drop_path, cfg.depth).tolist()
@@ -448,7 +481,7 @@ def qavit_forward(P, x: Tensor, cfg, train: bool = False, variant: str = "v1", t
     """QAViT.forward, QAViT.py:689-699 / QAViTv2.py:1045-1055."""
     var = VARIANTS[variant]
     T = patch_embed(P, x, cfg) + P["pos_embed"]
-    T = _drop(T, cfg.dropout, train)
+    T = _drop(T, cfg.dropout, train, "pos_drop")
     dpr = torch.linspace(0, cfg.drop_path, cfg.depth).tolist()
     for i in range(cfg.depth):
         T = quad_block(P, f"blocks.{i}", T, cfg, var, train, dpr[i], taps, sync)

@@ -194,6 +194,136 @@ def test_large_batch_step_vs_oracle_and_bf16(Q, oracle):
     assert not bad, bad[:8]
 
 
+class HipMasks:
+    """Mask provider for oracle.set_masks(): the EXACT keep masks the HIP model draws at every stochastic site, from the host replica
+    of the device counter RNG (conftest.rng_key / drop_keep / attn_keep_mask) and the model's own site ids.  Index contracts:
+    dropout = flat element index of the [rows, C] matrix; drop-path = sample index; attention = (problem = group * H + head,
+    (query << 16) | key).  SWA's proj dropout is drawn on token-ordered rows here and on window-ordered rows in the reference."""
+
+    def __init__(self, model, seed, step):
+        self.m, self.seed, self.step = model, seed, step
+        self.used = []
+
+    def __call__(self, name, kind, shape, p):
+        from conftest import attn_keep_mask, drop_keep, rng_key
+        m = self.m
+        self.used.append((name, kind))
+        if kind == "attn":
+            site = m.get_submodule(name[:-5])._site_attn
+            G, H, Nq, NK = shape
+            return torch.from_numpy(attn_keep_mask(self.seed, self.step, site, G, H, Nq, NK, p))
+        if kind == "path":
+            blk = m.get_submodule(name[:-4])
+            site = blk._dp1 if name.endswith(".dp1") else blk._dp2
+            return torch.from_numpy(drop_keep(rng_key(self.seed, self.step, site), np.arange(shape[0], dtype=np.uint64), p))
+        if name == "pos_drop":
+            site = m._pos_site
+        elif name.endswith(".cat_mlp"):
+            site = m.get_submodule(name[:-8])._site
+        elif name.endswith(".bottleneck_mlp.fc1"):
+            site = m.get_submodule(name[:-4])._s1
+        elif name.endswith(".bottleneck_mlp.fc2"):
+            site = m.get_submodule(name[:-4])._s2
+        elif name.endswith(".ccf_ffn.fc2"):
+            site = m.get_submodule(name[:-4])._site
+        else:
+            assert name.endswith(".proj"), name
+            site = m.get_submodule(name[:-5])._site
+        n = int(np.prod(shape))
+        keep = torch.from_numpy(drop_keep(rng_key(self.seed, self.step, site), np.arange(n, dtype=np.uint64), p))
+        if name.endswith(".swa.proj") and len(shape) == 3:
+            BW, NW, C = shape
+            ws = int(round(NW ** 0.5))
+            N = getattr(self, "tokens", NW)
+            if N != NW:                                     # token-ordered [B, N, C] -> the reference's window-ordered rows
+                B, Hs = BW * NW // N, int(round(N ** 0.5))
+                keep = keep.reshape(B, Hs // ws, ws, Hs // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(BW, NW, C)
+        return keep.reshape(shape)
+
+
+def test_train_step_with_dropout_vs_oracle(Q, oracle):
+    """The benchmarked numerics at model level: HQA-ViT CIFAR-100 at the reference's default dropout = 0.1 / drop_path = 0.1 (proj, MLP,
+    SDPA-probability, cat_mlp and pos dropouts, per-sample drop path).  fp32 step against the CPU oracle with the masks of every site
+    injected from the host RNG replica (logits, loss, bank, every parameter gradient), then the bf16 kernels against the fp32 ones on
+    the same step with the same masks."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    cfg = Q.HQAViTConfig()
+    assert cfg.dropout == 0.1 and cfg.drop_path == 0.1
+    model = Q.HQAViT(cfg)
+    Q.fill_module(model)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    P = {k: v.clone() for k, v in sd.items()}
+    for k in list(P):
+        if k.endswith(("global_bank.global_k", "global_bank.global_v", "global_bank.update_count")):
+            P[k] = P["global_bank." + k.rsplit(".", 1)[-1]]
+    names = [n for n, _ in model.named_parameters()]
+    for n in names:
+        P[n].requires_grad_(True)
+    g = torch.Generator().manual_seed(21)
+    B = 24
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, 100, (B,), generator=g)
+    seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
+
+    mdl = Q.HQAViT(cfg).cuda().train()       # ONE module for both precisions: dropout sites are per-module ids handed out at construction
+
+    def run(dtype):
+        m = mdl
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            out = m(x.cuda())
+        loss = torch.nn.functional.cross_entropy(out.float(), y.cuda(), label_smoothing=0.12)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert [int(v) for v in K.Runtime.get(0).rng.tolist()] == [seed, step]
+        return m, out.detach().float().cpu(), float(loss.detach()), {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}
+
+    m32, out32, loss32, g32 = run(torch.float32)
+    bank_k32 = m32.global_bank.global_k.detach().cpu().numpy().copy()
+    prov = HipMasks(m32, seed, step)
+    oracle.set_masks(prov)
+    try:
+        torch.set_num_threads(16)
+        ref = oracle.hqavit_forward(P, x, cfg, train=True)
+        ref_loss = oracle.loss_fn(ref, y, 0.12)
+        ref_loss.backward()
+    finally:
+        oracle.set_masks(None)
+    kinds = {k for _, k in prov.used}
+    assert kinds == {"attn", "drop", "path"} and len(prov.used) >= 8 * 11 + 3, (kinds, len(prov.used))
+    assert max_rel(out32.numpy(), ref.detach().numpy()) <= LOGIT_TOL
+    assert abs(loss32 - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach()))
+    assert max_rel(bank_k32, P["global_bank.global_k"].detach().numpy()) <= 1e-4
+    scale = max(float(P[n].grad.norm()) for n in names if P[n].grad is not None)
+    worst = []
+    for n in names:
+        if P[n].grad is None or zero_by_construction(n):
+            continue
+        r = P[n].grad
+        if float(r.norm()) < 1e-6 * scale:
+            continue
+        worst.append((float((g32[n] - r).norm() / r.norm()), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= GRAD_TOL * 2, worst[:5]
+    # the bf16 kernels (what bench.py runs) on the same step: same masks (pure functions of seed / step / site / element)
+    _, out16, loss16, g16 = run(torch.bfloat16)
+    assert abs(loss16 - loss32) <= 2e-2 * abs(loss32)
+    assert max_rel(out16.numpy(), out32.numpy()) <= 0.1
+    bad = []
+    for n in names:
+        if n not in g32 or n not in g16 or zero_by_construction(n) or float(g32[n].norm()) < 1e-4 * scale:
+            continue
+        a, b = g16[n].reshape(-1), g32[n].reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm() / b.norm())
+        lo, hi = (0.4, 2.5) if a.numel() <= 2 else (0.9, 1.1)
+        if cos < 0.97 or not (lo <= ratio <= hi):
+            bad.append((n, round(cos, 4), round(ratio, 4)))
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("variant", ["v1", "v2"])
 def test_qavit_224_vs_oracle(Q, oracle, variant):
     """QA-ViT at its own default size (224 px, patch 16: N=196, 7x7 windows, 135 MSDA landmarks of which 128 are keys):
