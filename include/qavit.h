@@ -205,14 +205,19 @@ int64_t qavit_attn_ws_floats(const qavit_attn_args* a);
 int qavit_nan_guard(int dtype, void* x, int64_t n, int* flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * Fused attention BRANCH for 16-token problems (every HQA-ViT CIFAR block works on 16 learned tokens): ONE launch for
+ * Fused attention BRANCH for 16-token problems (every HQA-ViT CIFAR block works on 16 learned tokens) and 64-token problems
+ * (HQAViT_IN_Tiny.py's 64 learned tokens, QAViT.py at 32 px: an 8x8 token grid): ONE launch for
  *   out = dropout( proj( efficient_attention( q, K_full, V_full, dropout_p ) ) )
  * with q / k / v computed in the kernel from the branch input x (= norm1's output):
  *   kind 0, SWA   (HQAViT_CIFAR100.py:441-469): qkv(x) on the one 4x4 window; K_full = [E_k^T k ; bank_k], V likewise
  *   kind 1, MSDA  (:496-532): q = qkv(x)[:, :C]; k, v = qkv(pooled)[:, C:], pooled[j] = mean_s x[idx[j*stride+s]], j < L;
  *                 K_full = [E_k[:L]^T k ; bank_k]   (the reference's zero padding to 128 rows is algebraic)
  *   kind 2, cross (:613-626): q = q_proj(x); K_full = sh_k, V_full = sh_v (k_proj / v_proj of the bank, computed by the caller)
- * Shapes are fixed: T = 16 tokens, C = 192, H = 4 heads of D = 48, S = 16 shared rows, KC = 32 Linformer rows; bf16 only.
+ * Shapes are fixed: T = 16 or 64 tokens, C = 192, H = 4 heads of D = 48, S = 16 shared rows, KC = 32 Linformer rows; bf16 only.
+ * T = 64: SWA = the four 4x4 windows of the 8x8 grid (window_partition with window 4, HQAViT_IN_Tiny.py:756-800: L = 16, rows gathered
+ * in the kernel, q / k / v / O saved at their token rows); MSDA = 64 queries against ONE key side per image from L <= 48 landmarks
+ * (kv_save / pooled_save hold L rows per image); cross = 64 queries against the 16 projected bank rows.  Dropout problems:
+ * SWA (image * 4 + window) * H + head with query 0..15, MSDA / cross image * H + head with query 0..63 -- as the unfused kernels.
  * Weights come in MFMA FRAGMENT order (qavit_pack_desc.pad = 1): wqkv_frag = packed [3C, C] (kind 2: [C, C]), wproj_frag =
  * packed [C, C].  Dropout masks follow the unfused kernels' contracts exactly (attention: attn_shared.h attn_drop_factor
  * with problem id = image * H + head; proj: the qavit_gemm_nt epilogue's drop_factor(key(site), row * C + col)), so a
@@ -240,6 +245,9 @@ typedef struct qavit_branch_args {
    * column C of kv_save [B*rows, ldkv_save], rows = T per image (SWA; kv_save = q_save + C elements gives the usual [B*T, 3C]
    * qkv matrix) or L landmark rows per image (MSDA); pooled_save [B*L, C] = MSDA's pooled landmarks.  kind 2 saves q only. */
   void* q_save; int64_t ldq_save; void* kv_save; int64_t ldkv_save; void* pooled_save;
+  /* optional (needs nan_flag): one int written by the NaN-rule launch of this call, 1 = the rule was applied (then o_save is zeroed
+   * too), 0 = not; hand it to qavit_branch_bwd, whose gradient through a tripped branch is exactly zero as the reference's is */
+  int* nan_trip;
 } qavit_branch_args;
 
 int qavit_branch_supported(int kind, int T, int C, int H, int D, int KC, int S, int L);   /* 1 if qavit_branch_fwd covers the shape */
@@ -304,7 +312,7 @@ int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream);
 /* ---------------------------------------------------------------------------------------------------
  * Fused branch BACKWARD, first half (csrc/branch_bwd.hip): the proj input-gradient GEMM and the attention-core backward of a
  * branch that went forward through qavit_branch_fwd with q_save / kv_save / o_save, in one launch (it replaces qavit_gemm_nt on
- * Wproj^T, qavit_attn_bwd and its reduction).  Same fixed shapes as qavit_branch_args; bf16 only.
+ * Wproj^T, qavit_attn_bwd and its reduction).  Same fixed shapes as qavit_branch_args (T = 16 or 64); bf16 only.
  *   in : dout [B*T, C] (gradient of the branch output), wprojT_frag = the proj weight TRANSPOSED in fragment order
  *        (qavit_pack_desc.pad = 3), q / k_tok / v_tok / o as saved by the forward (k_tok, v_tok: kv_rows rows per image, NULL for
  *        kind 2), E_k / E_v / sh_k / sh_v with their FORWARD-TIME values, the two dropout (p, site) pairs and rng of the forward.
@@ -315,6 +323,7 @@ int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream);
  *        qavit_ln_param_reduce, stride = parts_stride).  Kind 2 leaves the dE part unwritten.
  * ------------------------------------------------------------------------------------------------- */
 #define QAVIT_BRANCH_PARTS_FLOATS 7168
+#define QAVIT_BRANCH_PARTS_FLOATS_64 9216   /* T = 64: [ dE_k 48x32 | dE_v 48x32 | d sh_k 16x192 | d sh_v 16x192 ] (SWA uses the first 16 rows of the dE slots) */
 typedef struct qavit_branch_bwd_args {
   int dtype; int kind;
   int B, T, C, H, D, KC, S, L;
@@ -329,8 +338,10 @@ typedef struct qavit_branch_bwd_args {
   void* dq; int64_t lddq;
   void* dk_tok; void* dv_tok; int64_t lddkv;
   float* parts; int64_t parts_stride;
+  const int* nan_trip;   /* optional: the word qavit_branch_fwd's NaN-rule launch wrote (qavit_branch_args.nan_trip); != 0: the forward returned
+                          * proj(0), so dq = dk = dv = 0 and every partial sum is 0 (HQAViT_CIFAR100.py:356-357, :394-395); dz is still written */
 } qavit_branch_bwd_args;
-int qavit_branch_bwd_parts(int B);
+int qavit_branch_bwd_parts(int B, int T);   /* workgroups = rows of `parts`: ceil(B / 4) for T = 16, B for T = 64 */
 int qavit_branch_bwd(const qavit_branch_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -354,6 +365,7 @@ typedef struct qavit_cga_args {
   void* o_save;
   float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
   int* nan_flag;
+  int* nan_trip;   /* optional, as in qavit_branch_args: 1 / 0 written by the NaN-rule launch; a tripped call also zeroes o_save */
 } qavit_cga_args;
 int qavit_cga_supported(int T, int C, int G, int H, int S);
 int qavit_cga_fwd(const qavit_cga_args* a, void* stream);
@@ -377,6 +389,7 @@ typedef struct qavit_cga_bwd_args {
   void* dqkv;
   void* dx; int64_t lddx;
   float* parts;
+  const int* nan_trip;   /* optional: the forward's nan_trip word; != 0: dqkv = dx = 0 and zero partial sums (dz is still written) */
 } qavit_cga_bwd_args;
 int qavit_cga_bwd_parts(int B);
 int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream);

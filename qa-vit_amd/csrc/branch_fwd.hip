@@ -1,4 +1,5 @@
-// Fused attention BRANCH, forward, for the 16-learned-token problems of the CIFAR configuration (every HQA-ViT C100 block):
+// Fused attention BRANCH, forward, for the 16-learned-token problems of the CIFAR configuration (every HQA-ViT C100 block) and the
+// 64-token problems of Tiny-ImageNet's 64 learned tokens / QA-ViT at 32 px (TT = 64, see "64 TOKENS" below):
 //   out = dropout( proj( SDPA( q(x), [Linformer(k(x'), v(x')) ; bank rows], dropout_p ) ) )
 // in ONE launch -- the chain HQAViT_CIFAR100.py:441-469 (SWA: one 4x4 window = the 16 tokens), :496-532 (MSDA: keys from
 // the pooled dilated landmarks x'), :613-626 (cross: keys = projections of the bank) runs as  qkv GEMM -> Linformer ->
@@ -29,6 +30,17 @@
 //   Vf    = E_v^T v                            acc = Vf[4 consecutive keys][d = lane%16]          -> A operand of O^T
 //   O^T   = Vf^T P^T (+ bank rows from LDS)    acc = O[query = lane%16][4 consecutive d]          -> 8-byte segments of the O tile
 //   out   = (W_p O^T)^T    "transposed" GEMM on the O tile read back as 16x16x32 operands         -> 8-byte row segments
+//
+// 64 TOKENS (TT = 64; HQAViT_IN_Tiny.py:771-800, :826-862, :943-959, QAViT.py:588-636).  The 64-row tile is ONE image instead of four.
+//   SWA:   the image's four 4x4 windows ARE four independent 16-token problems (window_partition with window 4 on the 8x8 grid):
+//          the same kernel with the tile's rows gathered through the window map (sub_token) -- keys of a window = its own 16 tokens.
+//   cross: keys are the bank projections only, so the four 16-query tiles of the image are independent problems as well.
+//   MSDA:  the key side is ONE per (image, head): up to 48 landmarks pooled over all 64 tokens (40 for dilations (1, 2), stride 2),
+//          k / v of the landmark tiles, K_f = E_k^T k and V_f = E_v^T v contracted over the landmark tiles.  Both waves of a head
+//          compute it (3 landmark tiles instead of 2 images per weight fragment: +18 MFMAs per wave and part) and each runs the
+//          attention cores of its two query tiles against it.
+// The dropout masks keep the unfused kernels' contracts: problem id = (image * windows + window) * H + head for SWA, image * H + head
+// with query index 0..63 otherwise.
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
@@ -44,10 +56,15 @@ namespace {
 // the plain GEMM in operand layout (4 tokens of one column per lane -- 2-byte scattered stores); with SAVE the same weight and
 // token fragments run a second, transposed MFMA whose accumulator quads are 8-byte row segments: +72 MFMAs per wave (no extra
 // LDS reads) instead of a recompute GEMM launch per branch in backward.
-template <int KIND, bool SAVE>
+template <int KIND, bool SAVE, int TT>
 __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   constexpr bool MODE0 = (KIND != 2);                      // Linformer + bank keys (SWA / MSDA) vs bank-projection keys only (cross)
+  constexpr bool WIN = (KIND == 0);                        // TT = 64: the tile's sub-images are the 4x4 windows
+  constexpr bool KSH = (TT == 64 && KIND == 1);            // ONE key side per image (MSDA on 64 tokens), shared by the wave's two query tiles
+  constexpr int LT = KSH ? 3 : 1;                          // 16-row landmark tiles feeding the Linformer product
+  constexpr int NKS = KSH ? LT : NIW;                      // key-source row tiles a wave runs through the k / v GEMMs
+  constexpr int KI = KSH ? 1 : NIW;                        // K_f / V_f register sets per wave
   constexpr int KT0 = MODE0 ? 2 : 0, NKT = KT0 + 1, DT = 3, NKo = KT0 * 16;
   constexpr int NPART = MODE0 ? 3 : 1, NQKV = NPART * KST, NCH = NQKV + KST;      // chunks per tile: 24 (cross: 12)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
@@ -95,27 +112,27 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   const float pp = pdrop ? a.proj_drop_p : 0.f, pinv = pdrop ? 1.f / (1.f - a.proj_drop_p) : 1.f;
 
   // ---------------- global loads of the prologue, all issued before any is consumed ----------------
-  // token tiles: wave w stages rows 8 (w & 1) .. + 8 of image w >> 1 (16-byte pieces, 24 per row)
-  const int simg_raw = tile * NI + (wave >> 1);
-  const int simg = simg_raw < a.B ? simg_raw : a.B - 1;
+  // token tiles: wave w stages rows 8 (w & 1) .. + 8 of sub-image w >> 1 (16-byte pieces, 24 per row)
   bf16x8 xr[3];
 #pragma unroll
   for (int it = 0; it < 3; ++it) {
     const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24;
-    xr[it] = *reinterpret_cast<const bf16x8*>(xg + ((size_t)simg * BT + row) * a.ldx + 8 * c8);
+    xr[it] = *reinterpret_cast<const bf16x8*>(xg + (size_t)tile_row<TT, WIN>(tile, wave >> 1, row, a.B) * a.ldx + 8 * c8);
   }
-  // Linformer matrices as MFMA operand quads: lane holds E[l = 4 q4 + i][j = 16 jt + col], rows l >= L read as zero (the
-  // reference's zero padding is algebraic; MSDA has 10 landmarks in the 16-row tile)
-  float ek[KT0 > 0 ? KT0 : 1][4], ev[KT0 > 0 ? KT0 : 1][4];
+  // Linformer matrices as MFMA operand quads: lane holds E[l = 16 lt + 4 q4 + i][j = 16 jt + col], rows l >= L read as zero (the
+  // reference's zero padding is algebraic; MSDA has 10 landmarks in the 16-row tile, 40 in three tiles on 64 tokens)
+  float ek[LT][KT0 > 0 ? KT0 : 1][4], ev[LT][KT0 > 0 ? KT0 : 1][4];
   if (MODE0) {
 #pragma unroll
-    for (int jt = 0; jt < KT0; ++jt)
+    for (int lt = 0; lt < LT; ++lt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int l = 4 * q4 + i, lc = l < a.L ? l : 0;
-        ek[jt][i] = a.E_k[(size_t)lc * a.KC + jt * 16 + col];
-        ev[jt][i] = a.E_v[(size_t)lc * a.KC + jt * 16 + col];
-      }
+      for (int jt = 0; jt < KT0; ++jt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int l = 16 * lt + 4 * q4 + i, lc = l < a.L ? l : 0;
+          ek[lt][jt][i] = a.E_k[(size_t)lc * a.KC + jt * 16 + col];
+          ev[lt][jt][i] = a.E_v[(size_t)lc * a.KC + jt * 16 + col];
+        }
   }
   // biases [3C qkv | C proj] and the shared key / value rows of every head (the bank, or its projections for cross)
   constexpr int NB4 = (MODE0 ? 3 * BC : BC) / 4;
@@ -135,16 +152,18 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
     const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24;
     *reinterpret_cast<bf16x8*>(sx_all + (wave >> 1) * (16 * LDO) + row * LDO + 8 * c8) = xr[it];
   }
-  bf16x4 ekf[KT0 > 0 ? KT0 : 1], evf[KT0 > 0 ? KT0 : 1];
+  bf16x4 ekf[LT][KT0 > 0 ? KT0 : 1], evf[LT][KT0 > 0 ? KT0 : 1];
   if (MODE0) {
 #pragma unroll
-    for (int jt = 0; jt < KT0; ++jt)
+    for (int lt = 0; lt < LT; ++lt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = 4 * q4 + i < a.L;
-        ekf[jt][i] = (bf16)(ok ? ek[jt][i] : 0.f);
-        evf[jt][i] = (bf16)(ok ? ev[jt][i] : 0.f);
-      }
+      for (int jt = 0; jt < KT0; ++jt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = 16 * lt + 4 * q4 + i < a.L;
+          ekf[lt][jt][i] = (bf16)(ok ? ek[lt][jt][i] : 0.f);
+          evf[lt][jt][i] = (bf16)(ok ? ev[lt][jt][i] : 0.f);
+        }
   }
   if (tid < NB4) *reinterpret_cast<f32x4*>(sbias + 4 * tid) = bq;
   if (tid < BC / 4) *reinterpret_cast<f32x4*>(sbias + 3 * BC + 4 * tid) = bp;
@@ -163,15 +182,26 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   STAMP(1);
   if (KIND == 1) {
     // MSDA landmarks: pooled[j] = mean_s x[idx[j * stride + s]] (HQAViT_CIFAR100.py:499-501), j < L; fp32 mean, one rounding; rows
-    // j >= L are zero.  Wave w: image w >> 1, k-steps 3 (w & 1) .. + 3, from the staged token tile (two waves staged it: barrier).
+    // j >= L are zero.  From the staged token tile(s) (two waves staged each: barrier).
+    //   TT = 16: wave w: image w >> 1, k-steps 3 (w & 1) .. + 3.
+    //   TT = 64: the 18 (landmark tile, k-step) units of the image's 48-row landmark tile dealt over the 8 waves; idx = token 0 .. 63 = tile row.
     __syncthreads();
-    const bf16* sx = sx_all + (wave >> 1) * (16 * LDO);
-    bf16* sp = sp_all + (wave >> 1) * (16 * LDO);
-    const int j = col < a.L ? col : 0;
     const float inv = 1.f / (float)a.pool_stride;
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
-      const int s2 = 3 * (wave & 1) + s3;
+      int s2, lrow, src_tile, dst_tile;
+      bool act = true;
+      if (KSH) {
+        const int u = wave + NW * s3;
+        act = u < LT * KST;
+        const int uc = act ? u : 0;
+        dst_tile = uc / KST; s2 = uc - dst_tile * KST; lrow = 16 * dst_tile + col; src_tile = 0;
+      } else {
+        s2 = 3 * (wave & 1) + s3; lrow = col; src_tile = dst_tile = wave >> 1;
+      }
+      const bf16* sx = sx_all + src_tile * (16 * LDO);
+      bf16* sp = sp_all + dst_tile * (16 * LDO);
+      const int j = lrow < a.L ? lrow : 0;
       float sum[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) sum[e] = 0.f;
@@ -183,25 +213,32 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
       }
       bf16x8 o8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] = (bf16)(col < a.L ? sum[e] * inv : 0.f);
-      *reinterpret_cast<bf16x8*>(sp + col * LDO + 32 * s2 + 8 * q4) = o8;
+      for (int e = 0; e < 8; ++e) o8[e] = (bf16)(lrow < a.L ? sum[e] * inv : 0.f);
+      if (act) *reinterpret_cast<bf16x8*>(sp + col * LDO + 32 * s2 + 8 * q4) = o8;
     }
   }
   STAMP(2);
   __syncthreads();              // tiles and constants staged; every ordinary load above (and the ring's first chunks) drained: vmcnt is 0 here
   STAMP(3);
 
-  const int h = wave & 3;                                  // this wave's head and its two images in the QKV / attention phase
+  const int h = wave & 3;                                  // this wave's head and its two sub-images in the QKV / attention phase
   const int i0 = NIW * (wave >> 2);
-  int imgs[NIW];
   bool vimg[NIW];
+  int64_t qrow[NIW];                                       // global row of this lane's query (= token col of the sub-image)
+  int prob[NIW];                                           // attention-dropout problem (= image, or (image, window)) of each sub-image
 #pragma unroll
-  for (int i = 0; i < NIW; ++i) { const int ir = tile * NI + i0 + i; vimg[i] = ir < a.B; imgs[i] = vimg[i] ? ir : a.B - 1; }
+  for (int i = 0; i < NIW; ++i) {
+    vimg[i] = sub_valid<TT>(tile, i0 + i, a.B);
+    qrow[i] = tile_row<TT, WIN>(tile, i0 + i, col, a.B);
+    const int ir = tile * NI + i0 + i;
+    prob[i] = (TT == 64 && !WIN) ? tile : (TT == 64 ? ir : (ir < a.B ? ir : a.B - 1));
+  }
+  const int qoff = (TT == 64 && !WIN) ? 16 * i0 : 0;       // query index of the sub-image's first row inside its dropout problem (+ 16 i)
   bf16* qsv = reinterpret_cast<bf16*>(a.q_save);
   bf16* kvsv = reinterpret_cast<bf16*>(a.kv_save);
-  const int kv_rows = (KIND == 1) ? a.L : BT;              // key-token rows per image in kv_save
-  const bf16* sxw = sx_all + i0 * (16 * LDO) + col * LDO + 8 * q4;       // this lane's fragment base in its images' token tiles
-  const bf16* spw = sp_all + i0 * (16 * LDO) + col * LDO + 8 * q4;       // ... and landmark tiles (MSDA; else the token tiles)
+  const int kv_rows = (KIND == 1) ? a.L : BT;              // key-token rows per image in kv_save (SWA on 64 tokens: the token rows themselves)
+  const bf16* sxw = sx_all + i0 * (16 * LDO) + col * LDO + 8 * q4;       // this lane's fragment base in its sub-images' token tiles
+  const bf16* spw = sp_all + (KSH ? 0 : i0) * (16 * LDO) + col * LDO + 8 * q4;       // ... and landmark tiles (MSDA; else the token tiles)
 
   // Ring step for chunk c of the tile's schedule: wait until it has landed (chunks c+1 .. c+3 may stay in flight), then refill
   // the slot chunk c - 1 used.  A k-step chunk of a QKV part = 3 fragments (this head's tiles) x 2 images = 6 MFMAs per wave.
@@ -237,57 +274,78 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         qf[i][t] = cvt4(acc[i][t]);
-        if (SAVE && vimg[i]) *reinterpret_cast<bf16x4*>(qsv + ((size_t)imgs[i] * BT + col) * a.ldq_save + h * BD + t * 16 + 4 * q4) = qf[i][t];
+        if (SAVE && vimg[i]) *reinterpret_cast<bf16x4*>(qsv + (size_t)qrow[i] * a.ldq_save + h * BD + t * 16 + 4 * q4) = qf[i][t];
       }
   }
   STAMP(4);
-  bf16x4 kff[NIW][KT0 > 0 ? KT0 : 1][DT];
+  // global row of this lane's key-source row (token / landmark col of key-source tile ks) in kv_save
+  int64_t kvrow[NKS];
+  bool kvok[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (KSH) { kvok[ks] = 16 * ks + col < a.L; kvrow[ks] = (int64_t)tile * a.L + 16 * ks + col; }
+    else if (KIND == 1) { kvok[ks] = vimg[ks] && col < kv_rows; kvrow[ks] = (int64_t)prob[ks] * kv_rows + col; }
+    else { kvok[ks] = vimg[ks]; kvrow[ks] = qrow[ks]; }
+  }
+  bf16x4 kff[KI][KT0 > 0 ? KT0 : 1][DT];
   if (MODE0) {
     // ---- k: plain GEMM (acc quad = 4 consecutive tokens of column d = 16 t + col), then Kf^T = k^T E_k ----
-    f32x4 acc[NIW][DT], accT[SAVE ? NIW : 1][DT];
+    f32x4 acc[NKS][DT], accT[SAVE ? NKS : 1][DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const float b = sbias[BC + h * BD + t * 16 + col];
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) acc[i][t] = f32x4{b, b, b, b};
+      for (int i = 0; i < NKS; ++i) acc[i][t] = f32x4{b, b, b, b};
       if (SAVE) {
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + BC + h * BD + t * 16 + 4 * q4);
+        for (int i = 0; i < NKS; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + BC + h * BD + t * 16 + 4 * q4);
       }
     }
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
       QV_RING_STEP(KST + s);
       const char* slot = smraw + ((KST + s) % RING) * CHUNK_BYTES;
-      bf16x8 wf[DT], xf[NIW];
+      bf16x8 wf[DT], xf[NKS];
 #pragma unroll
       for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+      for (int i = 0; i < NKS; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) {
+        for (int i = 0; i < NKS; ++i) {
           acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
           if (SAVE) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
         }
     }
     if (SAVE) {                                            // k rows for backward: token = col (MSDA: landmark rows < L), 8-byte segments
 #pragma unroll
-      for (int i = 0; i < NIW; ++i)
+      for (int i = 0; i < NKS; ++i)
 #pragma unroll
         for (int t = 0; t < DT; ++t)
-          if (vimg[i] && col < kv_rows)
-            *reinterpret_cast<bf16x4*>(kvsv + ((size_t)imgs[i] * kv_rows + col) * a.ldkv_save + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
+          if (kvok[i])
+            *reinterpret_cast<bf16x4*>(kvsv + (size_t)kvrow[i] * a.ldkv_save + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
     }
+    if (KSH) {
 #pragma unroll
-    for (int i = 0; i < NIW; ++i)
+      for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const bf16x4 ktf = cvt4(acc[i][t]);
+        for (int jt = 0; jt < KT0; ++jt) {
+          f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jt = 0; jt < KT0; ++jt) kff[i][jt][t] = cvt4(mma16b(ktf, ekf[jt], f32x4{0.f, 0.f, 0.f, 0.f}));   // Kf[key = 16 jt + col][16 t + 4 q4 ..]
-      }
+          for (int lt = 0; lt < LT; ++lt) c = mma16b(cvt4(acc[lt][t]), ekf[lt][jt], c);     // contraction over the landmark tiles
+          kff[0][jt][t] = cvt4(c);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIW; ++i)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const bf16x4 ktf = cvt4(acc[i < NKS ? i : 0][t]);
+#pragma unroll
+          for (int jt = 0; jt < KT0; ++jt) kff[i < KI ? i : 0][jt][t] = cvt4(mma16b(ktf, ekf[0][jt], f32x4{0.f, 0.f, 0.f, 0.f}));   // Kf[key = 16 jt + col][16 t + 4 q4 ..]
+        }
+    }
   }
   STAMP(5);
   // ---- S^T[key][query] = K_full Q^T, softmax over keys on registers, attention dropout: independent images ----
@@ -303,7 +361,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
       for (int nt = 0; nt < NKT; ++nt) {
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < DT; ++t) acc2 = mma16(nt < KT0 ? as_s16(kff[i][nt < KT0 ? nt : 0][t]) : bkf[t], as_s16(qf[i][t]), acc2);
+        for (int t = 0; t < DT; ++t) acc2 = mma16(nt < KT0 ? as_s16(kff[KSH ? 0 : i][nt < KT0 ? nt : 0][t]) : bkf[t], as_s16(qf[i][t]), acc2);
         sc[nt] = acc2;
       }
       float mx = -INFINITY;
@@ -328,64 +386,76 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[nt][r] *= inv;
       if (adrop) {                                         // two keys per hash (drop_factor pairs 2m, 2m+1)
-        const uint32_t pkey = attn_drop_pkey(drop, imgs[i] * BH + h);
+        const uint32_t pkey = attn_drop_pkey(drop, prob[i] * BH + h);
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[nt][r] *= attn_drop_factor(drop, pkey, col, nt * 16 + 4 * q4 + r);
+          for (int r = 0; r < 4; ++r) sc[nt][r] *= attn_drop_factor(drop, pkey, qoff + 16 * i * (TT == 64 && !WIN ? 1 : 0) + col, nt * 16 + 4 * q4 + r);
       }
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt) pfr[i][nt] = cvt4(sc[nt]);
     }
   }
   STAMP(6);
-  bf16x4 vff[NIW][KT0 > 0 ? KT0 : 1][DT];
+  bf16x4 vff[KI][KT0 > 0 ? KT0 : 1][DT];
   if (MODE0) {
     // ---- v: plain GEMM, then Vf = E_v^T v (acc quad = 4 consecutive keys of column d) ----
-    f32x4 acc[NIW][DT], accT[SAVE ? NIW : 1][DT];
+    f32x4 acc[NKS][DT], accT[SAVE ? NKS : 1][DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const float b = sbias[2 * BC + h * BD + t * 16 + col];
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) acc[i][t] = f32x4{b, b, b, b};
+      for (int i = 0; i < NKS; ++i) acc[i][t] = f32x4{b, b, b, b};
       if (SAVE) {
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + 2 * BC + h * BD + t * 16 + 4 * q4);
+        for (int i = 0; i < NKS; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + 2 * BC + h * BD + t * 16 + 4 * q4);
       }
     }
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
       QV_RING_STEP(2 * KST + s);
       const char* slot = smraw + ((2 * KST + s) % RING) * CHUNK_BYTES;
-      bf16x8 wf[DT], xf[NIW];
+      bf16x8 wf[DT], xf[NKS];
 #pragma unroll
       for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+      for (int i = 0; i < NKS; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int i = 0; i < NIW; ++i) {
+        for (int i = 0; i < NKS; ++i) {
           acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
           if (SAVE) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
         }
     }
     if (SAVE) {                                            // v rows: the column block after k's in kv_save
 #pragma unroll
-      for (int i = 0; i < NIW; ++i)
+      for (int i = 0; i < NKS; ++i)
 #pragma unroll
         for (int t = 0; t < DT; ++t)
-          if (vimg[i] && col < kv_rows)
-            *reinterpret_cast<bf16x4*>(kvsv + ((size_t)imgs[i] * kv_rows + col) * a.ldkv_save + BC + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
+          if (kvok[i])
+            *reinterpret_cast<bf16x4*>(kvsv + (size_t)kvrow[i] * a.ldkv_save + BC + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
     }
+    if (KSH) {
 #pragma unroll
-    for (int i = 0; i < NIW; ++i)
+      for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const bf16x4 vtf = cvt4(acc[i][t]);
+        for (int jt = 0; jt < KT0; ++jt) {
+          f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jt = 0; jt < KT0; ++jt) vff[i][jt][t] = cvt4(mma16b(evf[jt], vtf, f32x4{0.f, 0.f, 0.f, 0.f}));   // Vf[key = 16 jt + 4 q4 ..][16 t + col]
-      }
+          for (int lt = 0; lt < LT; ++lt) c = mma16b(evf[lt][jt], cvt4(acc[lt][t]), c);
+          vff[0][jt][t] = cvt4(c);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIW; ++i)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const bf16x4 vtf = cvt4(acc[i < NKS ? i : 0][t]);
+#pragma unroll
+          for (int jt = 0; jt < KT0; ++jt) vff[i < KI ? i : 0][jt][t] = cvt4(mma16b(evf[0][jt], vtf, f32x4{0.f, 0.f, 0.f, 0.f}));   // Vf[key = 16 jt + 4 q4 ..][16 t + col]
+        }
+    }
   }
   STAMP(7);
   // ---- O^T[d][query] = V_full^T P^T -> columns 48 h .. of each image's O tile.  A NaN anywhere in q / k / v reaches O (the
@@ -400,7 +470,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
       for (int t = 0; t < DT; ++t) {
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < NKT; ++nt) acc2 = mma16(nt < KT0 ? as_s16(vff[i][nt < KT0 ? nt : 0][t]) : bvf[t], as_s16(pfr[i][nt]), acc2);
+        for (int nt = 0; nt < NKT; ++nt) acc2 = mma16(nt < KT0 ? as_s16(vff[KSH ? 0 : i][nt < KT0 ? nt : 0][t]) : bvf[t], as_s16(pfr[i][nt]), acc2);
         bad |= nan4(acc2);
         *reinterpret_cast<bf16x4*>(so_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(acc2);
       }
@@ -409,9 +479,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   // ================= proj: out = dropout(O . Wproj^T + b): WAVE = (IMAGE, COLUMN HALF), 6 output tiles, 6 k-step chunks =================
   {
     const int pi = wave >> 1, half = wave & 1;
-    const int img_raw = tile * NI + pi;
-    const bool valid = img_raw < a.B;
-    const int img = valid ? img_raw : a.B - 1;
+    const bool valid = sub_valid<TT>(tile, pi, a.B);
     const bf16* so = so_all + pi * (16 * LDO);
     bf16* sout = sx_all + pi * (16 * LDO);                 // the token tiles are dead once every wave is past its v phase (= past the
     bf16x8 of8[KST];                                       // barrier of the first proj chunk): they collect the output rows
@@ -436,7 +504,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
     for (int jj = 0; jj < CT / 2; ++jj) {
       if (pdrop) {
-        const uint32_t base = (uint32_t)(img * BT + col) * (uint32_t)BC + (uint32_t)((6 * half + jj) * 16 + 4 * q4);
+        const uint32_t base = (uint32_t)tile_row<TT, WIN>(tile, pi, col, a.B) * (uint32_t)BC + (uint32_t)((6 * half + jj) * 16 + 4 * q4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[jj][r] *= drop_factor(pkey_proj, base + r, pp, pinv);
       }
@@ -449,7 +517,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3) {
         const int s2 = 3 * half + s3;
-        *reinterpret_cast<bf16x8*>(osv + ((size_t)img * BT + col) * a.ldo + 32 * s2 + 8 * q4) = of8[s2];
+        *reinterpret_cast<bf16x8*>(osv + (size_t)tile_row<TT, WIN>(tile, pi, col, a.B) * a.ldo + 32 * s2 + 8 * q4) = of8[s2];
       }
     }
 #endif
@@ -457,10 +525,14 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
         const int p = lane + 64 * it, row = p / 12, c8 = 12 * half + p % 12;
-        *reinterpret_cast<bf16x8*>(og + ((size_t)img * BT + row) * a.ldo + 8 * c8) = *reinterpret_cast<const bf16x8*>(sout + row * LDO + 8 * c8);
-        if (SAVE && KIND == 1 && a.pooled_save && row < a.L)      // the landmark rows (operand of backward's dW_kv), from their LDS tile
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.pooled_save) + ((size_t)img * a.L + row) * BC + 8 * c8) =
-              *reinterpret_cast<const bf16x8*>(sp_all + pi * (16 * LDO) + row * LDO + 8 * c8);
+        *reinterpret_cast<bf16x8*>(og + (size_t)tile_row<TT, WIN>(tile, pi, row, a.B) * a.ldo + 8 * c8) = *reinterpret_cast<const bf16x8*>(sout + row * LDO + 8 * c8);
+        if (SAVE && KIND == 1 && a.pooled_save) {                 // the landmark rows (operand of backward's dW_kv), from their LDS tile
+          const int lrow = KSH ? 16 * pi + row : row;             // TT = 64: landmark tile pi (< LT) of the image
+          const int64_t prow = KSH ? (int64_t)tile * a.L + lrow : (int64_t)(tile * NI + pi) * a.L + lrow;
+          if (lrow < a.L && (!KSH || pi < LT))
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(a.pooled_save) + (size_t)prow * BC + 8 * c8) =
+                *reinterpret_cast<const bf16x8*>(sp_all + pi * (16 * LDO) + row * LDO + 8 * c8);
+        }
       }
     }
   }
@@ -474,8 +546,11 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 // efficient_attention's NaN rule (HQAViT_CIFAR100.py:356-357, :394-395) behind the fused branch: a NaN anywhere in q / k / v
 // or in the attention output zeroes the WHOLE attention output, so the branch returns dropout(proj(0)) = dropout(bias) rows.
 // The last workgroup to have read the flag resets it (flag[1] = arrival ticket), as qavit_nan_guard does.
+// For the backward pass: `trip` (optional) receives 1 / 0 = rule applied / not, and a tripped call zeroes the saved attention output
+// (o_save [rows, ldos], Co columns) -- the reference's zeros_like(q) has no history, so dW_proj = dz^T 0 = 0 and nothing flows back
+// through the attention core (qavit_branch_bwd / qavit_cga_bwd read `trip`).
 __global__ __launch_bounds__(256) void branch_nan_fix_kernel(bf16* out, int64_t ldo, int rows, int C, const float* bias, float p, int site,
-                                                             const int64_t* rng, int* flag) {
+                                                             const int64_t* rng, int* flag, int* trip, bf16* o_save, int64_t ldos, int Co) {
   __shared__ int f_s;
   if (threadIdx.x == 0) {
     f_s = *reinterpret_cast<volatile int*>(flag);
@@ -483,6 +558,7 @@ __global__ __launch_bounds__(256) void branch_nan_fix_kernel(bf16* out, int64_t 
     if (atomicAdd(flag + 1, 1) == (int)gridDim.x - 1) { flag[0] = 0; flag[1] = 0; }
   }
   __syncthreads();
+  if (trip && blockIdx.x == 0 && threadIdx.x == 0) *trip = f_s != 0 ? 1 : 0;
   if (f_s == 0) return;
   const bool on = p > 0.f && rng != nullptr;
   const uint32_t key = on ? rng_key(rng, site) : 0u;
@@ -493,18 +569,25 @@ __global__ __launch_bounds__(256) void branch_nan_fix_kernel(bf16* out, int64_t 
     if (on) v *= drop_factor(key, (uint32_t)r * (uint32_t)C + (uint32_t)c, p, inv);
     out[(size_t)r * ldo + c] = (bf16)v;
   }
+  if (o_save)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * Co; i += (int64_t)gridDim.x * blockDim.x) {
+      const int r = (int)(i / Co), c = (int)(i - (int64_t)r * Co);
+      o_save[(size_t)r * ldos + c] = (bf16)0.f;
+    }
 }
 
 int branch_validate(const qavit_branch_args* a) {
   if (!a) return set_error(QAVIT_EINVAL, "branch: null args");
   if (a->kind < 0 || a->kind > 2) return set_error(QAVIT_EINVAL, "branch: kind must be 0 (SWA), 1 (MSDA) or 2 (cross)");
   if (a->dtype != QAVIT_BF16) return set_error(QAVIT_EINVAL, "branch: the fused branch kernels are bf16 only (fp32 runs the unfused chain)");
-  if (a->T != BT || a->C != BC || a->H != BH || a->D != BD || a->S != 16)
-    return set_error(QAVIT_EINVAL, "branch: built for 16 tokens x 192 channels, 4 heads of 48, 16 bank rows");
+  if ((a->T != 16 && a->T != 64) || a->C != BC || a->H != BH || a->D != BD || a->S != 16)
+    return set_error(QAVIT_EINVAL, "branch: built for 16 or 64 tokens x 192 channels, 4 heads of 48, 16 bank rows");
   if (a->B <= 0 || !a->x || !a->out || !a->wqkv_frag || !a->wproj_frag || !a->bqkv || !a->bproj || !a->sh_k || !a->sh_v)
     return set_error(QAVIT_EINVAL, "branch: null operand");
-  if (a->kind != 2 && (a->KC != 32 || a->L <= 0 || a->L > 16 || !a->E_k || !a->E_v))
-    return set_error(QAVIT_EINVAL, "branch: SWA / MSDA need Linformer matrices with KC = 32 and 1 <= L <= 16");
+  const int lmax = (a->kind == 1 && a->T == 64) ? 48 : 16;
+  if (a->kind != 2 && (a->KC != 32 || a->L <= 0 || a->L > lmax || !a->E_k || !a->E_v))
+    return set_error(QAVIT_EINVAL, "branch: SWA / MSDA need Linformer matrices with KC = 32 and 1 <= L <= 16 (MSDA on 64 tokens: <= 48)");
+  if (a->kind == 0 && a->L != 16) return set_error(QAVIT_EINVAL, "branch: SWA works on 4x4 windows (L = 16)");
   if (a->kind == 1 && (!a->pool_idx || a->pool_stride <= 0)) return set_error(QAVIT_EINVAL, "branch: MSDA needs the landmark index table");
   if (a->q_save) {
     if ((reinterpret_cast<uintptr_t>(a->q_save) & 7) || a->ldq_save % 4) return set_error(QAVIT_EINVAL, "branch: q_save needs 8-byte alignment and ld % 4 == 0");
@@ -512,6 +595,7 @@ int branch_validate(const qavit_branch_args* a) {
       return set_error(QAVIT_EINVAL, "branch: kv_save (with q_save) needs 8-byte alignment and ld % 4 == 0");
     if (a->pooled_save && (reinterpret_cast<uintptr_t>(a->pooled_save) & 15)) return set_error(QAVIT_EINVAL, "branch: pooled_save needs 16-byte alignment");
   }
+  if (a->nan_trip && !a->nan_flag) return set_error(QAVIT_EINVAL, "branch: nan_trip is written by the NaN-rule launch, which needs nan_flag");
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (!al16(a->x) || !al16(a->out) || !al16(a->wqkv_frag) || !al16(a->wproj_frag) || !al16(a->bqkv) || !al16(a->bproj) || !al16(a->sh_k) || !al16(a->sh_v) ||
       (a->o_save && !al16(a->o_save)) || a->ldx % 8 || a->ldo % 8)
@@ -522,11 +606,13 @@ int branch_validate(const qavit_branch_args* a) {
 }  // namespace
 
 // the NaN -> zeros rule's rewrite launch, shared with the fused channel-group branch (cga.hip)
-void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag, hipStream_t st) {
+void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag,
+                           int* trip, void* o_save, int64_t ldos, int Co, hipStream_t st) {
   const int64_t n = (int64_t)rows * C;
   int nb = (int)((n + 2047) / 2048);
   if (nb > 64) nb = 64;
-  hipLaunchKernelGGL(branch_nan_fix_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<bf16*>(out), ldo, rows, C, bias, p, site, rng, flag);
+  hipLaunchKernelGGL(branch_nan_fix_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<bf16*>(out), ldo, rows, C, bias, p, site, rng, flag,
+                     trip, reinterpret_cast<bf16*>(o_save), ldos, Co);
 }
 
 }  // namespace qv
@@ -535,8 +621,10 @@ using namespace qv;
 
 extern "C" int qavit_branch_supported(int kind, int T, int C, int H, int D, int KC, int S, int L) {
   if (kind < 0 || kind > 2) return 0;
-  if (T != BT || C != BC || H != BH || D != BD || S != 16) return 0;
-  if (kind != 2 && (KC != 32 || L <= 0 || L > 16)) return 0;
+  if ((T != 16 && T != 64) || C != BC || H != BH || D != BD || S != 16) return 0;
+  const int lmax = (kind == 1 && T == 64) ? 48 : 16;
+  if (kind != 2 && (KC != 32 || L <= 0 || L > lmax)) return 0;
+  if (kind == 0 && L != 16) return 0;
   return 1;
 }
 
@@ -544,27 +632,30 @@ extern "C" int qavit_branch_fwd(const qavit_branch_args* a, void* stream) {
   int rc = branch_validate(a);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int grid = (a->B + NI - 1) / NI;                   // one 4-image tile per workgroup
-  static bool attr_done[3][2] = {{false, false}, {false, false}, {false, false}};
+  const bool wide = a->T == 64;
+  const int grid = wide ? a->B : (a->B + NI - 1) / NI;     // one 64-row tile per workgroup: 4 images of 16 tokens, or one image of 64
+  static bool attr_done[3][2][2] = {};
   const bool save = a->q_save != nullptr;
-#define QV_BRANCH_LAUNCH(K, S)                                                                                                           \
+#define QV_BRANCH_LAUNCH(K, S, TT)                                                                                                      \
   do {                                                                                                                                   \
-    if (!attr_done[K][S]) {                                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, sm_total(K)); \
-      attr_done[K][S] = true;                                                                                                            \
+    if (!attr_done[K][S][TT == 64]) {                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K, S, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, sm_total(K)); \
+      attr_done[K][S][TT == 64] = true;                                                                                                  \
     }                                                                                                                                    \
-    hipLaunchKernelGGL((branch_fwd_kernel<K, S>), dim3(grid), dim3(512), sm_total(K), st, *a);                                          \
+    hipLaunchKernelGGL((branch_fwd_kernel<K, S, TT>), dim3(grid), dim3(512), sm_total(K), st, *a);                                      \
   } while (0)
-  if (a->kind == 0) { if (save) QV_BRANCH_LAUNCH(0, true); else QV_BRANCH_LAUNCH(0, false); }
-  else if (a->kind == 1) { if (save) QV_BRANCH_LAUNCH(1, true); else QV_BRANCH_LAUNCH(1, false); }
-  else { if (save) QV_BRANCH_LAUNCH(2, true); else QV_BRANCH_LAUNCH(2, false); }
+#define QV_BRANCH_KIND(K)                                                                                                                \
+  do {                                                                                                                                   \
+    if (wide) { if (save) QV_BRANCH_LAUNCH(K, true, 64); else QV_BRANCH_LAUNCH(K, false, 64); }                                          \
+    else { if (save) QV_BRANCH_LAUNCH(K, true, 16); else QV_BRANCH_LAUNCH(K, false, 16); }                                               \
+  } while (0)
+  if (a->kind == 0) QV_BRANCH_KIND(0);
+  else if (a->kind == 1) QV_BRANCH_KIND(1);
+  else QV_BRANCH_KIND(2);
+#undef QV_BRANCH_KIND
 #undef QV_BRANCH_LAUNCH
-  if (a->nan_flag) {
-    const int64_t n = (int64_t)a->B * BT * BC;
-    int nb = (int)((n + 2047) / 2048);
-    if (nb > 64) nb = 64;
-    hipLaunchKernelGGL(branch_nan_fix_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<bf16*>(a->out), a->ldo, a->B * BT, BC, a->bproj,
-                       a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag);
-  }
+  if (a->nan_flag)
+    branch_nan_fix_launch(a->out, a->ldo, a->B * a->T, BC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, a->nan_trip,
+                          a->o_save, a->ldo, BC, st);
   return check_launch("branch_fwd");
 }

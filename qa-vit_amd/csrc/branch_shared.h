@@ -24,6 +24,26 @@ constexpr int SM_BANK = RING * CHUNK_BYTES, SM_BIAS = SM_BANK + 2 * 16 * LDB * 2
 // 61440 ring + 12800 bank + 3072 biases + 25600 O / output tiles + 25600 token tiles (+ 25600 landmark tiles, MSDA) = 128512 (154112) bytes
 constexpr int sm_total(int kind) { return kind == 1 ? SM_P + NI * OUT_BYTES : SM_P; }
 
+// Token rows of a 64-row tile.  TT = 16 (the CIFAR configuration's 16 learned tokens): the tile is 4 images of 16 tokens, sub-image
+// `sub` = image tile * 4 + sub.  TT = 64 (Tiny-ImageNet's 64 learned tokens, QA-ViT at 32 px without TokenLearner): the tile is ONE
+// image; its four 16-row sub-images are the four 4x4 windows of the 8x8 token grid for SWA (window_partition with window 4,
+// HQAViT_IN_Tiny.py:756-769: window (wy, wx), position (ty, tx) -> token (4 wy + ty) * 8 + 4 wx + tx) and the four query tiles
+// 16 sub .. 16 sub + 15 for MSDA / cross-attention.
+template <int TT, bool WINDOWS>
+__device__ __forceinline__ int sub_token(int sub, int r) {
+  if (TT == 64 && WINDOWS) return ((sub >> 1) * 4 + (r >> 2)) * 8 + (sub & 1) * 4 + (r & 3);
+  return (TT == 64 ? 16 * sub : 0) + r;
+}
+// global row (in a [B * TT, *] matrix) of row r of sub-image `sub` of tile `tile`; rows of images past the batch are clamped to the last image
+template <int TT, bool WINDOWS>
+__device__ __forceinline__ int64_t tile_row(int tile, int sub, int r, int B) {
+  if (TT == 64) return (int64_t)tile * 64 + sub_token<TT, WINDOWS>(sub, r);
+  const int img = tile * NI + sub;
+  return (int64_t)(img < B ? img : B - 1) * BT + r;
+}
+template <int TT>
+__device__ __forceinline__ bool sub_valid(int tile, int sub, int B) { return TT == 64 ? true : tile * NI + sub < B; }
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 

@@ -21,7 +21,8 @@
 
 namespace qv {
 
-void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag, hipStream_t st);
+void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag,
+                           int* trip, void* o_save, int64_t ldos, int Co, hipStream_t st);
 
 namespace {
 
@@ -230,6 +231,35 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
   bf16* dqg = reinterpret_cast<bf16*>(a.dqkv);
   bf16* dxg = reinterpret_cast<bf16*>(a.dx);
 
+  if (a.nan_trip && *a.nan_trip != 0) {
+    // the forward tripped the NaN rule: it returned proj(0), nothing flows back through the attention cores (HQAViT_CIFAR100.py:356-357,
+    // :394-395).  dz = masked dout (db_proj), dqkv = dx = 0, bank-row partials 0.
+    const bool pd = a.proj_drop_p > 0.f && a.rng != nullptr;
+    const uint32_t pk = pd ? rng_key(a.rng, a.proj_drop_site) : 0u;
+    const float ppp = pd ? a.proj_drop_p : 0.f, piv = pd ? 1.f / (1.f - a.proj_drop_p) : 1.f;
+    bf16x8 z8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z8[e] = (bf16)0.f;
+    if (valid) {
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int p = lane + 64 * it, row = 8 * half + p / 24, c8 = p % 24;
+        if (pd && dzg) {
+          bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gg + ((size_t)img * CT + row) * a.lddout + 8 * c8);
+          const uint32_t base = (uint32_t)(img * CT + row) * (uint32_t)CC + (uint32_t)(8 * c8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g8[e] = (bf16)((float)g8[e] * drop_factor(pk, base + e, ppp, piv));
+          *reinterpret_cast<bf16x8*>(dzg + ((size_t)img * CT + row) * a.lddz + 8 * c8) = g8;
+        }
+        *reinterpret_cast<bf16x8*>(dxg + ((size_t)img * CT + row) * a.lddx + 8 * c8) = z8;
+      }
+      // this wave's half of the image's dqkv rows: 8 tokens x 6 groups x 48 = 2304 contiguous elements
+      bf16* drow = dqg + ((size_t)img * CT + 8 * half) * CG * (3 * CCG);
+      for (int p = lane; p < 8 * CG * 3 * CCG / 8; p += 64) *reinterpret_cast<bf16x8*>(drow + 8 * p) = z8;
+    }
+    for (int e = tid; e < CGA_PART; e += 64 * CNW) a.parts[(size_t)blockIdx.x * CGA_PART + e] = 0.f;
+    return;
+  }
   bf16x8 xr[3], gr[3];
 #pragma unroll
   for (int it = 0; it < 3; ++it) {
@@ -438,6 +468,7 @@ int cga_validate(const qavit_cga_args* a) {
   if (a->T != CT || a->C != CC || a->G != CG || a->H != CH || a->D != CD || a->S != CS)
     return set_error(QAVIT_EINVAL, "cga: built for 16 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
   if (a->B <= 0 || !a->x || !a->out || !a->wqkv_rm || !a->wproj_rm || !a->bqkv || !a->bproj || !a->sh_k || !a->sh_v) return set_error(QAVIT_EINVAL, "cga: null operand");
+  if (a->nan_trip && !a->nan_flag) return set_error(QAVIT_EINVAL, "cga: nan_trip is written by the NaN-rule launch, which needs nan_flag");
   auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
   if (!al(a->x, 15) || !al(a->out, 15) || !al(a->wqkv_rm, 7) || !al(a->wproj_rm, 7) || !al(a->bqkv, 15) || !al(a->bproj, 15) || !al(a->sh_k, 15) || !al(a->sh_v, 3) ||
       (a->o_save && !al(a->o_save, 7)) || a->ldx % 8 || a->ldo % 8)
@@ -488,6 +519,7 @@ extern "C" int qavit_cga_fwd(const qavit_cga_args* a, void* stream) {
     attr_done = true;
   }
   hipLaunchKernelGGL(cga_fwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNW), SM_CGA, st, *a);
-  if (a->nan_flag) branch_nan_fix_launch(a->out, a->ldo, a->B * CT, CC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, st);
+  if (a->nan_flag)
+    branch_nan_fix_launch(a->out, a->ldo, a->B * CT, CC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, a->nan_trip, a->o_save, CO, CO, st);
   return check_launch("cga_fwd");
 }

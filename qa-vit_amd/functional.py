@@ -608,8 +608,8 @@ def _attn_drop(a, spec, rt):
 
 def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool_idx=None, pool_stride=0, Lk=0,
                    attn_drop=(0.0, 0), proj_drop=(0.0, 0), want_o=False, save=False):
-    """One launch for a whole attention branch on 16-token problems (csrc/branch_fwd.hip; include/qavit.h qavit_branch_args):
-    ``kind`` 0 = SWA, 1 = MSDA, 2 = cross.  ``x`` [B, 16, 192] bf16 (norm1's output); ``wqkv`` / ``wproj`` are the fp32
+    """One launch for a whole attention branch on 16- or 64-token problems (csrc/branch_fwd.hip; include/qavit.h qavit_branch_args):
+    ``kind`` 0 = SWA, 1 = MSDA, 2 = cross.  ``x`` [B, 16 | 64, 192] bf16 (norm1's output); ``wqkv`` / ``wproj`` are the fp32
     parameters (read through the fragment-packed copies of the WeightPack); ``sh_k`` / ``sh_v`` fp32 [16, 192] (the bank, or
     its k_proj / v_proj for cross).  No autograd: the caller owns the backward.  -> out [B, 16, 192] (and O when ``want_o``)."""
     K._require_cuda(x)
@@ -638,6 +638,11 @@ def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool
         o = torch.empty_like(out)
         a.o_save = o.data_ptr()
     saved = None
+    if save and rt.nan_guard:                              # did the NaN rule fire?  (read by the fused backward: zero gradient through the core)
+        trip = torch.empty(1, dtype=torch.int32, device=x.device)
+        a.nan_trip = trip.data_ptr()
+    else:
+        trip = None
     if save:                                               # q / k / v (and MSDA's landmarks) for the backward pass, written by the kernel
         esz = x.element_size()
         if kind == 0:
@@ -666,7 +671,7 @@ def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool
     K.branch_fwd(a)
     out = out.reshape(B, T, Cc)
     if save:
-        return out, o, saved
+        return out, o, saved, trip
     return (out, o) if want_o else out
 
 
@@ -682,12 +687,13 @@ class BranchFn(Function):
     def forward(ctx, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, meta):
         need = any(ctx.needs_input_grad)
         res = branch_forward(meta["kind"], x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k.reshape(-1, x.shape[-1]), sh_v.reshape(-1, x.shape[-1]),
-                             meta.get("pool_idx"), meta.get("pool_stride", 0), meta.get("Lk", x.shape[1] if meta["kind"] == 0 else 0), meta["attn_drop"], meta["proj_drop"],
+                             meta.get("pool_idx"), meta.get("pool_stride", 0), meta.get("Lk", 16 if meta["kind"] == 0 else 0), meta["attn_drop"], meta["proj_drop"],
                              want_o=need, save=need)
         if not need:
             return res
-        out, o, saved = res
+        out, o, saved, trip = res
         ctx.n_saved = len(saved)
+        ctx.trip = trip
         # The bank is mutated in place later in the same forward (GlobalTokenBank.write); the reference's SDPA backward sees
         # the values its forward used (torch.cat made a copy), so snapshot shared rows that alias a parameter (as AttnFn does).
         sk_s, sv_s = sh_k, sh_v
@@ -718,7 +724,9 @@ class BranchFn(Function):
         with torch.no_grad():
             if kind == 0:
                 qkv = saved[0]
-                spec = dict(mode=0, G=B, Nq=T, L=T, H=H, D=D, KC=E_k.shape[1], S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=T,
+                nwin = T // 16                              # 64 tokens: the four 4x4 windows through the row table
+                spec = dict(mode=0, G=B * nwin, Nq=16, L=16, H=H, D=D, KC=E_k.shape[1], S=S, groups_per_b=nwin, q_rows_per_b=T, k_rows_per_b=T,
+                            q_tbl=m.get("win_tbl") if nwin > 1 else None, k_tbl=m.get("win_tbl") if nwin > 1 else None,
                             q_off=0, k_off=Cc, v_off=2 * Cc, q_rows=B * T, drop=m["attn_drop"])
                 dq_t, _, ek_ret, ev_ret, sk_ret, sv_ret = _attn_bwd(qkv, None, E_k, E_v, sk_s, sv_s, sh_k_in, sh_v_in, spec, d_o)
                 dx = _linear_bwd(x2, wqkv, bqkv, dq_t, 0, 3 * Cc, ctx.needs_input_grad[0])
@@ -774,16 +782,18 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
     a.rng = rt.rng.data_ptr()
     if pd[0] > 0.0:
         a.dz, a.lddz = dz.data_ptr(), Cc
+    if getattr(ctx, "trip", None) is not None:
+        a.nan_trip = ctx.trip.data_ptr()
     esz = 2
     dkv = None
     if kind == 0:
         qkv = saved[0]
         dq = torch.empty_like(qkv)
         a.q, a.ldq = qkv.data_ptr(), 3 * Cc
-        a.k_tok, a.v_tok, a.ldkv, a.kv_rows = qkv.data_ptr() + Cc * esz, qkv.data_ptr() + 2 * Cc * esz, 3 * Cc, T
+        a.k_tok, a.v_tok, a.ldkv, a.kv_rows = qkv.data_ptr() + Cc * esz, qkv.data_ptr() + 2 * Cc * esz, 3 * Cc, 16
         a.dq, a.lddq = dq.data_ptr(), 3 * Cc
         a.dk_tok, a.dv_tok, a.lddkv = dq.data_ptr() + Cc * esz, dq.data_ptr() + 2 * Cc * esz, 3 * Cc
-        a.KC, a.L = E_k.shape[1], T
+        a.KC, a.L = E_k.shape[1], 16
     elif kind == 1:
         q, kv, p2 = saved
         Lk = m["Lk"]
@@ -800,8 +810,9 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
         a.dq, a.lddq = dq.data_ptr(), Cc
     if kind != 2:
         a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
-    nparts = K.branch_bwd_parts(B)
-    PF = K.BRANCH_PARTS_FLOATS
+    nparts = K.branch_bwd_parts(B, T)
+    PF = K.BRANCH_PARTS_FLOATS_64 if T == 64 else K.BRANCH_PARTS_FLOATS
+    PE = (48 if T == 64 else 16) * 32                      # floats per dE slot of a partial row: [dE_k | dE_v | d sh_k | d sh_v]
     parts = torch.empty(nparts * PF, dtype=torch.float32, device=x.device)
     a.parts, a.parts_stride = parts.data_ptr(), PF
     DeferDW.arm()
@@ -819,7 +830,12 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
         ek_buf, ek_ret = grad_sink(E_k)
         ev_buf, ev_ret = grad_sink(E_v)
         if ek_buf is not None or ev_buf is not None:
-            K.DeferredLN.push_raw(parts.data_ptr(), nparts, 512, K._p(ek_buf), K._p(ev_buf), PF, (parts, ek_buf, ev_buf))
+            ce = min(PE, E_k.numel())                       # SWA: the 16 window rows; MSDA: the slot (E has 128 rows, the first L <= 16 | 48 are used)
+            if ce == PE:
+                K.DeferredLN.push_raw(parts.data_ptr(), nparts, ce, K._p(ek_buf), K._p(ev_buf), PF, (parts, ek_buf, ev_buf))
+            else:
+                K.DeferredLN.push_raw(parts.data_ptr(), nparts, ce, K._p(ek_buf), None, PF, (parts, ek_buf))
+                K.DeferredLN.push_raw(parts.data_ptr() + PE * 4, nparts, ce, K._p(ev_buf), None, PF, (parts, ev_buf))
     leaf = sh_k_in.is_leaf and sh_v_in.is_leaf
     rec = None if leaf else DeferredBank.record_of(sh_k_in, sh_v_in)
     if leaf:
@@ -835,7 +851,7 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
         sv_buf = sv_ret = both[1] if sh_v_in.requires_grad else None
     half = (S * Cc) // 2
     descs = []
-    for buf, off in ((sk_buf, 1024), (sv_buf, 1024 + S * Cc)):
+    for buf, off in ((sk_buf, 2 * PE), (sv_buf, 2 * PE + S * Cc)):
         if buf is not None:
             descs.append((parts.data_ptr() + off * 4, nparts, half, buf.data_ptr(), buf.data_ptr() + half * 4, PF))
     if descs:
@@ -869,7 +885,7 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
 
 
 def branch_ok(kind, x, Lk, KC, S, heads) -> bool:
-    """Does the fused branch kernel cover this call?  (bf16, 16 tokens x 192 channels, 4 heads of 48, 16 shared rows, KC = 32)"""
+    """Does the fused branch kernel cover this call?  (bf16, 16 or 64 tokens x 192 channels, 4 heads of 48, 16 shared rows, KC = 32)"""
     if x.dtype != torch.bfloat16 or x.dim() != 3 or not x.is_cuda or os.environ.get("QAVIT_FUSED_BRANCH", "1") == "0":
         return False
     B, T, Cc = x.shape
@@ -924,10 +940,15 @@ class CGABranchFn(Function):
         a.attn_drop_p, a.attn_drop_site = float(ad[0]), int(ad[1])
         a.proj_drop_p, a.proj_drop_site = float(pd[0]), int(pd[1])
         a.rng = rt.rng.data_ptr()
+        trip = None
         if rt.nan_guard:
             a.nan_flag = rt.nan_flag.data_ptr()
+            if need:
+                trip = torch.empty(1, dtype=torch.int32, device=x.device)
+                a.nan_trip = trip.data_ptr()
         L.check(L.load().qavit_cga_fwd(C.byref(a), K.stream()), "cga_fwd")
         if need:
+            ctx.trip = trip
             ctx.meta = meta
             ctx.save_for_backward(x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk, shv, o)
             ctx.sh_in = (sh_k, sh_v)
@@ -1005,6 +1026,8 @@ def _cga_backward_fused(ctx, dout, x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk,
     a.dqkv = dqkv.data_ptr()
     a.dx, a.lddx = dx.data_ptr(), Cc
     a.parts = parts.data_ptr()
+    if getattr(ctx, "trip", None) is not None:
+        a.nan_trip = ctx.trip.data_ptr()
     DeferDW.arm()
     L.check(L.load().qavit_cga_bwd(C.byref(a), K.stream()), "cga_bwd")
     # dW_proj += dz^T O, db_proj += colsum(dz)

@@ -391,11 +391,12 @@ def branch_bwd(a):
     L.check(L.load().qavit_branch_bwd(C.byref(a), stream()), "branch_bwd")
 
 
-def branch_bwd_parts(B) -> int:
-    return int(L.load().qavit_branch_bwd_parts(int(B)))
+def branch_bwd_parts(B, T=16) -> int:
+    return int(L.load().qavit_branch_bwd_parts(int(B), int(T)))
 
 
-BRANCH_PARTS_FLOATS = 7168
+BRANCH_PARTS_FLOATS = 7168            # include/qavit.h QAVIT_BRANCH_PARTS_FLOATS: [dE_k 16x32 | dE_v 16x32 | d sh_k 16x192 | d sh_v 16x192]
+BRANCH_PARTS_FLOATS_64 = 9216         # ... _64 (T = 64): the dE slots hold 48 rows
 
 
 def nan_guard(x, flag):

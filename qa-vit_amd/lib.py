@@ -32,7 +32,7 @@ class CgaArgs(C.Structure):
         ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("G", i32), ("H", i32), ("D", i32), ("S", i32),
         ("x", vp), ("ldx", i64), ("wqkv_rm", vp), ("bqkv", vp), ("wproj_rm", vp), ("bproj", vp), ("sh_k", vp), ("sh_v", vp),
         ("out", vp), ("ldo", i64), ("o_save", vp),
-        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp), ("nan_flag", vp),
+        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp), ("nan_flag", vp), ("nan_trip", vp),
     ]
 
 
@@ -58,7 +58,7 @@ class CgaBwdArgs(C.Structure):
         ("dout", vp), ("lddout", i64), ("x", vp), ("ldx", i64), ("wqkv_rm", vp), ("wqkvT_rm", vp), ("bqkv", vp), ("wprojT_rm", vp),
         ("sh_k", vp), ("sh_v", vp),
         ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
-        ("dz", vp), ("lddz", i64), ("dqkv", vp), ("dx", vp), ("lddx", i64), ("parts", vp),
+        ("dz", vp), ("lddz", i64), ("dqkv", vp), ("dx", vp), ("lddx", i64), ("parts", vp), ("nan_trip", vp),
     ]
 
 
@@ -70,7 +70,7 @@ class BranchBwdArgs(C.Structure):
         ("E_k", vp), ("E_v", vp), ("sh_k", vp), ("sh_v", vp),
         ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
         ("dz", vp), ("lddz", i64), ("dq", vp), ("lddq", i64), ("dk_tok", vp), ("dv_tok", vp), ("lddkv", i64),
-        ("parts", vp), ("parts_stride", i64),
+        ("parts", vp), ("parts_stride", i64), ("nan_trip", vp),
     ]
 
 
@@ -104,7 +104,7 @@ class BranchArgs(C.Structure):
         ("out", vp), ("ldo", i64), ("o_save", vp),
         ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
         ("nan_flag", vp), ("reserved", i32),
-        ("q_save", vp), ("ldq_save", i64), ("kv_save", vp), ("ldkv_save", i64), ("pooled_save", vp),
+        ("q_save", vp), ("ldq_save", i64), ("kv_save", vp), ("ldkv_save", i64), ("pooled_save", vp), ("nan_trip", vp),
     ]
 
 
@@ -135,7 +135,7 @@ _SIGS = {
     "qavit_layernorm_bwd_multi": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_parts": (i32, [i32, i32]),
-    "qavit_branch_bwd_parts": (i32, [i32]),
+    "qavit_branch_bwd_parts": (i32, [i32, i32]),
     "qavit_cga_supported": (i32, [i32, i32, i32, i32, i32]),
     "qavit_cga_fwd": (i32, [vp, vp]),
     "qavit_cga_bwd_parts": (i32, [i32]),

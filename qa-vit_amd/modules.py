@@ -130,11 +130,13 @@ class EfficientSpatialWindowAttention(_Branch):
                 return t
             tbl = K.Runtime.get(x.device).table(("win", Hs, ws), build)
         p = self.dropout.p if self.training else 0.0
-        if nw == 1 and F.branch_ok(0, x, N, self.linformer.compressed_len, self.global_bank.bank_size, self.num_heads):
-            # one window = the image's tokens: the whole branch is one launch (csrc/branch_fwd.hip)
+        if ((nw == 1 and N == 16) or (nw == 2 and N == 64)) and ws == 4 and self.linformer.seq_len == 16 and \
+                F.branch_ok(0, x, 16, self.linformer.compressed_len, self.global_bank.bank_size, self.num_heads):
+            # 16 tokens: one window = the image's tokens; 64 tokens: the four windows of the 8x8 grid, gathered in the kernel -- the whole
+            # branch is one launch either way (csrc/branch_fwd.hip)
             out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
                                    self.global_bank.global_k, self.global_bank.global_v,
-                                   dict(kind=0, attn_drop=(p, self._site_attn), proj_drop=(p, self._site), bank_snap=self._snap()))
+                                   dict(kind=0, attn_drop=(p, self._site_attn), proj_drop=(p, self._site), bank_snap=self._snap(), win_tbl=tbl))
             self._write(out)
             return out
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias).reshape(B * N, 3 * C)
@@ -188,7 +190,8 @@ class EfficientMultiScaleDilatedAttention(_Branch):
         NP = idx.numel() // stride
         p = self.dropout.p if self.training else 0.0
         same = x_q is x or (x_q.data_ptr() == x.data_ptr() and x_q.shape == x.shape and x_q.stride() == x.stride())
-        if same and NP <= 16 and F.branch_ok(1, x, NP, self.linformer.compressed_len, self.global_bank.bank_size, self.num_heads):
+        if same and NP <= (48 if N == 64 else 16) and NP <= self.linformer.seq_len and \
+                F.branch_ok(1, x, NP, self.linformer.compressed_len, self.global_bank.bank_size, self.num_heads):
             out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
                                    self.global_bank.global_k, self.global_bank.global_v,
                                    dict(kind=1, pool_idx=idx, pool_stride=stride, Lk=NP, attn_drop=(p, self._site_attn), proj_drop=(p, self._site),

@@ -797,6 +797,11 @@ def _branch_reference(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, idx, st
     """The reference chain in fp32 torch (HQAViT_CIFAR100.py:441-469 / :496-532 / :613-626 without the bank write)."""
     B, T, C = x.shape
     H, D = 4, C // 4
+    if kind == 0 and T == 64:          # window_partition (HQAViT_IN_Tiny.py:756-769): four 4x4 windows = four problems; window_reverse below
+        xw = x.view(B, 2, 4, 2, 4, C).permute(0, 1, 3, 2, 4, 5).reshape(B * 4, 16, C)
+        out, o = _branch_reference(kind, xw, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, idx, stride, keep, p_attn)
+        rev = lambda t: t.view(B, 2, 2, 4, 4, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 64, C)
+        return rev(out), rev(o)
     if kind == 2:
         q = TF.linear(x, wqkv, bqkv).view(B, T, H, D).transpose(1, 2)
         k = bk.view(1, -1, H, D).transpose(1, 2).expand(B, -1, -1, -1)
@@ -822,17 +827,45 @@ def _branch_reference(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, idx, st
     return TF.linear(o, wproj, bproj), o
 
 
+def _msda_idx(T, stride=2, dil=(1, 2)):
+    """MSDA's landmark source rows (HQAViT_CIFAR100.py:497-501): dilated grids concatenated, cut to a multiple of the pooling stride."""
+    Hs = int(round(T ** 0.5))
+    t = [y * Hs + xx for d in dil for y in range(0, Hs, d) for xx in range(0, Hs, d)]
+    t = t[: (len(t) // stride) * stride]
+    return torch.tensor(t, dtype=torch.int32, device=DEV), len(t) // stride
+
+
+def _win_tbl(T):
+    """Row table of window_partition with window 4 on the sqrt(T) grid (what modules.EfficientSpatialWindowAttention builds)."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    Hs, ws = int(round(T ** 0.5)), 4
+    nw = Hs // ws
+    return K.Runtime.get(0).table(("win", Hs, ws), lambda: [(wy * ws + ty) * Hs + wx * ws + tx for wy in range(nw) for wx in range(nw) for ty in range(ws) for tx in range(ws)])
+
+
+def _attn_keep(seed, step, site, kind, B, T, H, NK, drop):
+    """The attention-dropout mask of a fused branch in the torch reference's batch order: SWA on 64 tokens = B * 4 window problems of 16
+    queries; everything else B problems of T queries."""
+    from conftest import attn_keep_mask
+    if drop <= 0:
+        return None
+    G, Nq = (B * (T // 16), 16) if kind == 0 else (B, T)
+    return torch.from_numpy(attn_keep_mask(seed, step, site, G, H, Nq, NK, drop)).to(DEV)
+
+
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-@pytest.mark.parametrize("B", [5, 64, 1030])
+@pytest.mark.parametrize("B,T", [(5, 16), (64, 16), (1030, 16), (3, 64), (130, 64)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_fused_branch_forward(F, Q, kind, B, drop):
+def test_fused_branch_forward(F, Q, kind, B, T, drop):
     """bf16 fused branch against the fp32 torch chain on the same (bf16-rounded) inputs; with dropout the reference uses the
     exact masks the kernel drew (attention mask from the host RNG replica; proj mask read off the kept entries).
-    B = 5: a ragged last tile (4 images per workgroup); B = 1030: more tiles than one round of workgroups."""
+    T = 16, B = 5: a ragged last tile (4 images per workgroup); B = 1030: more tiles than one round of workgroups.
+    T = 64 (Tiny-ImageNet's 64 learned tokens / QA-ViT at 32 px): SWA over the four 4x4 windows of the 8x8 grid, MSDA with 40 landmarks
+    (three landmark tiles, one key side per image), cross-attention over 64 queries."""
     import importlib
-    from conftest import attn_keep_mask
     K = importlib.import_module("qa-vit_amd.kernels")
-    T, C, H, S, KC = 16, 192, 4, 16, 32
+    C, H, S, KC = 192, 4, 16, 32
     x = leaf(B, T, C, seed=300).detach().to(torch.bfloat16)
     n_qkv = C if kind == 2 else 3 * C
     wqkv, bqkv = leaf(n_qkv, C, scale=0.08, seed=301).detach(), leaf(n_qkv, scale=0.1, seed=302).detach()
@@ -844,18 +877,14 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
         Ek, Ev = leaf(rows, KC, scale=0.3, seed=305).detach(), leaf(rows, KC, scale=0.3, seed=306).detach()
         Lk = 16
     if kind == 1:
-        t = [y * 4 + xx for d in (1, 2) for y in range(0, 4, d) for xx in range(0, 4, d)]
         stride = 2
-        t = t[: (len(t) // stride) * stride]
-        idx = torch.tensor(t, dtype=torch.int32, device=DEV)
-        Lk = len(t) // stride
+        idx, Lk = _msda_idx(T, stride)
+        assert Lk == (10 if T == 16 else 40)
     bk, bv = leaf(1, S, C, scale=0.5, seed=307).detach(), leaf(1, S, C, scale=0.5, seed=308).detach()
     sa, sp = K.new_site(), K.new_site()
     seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
     NK = S if kind == 2 else KC + S
-    keep = None
-    if drop > 0:
-        keep = torch.from_numpy(attn_keep_mask(seed, step, sa, B, H, T, NK, drop)).to(DEV)
+    keep = _attn_keep(seed, step, sa, kind, B, T, H, NK, drop)
     out, o = F.branch_forward(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk.reshape(S, C), bv.reshape(S, C), idx, stride, Lk,
                               attn_drop=(drop, sa), proj_drop=(drop, sp), want_o=True)
     wq_r, wp_r = wqkv.to(torch.bfloat16).float(), wproj.to(torch.bfloat16).float()         # the kernel reads bf16 weights
@@ -874,8 +903,8 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
         assert rel(out, ref) <= 3e-2
     # the projections the kernel saves for the backward pass (k / v through its second, transposed MFMA)
     if drop == 0.0:
-        out_s, o_s, saved = F.branch_forward(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk.reshape(S, C), bv.reshape(S, C), idx, stride, Lk,
-                                             want_o=True, save=True)
+        out_s, o_s, saved, _trip = F.branch_forward(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk.reshape(S, C), bv.reshape(S, C), idx, stride, Lk,
+                                                    want_o=True, save=True)
         assert torch.equal(out_s, out) and torch.equal(o_s, o)
         xf32 = x.float().reshape(B * T, C)
         if kind == 0:
@@ -891,7 +920,10 @@ def test_fused_branch_forward(F, Q, kind, B, drop):
     if drop == 0.0:
         if kind == 0:
             qkv = F.linear(x, wqkv, bqkv).reshape(B * T, 3 * C)
-            spec = dict(mode=0, G=B, Nq=T, L=T, H=H, D=C // H, KC=KC, S=S, groups_per_b=1, q_rows_per_b=T, k_rows_per_b=T, q_off=0, k_off=C, v_off=2 * C, q_rows=B * T)
+            nwin = T // 16
+            tbl = _win_tbl(T) if nwin > 1 else None
+            spec = dict(mode=0, G=B * nwin, Nq=16, L=16, H=H, D=C // H, KC=KC, S=S, groups_per_b=nwin, q_rows_per_b=T, k_rows_per_b=T, q_tbl=tbl, k_tbl=tbl,
+                        q_off=0, k_off=C, v_off=2 * C, q_rows=B * T)
             o2 = F.AttnFn.apply(qkv, None, Ek, Ev, bk, bv, spec)
         elif kind == 1:
             pooled = F.GatherPoolFn.apply(x, idx, stride)
@@ -914,26 +946,22 @@ def _proj_keep(seed, step, site, rows, C, p):
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-@pytest.mark.parametrize("B", [5, 64, 1030])
+@pytest.mark.parametrize("B,T", [(5, 16), (64, 16), (1030, 16), (3, 64), (130, 64)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_fused_branch_backward(F, Q, kind, B, drop):
+def test_fused_branch_backward(F, Q, kind, B, T, drop):
     """BranchFn's backward through the fused kernel (proj input gradient + attention-core backward in one launch, csrc/branch_bwd.hip)
     (1) against fp32 torch autograd of the reference chain (HQAViT_CIFAR100.py:441-469 / :496-532 / :613-626) on the same bf16-rounded
     operands with the EXACT dropout masks the kernels drew (attention mask and proj mask from the host RNG replica), every gradient
     compared directly: x, both weights and biases, the Linformer matrices, the shared (bank) rows; and (2) against its backward through
     the unfused kernels (same forward launch, same masks, same saved projections: the two differ only in where bf16 roundings fall)."""
     import importlib
-    from conftest import attn_keep_mask
     K = importlib.import_module("qa-vit_amd.kernels")
-    T, C, H, S, KC = 16, 192, 4, 16, 32
+    C, H, S, KC = 192, 4, 16, 32
     n_qkv = C if kind == 2 else 3 * C
     idx, stride, Lk = None, 0, 0
     if kind == 1:
-        t = [y * 4 + xx for d in (1, 2) for y in range(0, 4, d) for xx in range(0, 4, d)]
         stride = 2
-        t = t[: (len(t) // stride) * stride]
-        idx = torch.tensor(t, dtype=torch.int32, device=DEV)
-        Lk = len(t) // stride
+        idx, Lk = _msda_idx(T, stride)
     sa, sp = K.new_site(), K.new_site()
     seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
     gout = leaf(B, T, C, seed=399).detach().to(torch.bfloat16)
@@ -954,6 +982,8 @@ def test_fused_branch_backward(F, Q, kind, B, drop):
         meta = dict(kind=kind, attn_drop=(drop, sa), proj_drop=(drop, sp))
         if kind == 1:
             meta.update(pool_idx=idx, pool_stride=stride, Lk=Lk)
+        if kind == 0 and T == 64:
+            meta.update(win_tbl=_win_tbl(T))
         old = F._BRANCH_BWD
         F._BRANCH_BWD = fused
         try:
@@ -974,7 +1004,7 @@ def test_fused_branch_backward(F, Q, kind, B, drop):
         assert rel(g1[k_], g2[k_]) <= 3e-2, (k_, rel(g1[k_], g2[k_]))
     # ---- (1) fp32 torch autograd of the reference chain, exact masks ----
     NK = S if kind == 2 else KC + S
-    keep = torch.from_numpy(attn_keep_mask(seed, step, sa, B, H, T, NK, drop)).to(DEV) if drop > 0 else None
+    keep = _attn_keep(seed, step, sa, kind, B, T, H, NK, drop)
     r = dict(x=leaf(B, T, C, seed=300).detach().to(torch.bfloat16).float(),
              wqkv=leaf(n_qkv, C, scale=0.08, seed=301).detach().to(torch.bfloat16).float(), bqkv=leaf(n_qkv, scale=0.1, seed=302).detach(),
              wproj=leaf(C, C, scale=0.08, seed=303).detach().to(torch.bfloat16).float(), bproj=leaf(C, scale=0.1, seed=304).detach(),
@@ -1088,9 +1118,9 @@ def test_fused_cga_branch(F, Q, B, drop):
             assert k_ in g1, k_
 
 
-@pytest.mark.parametrize("B", [5, 1030])
+@pytest.mark.parametrize("B,T", [(5, 16), (1030, 16), (7, 64)])
 @pytest.mark.parametrize("kind", [0, 1, 2, "cga"])
-def test_fused_branch_nan_rule(F, Q, kind, B):
+def test_fused_branch_nan_rule(F, Q, kind, B, T):
     """efficient_attention's NaN rule (HQAViT_CIFAR100.py:356-357, :394-395) inside the fused branch kernels: one NaN in the input zeroes
     the whole attention output, so every output row is the proj bias (dropout off); the flag words are reset by the launch itself
     (last workgroup), so the next, clean launch is untouched.  B = 1030: more workgroups than one round."""
@@ -1098,7 +1128,9 @@ def test_fused_branch_nan_rule(F, Q, kind, B):
     K = importlib.import_module("qa-vit_amd.kernels")
     rt = K.Runtime.get(0)
     assert rt.nan_guard
-    T, C, S, KC = 16, 192, 16, 32
+    C, S, KC = 192, 16, 32
+    if kind == "cga" and T != 16 and not F.cga_ok(torch.empty(1, T, C, dtype=torch.bfloat16, device=DEV), 6, 4, S):
+        pytest.skip("fused channel-group kernel not built for this token count")
     x = leaf(B, T, C, seed=700).detach().to(torch.bfloat16)
     bad = x.clone()
     bad[B // 2, 7, 11] = float("nan")
@@ -1126,11 +1158,8 @@ def test_fused_branch_nan_rule(F, Q, kind, B):
             Ek, Ev = leaf(rows, KC, scale=0.3, seed=305).detach(), leaf(rows, KC, scale=0.3, seed=306).detach()
             Lk = 16
         if kind == 1:
-            t = [y * 4 + xx for d in (1, 2) for y in range(0, 4, d) for xx in range(0, 4, d)]
             stride = 2
-            t = t[: (len(t) // stride) * stride]
-            idx = torch.tensor(t, dtype=torch.int32, device=DEV)
-            Lk = len(t) // stride
+            idx, Lk = _msda_idx(T, stride)
         bk, bv = leaf(S, C, scale=0.5, seed=307).detach(), leaf(S, C, scale=0.5, seed=308).detach()
         run = lambda inp: F.branch_forward(kind, inp, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, idx, stride, Lk,
                                            attn_drop=(0.0, 0), proj_drop=(0.0, 0))
@@ -1143,6 +1172,94 @@ def test_fused_branch_nan_rule(F, Q, kind, B):
     assert torch.equal(poisoned.reshape(-1, C), bias.to(torch.bfloat16).expand(B * T, C))
     clean1 = run(x)
     assert torch.equal(clean1, clean0)
+
+
+@pytest.mark.parametrize("B,T", [(6, 16), (3, 64)])
+@pytest.mark.parametrize("kind", [0, 1, 2, "cga"])
+def test_fused_branch_nan_rule_backward(F, Q, kind, B, T):
+    """The NaN rule in the fused BACKWARD kernels: efficient_attention returns zeros_like(q) when it sees a NaN (HQAViT_CIFAR100.py:356-357,
+    :394-395), a tensor without history -- so after a tripped forward the gradient through the branch is exactly zero for x, the q/k/v
+    weights, the Linformer matrices and the bank rows; dW_proj = dz^T 0 = 0; only db_proj = colsum(dout) flows (proj(0) = bias).
+    The next, clean call through the same kernels has ordinary gradients."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    M = importlib.import_module("qa-vit_amd.modules")
+    rt = K.Runtime.get(0)
+    assert rt.nan_guard
+    C, S, KC = 192, 16, 32
+    gout = leaf(B, T, C, seed=811).detach().to(torch.bfloat16)
+    if kind == "cga":
+        if not F.cga_ok(torch.empty(1, T, C, dtype=torch.bfloat16, device=DEV), 6, 4, S):
+            pytest.skip("fused channel-group kernel not built for this token count")
+        cfg = Q.HQAViTConfig()
+        cfg.dropout = 0.0
+        bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+        ctx = M._Ctx("hqa")
+        ctx.bank_writes = False
+        mod = M.EfficientChannelGroupAttention(cfg, bank, ctx).to(DEV).train()
+        params = dict(mod.named_parameters())
+        params = {n: p for n, p in params.items() if not n.startswith("norm.") and ("global_bank." not in n or n.endswith(("global_k", "global_v")))}
+        run = lambda inp: mod(inp)
+        pbias, pw = "proj.bias", "proj.weight"
+    else:
+        n_qkv = C if kind == 2 else 3 * C
+        params = dict(wqkv=leaf(n_qkv, C, scale=0.08, seed=301), bqkv=leaf(n_qkv, scale=0.1, seed=302), wproj=leaf(C, C, scale=0.08, seed=303), bproj=leaf(C, scale=0.3, seed=304),
+                      bk=leaf(1, S, C, scale=0.5, seed=307), bv=leaf(1, S, C, scale=0.5, seed=308))
+        Ek = Ev = idx = None
+        stride, Lk = 0, 0
+        if kind != 2:
+            rows = 16 if kind == 0 else 128
+            params.update(Ek=leaf(rows, KC, scale=0.3, seed=305), Ev=leaf(rows, KC, scale=0.3, seed=306))
+        meta = dict(kind=kind, attn_drop=(0.0, 0), proj_drop=(0.0, 0))
+        if kind == 1:
+            stride = 2
+            idx, Lk = _msda_idx(T, stride)
+            meta.update(pool_idx=idx, pool_stride=stride, Lk=Lk)
+        if kind == 0 and T == 64:
+            meta.update(win_tbl=_win_tbl(T))
+
+        def run(inp):
+            sk, sv = params["bk"], params["bv"]
+            if kind == 2:
+                sk, sv = (sk * 1.0).reshape(S, C), (sv * 1.0).reshape(S, C)
+            return F.BranchFn.apply(inp, params["wqkv"], params["bqkv"], params["wproj"], params["bproj"], params.get("Ek"), params.get("Ev"), sk, sv, meta)
+        pbias, pw = "bproj", "wproj"
+    x0 = leaf(B, T, C, seed=810).detach().to(torch.bfloat16)
+    clean_bk = None if kind == "cga" else params["bk"].detach().clone()
+    for poisoned in (True, False):
+        x = x0.clone()
+        # the NaN enters through the shared key rows (k_full has a NaN; x stays clean so that "zero" is checkable for the q/k/v weights:
+        # their gradient GEMM multiplies the zero dq/dk/dv with x).  Channel-group branch: through x itself (its shared rows are
+        # projections of the bank computed upstream); there the q/k/v weight gradients are 0 . NaN and are not checked.
+        if kind == "cga":
+            if poisoned:
+                x[B // 2, 5, 17] = float("nan")
+        else:
+            with torch.no_grad():
+                params["bk"].copy_(clean_bk)
+                if poisoned:
+                    params["bk"][0, 3, 40] = float("nan")
+        x.requires_grad_(True)
+        for p_ in params.values():
+            p_.grad = None
+        out = run(x)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        assert rt.nan_flag.tolist() == [0, 0]
+        if poisoned:
+            assert torch.equal(out.detach().reshape(-1, C), params[pbias].detach().to(torch.bfloat16).expand(B * T, C))
+            assert float(x.grad.float().abs().max()) == 0.0
+            for n, p_ in params.items():
+                if n == pbias:
+                    assert rel(p_.grad, gout.float().reshape(-1, C).sum(0)) <= 1e-2
+                elif kind == "cga" and n in ("q_proj.weight", "k_proj.weight", "v_proj.weight"):
+                    continue
+                else:
+                    assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, n
+        else:
+            assert torch.isfinite(x.grad.float()).all() and float(x.grad.float().abs().max()) > 0
+            for n, p_ in params.items():
+                assert p_.grad is not None and torch.isfinite(p_.grad).all() and float(p_.grad.abs().max()) > 0, n
 
 
 @pytest.mark.parametrize("B", [3, 64, 1030])
