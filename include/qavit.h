@@ -349,7 +349,7 @@ int qavit_branch_bwd(const qavit_branch_bwd_args* a, void* stream);
  * problems: per image, for each of the G = 6 channel groups (32 channels) q / k / v = Linear(32 -> 16) of the group's slice of x,
  * 4 heads of D = 4 over [16 token keys ; 16 projected bank rows], softmax (+ attention dropout), P.V, then proj(96 -> 192) + bias
  * (+ dropout) over the concatenated groups -- ONE launch instead of qkv GEMM, attention kernel, NaN guard and proj GEMM.
- * Fixed shapes: T = 16, C = 192, G = 6, H = 4, D = 4, S = 16; bf16.  wqkv_rm = [Wq; Wk; Wv] stacked [48, 32] bf16 row-major,
+ * Fixed shapes: T = 16 or 64 (csrc/cga64.hip: 64 token keys + 16 bank rows per (group, head)), C = 192, G = 6, H = 4, D = 4, S = 16; bf16.  wqkv_rm = [Wq; Wk; Wv] stacked [48, 32] bf16 row-major,
  * wproj_rm = [192, 96] bf16 row-major (both from qavit_pack_weights), biases fp32, sh_k / sh_v = the bank projections [16, 16] fp32.
  * Dropout contracts as the unfused chain (attention: problem id = (image * 6 + group) * 4 + head; proj: row * C + col);
  * nan_flag as in qavit_branch_args.  o_save (optional) [B*16, 96]: the attention output, operand of backward's dW_proj.
@@ -391,7 +391,7 @@ typedef struct qavit_cga_bwd_args {
   float* parts;
   const int* nan_trip;   /* optional: the forward's nan_trip word; != 0: dqkv = dx = 0 and zero partial sums (dz is still written) */
 } qavit_cga_bwd_args;
-int qavit_cga_bwd_parts(int B);
+int qavit_cga_bwd_parts(int B, int T);   /* workgroups = rows of `parts`: ceil(B / 4) for T = 16, B for T = 64 */
 int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@
 
 namespace qv {
 
+int cga64_fwd_launch(const qavit_cga_args* a, hipStream_t st);       // cga64.hip: the same branch on 64-token problems
+int cga64_bwd_launch(const qavit_cga_bwd_args* a, hipStream_t st);
 void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag,
                            int* trip, void* o_save, int64_t ldos, int Co, hipStream_t st);
 
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
 int cga_validate(const qavit_cga_args* a) {
   if (!a) return set_error(QAVIT_EINVAL, "cga: null args");
   if (a->dtype != QAVIT_BF16) return set_error(QAVIT_EINVAL, "cga: the fused channel-group kernel is bf16 only");
-  if (a->T != CT || a->C != CC || a->G != CG || a->H != CH || a->D != CD || a->S != CS)
-    return set_error(QAVIT_EINVAL, "cga: built for 16 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
+  if ((a->T != CT && a->T != 64) || a->C != CC || a->G != CG || a->H != CH || a->D != CD || a->S != CS)
+    return set_error(QAVIT_EINVAL, "cga: built for 16 or 64 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
   if (a->B <= 0 || !a->x || !a->out || !a->wqkv_rm || !a->wproj_rm || !a->bqkv || !a->bproj || !a->sh_k || !a->sh_v) return set_error(QAVIT_EINVAL, "cga: null operand");
   if (a->nan_trip && !a->nan_flag) return set_error(QAVIT_EINVAL, "cga: nan_trip is written by the NaN-rule launch, which needs nan_flag");
   auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
@@ -482,13 +484,13 @@ int cga_validate(const qavit_cga_args* a) {
 
 using namespace qv;
 
-extern "C" int qavit_cga_bwd_parts(int B) { return B > 0 ? (B + CNI - 1) / CNI : 0; }
+extern "C" int qavit_cga_bwd_parts(int B, int T) { return B > 0 ? (T == 64 ? B : (B + CNI - 1) / CNI) : 0; }
 
 extern "C" int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream) {
   if (!a) return set_error(QAVIT_EINVAL, "cga_bwd: null args");
   if (a->dtype != QAVIT_BF16) return set_error(QAVIT_EINVAL, "cga_bwd: bf16 only");
-  if (a->T != CT || a->C != CC || a->G != CG || a->H != CH || a->D != CD || a->S != CS)
-    return set_error(QAVIT_EINVAL, "cga_bwd: built for 16 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
+  if ((a->T != CT && a->T != 64) || a->C != CC || a->G != CG || a->H != CH || a->D != CD || a->S != CS)
+    return set_error(QAVIT_EINVAL, "cga_bwd: built for 16 or 64 tokens x 192 channels, 6 groups, 4 heads of 4, 16 bank rows");
   if (a->B <= 0 || !a->x || !a->dout || !a->wqkv_rm || !a->wqkvT_rm || !a->wprojT_rm || !a->bqkv || !a->sh_k || !a->sh_v || !a->dqkv || !a->dx || !a->parts)
     return set_error(QAVIT_EINVAL, "cga_bwd: null operand");
   if (a->proj_drop_p > 0.f && a->rng && !a->dz) return set_error(QAVIT_EINVAL, "cga_bwd: proj dropout needs dz");
@@ -498,6 +500,7 @@ extern "C" int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream) {
     return set_error(QAVIT_EINVAL, "cga_bwd: alignment (activations 16 bytes / ld % 8; weights, dqkv, dx 8 bytes; biases, bank rows, parts 16 bytes)");
   static_assert(CGA_PART == QAVIT_CGA_PARTS_FLOATS, "header constant out of date");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->T == 64) return cga64_bwd_launch(a, st);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cga_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_CGA_BWD);
@@ -507,12 +510,13 @@ extern "C" int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream) {
   return check_launch("cga_bwd");
 }
 
-extern "C" int qavit_cga_supported(int T, int C, int G, int H, int S) { return (T == CT && C == CC && G == CG && H == CH && S == CS) ? 1 : 0; }
+extern "C" int qavit_cga_supported(int T, int C, int G, int H, int S) { return ((T == CT || T == 64) && C == CC && G == CG && H == CH && S == CS) ? 1 : 0; }
 
 extern "C" int qavit_cga_fwd(const qavit_cga_args* a, void* stream) {
   int rc = cga_validate(a);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->T == 64) return cga64_fwd_launch(a, st);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cga_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_CGA);

@@ -1008,7 +1008,7 @@ def _cga_backward_fused(ctx, dout, x, wq, bq, wk, bk, wv, bv, wproj, bproj, shk,
     _, WpT = pk.get(wproj, x.dtype)
     dqkv = torch.empty(M, 3 * ccg, dtype=x.dtype, device=x.device)
     dx = torch.empty(B * T, Cc, dtype=x.dtype, device=x.device)
-    nparts = int(L.load().qavit_cga_bwd_parts(B))
+    nparts = int(L.load().qavit_cga_bwd_parts(B, T))
     parts = torch.empty(nparts * 512, dtype=torch.float32, device=x.device)
     a = L.CgaBwdArgs()
     a.dtype = K.dt_code(x.dtype)
@@ -1539,6 +1539,8 @@ class CompressFuseFn(Function):
         means = [torch.empty(M, dtype=torch.float32, device=dev) for _ in range(nb)]
         rstds = [torch.empty(M, dtype=torch.float32, device=dev) for _ in range(nb)]
         T_ = args[0].shape[-2] if args[0].dim() >= 2 else 0
+        if T_ > 16 and T_ % 16 == 0:
+            T_ = 16                                         # the node is token-wise: 64 tokens per image = four 16-token problems to the kernel
         if (_CFUSE and dt == torch.bfloat16 and nb == 4 and M % max(T_, 1) == 0 and all(a_ is not None for a_ in args[:20])
                 and L.load().qavit_compress_fuse_supported(T_, Kd, nb, Cb)):
             # norms, compress Linears, concat and fusion scaling in ONE launch (csrc/cfuse.hip)
@@ -1592,6 +1594,8 @@ class CompressFuseFn(Function):
         if fbuf is None:
             fbuf = torch.zeros(nb, dtype=torch.float32, device=dev)
         T_ = xshape[-2] if len(xshape) >= 2 else 0
+        if T_ > 16 and T_ % 16 == 0:
+            T_ = 16
         gs_all = [grad_sink(prm[4 * i]) for i in range(nb)]
         bs_all = [grad_sink(prm[4 * i + 1]) for i in range(nb)]
         if (_CFUSE_BWD and dt == torch.bfloat16 and nb == 4 and T_ > 0 and all(g_[0] is not None for g_ in gs_all) and all(b_[0] is not None for b_ in bs_all)

@@ -138,7 +138,7 @@ _SIGS = {
     "qavit_branch_bwd_parts": (i32, [i32, i32]),
     "qavit_cga_supported": (i32, [i32, i32, i32, i32, i32]),
     "qavit_cga_fwd": (i32, [vp, vp]),
-    "qavit_cga_bwd_parts": (i32, [i32]),
+    "qavit_cga_bwd_parts": (i32, [i32, i32]),
     "qavit_compress_fuse_supported": (i32, [i32, i32, i32, i32]),
     "qavit_compress_fuse_fwd": (i32, [vp, vp]),
     "qavit_compress_fuse_bwd_parts": (i32, [i32]),

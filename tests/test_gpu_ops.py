@@ -1044,8 +1044,8 @@ def _cga_reference(x, P, G, H, keep, p_attn):
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.1])
-@pytest.mark.parametrize("B", [3, 64, 1030])
-def test_fused_cga_branch(F, Q, B, drop):
+@pytest.mark.parametrize("B,T", [(3, 16), (64, 16), (1030, 16), (3, 64), (130, 64)])
+def test_fused_cga_branch(F, Q, B, T, drop):
     """The channel-group branch through the fused kernel (csrc/cga.hip: q/k/v projections of the six groups, 4 heads of D = 4 over
     tokens + projected bank rows, softmax + dropout, P.V, proj + dropout in one launch) against the unfused chain of the same module:
     identical dropout masks (same sites / counters), so outputs and every gradient agree to bf16 rounding."""
@@ -1055,8 +1055,9 @@ def test_fused_cga_branch(F, Q, B, drop):
     cfg = Q.HQAViTConfig()
     cfg.dropout = drop
     res = []
-    x0 = leaf(B, 16, cfg.embed_dim, seed=600).detach().to(torch.bfloat16)
-    g0 = leaf(B, 16, cfg.embed_dim, seed=601).detach().to(torch.bfloat16)
+    x0 = leaf(B, T, cfg.embed_dim, seed=600).detach().to(torch.bfloat16)
+    g0 = leaf(B, T, cfg.embed_dim, seed=601).detach().to(torch.bfloat16)
+    assert F.cga_ok(x0, cfg.num_channel_groups, cfg.num_heads, cfg.global_bank_size)
     for fused in (True, "fwd", False):                         # fused forward + fused backward / fused forward only / unfused chain
         torch.manual_seed(1)
         bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
@@ -1089,7 +1090,7 @@ def test_fused_cga_branch(F, Q, B, drop):
     # ---- fp32 torch autograd of the reference module (HQAViT_CIFAR100.py:559-595) on the bf16-rounded operands, exact masks ----
     from conftest import attn_keep_mask
     seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
-    T, C, G, H, S = 16, cfg.embed_dim, cfg.num_channel_groups, cfg.num_heads, cfg.global_bank_size
+    C, G, H, S = cfg.embed_dim, cfg.num_channel_groups, cfg.num_heads, cfg.global_bank_size
     keep = torch.from_numpy(attn_keep_mask(seed, step, 9002, B * G, H, T, T + S, drop)).to(DEV) if drop > 0 else None
     keep_p = _proj_keep(seed, step, 9001, B * T, C, drop).reshape(B, T, C).float() if drop > 0 else None
     torch.manual_seed(1)
@@ -1262,11 +1263,12 @@ def test_fused_branch_nan_rule_backward(F, Q, kind, B, T):
                 assert p_.grad is not None and torch.isfinite(p_.grad).all() and float(p_.grad.abs().max()) > 0, n
 
 
-@pytest.mark.parametrize("B", [3, 64, 1030])
-def test_fused_compress_fuse(F, Q, B):
+@pytest.mark.parametrize("B,T", [(3, 16), (64, 16), (1030, 16), (3, 64), (130, 64)])
+def test_fused_compress_fuse(F, Q, B, T):
     """CompressFuseFn through the one-launch forward (csrc/cfuse.hip: four LayerNorms, four Linear(192 -> 48), concat, softmax-weighted
-    scaling) against the three-launch forward, and both against torch; the backward (shared) runs on what each forward saved."""
-    T, C, Cb, nb = 16, 192, 48, 4
+    scaling) against the three-launch forward, and both against torch; the backward (shared) runs on what each forward saved.
+    T = 64: the node is token-wise, an image's 64 tokens go to the kernel as four 16-token problems."""
+    C, Cb, nb = 192, 48, 4
     outs = []
     for fused in (True, "fwd", False):                         # fused forward + backward / fused forward only / unfused
         xs = [leaf(B, T, C, seed=700 + i).detach().to(torch.bfloat16).requires_grad_(True) for i in range(nb)]
