@@ -48,7 +48,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--config", default="c100", choices=["c100", "tin"], help="c100 = the BASELINE metric's model (default); tin = HQAViT_IN_Tiny defaults (64x64, 200 classes)")
+    ap.add_argument("--config", default="c100", choices=["c100", "tin", "q32"], help="c100 = the BASELINE metric's model (default); tin = HQAViT_IN_Tiny defaults (64x64, 200 classes); "
+                    "q32 = BASELINE config 2: QAViT.py at 32 px (N = 64 tokens, no TokenLearner), forward only (use with --eval, --batch 512)")
+    ap.add_argument("--eval", action="store_true", help="forward-only in eval mode (q32: BASELINE config 2)")
+    ap.add_argument("--variant", default="v1", choices=["v1", "v2"], help="q32: QAViT.py (v1) or QAViTv2.py (v2) block variant")
     ap.add_argument("--mix", action="store_true", help="include device-side CutMix/MixUp + mixed loss in the step (off: the BASELINE metric)")
     ap.add_argument("--fwd-bwd-only", action="store_true", help="time forward+backward(+all-reduce) without the optimiser")
     return ap.parse_args()
@@ -240,8 +243,134 @@ def cpu_baseline(batch=32, budget_s=20.0, tin=False):
             "sample": f"HQA-ViT {'Tiny-ImageNet' if tin else 'CIFAR-100'} train fwd+bwd, B={batch}, fp32, {len(times)} timed steps after 2 warm-up, median {med * 1e3:.0f} ms/step"}
 
 
+QA32_MFLOP_PER_IMG_EVAL = 709.9    # QA-ViT (img 32, patch 4, window 4, dilations (1,2), linformer_k 32) eval forward
+
+
+def cpu_baseline_q32(variant, budget_s=20.0):
+    """CPU oracle timed on this host: QA-ViT@32 eval forward on a bounded sample (B = 64)."""
+    import qavit_amd as Q
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import qavit_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = max(1, min(cores, int(os.environ.get("QAVIT_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    cfg = Q.qavit32_config()
+    model = Q.QAViT(cfg, variant)
+    Q.fill_module(model)
+    P = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in list(P):
+        if k.endswith(("global_bank.global_k", "global_bank.global_v", "global_bank.update_count")):
+            P[k] = P["global_bank." + k.rsplit(".", 1)[-1]]
+    g = torch.Generator().manual_seed(1234)
+    batch = 64
+    x = torch.randn(batch, 3, 32, 32, generator=g)
+    times, t_start, it = [], time.time(), 0
+    with torch.no_grad():
+        while True:
+            t0 = time.time()
+            O.qavit_forward(P, x, cfg, train=False, variant=variant)
+            dt = time.time() - t0
+            if it >= 2:
+                times.append(dt)
+            it += 1
+            if (time.time() - t_start > budget_s and len(times) >= 3) or len(times) >= 12:
+                break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(batch / med, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"QA-ViT@32 ({variant}) eval forward, B={batch}, fp32, {len(times)} timed passes after 2 warm-up, median {med * 1e3:.0f} ms"}
+
+
+def bench_q32_eval(args):
+    """BASELINE.json configs[1]: QAViT.py forward-only on a synthetic 32x32x3 batch of 512, one GPU, eval mode, one hipGraph per pass."""
+    import qavit_amd as Q
+    Q.lib.load()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B = args.batch
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg = Q.qavit32_config()
+    model = Q.QAViT(cfg, args.variant)
+    Q.fill_module(model)
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=cdt == torch.bfloat16):
+            return model(x)
+    mode = "eager"
+    run = fwd
+    out = None
+    if not args.no_graph:
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(3):
+                fwd()
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out = fwd()
+        run = gr.replay
+        mode = "hipgraph"
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if out is None:
+        out = fwd()
+    ms = dt / args.steps * 1e3
+    value = B * args.steps / dt
+    tfl = value * QA32_MFLOP_PER_IMG_EVAL * 1e6 / 1e12
+    res = {
+        "metric": "eval images/sec (forward only) QA-ViT 32x32", "value": round(value, 1), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"QAViT.py ({args.variant}) forward only, eval mode (BASELINE config 2)", "weights": f"qavit32_config(): img 32, patch 4, window 4, dilations (1,2), linformer_k 32; "
+                   f"{sum(p.numel() for p in model.parameters()):,} parameters, random-init (key-seeded filler)", "global_batch": B, "per_gpu_batch": B, "image": "32x32x3", "parallelism": "dp1",
+                   "launch": mode, "finite": bool(torch.isfinite(out.float()).all()), "algorithmic_tflops_per_s": round(tfl, 2), "algorithmic_mfma_frac": round(tfl / PEAK_BF16_TFLOPS, 5)},
+    }
+    if not args.no_kernel_timing:
+        import importlib
+        lib = importlib.import_module("qa-vit_amd.lib").load()
+        fwd(); torch.cuda.synchronize()
+        with KernelTimer(lib) as kt:
+            fwd()
+            fam = kt.summary()
+        name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        tfl_k = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        peak_fl = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+        mfma_bound = (tfl_k / peak_fl) >= (gbs / PEAK_HBM_GBS)
+        ach, peak, unit = (tfl_k, peak_fl, "TFLOP/s") if mfma_bound else (gbs, PEAK_HBM_GBS, "GB/s")
+        res["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
+                           "traffic": None, "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
+                           "device_ms_per_step_all_entry_points": round(sum(v["ms"] for v in fam.values()), 3),
+                           "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3)} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:10]}}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_q32(args.variant)
+    print(json.dumps(res))
+
+
 def main():
     args = parse()
+    if args.config == "q32":
+        if not args.eval:
+            raise SystemExit("--config q32 is BASELINE config 2 (forward only): run it with --eval [--batch 512]")
+        if "--batch" not in " ".join(sys.argv):
+            args.batch = 512
+        return bench_q32_eval(args)
+    if args.eval:
+        raise SystemExit("--eval is the q32 leg (BASELINE config 2); the c100 / tin legs time the full training step")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -13,8 +13,32 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libqavit_hip.so")
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
 FLAGS += os.environ.get("QAVIT_EXTRA_HIPCC_FLAGS", "").split()       # diagnostic builds, e.g. -DQAVIT_BRANCH_STAMPS (tools/branch_stamps.py)
+
+# A spill is HBM traffic and a dependent round trip per access: no kernel of a training / inference step may use scratch memory.  The
+# build reads hipcc's per-kernel resource remarks and FAILS on a non-zero ScratchSize unless the (mangled) kernel name contains one of
+# these strings -- instantiations no shipped configuration launches:
+ALLOW_SCRATCH = (
+    "dwconv_bwd8_kernel",                 # the one-lane-per-channel 8x8 backward: superseded by dwconv_bwdt (kept for tools/bench_dw.py)
+    "layernorm_bwd_v4_kernelIfLi2", "layernorm_bwd_v4_kernelIfLi4", "layernorm_bwd_v4_kernelIDF16bLi2", "layernorm_bwd_v4_kernelIDF16bLi4",
+    "layernorm_bwd_v4_multi_kernelIfLi2",  # LayerNorm backward over 257..1024 channels: every LayerNorm of the models has C <= 256
+    "bank_stats_kernel",                  # fp32 parity path of the chunked (224 px) bank statistics
+    "sln_bwd_kernel",                     # spatial LayerNorm backward of the v2 stem at 64 rows per thread (fp32 / bf16): v2-stem variant only
+)
+
+
+def _scratch_report(stderr: str):
+    """-> [(kernel, bytes_per_lane, vgprs)] from -Rpass-analysis=kernel-resource-usage remarks."""
+    out, name, vg = [], None, 0
+    for line in stderr.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[-R")[0].strip()
+        elif "    VGPRs:" in line and "remark" in line:
+            vg = int(line.split("VGPRs:")[1].split("[")[0])
+        elif "ScratchSize [bytes/lane]:" in line and name:
+            out.append((name, int(line.split("ScratchSize [bytes/lane]:")[1].split("[")[0]), vg))
+    return out
 
 
 def _hipcc():
@@ -46,8 +70,19 @@ def build(verbose: bool = False, force: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
+        rep = _scratch_report(r.stderr)
+        bad = [(k, b) for k, b, _ in rep if b > 0 and not any(a in k for a in ALLOW_SCRATCH)]
+        if bad:
+            if "-o" in cmd and os.path.exists(cmd[cmd.index("-o") + 1]):
+                os.remove(cmd[cmd.index("-o") + 1])            # do not let a later build link the spilling object
+            raise RuntimeError("kernels with scratch memory (spills) in " + cmd[-3] + ": " + ", ".join(f"{k}: {b} B/lane" for k, b in bad))
+        if "-c" in cmd:                                        # per-kernel registers / scratch beside the object (tools read it)
+            with open(cmd[cmd.index("-o") + 1][:-2] + ".res", "w") as f:
+                f.writelines(f"{k} vgprs={v} scratch={b}\n" for k, b, v in rep)
+        if verbose:
+            other = "\n".join(l for l in r.stderr.splitlines() if "warning:" in l or "error:" in l)
+            if other.strip():
+                print(other, file=sys.stderr)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(1024) void bank_apply192_kernel(float* __restrict__
   extern __shared__ __attribute__((aligned(16))) float u[];   // [C] + fold scratch [groups][C]
   constexpr int RW = 12, KW = 3, NWV = 16, FMAX = 16;
   const int s = blockIdx.x;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform: the per-row scalars below (bias, old bank values) then take
+                                                                        // scalar loads into SGPRs -- 36 registers per lane less (the kernel spilled at 128)
   float w[RW][KW], bcr[RW], okr[RW], ovr[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) {

@@ -215,7 +215,8 @@ constexpr int SMB_WP = 0, SMB_GT = WP_FRAGS * 512, SMB_XT = SMB_GT + CNI * CT * 
 
 __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, q4 = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, q4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the per-wave tile bases and image offsets live in SGPRs (the kernel sat at 256 VGPRs + 20 B of scratch)
   bf16* swp = reinterpret_cast<bf16*>(smraw + SMB_WP);      // Wp^T fragments: (o tile, c tile): lane = o, 4 consecutive c
   const int wimg = wave >> 1, half = wave & 1;             // image wimg of the tile, channel groups 3 half .. 3 half + 2
   bf16* gt = reinterpret_cast<bf16*>(smraw + SMB_GT) + wimg * (CT * LDX);

@@ -263,6 +263,20 @@ class DeferDW:
         cls._launch()
 
     @classmethod
+    def flush_range(cls, lo: int, hi: int):
+        """Data-parallel sync point: complete the gradients stored in [lo, hi) of the flat gradient buffer (the bucket prefix about to be
+        all-reduced) and nothing else.  The bank projections' deferred backward and this stream's LayerNorm partial rows are cheap single
+        launches and are run whole; weight-gradient GEMMs outside the range and everything another stream queued wait for the end."""
+        if not cls._armed:
+            return
+        if DeferredBank.queue:
+            K.DeferredLN.flush(home_only=True)
+            DeferredBank.run()
+        K.DeferredTN.flush_range(lo, hi)
+        K.DeferredLN.flush(home_only=True)
+        K.DeferredTN.join()
+
+    @classmethod
     def flush_home(cls):
         """Launch what the arming stream has queued so far and leave the other streams' entries for the end of the pass: called where
         this stream's backward is (almost) over while another stream's chain still runs (HQAViT: the CNN lateral path's backward

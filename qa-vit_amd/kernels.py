@@ -213,6 +213,26 @@ class DeferredTN:
         cls._dirty.add(dev)
 
     @classmethod
+    def flush_range(cls, lo: int, hi: int):
+        """Launch only the queued problems of THIS stream whose destination (weight or bias gradient) lies in the address range
+        [lo, hi) -- a data-parallel sync point needs exactly the gradients of the bucket it is about to reduce; everything else (other
+        stages' problems, the lateral stream's) stays queued for the one grouped launch at the end of backward, where stream-K has the
+        most problems to balance."""
+        if not cls.queue:
+            return
+        now, keep = [], []
+        for e in cls.queue:
+            a = e[0]
+            c, cs = int(a.C or 0), int(a.colsum or 0)
+            hit = e[2] is None and ((lo <= c < hi) or (cs and lo <= cs < hi))
+            (now if hit else keep).append(e)
+        if not now:
+            return
+        cls.queue = now
+        cls.flush()
+        cls.queue = keep + cls.queue
+
+    @classmethod
     def join(cls):
         """The current stream waits for the weight-gradient stream (before anything reads .grad)."""
         if not cls._dirty:

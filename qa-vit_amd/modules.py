@@ -14,7 +14,6 @@ import os
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as TF
 
 from . import functional as F
 from . import kernels as K
@@ -525,16 +524,18 @@ def _conv1x1_tokens(t, conv: nn.Conv2d, alias: bool = False):
 
 def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool, gelu: bool = False):
     """nn.BatchNorm2d (+ nn.GELU when ``gelu``) on channel-last tokens == batch norm over the rows of [B*H*W, C]
-    (per-rank batch statistics) -- csrc/bnorm.hip; channel counts its 16-byte vectors do not tile take the stock op."""
+    (per-rank batch statistics) -- csrc/bnorm.hip; anything it does not cover raises (no stock-op fallback)."""
     B, N, C = t.shape
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    if K.bn_supported(t.dtype, C) and bn.running_mean is not None and bn.momentum is not None and bn.affine:
-        y = F.BatchNormFn.apply(t.reshape(B * N, C), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, gelu, training)
-        return y.reshape(B, N, C)
-    y = TF.batch_norm(t.reshape(B * N, C), bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
-    y = y.reshape(B, N, C)
-    return TF.gelu(y) if gelu else y
+    if not (K.bn_supported(t.dtype, C) and bn.running_mean is not None and bn.momentum is not None and bn.affine):
+        # no stock-op fallback on the hot path: the reference's stems are nn.BatchNorm2d(32 | 64 | 128 | 256) with affine parameters, running
+        # statistics and a fixed momentum (HQAViT_CIFAR100.py:753-775); anything else has no HIP kernel and says so
+        raise NotImplementedError(f"BatchNorm over {C} channels ({t.dtype}; affine={bn.affine}, track_running_stats={bn.running_mean is not None}, "
+                                  f"momentum={bn.momentum}) has no HIP kernel: csrc/bnorm.hip covers channel counts its 16-byte vectors tile, "
+                                  "affine, with running statistics and a fixed momentum")
+    y = F.BatchNormFn.apply(t.reshape(B * N, C), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, gelu, training)
+    return y.reshape(B, N, C)
 
 
 class ConvNeXtBlock(nn.Module):
@@ -707,11 +708,11 @@ class LMFAdapter(nn.Module):
             f2 = F.DwConvFn.apply(t, self.dwconv_5x5.weight, self.dwconv_5x5.bias, H, W)
             cat = torch.cat([f1, f2, t], -1)
         h = _conv1x1_tokens(cat, self.proj)
-        if H != self.target_hw or W != self.target_hw:      # :840-842 (not hit by the in-scope configs)
-            B = h.shape[0]
-            img = TF.interpolate(h.transpose(1, 2).reshape(B, -1, H, W).float(), size=(self.target_hw, self.target_hw),
-                                 mode="bilinear", align_corners=False)
-            h = _to_tokens(img).to(t.dtype)
+        if H != self.target_hw or W != self.target_hw:
+            # HQAViT_CIFAR100.py:840-842 resizes bilinearly when the stem's map is not the token grid.  Every shipped configuration has
+            # stem stride 4 = patch size 4 (8x8 on 8x8, 16x16 on 16x16): there is no HIP kernel for the resize and no stock-op fallback
+            raise NotImplementedError(f"LMFAdapter: stem map {H}x{W} != token grid {self.target_hw}x{self.target_hw}: the bilinear resize "
+                                      "(HQAViT_CIFAR100.py:840-842) is not built -- no shipped configuration reaches it")
         return F.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps, act="gelu")
 
     def forward(self, feat):

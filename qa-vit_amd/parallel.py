@@ -55,17 +55,25 @@ class SyncPoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        try:                                   # deferred weight-gradient GEMMs must land before their bucket is reduced
-            from .functional import DeferDW
-            DeferDW.flush()
-        except ImportError:
-            pass
-        ctx.reducer.reached(ctx.tag)
+        rng = ctx.reducer.ready_range(ctx.tag)
+        if rng is not None:                    # a bucket becomes complete here: its deferred weight-gradient GEMMs must land before it is reduced
+            try:
+                from .functional import DeferDW
+                if GradReducer.FLUSH_ALL:
+                    DeferDW.flush()
+                else:
+                    DeferDW.flush_range(*rng)
+            except ImportError:
+                pass
+            ctx.reducer.reached(ctx.tag)
         return g, None, None
 
 
 class GradReducer:
     """Bucketed all-reduce of a flat gradient buffer, overlapped with backward on a side stream."""
+
+    # QAVIT_DDP_FLUSH_ALL=1: the round-2 behaviour (every sync point launches everything queued, the lateral stream's problems included)
+    FLUSH_ALL = __import__("os").environ.get("QAVIT_DDP_FLUSH_ALL", "0") != "0"
 
     def __init__(self, group=None, bucket_bytes: int = 4 << 20):
         self.group = group
@@ -136,6 +144,15 @@ class GradReducer:
                 self._works.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._next = upto_bucket
 
+    def ready_range(self, tag):
+        """Address range [lo, hi) of the flat gradient buffer that becomes reducible when ``tag`` fires (the buckets not yet launched),
+        or None when no new bucket is complete at this tag."""
+        upto = self.ready_at.get(tag, 0)
+        if self._flat is None or upto <= self._next:
+            return None
+        base = self._flat.data_ptr()
+        return base + 4 * self.bounds[self._next][0], base + 4 * self.bounds[upto - 1][1]
+
     def reached(self, tag):
         self._launch(self.ready_at.get(tag, 0))
 
@@ -160,12 +177,17 @@ class DataParallel:
     """
 
     def __init__(self, model: torch.nn.Module, group=None, bucket_bytes: int = 4 << 20, bank_sync: str = "exact",
-                 bank_broadcast_every: int = 50, seed: int = 0x5EED, bn_sync: str = "exact"):
+                 bank_broadcast_every: int = 50, seed: int = 0x5EED, bn_sync: str = "exact", sync_tags=None):
+        """``sync_tags``: the subset of stage boundaries at which buckets are launched during backward (None = all seven; the
+        environment variable QAVIT_DDP_TAGS = comma-separated tags overrides): every sync point costs a grouped weight-gradient launch
+        over fewer problems than the single end-of-backward one, so on a fast fabric fewer, larger overlapped reductions win."""
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs torch.distributed.init_process_group first")
         self.model, self.group = model, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.bank_sync, self.bank_every, self._steps = bank_sync, bank_broadcast_every, 0
+        env = __import__("os").environ.get("QAVIT_DDP_TAGS")
+        self.sync_tags = tuple(t for t in env.split(",") if t) if env is not None else (tuple(sync_tags) if sync_tags is not None else None)
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=group)
@@ -204,6 +226,8 @@ class DataParallel:
                 # gradients of everything ordered at or before `tag` are complete when backward passes the sync
                 # point placed BEFORE that module group in forward
                 stage_tags.append((tag, _prefix_pred(tag)))
+        if self.sync_tags is not None:
+            stage_tags = [(t, p) for t, p in stage_tags if t in self.sync_tags]
         self.reducer.plan(names, offsets, stage_tags)
         self.reducer.attach(trainer.flat_g)
 

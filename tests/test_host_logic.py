@@ -252,3 +252,25 @@ def test_init_distributions_match_reference(tag, golden_r2, Q):
         if not (float(t.abs().max()) <= 1.6 * max(abs(lo), abs(hi)) + 1e-12 or k < 64):
             bad.append((n, "range", lo, hi, float(t.min()), float(t.max())))
     assert not bad, bad[:8]
+
+
+def test_no_stock_op_fallbacks_on_the_hot_path(Q):
+    """Shapes the HIP kernels do not cover raise instead of silently taking a stock torch op: a BatchNorm bnorm.hip does not cover
+    (no affine parameters / no running statistics / a channel count its vectors do not tile), LMFAdapter's bilinear resize
+    (HQAViT_CIFAR100.py:840-842, reached by no shipped configuration), SWA window padding (:424-428)."""
+    import importlib
+    import pytest
+    M = importlib.import_module("qa-vit_amd.modules")
+    t = torch.zeros(2, 64, 36)
+    for bn in (torch.nn.BatchNorm2d(36, affine=False), torch.nn.BatchNorm2d(36, track_running_stats=False), torch.nn.BatchNorm2d(36, momentum=None)):
+        with pytest.raises(NotImplementedError, match="no HIP kernel"):
+            M._bn_tokens(t, bn, True)
+    with pytest.raises(NotImplementedError, match="no HIP kernel"):
+        M._bn_tokens(torch.zeros(2, 64, 30), torch.nn.BatchNorm2d(30), True)          # 30 channels: not a multiple of the fp32 vector
+    cfg = Q.HQAViTConfig()
+    bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim)
+    swa = M.EfficientSpatialWindowAttention(cfg, bank, M._Ctx("hqa"))
+    with pytest.raises(NotImplementedError, match="window padding"):
+        swa(torch.zeros(1, 36, cfg.embed_dim))                                        # 6x6 grid, window 4
+    src = open(M.__file__).read()
+    assert "TF." not in src and "torch.nn.functional" not in src                     # the module file holds no stock functional op at all
