@@ -74,6 +74,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   bf16* so_all = reinterpret_cast<bf16*>(smraw + SM_OUT);
   bf16* sx_all = reinterpret_cast<bf16*>(smraw + SM_X);                  // the 4 images' token tiles [16][LDO] (MSDA: + landmark tiles)
   bf16* sp_all = reinterpret_cast<bf16*>(smraw + (KIND == 1 ? SM_P : SM_X));
+  bf16* sp_all_q = reinterpret_cast<bf16*>(smraw + SM_P);
   const int S = a.S, NK = NKo + S;
   const float scale = rsqrtf((float)BD);
   const bf16* xg = reinterpret_cast<const bf16*>(a.x);
@@ -242,11 +243,33 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 
   // Ring step for chunk c of the tile's schedule: wait until it has landed (chunks c+1 .. c+3 may stay in flight), then refill
   // the slot chunk c - 1 used.  A k-step chunk of a QKV part = 3 fragments (this head's tiles) x 2 images = 6 MFMAs per wave.
+  // SAVE: q / k / v rows for the backward pass leave through LDS staging tiles as whole rows in 16-byte pieces (a "burst" = exactly 3
+  // store instructions per wave, unconditional: sub-images past the batch are replicas of the last image and rewrite its rows with the
+  // same values), issued right behind the barrier of ring step B1 (q rows), B2 (k rows, SWA) and B3 (v rows, SWA).  Straight from the
+  // accumulator quads a store instruction wrote 32 contiguous bytes into each of 16 rows, and the uncounted stores made every following
+  // counted wait drain the whole ring.
+  // With SAVE the attention output O (operand of backward's dW_proj; o_save is required then) leaves the same way from the O tiles behind
+  // the first proj step's barrier (step NQKV) instead of from registers at the kernel's tail, where nothing is left to overlap it.
+  constexpr int B1 = KST, B2 = (SAVE && KIND == 0) ? 2 * KST : -100, B3 = NQKV;
+  constexpr int N1 = (KIND == 2) ? 0 : 3, N2 = 3, N3 = (KIND == 0) ? 6 : (KIND == 2 ? 6 : 3);      // stores per burst (cross: q and O rows both at step NQKV = KST)
+  auto burst_extra = [](int c, int b, int n) { return (c > b && c <= b + AHEAD) ? n : 0; };
 #define QV_RING_STEP(c)                                                                         \
   do {                                                                                          \
-    ring_wait((NCH - 1 - (c)) < (AHEAD - 1) ? (NCH - 1 - (c)) : (AHEAD - 1));                   \
+    ring_wait((NCH - 1 - (c)) < (AHEAD - 1) ? (NCH - 1 - (c)) : (AHEAD - 1),                    \
+              SAVE ? burst_extra((c), B1, N1) + burst_extra((c), B2, N2) + burst_extra((c), B3, N3) : 0);   \
     if ((c) + AHEAD < NCH) issue((c) + AHEAD);                                                  \
   } while (0)
+  // the burst: wave w stores rows 8 (w & 1) .. + 8 of sub-image w >> 1 from its staging tile
+  auto store_rows = [&](const bf16* stage, bf16* gdst, int64_t ld) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24;
+      const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(stage + (wave >> 1) * (16 * LDO) + row * LDO + 8 * c8);
+      *reinterpret_cast<bf16x8*>(gdst + (size_t)tile_row<TT, WIN>(tile, wave >> 1, row, a.B) * ld + 8 * c8) = v8;
+      if (KSH) asm volatile("" ::: "memory");              // one piece at a time: this variant has no registers for three pieces in flight
+    }
+  };
+  bf16* qstage = (KIND == 2) ? sp_all_q : so_all;           // cross: the O quads follow the q phase directly, its q rows stage in a region of their own
 
   bf16x4 qf[NIW][DT];
   {
@@ -274,29 +297,34 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         qf[i][t] = cvt4(acc[i][t]);
-        if (SAVE && vimg[i]) *reinterpret_cast<bf16x4*>(qsv + (size_t)qrow[i] * a.ldq_save + h * BD + t * 16 + 4 * q4) = qf[i][t];
+        if (SAVE) *reinterpret_cast<bf16x4*>(qstage + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = qf[i][t];
       }
   }
   STAMP(4);
   // global row of this lane's key-source row (token / landmark col of key-source tile ks) in kv_save
-  int64_t kvrow[NKS];
-  bool kvok[NKS];
+  // MSDA: the landmark rows (< L per image; on 64 tokens three 16-row tiles per image) of a staging region out as whole rows.  NOT a counted
+  // burst (waves whose rows are all past L skip instructions): the waits that follow drain the ring as they always did for this branch.
+  auto store_landmark_rows = [&](const bf16* stage, bf16* gdst, int64_t ld) {
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    if (KSH) { kvok[ks] = 16 * ks + col < a.L; kvrow[ks] = (int64_t)tile * a.L + 16 * ks + col; }
-    else if (KIND == 1) { kvok[ks] = vimg[ks] && col < kv_rows; kvrow[ks] = (int64_t)prob[ks] * kv_rows + col; }
-    else { kvok[ks] = vimg[ks]; kvrow[ks] = qrow[ks]; }
-  }
+    for (int it = 0; it < 3; ++it) {
+      const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24, st = wave >> 1;
+      const int l = KSH ? 16 * st + row : row;
+      const bool ok = l < a.L && (KSH ? st < LT : sub_valid<TT>(tile, st, a.B));
+      const int64_t grow = KSH ? (int64_t)tile * a.L + l : (int64_t)(tile * NI + st) * a.L + l;
+      if (ok) *reinterpret_cast<bf16x8*>(gdst + (size_t)grow * ld + 8 * c8) = *reinterpret_cast<const bf16x8*>(stage + st * (16 * LDO) + row * LDO + 8 * c8);
+    }
+  };
   bf16x4 kff[KI][KT0 > 0 ? KT0 : 1][DT];
   if (MODE0) {
     // ---- k: plain GEMM (acc quad = 4 consecutive tokens of column d = 16 t + col), then Kf^T = k^T E_k ----
-    f32x4 acc[NKS][DT], accT[SAVE ? NKS : 1][DT];
+    constexpr bool SAVET = SAVE && KIND == 0;              // SWA: k rows through a second, transposed MFMA (8-byte row segments into the staging tile)
+    f32x4 acc[NKS][DT], accT[SAVET ? NKS : 1][DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const float b = sbias[BC + h * BD + t * 16 + col];
 #pragma unroll
       for (int i = 0; i < NKS; ++i) acc[i][t] = f32x4{b, b, b, b};
-      if (SAVE) {
+      if (SAVET) {
 #pragma unroll
         for (int i = 0; i < NKS; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + BC + h * BD + t * 16 + 4 * q4);
       }
@@ -304,6 +332,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
       QV_RING_STEP(KST + s);
+      if (SAVE && s == 0) store_rows(qstage, qsv, a.ldq_save);      // every head's q quads are in the staging tiles (this step's barrier)
       const char* slot = smraw + ((KST + s) % RING) * CHUNK_BYTES;
       bf16x8 wf[DT], xf[NKS];
 #pragma unroll
@@ -315,16 +344,24 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
         for (int i = 0; i < NKS; ++i) {
           acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
-          if (SAVE) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
+          if (SAVET) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
         }
     }
-    if (SAVE) {                                            // k rows for backward: token = col (MSDA: landmark rows < L), 8-byte segments
+    if (SAVE && KIND == 0) {                               // k rows for backward: into the (free) O tiles, out as whole rows behind the next barrier
 #pragma unroll
       for (int i = 0; i < NKS; ++i)
 #pragma unroll
         for (int t = 0; t < DT; ++t)
-          if (kvok[i])
-            *reinterpret_cast<bf16x4*>(kvsv + (size_t)kvrow[i] * a.ldkv_save + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
+          *reinterpret_cast<bf16x4*>(so_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
+    } else if (SAVE) {
+      // MSDA: the landmark rows' k from the plain GEMM's accumulators (4 consecutive rows of one column per lane: 2-byte LDS stores) into
+      // the O tiles (free until the cores' output), out as whole rows behind the next barrier -- no transposed MFMA, no registers for it
+#pragma unroll
+      for (int i = 0; i < NKS; ++i)
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) so_all[((KSH ? i : i0 + i) * 16 + 4 * q4 + r) * LDO + h * BD + t * 16 + col] = (bf16)acc[i][t][r];
     }
     if (KSH) {
 #pragma unroll
@@ -400,13 +437,14 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   bf16x4 vff[KI][KT0 > 0 ? KT0 : 1][DT];
   if (MODE0) {
     // ---- v: plain GEMM, then Vf = E_v^T v (acc quad = 4 consecutive keys of column d) ----
-    f32x4 acc[NKS][DT], accT[SAVE ? NKS : 1][DT];
+    constexpr bool SAVET = SAVE && KIND == 0;
+    f32x4 acc[NKS][DT], accT[SAVET ? NKS : 1][DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
       const float b = sbias[2 * BC + h * BD + t * 16 + col];
 #pragma unroll
       for (int i = 0; i < NKS; ++i) acc[i][t] = f32x4{b, b, b, b};
-      if (SAVE) {
+      if (SAVET) {
 #pragma unroll
         for (int i = 0; i < NKS; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + 2 * BC + h * BD + t * 16 + 4 * q4);
       }
@@ -414,6 +452,8 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
       QV_RING_STEP(2 * KST + s);
+      if (SAVE && KIND == 0 && s == 0) store_rows(so_all, kvsv, a.ldkv_save);
+      if (SAVE && KIND == 1 && s == 0) store_landmark_rows(so_all, kvsv, a.ldkv_save);
       const char* slot = smraw + ((2 * KST + s) % RING) * CHUNK_BYTES;
       bf16x8 wf[DT], xf[NKS];
 #pragma unroll
@@ -425,16 +465,26 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
         for (int i = 0; i < NKS; ++i) {
           acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], wf[t], acc[i][t], 0, 0, 0);
-          if (SAVE) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
+          if (SAVET) accT[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[i], accT[i][t], 0, 0, 0);
         }
     }
-    if (SAVE) {                                            // v rows: the column block after k's in kv_save
+    if (SAVE && KIND == 0) {
+      // v rows: the O tiles take the attention output before the next barrier, so these stage in the token tiles -- dead once EVERY wave
+      // has read its last token fragments (one extra barrier per tile); out as whole rows behind the first proj step's barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int i = 0; i < NKS; ++i)
 #pragma unroll
         for (int t = 0; t < DT; ++t)
-          if (kvok[i])
-            *reinterpret_cast<bf16x4*>(kvsv + (size_t)kvrow[i] * a.ldkv_save + BC + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
+          *reinterpret_cast<bf16x4*>(sx_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
+    } else if (SAVE) {                                     // MSDA: the landmark rows' v into the token tiles (dead since the q phase: k / v read the landmark tiles)
+#pragma unroll
+      for (int i = 0; i < NKS; ++i)
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sx_all[((KSH ? i : i0 + i) * 16 + 4 * q4 + r) * LDO + h * BD + t * 16 + col] = (bf16)acc[i][t][r];
     }
     if (KSH) {
 #pragma unroll
@@ -489,6 +539,10 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
       QV_RING_STEP(NQKV + s);                              // s == 0: this barrier also publishes the 4 heads' O quads
+      if (SAVE && KIND == 0 && s == 0) store_rows(sx_all, kvsv + BC, a.ldkv_save);      // ... and the staged v rows
+      if (SAVE && KIND == 2 && s == 0) store_rows(qstage, qsv, a.ldq_save);             // cross: the q rows (its q phase is directly followed by the cores)
+      if (SAVE && KIND == 1 && s == 0) store_landmark_rows(sx_all, kvsv + BC, a.ldkv_save);
+      if (SAVE && s == 0) store_rows(so_all, osv, a.ldo);                               // the attention output rows
       if (s == 0) {
 #pragma unroll
         for (int s2 = 0; s2 < KST; ++s2) of8[s2] = *reinterpret_cast<const bf16x8*>(so + col * LDO + 32 * s2 + 8 * q4);
@@ -513,7 +567,7 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
     // ---------------- output rows: LDS tile -> global, 16-byte pieces (this wave's 96 columns: 12 per row) ----------------
     wave_sync();
 #ifndef QAVIT_BRANCH_STAMPS
-    if (osv && valid) {                                    // attention output rows (operand of backward's dW_proj): this wave's k-steps
+    if (!SAVE && osv && valid) {                           // attention output rows without the other saves: from registers, this wave's k-steps
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3) {
         const int s2 = 3 * half + s3;
@@ -590,9 +644,10 @@ int branch_validate(const qavit_branch_args* a) {
   if (a->kind == 0 && a->L != 16) return set_error(QAVIT_EINVAL, "branch: SWA works on 4x4 windows (L = 16)");
   if (a->kind == 1 && (!a->pool_idx || a->pool_stride <= 0)) return set_error(QAVIT_EINVAL, "branch: MSDA needs the landmark index table");
   if (a->q_save) {
-    if ((reinterpret_cast<uintptr_t>(a->q_save) & 7) || a->ldq_save % 4) return set_error(QAVIT_EINVAL, "branch: q_save needs 8-byte alignment and ld % 4 == 0");
-    if (a->kind != 2 && (!a->kv_save || (reinterpret_cast<uintptr_t>(a->kv_save) & 7) || a->ldkv_save % 4))
-      return set_error(QAVIT_EINVAL, "branch: kv_save (with q_save) needs 8-byte alignment and ld % 4 == 0");
+    if (!a->o_save) return set_error(QAVIT_EINVAL, "branch: q_save comes with o_save (the backward pass needs both)");
+    if ((reinterpret_cast<uintptr_t>(a->q_save) & 15) || a->ldq_save % 8) return set_error(QAVIT_EINVAL, "branch: q_save needs 16-byte alignment and ld % 8 == 0");
+    if (a->kind != 2 && (!a->kv_save || (reinterpret_cast<uintptr_t>(a->kv_save) & 15) || a->ldkv_save % 8))
+      return set_error(QAVIT_EINVAL, "branch: kv_save (with q_save) needs 16-byte alignment and ld % 8 == 0");
     if (a->pooled_save && (reinterpret_cast<uintptr_t>(a->pooled_save) & 15)) return set_error(QAVIT_EINVAL, "branch: pooled_save needs 16-byte alignment");
   }
   if (a->nan_trip && !a->nan_flag) return set_error(QAVIT_EINVAL, "branch: nan_trip is written by the NaN-rule launch, which needs nan_flag");

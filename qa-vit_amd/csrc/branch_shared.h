@@ -21,8 +21,8 @@ constexpr int GLDS_PER_CHUNK = 2;                          // LDS-DMA instructio
 constexpr int LDB = BC + 8, LDO = BC + 8;                  // shared bank tiles [16][LDB]; per-image O / output tiles [16][LDO]
 constexpr int SM_BANK = RING * CHUNK_BYTES, SM_BIAS = SM_BANK + 2 * 16 * LDB * 2, SM_OUT = SM_BIAS + 4 * BC * 4,
               OUT_BYTES = 16 * LDO * 2, SM_X = SM_OUT + NI * OUT_BYTES, SM_P = SM_X + NI * OUT_BYTES;
-// 61440 ring + 12800 bank + 3072 biases + 25600 O / output tiles + 25600 token tiles (+ 25600 landmark tiles, MSDA) = 128512 (154112) bytes
-constexpr int sm_total(int kind) { return kind == 1 ? SM_P + NI * OUT_BYTES : SM_P; }
+// 61440 ring + 12800 bank + 3072 biases + 25600 O / output tiles + 25600 token tiles (+ 25600 landmark tiles (MSDA) / q staging tiles (cross)) = 128512 (154112) bytes
+constexpr int sm_total(int kind) { return kind != 0 ? SM_P + NI * OUT_BYTES : SM_P; }   // kind 2: the region stages the q rows it saves for backward
 
 // Token rows of a 64-row tile.  TT = 16 (the CIFAR configuration's 16 learned tokens): the tile is 4 images of 16 tokens, sub-image
 // `sub` = image tile * 4 + sub.  TT = 64 (Tiny-ImageNet's 64 learned tokens, QA-ViT at 32 px without TokenLearner): the tile is ONE
@@ -67,12 +67,25 @@ __device__ __forceinline__ void issue_chunk(const char* wpacked, int t0, int s, 
     __builtin_amdgcn_global_load_lds((glb_void_t*)(wpacked + (size_t)((t0 + j) * KST + s) * 1024 + lane * 16), (lds_void_t*)(slot + j * 1024), 16, 0, 0);
   }
 }
-// `newer` = chunks issued after the one about to be consumed (0 .. AHEAD-1).  This wave's share of it has landed once at most
-// those are outstanding; the barrier makes it true for all waves.
-__device__ __forceinline__ void ring_wait(int newer) {     // called with unrolled-loop constants: the chain folds
-  if (newer >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (newer == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (newer == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+// `newer` = chunks issued after the one about to be consumed (0 .. AHEAD-1); `extra` = counted global STORES this wave has issued after
+// that chunk's LDS-DMA (vmcnt counts loads, stores and LDS-DMA together, in issue order: "all but the N youngest are done").  This wave's
+// share of the chunk has landed once at most 2 newer + extra operations are outstanding; the barrier makes it true for all waves.
+// Stores the caller does NOT count only make the wait stricter than needed (the pipeline drains), never wrong; a counted store that
+// was not issued would be wrong -- counted bursts are unconditional.
+__device__ __forceinline__ void ring_wait(int newer, int extra = 0) {     // called with unrolled-loop constants: the chain folds
+  const int n = 2 * (newer > AHEAD - 1 ? AHEAD - 1 : newer) + extra;
+  if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();

@@ -22,10 +22,12 @@ t = [y * 4 + xx for d in (1, 2) for y in range(0, 4, d) for xx in range(0, 4, d)
 idx = torch.tensor(t, dtype=torch.int32, device=dev); NP = len(t) // 2
 sa, sp = K.new_site(), K.new_site()
 P = 0.1
-def fused(kind):
-    if kind == 0: return F.branch_forward(0, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, None, 0, 16, (P, sa), (P, sp))
-    if kind == 1: return F.branch_forward(1, x, wqkv, bqkv, wproj, bproj, Ek2, Ev2, bk, bv, idx, 2, NP, (P, sa), (P, sp))
-    return F.branch_forward(2, x, wq, bq, wproj, bproj, None, None, bk, bv, None, 0, 0, (P, sa), (P, sp))
+def fused(kind, save=False):
+    kw = dict(want_o=save, save=save)
+    if kind == 0: return F.branch_forward(0, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, None, 0, 16, (P, sa), (P, sp), **kw)
+    if kind == 1: return F.branch_forward(1, x, wqkv, bqkv, wproj, bproj, Ek2, Ev2, bk, bv, idx, 2, NP, (P, sa), (P, sp), **kw)
+    return F.branch_forward(2, x, wq, bq, wproj, bproj, None, None, bk, bv, None, 0, 0, (P, sa), (P, sp), **kw)
+def fused_save(kind): return fused(kind, True)
 def unfused(kind):
     if kind == 0:
         qkv = F.linear(x, wqkv, bqkv).reshape(B * T, 3 * C)
@@ -46,7 +48,7 @@ def unfused(kind):
 FL = {0: 3.54 + 0.39 + 0.59 + 1.18, 1: 1.18 + 2.21 * NP / 10 + 0.25 + 0.59 + 1.18, 2: 1.18 + 0.20 + 1.18}
 with torch.no_grad():
     for kind, name in ((0, "swa"), (1, "msda"), (2, "cross")):
-        for label, fn in (("fused", fused), ("unfused", unfused)):
+        for label, fn in (("fused", fused), ("fused+sv", fused_save), ("unfused", unfused)):
             for _ in range(3): fn(kind)
             torch.cuda.synchronize()
             gph = torch.cuda.CUDAGraph()
