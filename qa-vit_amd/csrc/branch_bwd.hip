@@ -459,7 +459,9 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
       f32x4 c = zero4;
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt) c = mma16(nt < KT0 ? kfb[nt < KT0 ? nt : 0][t] : bkT[t], dsT[nt], c);
-      *reinterpret_cast<bf16x4*>(dqg + (size_t)qrow * a.lddq + h * BD + t * 16 + 4 * q4) = cvt4(c);
+      // into this head's columns of the sub-image's q tile (its q fragments are in registers; no other wave reads these columns): the
+      // rows leave whole, in 16-byte pieces, once every head is done -- 8-byte segments straight from the quads touch 16 rows per store
+      *reinterpret_cast<bf16x4*>(sq_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(c);
     }
     // ---- dKf, dVf: contraction over queries ----
 #pragma unroll
@@ -476,8 +478,6 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
           dvfS[jt][t] = mma16(pd2[jt], doT[t], dvfS[jt][t]);
         }
     } else if (MODE0) {
-      int64_t krow = qrow;                                   // SWA: the window's own token rows
-      if (KIND == 1) krow = (qrow / BT) * a.kv_rows + col;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         f32x4 ck = zero4, cv = zero4;
@@ -492,19 +492,38 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
           dEk[jt] = mma16(kR[t], dkfT, dEk[jt]);                  // dE_k[l = 4 q4 + r][j = col] += sum_d k[l][d] dKf[j][d]
           dEv[jt] = mma16(vR[t], dvfT, dEv[jt]);
         }
-        if (col < a.kv_rows) {
-          *reinterpret_cast<bf16x4*>(dkg + (size_t)krow * a.lddkv + h * BD + t * 16 + 4 * q4) = cvt4(ck);
-          *reinterpret_cast<bf16x4*>(dvg + (size_t)krow * a.lddkv + h * BD + t * 16 + 4 * q4) = cvt4(cv);
-        }
+        // dk / dv rows: into this head's columns of the sub-image's k / v tiles, out as whole rows below
+        *reinterpret_cast<bf16x4*>(sk_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(ck);
+        *reinterpret_cast<bf16x4*>(sv_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(cv);
       }
     }
   }
 
+  // dq (SWA / MSDA on 16 tokens: also dk, dv) rows out of the tiles: wave w stores rows 8 (w & 1) .. + 8 of sub-image w >> 1
+  auto store_rows_out = [&]() {
+    if (!sub_valid<TT>(tile, wave >> 1, a.B)) return;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24, st = wave >> 1;
+      const int64_t grow = tile_row<TT, WIN>(tile, st, row, a.B);
+      *reinterpret_cast<bf16x8*>(dqg + (size_t)grow * a.lddq + 8 * c8) = *reinterpret_cast<const bf16x8*>(sq_all + st * (16 * LDO) + row * LDO + 8 * c8);
+      if (KSH) asm volatile("" ::: "memory");              // one piece at a time: this variant runs at the register limit
+      if (MODE0 && !KSH) {
+        const int64_t krow = KIND == 1 ? (grow / BT) * a.kv_rows + row : grow;          // MSDA: landmark rows < kv_rows of the image; SWA: the token rows
+        if (KIND == 0 || row < a.kv_rows) {
+          *reinterpret_cast<bf16x8*>(dkg + (size_t)krow * a.lddkv + 8 * c8) = *reinterpret_cast<const bf16x8*>(sk_all + st * (16 * LDO) + row * LDO + 8 * c8);
+          *reinterpret_cast<bf16x8*>(dvg + (size_t)krow * a.lddkv + 8 * c8) = *reinterpret_cast<const bf16x8*>(sv_all + st * (16 * LDO) + row * LDO + 8 * c8);
+        }
+      }
+    }
+  };
   f32x4 dEt[LT][KT0a];                                     // MSDA on 64 tokens: dE_k (key-side wave) or dE_v (value-side wave) of this head
   if (KSH) {
     // ---- dK_f / dV_f of the image: this wave's partial + the partial of the head's other wave.  Wave h (< 4) finishes the KEY side of
     // head h, wave h + 4 the VALUE side; each parks the partial of the side it does not finish (fp32, [jt][t] accumulator quads). ----
-    __syncthreads();                                       // the q / dO tiles are dead: their region takes the parked partials
+    __syncthreads();                                       // the q / dO tiles are dead and every head's dq quads are in the q tiles
+    store_rows_out();                                      // dq rows out before the region takes the parked partials
+    __syncthreads();
     float* park = reinterpret_cast<float*>(smraw + BW_SM_G);           // [head][side] x 6 quads x 64 lanes x 4 floats = 6 KB each (48 KB <= 51.2 KB)
     const int mine = wave >> 2;                            // 0: key side, 1: value side
     {
@@ -561,6 +580,10 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
     }
   }
 
+  if (!KSH) {
+    __syncthreads();                                       // every head's quads are in the tiles
+    store_rows_out();
+  }
   // ================= sums over the tile's images and heads -> one row of partial sums =================
   __syncthreads();                                         // every tile is dead: the ring region takes the fp32 scratch
   float* red = reinterpret_cast<float*>(smraw);            // [dE 2 * PART_E | dsh 2 * 3072] then the dE staging: image pair 1 parks, image pair 0 adds
@@ -589,13 +612,15 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
     float* re = red + PART_FLOATS;
     if (KSH) {
       // dE: the key-side wave of each head holds dE_k, the value-side wave dE_v -> LDS [4 heads][2][48][32], then 3072 sums of 4
+      int q4t = q4;
+      asm volatile("" : "+v"(q4t));                        // opaque here: hipcc otherwise forms these 24 row indices at kernel entry and spills them
 #pragma unroll
       for (int lt = 0; lt < LT; ++lt)
 #pragma unroll
         for (int jt = 0; jt < KT0; ++jt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            re[(h * 2 + (wave >> 2)) * PART_E + (16 * lt + 4 * q4 + r) * 32 + jt * 16 + col] = dEt[lt][jt][r];
+            re[(h * 2 + (wave >> 2)) * PART_E + (16 * lt + 4 * q4t + r) * 32 + jt * 16 + col] = dEt[lt][jt][r];
       __syncthreads();
       for (int e = tid; e < 2 * PART_E; e += 512) {
         const int side = e / PART_E, o = e - side * PART_E;
@@ -642,8 +667,8 @@ int branch_bwd_validate(const qavit_branch_bwd_args* a) {
     if (a->kv_rows <= 0 || a->kv_rows > lmax || a->kv_rows < a->L) return set_error(QAVIT_EINVAL, "branch_bwd: kv_rows must cover the L Linformer rows (<= 16; MSDA on 64 tokens <= 48)");
     if (a->kind == 0 && (a->L != 16 || a->kv_rows != 16)) return set_error(QAVIT_EINVAL, "branch_bwd: SWA works on 4x4 windows (L = kv_rows = 16)");
     if (a->ldkv % 8 || a->lddkv % 4 || (reinterpret_cast<uintptr_t>(a->k_tok) & 15) || (reinterpret_cast<uintptr_t>(a->v_tok) & 15) ||
-        (reinterpret_cast<uintptr_t>(a->dk_tok) & 7) || (reinterpret_cast<uintptr_t>(a->dv_tok) & 7))
-      return set_error(QAVIT_EINVAL, "branch_bwd: k / v rows need 16-byte alignment (ld % 8), dk / dv 8-byte (ld % 4)");
+        (reinterpret_cast<uintptr_t>(a->dk_tok) & 15) || (reinterpret_cast<uintptr_t>(a->dv_tok) & 15) || a->lddkv % 8)
+      return set_error(QAVIT_EINVAL, "branch_bwd: k / v rows and dk / dv need 16-byte alignment (ld % 8)");
   }
   if (a->proj_drop_p > 0.f && a->rng && !a->dz) return set_error(QAVIT_EINVAL, "branch_bwd: proj dropout needs dz (the masked gradient is the operand of dW_proj)");
   if (a->parts_stride < part_floats(a->T) || (reinterpret_cast<uintptr_t>(a->parts) & 15) || a->parts_stride % 4)
@@ -651,8 +676,8 @@ int branch_bwd_validate(const qavit_branch_bwd_args* a) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (!al16(a->dout) || !al16(a->wprojT_frag) || !al16(a->q) || !al16(a->sh_k) || !al16(a->sh_v) || (a->dz && !al16(a->dz)) ||
       a->lddout % 8 || a->ldq % 8 || (a->dz && a->lddz % 8) || (reinterpret_cast<uintptr_t>(a->o) & 7) || a->ldo % 4 ||
-      (reinterpret_cast<uintptr_t>(a->dq) & 7) || a->lddq % 4)
-    return set_error(QAVIT_EINVAL, "branch_bwd: operands must be 16-byte aligned with leading dimensions a multiple of 8 elements (o, dq: 8 bytes / 4 elements)");
+      (reinterpret_cast<uintptr_t>(a->dq) & 15) || a->lddq % 8)
+    return set_error(QAVIT_EINVAL, "branch_bwd: operands must be 16-byte aligned with leading dimensions a multiple of 8 elements (o: 8 bytes / 4 elements)");
   return QAVIT_OK;
 }
 

@@ -62,3 +62,42 @@ with torch.no_grad():
             us = e0.elapsed_time(e1) * 1e3 / (reps * 10)
             tf = FL[kind] * 1e6 * B / (us * 1e-6) / 1e12
             print(f"{name:6s} {label:8s} B={B}: {us:8.2f} us / branch forward   {tf:7.1f} TFLOP/s algorithmic = {100 * tf / 2500:5.2f} % of 2.5 PF", flush=True)
+
+# ---- training form: BranchFn forward (saves) + fused backward (csrc/branch_bwd.hip) + the qkv input-gradient GEMM(s), replayed from a hipGraph
+def train_pair(kind):
+    xg = x.detach().clone().requires_grad_(True)
+    if kind == 2:
+        ps = [t.detach().clone().requires_grad_(True) for t in (wq, bq, wproj, bproj)]
+        sk0, sv0 = bk.detach().clone().requires_grad_(True), bv.detach().clone().requires_grad_(True)
+        args = None
+    else:
+        ps = [t.detach().clone().requires_grad_(True) for t in (wqkv, bqkv, wproj, bproj, Ek if kind == 0 else Ek2, Ev if kind == 0 else Ev2)]
+        gk, gv = bk.detach().clone().reshape(1, S, C).requires_grad_(True), bv.detach().clone().reshape(1, S, C).requires_grad_(True)
+        meta = dict(kind=kind, attn_drop=(P, sa), proj_drop=(P, sp))
+        if kind == 1:
+            meta.update(pool_idx=idx, pool_stride=2, Lk=NP)
+        args = (xg, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], gk, gv, meta)
+    gout = torch.randn(B, T, C, device=dev).to(torch.bfloat16)
+    def step():
+        if kind == 2:       # the shared rows are activations here (projections of the bank): a fresh node per step
+            out = F.BranchFn.apply(xg, ps[0], ps[1], ps[2], ps[3], None, None, sk0 * 1.0, sv0 * 1.0, dict(kind=2, attn_drop=(P, sa), proj_drop=(P, sp)))
+        else:
+            out = F.BranchFn.apply(*args)
+        out.backward(gout)
+        xg.grad = None
+    return step
+for kind, name in ((0, "swa"), (1, "msda"), (2, "cross")):
+    step = train_pair(kind)
+    s_ = torch.cuda.Stream(); s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        for _ in range(3): step()
+    torch.cuda.current_stream().wait_stream(s_); torch.cuda.synchronize()
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph):
+        for _ in range(5): step()
+    gph.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): gph.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:6s} fwd+bwd  B={B}: {e0.elapsed_time(e1) * 1e3 / (reps * 5):8.2f} us / branch (forward with saves, fused backward, qkv dX GEMM, grouped dW + reduce)", flush=True)
