@@ -50,6 +50,10 @@
 
 namespace qv {
 
+#ifdef QAVIT_BRANCH_STAMPS
+__device__ unsigned long long qv_branch_stamps[4096 * 16];
+#endif
+
 namespace {
 
 // KIND 0 = SWA, 1 = MSDA, 2 = cross.  SAVE: also write q / k / v (and MSDA's pooled landmarks) for the backward pass.  k and v leave
@@ -83,8 +87,8 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   const char* wqkv = reinterpret_cast<const char*>(a.wqkv_frag);
   const char* wproj = reinterpret_cast<const char*>(a.wproj_frag);
   bool bad = false;
-#ifdef QAVIT_BRANCH_STAMPS   // diagnostic build only (tools/branch_stamps.py): s_memtime at the phase boundaries, 16 words per workgroup into o_save
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.o_save) + (size_t)blockIdx.x * 16;
+#ifdef QAVIT_BRANCH_STAMPS   // diagnostic build only (tools/branch_stamps.py): s_memtime at the phase boundaries, 16 words per workgroup into a buffer of their own
+  unsigned long long* stamps = qv_branch_stamps + (size_t)(blockIdx.x & 4095) * 16;
 #define STAMP(k) do { if (tid == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
@@ -278,15 +282,27 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
     for (int i = 0; i < NIW; ++i)
 #pragma unroll
       for (int t = 0; t < DT; ++t) acc[i][t] = *reinterpret_cast<const f32x4*>(sbias + h * BD + t * 16 + 4 * q4);
+    // Fragment reads run ONE k-step ahead of the MFMAs (here and in the k / v / proj loops): the ring step of chunk s + 1 (wait, barrier,
+    // refill) and the LDS reads of its fragments are issued before the MFMAs of chunk s, so the reads' latency and the barrier's skew
+    // hide behind matrix work instead of standing between two chunks' MFMAs (a chunk was ~600 cycles for 96 of MFMA per wave).
+    bf16x8 wfn[DT], xfn[NIW];
+    auto lds_q = [&](int s) {
+      const char* slot = smraw + (s % RING) * CHUNK_BYTES;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wfn[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) xfn[i] = *reinterpret_cast<const bf16x8*>(sxw + i * (16 * LDO) + 32 * s);
+    };
+    QV_RING_STEP(0);
+    lds_q(0);
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
-      QV_RING_STEP(s);
-      const char* slot = smraw + (s % RING) * CHUNK_BYTES;
       bf16x8 wf[DT], xf[NIW];
 #pragma unroll
-      for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+      for (int t = 0; t < DT; ++t) wf[t] = wfn[t];
 #pragma unroll
-      for (int i = 0; i < NIW; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sxw + i * (16 * LDO) + 32 * s);
+      for (int i = 0; i < NIW; ++i) xf[i] = xfn[i];
+      if (s + 1 < KST) { QV_RING_STEP(s + 1); lds_q(s + 1); }
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -329,16 +345,25 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
         for (int i = 0; i < NKS; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + BC + h * BD + t * 16 + 4 * q4);
       }
     }
+    bf16x8 wfn[DT], xfn[NKS];
+    auto lds_k = [&](int s) {
+      const char* slot = smraw + ((KST + s) % RING) * CHUNK_BYTES;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wfn[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int i = 0; i < NKS; ++i) xfn[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+    };
+    QV_RING_STEP(KST);
+    if (SAVE) store_rows(qstage, qsv, a.ldq_save);         // every head's q quads are in the staging tiles (this step's barrier)
+    lds_k(0);
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
-      QV_RING_STEP(KST + s);
-      if (SAVE && s == 0) store_rows(qstage, qsv, a.ldq_save);      // every head's q quads are in the staging tiles (this step's barrier)
-      const char* slot = smraw + ((KST + s) % RING) * CHUNK_BYTES;
       bf16x8 wf[DT], xf[NKS];
 #pragma unroll
-      for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+      for (int t = 0; t < DT; ++t) wf[t] = wfn[t];
 #pragma unroll
-      for (int i = 0; i < NKS; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+      for (int i = 0; i < NKS; ++i) xf[i] = xfn[i];
+      if (s + 1 < KST) { QV_RING_STEP(KST + s + 1); lds_k(s + 1); }
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -449,17 +474,26 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
         for (int i = 0; i < NKS; ++i) accT[i][t] = *reinterpret_cast<const f32x4*>(sbias + 2 * BC + h * BD + t * 16 + 4 * q4);
       }
     }
+    bf16x8 wfn[DT], xfn[NKS];
+    auto lds_v = [&](int s) {
+      const char* slot = smraw + ((2 * KST + s) % RING) * CHUNK_BYTES;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wfn[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+#pragma unroll
+      for (int i = 0; i < NKS; ++i) xfn[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+    };
+    QV_RING_STEP(2 * KST);
+    if (SAVE && KIND == 0) store_rows(so_all, kvsv, a.ldkv_save);
+    if (SAVE && KIND == 1) store_landmark_rows(so_all, kvsv, a.ldkv_save);
+    lds_v(0);
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
-      QV_RING_STEP(2 * KST + s);
-      if (SAVE && KIND == 0 && s == 0) store_rows(so_all, kvsv, a.ldkv_save);
-      if (SAVE && KIND == 1 && s == 0) store_landmark_rows(so_all, kvsv, a.ldkv_save);
-      const char* slot = smraw + ((2 * KST + s) % RING) * CHUNK_BYTES;
       bf16x8 wf[DT], xf[NKS];
 #pragma unroll
-      for (int t = 0; t < DT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(slot + ((3 * h + t) * 64 + lane) * 16);
+      for (int t = 0; t < DT; ++t) wf[t] = wfn[t];
 #pragma unroll
-      for (int i = 0; i < NKS; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(spw + i * (16 * LDO) + 32 * s);
+      for (int i = 0; i < NKS; ++i) xf[i] = xfn[i];
+      if (s + 1 < KST) { QV_RING_STEP(2 * KST + s + 1); lds_v(s + 1); }
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -469,15 +503,13 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
         }
     }
     if (SAVE && KIND == 0) {
-      // v rows: the O tiles take the attention output before the next barrier, so these stage in the token tiles -- dead once EVERY wave
-      // has read its last token fragments (one extra barrier per tile); out as whole rows behind the first proj step's barrier
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      // v rows: the O tiles take the attention output before the next barrier and the token tiles are still being read by slower
+      // waves, so these stage in a region of their own; out as whole rows behind the first proj step's barrier
 #pragma unroll
       for (int i = 0; i < NKS; ++i)
 #pragma unroll
         for (int t = 0; t < DT; ++t)
-          *reinterpret_cast<bf16x4*>(sx_all + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
+          *reinterpret_cast<bf16x4*>(sp_all_q + (i0 + i) * (16 * LDO) + col * LDO + h * BD + t * 16 + 4 * q4) = cvt4(accT[i][t]);
     } else if (SAVE) {                                     // MSDA: the landmark rows' v into the token tiles (dead since the q phase: k / v read the landmark tiles)
 #pragma unroll
       for (int i = 0; i < NKS; ++i)
@@ -536,21 +568,26 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
     f32x4 acc[CT / 2];
 #pragma unroll
     for (int jj = 0; jj < CT / 2; ++jj) acc[jj] = *reinterpret_cast<const f32x4*>(sbias + 3 * BC + (6 * half + jj) * 16 + 4 * q4);
+    bf16x8 wfn[CT / 2];
+    auto lds_p = [&](int s) {
+      const char* slot = smraw + ((NQKV + s) % RING) * CHUNK_BYTES;
+#pragma unroll
+      for (int jj = 0; jj < CT / 2; ++jj) wfn[jj] = *reinterpret_cast<const bf16x8*>(slot + ((6 * half + jj) * 64 + lane) * 16);
+    };
+    QV_RING_STEP(NQKV);                                    // this barrier also publishes the 4 heads' O quads
+    if (SAVE && KIND == 0) store_rows(sp_all_q, kvsv + BC, a.ldkv_save);    // ... and the staged v rows
+    if (SAVE && KIND == 2) store_rows(qstage, qsv, a.ldq_save);             // cross: the q rows (its q phase is directly followed by the cores)
+    if (SAVE && KIND == 1) store_landmark_rows(sx_all, kvsv + BC, a.ldkv_save);
+    if (SAVE) store_rows(so_all, osv, a.ldo);                               // the attention output rows
+#pragma unroll
+    for (int s2 = 0; s2 < KST; ++s2) of8[s2] = *reinterpret_cast<const bf16x8*>(so + col * LDO + 32 * s2 + 8 * q4);
+    lds_p(0);
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
-      QV_RING_STEP(NQKV + s);                              // s == 0: this barrier also publishes the 4 heads' O quads
-      if (SAVE && KIND == 0 && s == 0) store_rows(sx_all, kvsv + BC, a.ldkv_save);      // ... and the staged v rows
-      if (SAVE && KIND == 2 && s == 0) store_rows(qstage, qsv, a.ldq_save);             // cross: the q rows (its q phase is directly followed by the cores)
-      if (SAVE && KIND == 1 && s == 0) store_landmark_rows(sx_all, kvsv + BC, a.ldkv_save);
-      if (SAVE && s == 0) store_rows(so_all, osv, a.ldo);                               // the attention output rows
-      if (s == 0) {
-#pragma unroll
-        for (int s2 = 0; s2 < KST; ++s2) of8[s2] = *reinterpret_cast<const bf16x8*>(so + col * LDO + 32 * s2 + 8 * q4);
-      }
-      const char* slot = smraw + ((NQKV + s) % RING) * CHUNK_BYTES;
       bf16x8 wf[CT / 2];
 #pragma unroll
-      for (int jj = 0; jj < CT / 2; ++jj) wf[jj] = *reinterpret_cast<const bf16x8*>(slot + ((6 * half + jj) * 64 + lane) * 16);
+      for (int jj = 0; jj < CT / 2; ++jj) wf[jj] = wfn[jj];
+      if (s + 1 < KST) { QV_RING_STEP(NQKV + s + 1); lds_p(s + 1); }
 #pragma unroll
       for (int jj = 0; jj < CT / 2; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], of8[s], acc[jj], 0, 0, 0);
     }
@@ -566,15 +603,13 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
     }
     // ---------------- output rows: LDS tile -> global, 16-byte pieces (this wave's 96 columns: 12 per row) ----------------
     wave_sync();
-#ifndef QAVIT_BRANCH_STAMPS
-    if (!SAVE && osv && valid) {                           // attention output rows without the other saves: from registers, this wave's k-steps
+    if (!SAVE && osv && valid) {                           // attention output rows without the other saves: whole rows from the O tile (all heads' quads are in since the proj phase's first barrier)
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) {
-        const int s2 = 3 * half + s3;
-        *reinterpret_cast<bf16x8*>(osv + (size_t)tile_row<TT, WIN>(tile, pi, col, a.B) * a.ldo + 32 * s2 + 8 * q4) = of8[s2];
+      for (int it = 0; it < 3; ++it) {
+        const int p = lane + 64 * it, row = p / 12, c8 = 12 * half + p % 12;
+        *reinterpret_cast<bf16x8*>(osv + (size_t)tile_row<TT, WIN>(tile, pi, row, a.B) * a.ldo + 8 * c8) = *reinterpret_cast<const bf16x8*>(so + row * LDO + 8 * c8);
       }
     }
-#endif
     if (valid) {
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
@@ -683,6 +718,12 @@ extern "C" int qavit_branch_supported(int kind, int T, int C, int H, int D, int 
   return 1;
 }
 
+#ifdef QAVIT_BRANCH_STAMPS
+extern "C" int qavit_branch_stamps(void* host_dst, int nwg) {   // diagnostic build: the last launch's stamps, 16 words per workgroup
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(qv_branch_stamps), (size_t)nwg * 16 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" int qavit_branch_fwd(const qavit_branch_args* a, void* stream) {
   int rc = branch_validate(a);
   if (rc) return rc;
@@ -694,10 +735,10 @@ extern "C" int qavit_branch_fwd(const qavit_branch_args* a, void* stream) {
 #define QV_BRANCH_LAUNCH(K, S, TT)                                                                                                      \
   do {                                                                                                                                   \
     if (!attr_done[K][S][TT == 64]) {                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K, S, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, sm_total(K)); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(branch_fwd_kernel<K, S, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, sm_total(K, S)); \
       attr_done[K][S][TT == 64] = true;                                                                                                  \
     }                                                                                                                                    \
-    hipLaunchKernelGGL((branch_fwd_kernel<K, S, TT>), dim3(grid), dim3(512), sm_total(K), st, *a);                                      \
+    hipLaunchKernelGGL((branch_fwd_kernel<K, S, TT>), dim3(grid), dim3(512), sm_total(K, S), st, *a);                                   \
   } while (0)
 #define QV_BRANCH_KIND(K)                                                                                                                \
   do {                                                                                                                                   \

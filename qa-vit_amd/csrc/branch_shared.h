@@ -22,7 +22,7 @@ constexpr int LDB = BC + 8, LDO = BC + 8;                  // shared bank tiles 
 constexpr int SM_BANK = RING * CHUNK_BYTES, SM_BIAS = SM_BANK + 2 * 16 * LDB * 2, SM_OUT = SM_BIAS + 4 * BC * 4,
               OUT_BYTES = 16 * LDO * 2, SM_X = SM_OUT + NI * OUT_BYTES, SM_P = SM_X + NI * OUT_BYTES;
 // 61440 ring + 12800 bank + 3072 biases + 25600 O / output tiles + 25600 token tiles (+ 25600 landmark tiles (MSDA) / q staging tiles (cross)) = 128512 (154112) bytes
-constexpr int sm_total(int kind) { return kind != 0 ? SM_P + NI * OUT_BYTES : SM_P; }   // kind 2: the region stages the q rows it saves for backward
+constexpr int sm_total(int kind, bool save) { return (kind == 1 || save) ? SM_P + NI * OUT_BYTES : SM_P; }   // the region: MSDA's landmark tiles; SWA's v / cross's q staging tiles when they save for backward
 
 // Token rows of a 64-row tile.  TT = 16 (the CIFAR configuration's 16 learned tokens): the tile is 4 images of 16 tokens, sub-image
 // `sub` = image tile * 4 + sub.  TT = 64 (Tiny-ImageNet's 64 learned tokens, QA-ViT at 32 px without TokenLearner): the tile is ONE
