@@ -395,6 +395,38 @@ int qavit_cga_bwd_parts(int B, int T);   /* workgroups = rows of `parts`: ceil(B
 int qavit_cga_bwd(const qavit_cga_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * BottleneckMLP + residual of a QuadAttentionBlock (HQAViT_CIFAR100.py:643-656, :1082-1083) in one launch each way (csrc/mlp2.hip):
+ *   out = resid + drop_path( dropout2( (dropout1(GELU(y W1^T + b1))) W2^T + b2 ) )      W1 [Hd, C], W2 [C, Hd], C = 192, Hd = 96; bf16
+ * It replaces two qavit_gemm_nt launches (fc1 with GELU + dropout epilogue, fc2 with dropout + drop-path + residual epilogue) and keeps
+ * their contracts: dropout masks drop_factor(key(site), row * N + col) with N = Hd (site 1) / C (site 2), drop path row / dp_rows;
+ * w1_rm / w2_rm are the bf16 row-major copies qavit_pack_weights makes.  z1 (pre-GELU) and h1 (post-dropout) [M, Hd] are written for
+ * the backward pass when given (both or neither): h1 is the operand of dW2, z1 feeds GELU'.
+ * Backward: g = d out [M, C] -> dz2 = g * drop_path * dropout2 (operand of dW2 with h1; may be NULL without either mask: dz2 == g),
+ * dz1 [M, Hd] = (dz2 W2) * dropout1 * GELU'(z1) (operand of dW1 with y), dy [M, C] = dz1 W1.  d resid == g (the caller aliases it).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct qavit_mlp2_args {
+  int dtype; int M, C, Hd;
+  const void* y; int64_t ldy;
+  const void* resid; int64_t ldr;
+  const void* w1_rm; const float* b1;
+  const void* w2_rm; const float* b2;
+  float drop1_p; int drop1_site; float drop2_p; int drop2_site; float dp_p; int dp_site; int dp_rows; const int64_t* rng;
+  void* out; int64_t ldo;
+  void* z1; void* h1;
+} qavit_mlp2_args;
+typedef struct qavit_mlp2_bwd_args {
+  int dtype; int M, C, Hd;
+  const void* g; int64_t ldg;
+  const void* z1;
+  const void* w1_rm; const void* w2_rm;
+  float drop1_p; int drop1_site; float drop2_p; int drop2_site; float dp_p; int dp_site; int dp_rows; const int64_t* rng;
+  void* dz2; void* dz1; void* dy; int64_t lddy;
+} qavit_mlp2_bwd_args;
+int qavit_mlp2_supported(int C, int Hd);
+int qavit_mlp2_fwd(const qavit_mlp2_args* a, void* stream);
+int qavit_mlp2_bwd(const qavit_mlp2_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * QuadAttentionBlock's HybridFusion(concat_i compress_i(norm_i(branch_i))) (HQAViT_CIFAR100.py:904-925, :1075-1081), forward, in one
  * launch for 16 tokens x 192 channels, 4 branches of Linear(192 -> 48): x[i] [B*16, 192] bf16 (contiguous rows), w_rm[i] [48, 192]
  * bf16 row-major, bias[i] fp32 or NULL, fw = the 4 fusion logits.  Writes cat [B*16, 192] (unscaled concat), y = cat * softmax(fw)

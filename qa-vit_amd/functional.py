@@ -1679,6 +1679,89 @@ class CompressFuseFn(Function):
         return (fret, None, *grads)
 
 
+_MLP2 = os.environ.get("QAVIT_FUSED_MLP", "1") != "0"
+
+
+def mlp2_ok(y, resid, w1, w2) -> bool:
+    """Does csrc/mlp2.hip cover this bottleneck MLP?  (bf16 rows of 192 channels, hidden 96)"""
+    return (_MLP2 and y.is_cuda and y.dtype == torch.bfloat16 and resid.dtype == torch.bfloat16 and y.shape == resid.shape and w1.dim() == 2 and
+            tuple(w2.shape) == (w1.shape[1], w1.shape[0]) and bool(L.load().qavit_mlp2_supported(w1.shape[1], w1.shape[0])) and y.shape[-1] == w1.shape[1])
+
+
+class Mlp2Fn(Function):
+    """x1 = resid + drop_path(dropout(fc2(dropout(GELU(fc1(y)))))) -- BottleneckMLP + residual (HQAViT_CIFAR100.py:643-656, :1082-1083) --
+    as ONE launch forward and ONE backward (csrc/mlp2.hip) instead of two GEMM launches each way.  ``opts``: drop1 / drop2 = (p, site),
+    dp = (p, site, rows per sample).  The residual's gradient is the incoming gradient itself (returned as is: the caller's alias mechanics
+    add it where the residual came from); weight gradients are deferred grouped GEMMs on the operands the kernels write."""
+
+    @staticmethod
+    def forward(ctx, y, resid, w1, b1, w2, b2, opts):
+        K._require_cuda(y, w1)
+        rt = _rt(y)
+        C_ = y.shape[-1]
+        Hd = w1.shape[0]
+        y2 = y.reshape(-1, C_)
+        r2 = resid.reshape(-1, C_)
+        y2 = y2 if y2.is_contiguous() else y2.contiguous()
+        r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        M = y2.shape[0]
+        pk = pack_for(y.device)
+        W1c, W2c = pk.get(w1, y.dtype)[0], pk.get(w2, y.dtype)[0]
+        need = any(ctx.needs_input_grad)
+        out = torch.empty(M, C_, dtype=y.dtype, device=y.device)
+        z1 = torch.empty(M, Hd, dtype=y.dtype, device=y.device) if need else None
+        h1 = torch.empty(M, Hd, dtype=y.dtype, device=y.device) if need else None
+        d1, d2, dp = opts.get("drop1") or (0.0, 0), opts.get("drop2") or (0.0, 0), opts.get("dp") or (0.0, 0, 1)
+        a = L.Mlp2Args()
+        a.dtype, a.M, a.C, a.Hd = K.dt_code(y.dtype), M, C_, Hd
+        a.y, a.ldy, a.resid, a.ldr = y2.data_ptr(), C_, r2.data_ptr(), C_
+        a.w1_rm, a.b1, a.w2_rm, a.b2 = W1c.data_ptr(), b1.data_ptr(), W2c.data_ptr(), b2.data_ptr()
+        a.drop1_p, a.drop1_site, a.drop2_p, a.drop2_site = float(d1[0]), int(d1[1]), float(d2[0]), int(d2[1])
+        a.dp_p, a.dp_site, a.dp_rows = float(dp[0]), int(dp[1]), int(dp[2])
+        a.rng = rt.rng.data_ptr()
+        a.out, a.ldo = out.data_ptr(), C_
+        a.z1, a.h1 = K._p(z1), K._p(h1)
+        L.check(L.load().qavit_mlp2_fwd(C.byref(a), K.stream()), "mlp2_fwd")
+        if need:
+            ctx.meta = (M, C_, Hd, d1, d2, dp, y.shape)
+            ctx.save_for_backward(y2, w1, b1, w2, b2, z1, h1)
+        return out.reshape(y.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        y2, w1, b1, w2, b2, z1, h1 = ctx.saved_tensors
+        M, C_, Hd, d1, d2, dp, yshape = ctx.meta
+        rt = _rt(y2)
+        g2 = g.reshape(M, C_)
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        masked = d2[0] > 0.0 or dp[0] > 0.0
+        dz2 = torch.empty_like(g2) if masked else g2
+        dz1 = torch.empty(M, Hd, dtype=y2.dtype, device=y2.device)
+        dy = torch.empty(M, C_, dtype=y2.dtype, device=y2.device)
+        pk = pack_for(y2.device)
+        a = L.Mlp2BwdArgs()
+        a.dtype, a.M, a.C, a.Hd = K.dt_code(y2.dtype), M, C_, Hd
+        a.g, a.ldg, a.z1 = g2.data_ptr(), C_, z1.data_ptr()
+        a.w1_rm, a.w2_rm = pk.get(w1, y2.dtype)[0].data_ptr(), pk.get(w2, y2.dtype)[0].data_ptr()
+        a.drop1_p, a.drop1_site, a.drop2_p, a.drop2_site = float(d1[0]), int(d1[1]), float(d2[0]), int(d2[1])
+        a.dp_p, a.dp_site, a.dp_rows = float(dp[0]), int(dp[1]), int(dp[2])
+        a.rng = rt.rng.data_ptr()
+        a.dz2 = dz2.data_ptr() if masked else None
+        a.dz1, a.dy, a.lddy = dz1.data_ptr(), dy.data_ptr(), C_
+        DeferDW.arm()
+        L.check(L.load().qavit_mlp2_bwd(C.byref(a), K.stream()), "mlp2_bwd")
+        # dW2 += dz2^T h1, db2 += colsum(dz2);  dW1 += dz1^T y, db1 += colsum(dz1)
+        for dz, xin, w, b, n, kd in ((dz2, h1, w2, b2, C_, Hd), (dz1, y2, w1, b1, Hd, C_)):
+            wbuf, _ = grad_sink(w)
+            bbuf, _ = grad_sink(b)
+            if wbuf is None and bbuf is None:
+                continue
+            if wbuf is None:
+                wbuf = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+            K.gemm_tn(dz, xin, wbuf, M, n, kd, n, kd, kd, bbuf)
+        return (dy.reshape(yshape) if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
 class FanOutFn(Function):
     """k aliases of x; backward sums the k incoming gradients in ONE kernel (autograd's own fan-in is k-1 pairwise adds).
     Use where a tensor feeds several consumers: ``a, b, c = FanOutFn.apply(x, 3)``."""

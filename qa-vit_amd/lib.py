@@ -62,6 +62,24 @@ class CgaBwdArgs(C.Structure):
     ]
 
 
+class Mlp2Args(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("M", i32), ("C", i32), ("Hd", i32),
+        ("y", vp), ("ldy", i64), ("resid", vp), ("ldr", i64), ("w1_rm", vp), ("b1", vp), ("w2_rm", vp), ("b2", vp),
+        ("drop1_p", f32), ("drop1_site", i32), ("drop2_p", f32), ("drop2_site", i32), ("dp_p", f32), ("dp_site", i32), ("dp_rows", i32), ("rng", vp),
+        ("out", vp), ("ldo", i64), ("z1", vp), ("h1", vp),
+    ]
+
+
+class Mlp2BwdArgs(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("M", i32), ("C", i32), ("Hd", i32),
+        ("g", vp), ("ldg", i64), ("z1", vp), ("w1_rm", vp), ("w2_rm", vp),
+        ("drop1_p", f32), ("drop1_site", i32), ("drop2_p", f32), ("drop2_site", i32), ("dp_p", f32), ("dp_site", i32), ("dp_rows", i32), ("rng", vp),
+        ("dz2", vp), ("dz1", vp), ("dy", vp), ("lddy", i64),
+    ]
+
+
 class BranchBwdArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("kind", i32), ("B", i32), ("T", i32), ("C", i32), ("H", i32), ("D", i32), ("KC", i32), ("S", i32), ("L", i32),
@@ -144,6 +162,9 @@ _SIGS = {
     "qavit_compress_fuse_bwd_parts": (i32, [i32]),
     "qavit_compress_fuse_bwd": (i32, [vp, vp]),
     "qavit_cga_bwd": (i32, [vp, vp]),
+    "qavit_mlp2_supported": (i32, [i32, i32]),
+    "qavit_mlp2_fwd": (i32, [vp, vp]),
+    "qavit_mlp2_bwd": (i32, [vp, vp]),
     "qavit_ccf_bwd_parts": (i32, [i32]),
     "qavit_branch_bwd": (i32, [vp, vp]),
     "qavit_ln_param_reduce": (i32, [vp, i32, vp]),

@@ -422,8 +422,13 @@ class QuadAttentionBlock(nn.Module):
         mlp = self.bottleneck_mlp
         p = mlp.dropout.p if tr else 0.0
         dp = (self._dp if tr else 0.0)
-        h = F.linear(fused, mlp.fc1.weight, mlp.fc1.bias, act="gelu", drop=(p, mlp._s1))
-        x = F.linear(h, mlp.fc2.weight, mlp.fc2.bias, drop=(p, mlp._s2), dp=(dp, self._dp1, N), resid=xr)
+        if F.mlp2_ok(fused, xr, mlp.fc1.weight, mlp.fc2.weight):
+            # fc1 + GELU + dropout -> fc2 + dropout + drop path + residual: one launch each way (csrc/mlp2.hip)
+            x = F.Mlp2Fn.apply(fused, xr, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias,
+                               dict(drop1=(p, mlp._s1), drop2=(p, mlp._s2), dp=(dp, self._dp1, N)))
+        else:
+            h = F.linear(fused, mlp.fc1.weight, mlp.fc1.bias, act="gelu", drop=(p, mlp._s1))
+            x = F.linear(h, mlp.fc2.weight, mlp.fc2.bias, drop=(p, mlp._s2), dp=(dp, self._dp1, N), resid=xr)
         u, xr2 = self.ccf_ffn.branch(x, self.norm2)
         gamma = self.ccf_ffn.gamma if self._rt.ccf_norm else None
         return F.ScaleAddFn.apply(xr2, u, gamma, (dp, self._dp2, N))

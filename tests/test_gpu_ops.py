@@ -1318,6 +1318,61 @@ def test_fused_compress_fuse(F, Q, B, T):
             assert rel(a_, b_) <= 4e-2, (nm, rel(a_, b_))
 
 
+@pytest.mark.parametrize("drop,dp", [(0.0, 0.0), (0.1, 0.2)])
+@pytest.mark.parametrize("M,T", [(16 * 5 + 0, 16), (1000, 8), (16384, 16)])
+def test_fused_mlp2(F, Q, M, T, drop, dp):
+    """BottleneckMLP + residual in one launch each way (csrc/mlp2.hip) against (1) fp32 torch autograd of
+    x + drop_path(dropout(fc2(dropout(gelu(fc1(y)))))) (HQAViT_CIFAR100.py:651-656, :1082-1083) on the bf16-rounded operands with the
+    exact masks (host RNG replica), every gradient compared, and (2) the two-GEMM chain it replaces (same masks by contract).
+    M = 1000: a ragged last tile of 64 rows."""
+    import importlib
+    from conftest import rng_key, drop_keep
+    K = importlib.import_module("qa-vit_amd.kernels")
+    C, Hd = 192, 96
+    s1, s2, sp = K.new_site(), K.new_site(), K.new_site()
+    seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
+    gout = leaf(M, C, seed=905).detach().to(torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        y = leaf(M, C, seed=900).detach().to(torch.bfloat16).requires_grad_(True)
+        x = leaf(M, C, seed=901).detach().to(torch.bfloat16).requires_grad_(True)
+        w1, b1 = leaf(Hd, C, scale=0.08, seed=902), leaf(Hd, scale=0.1, seed=903)
+        w2, b2 = leaf(C, Hd, scale=0.1, seed=904), leaf(C, scale=0.1, seed=906)
+        if fused:
+            assert F.mlp2_ok(y, x, w1, w2)
+            out = F.Mlp2Fn.apply(y, x, w1, b1, w2, b2, dict(drop1=(drop, s1), drop2=(drop, s2), dp=(dp, sp, T)))
+        else:
+            h = F.linear(y, w1, b1, act="gelu", drop=(drop, s1))
+            out = F.linear(h, w2, b2, drop=(drop, s2), dp=(dp, sp, T), resid=x)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        res.append((out.detach().float(), dict(y=y.grad.float(), x=x.grad.float(), w1=w1.grad, b1=b1.grad, w2=w2.grad, b2=b2.grad)))
+    (o1, g1), (o2, g2) = res
+    assert rel(o1, o2) <= 1e-2
+    for k_ in g1:
+        assert rel(g1[k_], g2[k_]) <= 3e-2, (k_, rel(g1[k_], g2[k_]))
+    # fp32 torch autograd with the exact masks
+    r = dict(y=leaf(M, C, seed=900).detach().to(torch.bfloat16).float(), x=leaf(M, C, seed=901).detach().to(torch.bfloat16).float(),
+             w1=leaf(Hd, C, scale=0.08, seed=902).detach().to(torch.bfloat16).float(), b1=leaf(Hd, scale=0.1, seed=903).detach(),
+             w2=leaf(C, Hd, scale=0.1, seed=904).detach().to(torch.bfloat16).float(), b2=leaf(C, scale=0.1, seed=906).detach())
+    for v in r.values():
+        v.requires_grad_(True)
+    h = TF.gelu(TF.linear(r["y"], r["w1"], r["b1"]))
+    if drop > 0:
+        h = h * torch.from_numpy(drop_keep(rng_key(seed, step, s1), np.arange(M * Hd, dtype=np.uint64), drop).reshape(M, Hd)).to(DEV).float() / (1 - drop)
+    u = TF.linear(h, r["w2"], r["b2"])
+    if drop > 0:
+        u = u * torch.from_numpy(drop_keep(rng_key(seed, step, s2), np.arange(M * C, dtype=np.uint64), drop).reshape(M, C)).to(DEV).float() / (1 - drop)
+    if dp > 0:
+        keep = torch.from_numpy(drop_keep(rng_key(seed, step, sp), np.arange((M + T - 1) // T, dtype=np.uint64), dp)).to(DEV).float() / (1 - dp)
+        u = u * keep.repeat_interleave(T)[:M, None]
+    ref = r["x"] + u
+    assert rel(o1, ref) <= 2e-2
+    ref.backward(gout.float())
+    for k_ in g1:
+        assert rel(g1[k_], r[k_].grad) <= 4e-2, (k_, rel(g1[k_], r[k_].grad))
+
+
 def test_partial_row_reduce(F, Q):
     """qavit_ln_param_reduce: dst halves += column sums of n partial rows, dense rows and rows embedded in a wider record (stride) --
     the end-of-backward fold of the LayerNorm dgamma/dbeta partials and of the fused branch backward's dE / shared-row partials."""
