@@ -316,6 +316,13 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
 #pragma unroll
   for (int jt = 0; jt < KT0a; ++jt) { dEk[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; dEv[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  s16x4 idq;                                               // the 16 x 16 identity as a B operand: element (k = 4 q4 + j, column col)
+  {
+    bf16x4 t1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t1[j] = (bf16)((4 * q4 + j == col) ? 1.f : 0.f);
+    idq = as_s16(t1);
+  }
   // MSDA on 64 tokens: K_f, V_f of the image's landmark rows, ONCE per wave, in both layouts; dK_f / dV_f summed over its query tiles
   s16x4 kfa[KT0a][DT], kfb[KT0a][DT], vfa[KT0a][DT], vfb[KT0a][DT];
   f32x4 dkfS[KSH ? KT0a : 1][KSH ? DT : 1], dvfS[KSH ? KT0a : 1][KSH ? DT : 1];
@@ -382,23 +389,21 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
         }
       }
     }
-    // ---- S and dP in both orientations ----
-    f32x4 sT[NKT], s2[NKT], dpT[NKT], dp2[NKT];
+    // ---- S^T and dP^T (lane = query, registers = keys) ----
+    f32x4 sT[NKT], dpT[NKT];
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt) {
-      f32x4 c1 = zero4, c2 = zero4, c3 = zero4, c4 = zero4;
+      f32x4 c1 = zero4, c3 = zero4;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         const s16x4 ka = nt < KT0 ? kfa[nt < KT0 ? nt : 0][t] : bkA[t];
         const s16x4 va = nt < KT0 ? vfa[nt < KT0 ? nt : 0][t] : bvA[t];
         c1 = mma16(ka, qB[t], c1);                          // S^T[key = 4 q4 + r][query = col]
-        c2 = mma16(qB[t], ka, c2);                          // S  [query = 4 q4 + r][key = col]
         c3 = mma16(va, doB[t], c3);                         // dP^T
-        c4 = mma16(doB[t], va, c4);                         // dP
       }
-      sT[nt] = c1; s2[nt] = c2; dpT[nt] = c3; dp2[nt] = c4;
+      sT[nt] = c1; dpT[nt] = c3;
     }
-    // softmax statistics per query from the first orientation
+    // softmax statistics per query
     float mx = -INFINITY;
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt)
@@ -417,41 +422,24 @@ __global__ __launch_bounds__(512) void branch_bwd_kernel(qavit_branch_bwd_args a
     sum = rows4_sum(sum);
     const float inv = 1.f / sum;
     const uint32_t pkey = adrop ? attn_drop_pkey(drop, prob * BH + h) : 0u;
-    // first orientation: P^T, dS^T (lane = query)
-    s16x4 dsT[NKT];
+    // (P m)^T, dS^T as bf16 quads; the other orientation (lane = key, registers = queries), which the contractions over QUERIES need,
+    // by ONE MFMA against the identity each: a quad tile in accumulator layout read as an A operand is its own transpose, so the
+    // product with I is exactly the transposed tile (bf16 values x 1.0) -- S and dP are not formed a second time, no second round of
+    // exponentials, dropout hashes and statistic permutes.
+    s16x4 dsT[NKT], ds2[NKT], pd2[NKT];
 #pragma unroll
     for (int nt = 0; nt < NKT; ++nt) {
-      f32x4 d;
+      f32x4 d, pm;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = sT[nt][r] * inv;
         const float m = adrop ? attn_drop_factor(drop, pkey, qoff + col, nt * 16 + 4 * q4 + r) : 1.f;
+        pm[r] = p * m;
         d[r] = p * (dpT[nt][r] * m - dpart) * scale;
       }
       dsT[nt] = cvt4s(d);
-    }
-    // second orientation (lane = key, registers = queries 4 q4 + r): statistics by lane permute
-    float mxq[4], invq[4], dq_[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      mxq[r] = __shfl(mx, 4 * q4 + r, 64);
-      invq[r] = __shfl(inv, 4 * q4 + r, 64);
-      dq_[r] = __shfl(dpart, 4 * q4 + r, 64);
-    }
-    s16x4 ds2[NKT], pd2[NKT];
-#pragma unroll
-    for (int nt = 0; nt < NKT; ++nt) {
-      f32x4 d, pm;
-      const bool ok = nt * 16 + col < NK;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = ok ? __expf(s2[nt][r] * scale - mxq[r]) * invq[r] : 0.f;
-        const float m = adrop ? attn_drop_factor(drop, pkey, qoff + 4 * q4 + r, nt * 16 + col) : 1.f;
-        pm[r] = p * m;
-        d[r] = p * (dp2[nt][r] * m - dq_[r]) * scale;
-      }
-      ds2[nt] = cvt4s(d);
-      pd2[nt] = cvt4s(pm);
+      ds2[nt] = cvt4s(mma16(dsT[nt], idq, zero4));           // dS  [query = 4 q4 + r][key = col]
+      pd2[nt] = cvt4s(mma16(cvt4s(pm), idq, zero4));         // P m [query = 4 q4 + r][key = col]
     }
     // ---- dQ^T[d][query] = sum_key Kf[key][d] dS^T[key][query]: 8-byte row segments of dq ----
 #pragma unroll

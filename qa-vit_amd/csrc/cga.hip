@@ -326,6 +326,13 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
   const float scale = 0.5f;
   const s16x4 zero_s = {0, 0, 0, 0};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  s16x4 idq;                                               // the 16 x 16 identity as a B operand: element (k = 4 q4 + j, column col)
+  {
+    bf16x4 t1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t1[j] = (bf16)((4 * q4 + j == col) ? 1.f : 0.f);
+    idq = as_s16(t1);
+  }
   __syncthreads();
 
   // ---- dO = gm Wp in both layouts: dob[g] lane = query, 4 dims (B operand);  dop[g] lane = dim, 4 queries ----
@@ -371,9 +378,7 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
       const bool mine = q4 == h;
       const s16x4 qm = mine ? qb : zero_s, dom = mine ? dob[gl] : zero_s;
       f32x4 sT0 = mma16(ka, qm, zero4), sT1 = mma16(bkA, qm, zero4);        // S^T[key][query = col]
-      f32x4 s20 = mma16(qm, ka, zero4), s21 = mma16(qm, bkA, zero4);        // S  [query = 4 q4 + r][key = col]
       const f32x4 dT0 = mma16(va, dom, zero4), dT1 = mma16(bvA, dom, zero4);  // dP^T
-      const f32x4 d20 = mma16(dom, va, zero4), d21 = mma16(dom, bvA, zero4);  // dP
       float mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { sT0[r] *= scale; sT1[r] *= scale; mx = fmaxf(mx, fmaxf(sT0[r], sT1[r])); }
@@ -385,12 +390,14 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
       const float inv = 1.f / sum;
       const uint32_t pkey = adrop ? attn_drop_pkey(drop, (img * CG + g) * CH + h) : 0u;
       float m0[4], m1[4], dsum = 0.f;
+      f32x4 pm0, pm1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         m0[r] = adrop ? attn_drop_factor(drop, pkey, col, 4 * q4 + r) : 1.f;
         m1[r] = adrop ? attn_drop_factor(drop, pkey, col, CT + 4 * q4 + r) : 1.f;
         sT0[r] *= inv; sT1[r] *= inv;                      // P^T
-        dsum += sT0[r] * m0[r] * dT0[r] + sT1[r] * m1[r] * dT1[r];
+        pm0[r] = sT0[r] * m0[r]; pm1[r] = sT1[r] * m1[r];  // (P m)^T
+        dsum += pm0[r] * dT0[r] + pm1[r] * dT1[r];
       }
       dsum = rows4_sum(dsum);                    // D[query = col] = sum_keys (P m) dP
       f32x4 e0, e1;
@@ -400,19 +407,10 @@ __global__ __launch_bounds__(64 * CNW) void cga_bwd_kernel(qavit_cga_bwd_args a)
         e1[r] = sT1[r] * (dT1[r] * m1[r] - dsum) * scale;
       }
       const s16x4 dsT0 = as_s16(cvt4c(e0)), dsT1 = as_s16(cvt4c(e1));
-      // second orientation: lane = key (col), registers = queries 4 q4 + r
-      f32x4 f0, f1, p0, p1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float mxq = __shfl(mx, 4 * q4 + r, 64), invq = __shfl(inv, 4 * q4 + r, 64), dq_ = __shfl(dsum, 4 * q4 + r, 64);
-        const float pa = __expf(s20[r] * scale - mxq) * invq, pb = __expf(s21[r] * scale - mxq) * invq;
-        const float ma = adrop ? attn_drop_factor(drop, pkey, 4 * q4 + r, col) : 1.f;
-        const float mb = adrop ? attn_drop_factor(drop, pkey, 4 * q4 + r, CT + col) : 1.f;
-        p0[r] = pa * ma; p1[r] = pb * mb;
-        f0[r] = pa * (d20[r] * ma - dq_) * scale;
-        f1[r] = pb * (d21[r] * mb - dq_) * scale;
-      }
-      const s16x4 ds20 = as_s16(cvt4c(f0)), ds21 = as_s16(cvt4c(f1)), pd20 = as_s16(cvt4c(p0)), pd21 = as_s16(cvt4c(p1));
+      // the other orientation (lane = key, registers = queries): a quad tile in accumulator layout read as an A operand is its own
+      // transpose, so one MFMA against the identity gives dS / P m exactly -- no second S / dP, exponentials or dropout hashes
+      const s16x4 ds20 = as_s16(cvt4c(mma16(dsT0, idq, zero4))), ds21 = as_s16(cvt4c(mma16(dsT1, idq, zero4)));
+      const s16x4 pd20 = as_s16(cvt4c(mma16(as_s16(cvt4c(pm0)), idq, zero4))), pd21 = as_s16(cvt4c(mma16(as_s16(cvt4c(pm1)), idq, zero4)));
       // dQ^T[d][query] = sum_key K[key][d] dS^T[key][query]  (tokens + bank rows); valid where d is in head h = this lane group
       f32x4 t = mma16(kp, dsT0, zero4);
       t = mma16(bkP, dsT1, t);

@@ -320,6 +320,13 @@ __global__ __launch_bounds__(64 * BW_WAVES) void cga64_bwd_kernel(qavit_cga_bwd_
   const float scale = 0.5f;
   const s16x4 zero_s = {0, 0, 0, 0};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  s16x4 idq;                                               // the 16 x 16 identity as a B operand: element (k = 4 q4 + j, column col)
+  {
+    bf16x4 t1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t1[j] = (bf16)((4 * q4 + j == col) ? 1.f : 0.f);
+    idq = as_s16(t1);
+  }
   __syncthreads();
 
   const int g = wave;
@@ -382,44 +389,42 @@ __global__ __launch_bounds__(64 * BW_WAVES) void cga64_bwd_kernel(qavit_cga_bwd_
       const float inv = 1.f / sum;
       const uint32_t pkey = adrop ? attn_drop_pkey(drop, (img * WG + g) * WH + h) : 0u;
       float dsum = 0.f;
+      s16x4 pmq[NKT];                                      // (P m)^T quads, bf16
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x4 pm;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float m = adrop ? attn_drop_factor(drop, pkey, 16 * qt + col, 16 * kt + 4 * q4 + r) : 1.f;
           sT[kt][r] *= inv;                                // P^T
+          pm[r] = sT[kt][r] * m;
           dT[kt][r] *= m;                                  // dP^T m
           dsum += sT[kt][r] * dT[kt][r];
         }
+        pmq[kt] = cv4s(pm);
+      }
       dsum = rows4_sum(dsum);                              // D[query = col] = sum_keys (P m) dP
       // dQ^T[d][query] = sum_key K[key][d] dS^T[key][query] (tokens + bank rows); valid where d is in head h = this lane group
       f32x4 t = zero4;
+      s16x4 dsq[NKT];                                      // dS^T quads, bf16
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
         f32x4 e;
 #pragma unroll
         for (int r = 0; r < 4; ++r) e[r] = sT[kt][r] * (dT[kt][r] - dsum) * scale;      // dS^T
-        t = mma16(kt < QT ? kp[kt < QT ? kt : 0] : bkP, cv4s(e), t);
+        dsq[kt] = cv4s(e);
+        t = mma16(kt < QT ? kp[kt < QT ? kt : 0] : bkP, dsq[kt], t);
       }
       if (mine) dq = t;
-      // second orientation, key tile by key tile: lane = key (col), registers = queries 4 q4 + r
-      float mxq[4], invq[4], dq_[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { mxq[r] = __shfl(mx, 4 * q4 + r, 64); invq[r] = __shfl(inv, 4 * q4 + r, 64); dq_[r] = __shfl(dsum, 4 * q4 + r, 64); }
+      // The other orientation (lane = key, registers = queries 4 q4 + r), which the contractions over QUERIES need: a quad tile in
+      // accumulator layout read as an A operand is its own transpose, so ONE MFMA against the identity turns (P m)^T / dS^T into
+      // P m / dS exactly (bf16 values x 1.0) -- instead of forming S and dP a second time and redoing the exponentials and the
+      // dropout hashes, which were ~45 % of this kernel's vector instructions.
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-        const f32x4 s2 = mma16(qm, kt < QT ? ka[kt < QT ? kt : 0] : bkA, zero4);        // S [query = 4 q4 + r][key = col]
-        const f32x4 d2 = mma16(dom, kt < QT ? va[kt < QT ? kt : 0] : bvA, zero4);       // dP
-        f32x4 f, pm;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s2[r] * scale - mxq[r]) * invq[r];
-          const float m = adrop ? attn_drop_factor(drop, pkey, 16 * qt + 4 * q4 + r, 16 * kt + col) : 1.f;
-          pm[r] = p * m;
-          f[r] = p * (d2[r] * m - dq_[r]) * scale;
-        }
+        const f32x4 f = mma16(dsq[kt], idq, zero4), pm2 = mma16(pmq[kt], idq, zero4);   // dS / P m [query = 4 q4 + r][key = col]
         // dK^T[d][key] = sum_query Q[query][d] dS[query][key];  dV^T[d][key] = sum_query dO[query][d] (P m)[query][key]
-        const f32x4 tk = mma16(qp, cv4s(f), zero4), tv = mma16(dop, cv4s(pm), zero4);
+        const f32x4 tk = mma16(qp, cv4s(f), zero4), tv = mma16(dop, cv4s(pm2), zero4);
         if (kt < QT) {
           if (mine) {
 #pragma unroll
