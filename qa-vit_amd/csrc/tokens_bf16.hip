@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void upmix2_fwd_kernel(const bf16* xc, const f
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) { ga[ct] = gamma[ct * 16 + col]; be[ct] = beta[ct * 16 + col]; }
   const float invC = 1.f / (float)L::C;
+  bf16* yt = sm + L::dup + wave * 16 * L::LDC;                 // this wave's output tile [16][LDC]
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
@@ -234,9 +235,21 @@ __global__ __launch_bounds__(256) void upmix2_fwd_kernel(const bf16* xc, const f
         const float rstd = rsqrtf(grp_sum<16>(s2) * invC + eps);
         const size_t row = (size_t)b * L::N + nt * 16 + 4 * q4 + r;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) y[row * L::C + ct * 16 + col] = (bf16)((acc[ct][r] - mean) * rstd * ga[ct] + be[ct]);
+        for (int ct = 0; ct < CT; ++ct) yt[(4 * q4 + r) * L::LDC + ct * 16 + col] = (bf16)((acc[ct][r] - mean) * rstd * ga[ct] + be[ct]);
         if (col == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
       }
+      // the tile's 16 rows out of the wave's LDS slice as whole rows (8-byte pieces): two-byte stores of four rows per instruction were
+      // the kernel's store path
+      wave_sync();
+      {
+        constexpr int CH = L::C / 4;
+        bf16* ys = y + ((size_t)b * L::N + nt * 16) * L::C;
+        for (int i = lane; i < 16 * CH; i += 64) {
+          const int n = i / CH, ch = i - n * CH;
+          *reinterpret_cast<bf16x4*>(ys + (size_t)n * L::C + 4 * ch) = *reinterpret_cast<const bf16x4*>(yt + n * L::LDC + 4 * ch);
+        }
+      }
+      wave_sync();
     }
   }
 }
@@ -277,8 +290,21 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       __syncthreads();                                           // xc staged / previous chunk consumed
       const int nt = wave + 4 * tw;
       if (nt < NT) {
+        // this wave's 16 dy rows: whole rows in 8-byte pieces into its slice of the dup tile (read element-wise below, then overwritten
+        // in place by du) -- 48 two-byte global loads per lane were the kernel's load path
+        constexpr bool STAGE_DY = NT <= 4;                       // (the 256-token variant already holds 512 registers per lane)
+        if (STAGE_DY) {
+          constexpr int CH = L::C / 4;
+          const bf16* dys = dy + ((size_t)b * L::N + nt * 16) * L::C;
+          bf16* dtw = sm + L::dup + wave * 16 * L::LDC;
+          for (int i = lane; i < 16 * CH; i += 64) {
+            const int n = i / CH, ch = i - n * CH;
+            *reinterpret_cast<bf16x4*>(dtw + n * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(dys + (size_t)n * L::C + 4 * ch);
+          }
+        }
         f32x4 acc[CT];
         up_tile<NT, MT, CT>(sm + L::wt, sm + L::xc, bias, nt, acc);
+        if (STAGE_DY) wave_sync();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t row = (size_t)b * L::N + nt * 16 + 4 * q4 + r;
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
           float c1 = 0.f, c2 = 0.f;
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
-            const float d = (float)dy[row * L::C + ct * 16 + col];
+            const float d = STAGE_DY ? (float)sm[L::dup + (wave * 16 + 4 * q4 + r) * L::LDC + ct * 16 + col] : (float)dy[row * L::C + ct * 16 + col];
             const float xh = (acc[ct][r] - mu) * rs;
             acc[ct][r] = xh;
             g[ct] = d * ga[ct];
@@ -302,6 +328,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
           rsum = grp_sum<16>(rsum);
           if (col == 0) dba[nt * 16 + 4 * q4 + r] += rsum;       // this row belongs to this wave only
         }
+        if (STAGE_DY) wave_sync();                               // every lane has read its dy elements: the slice takes du
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc_to_lds(sm + L::dup, L::LDC, wave * 16, ct * 16, acc[ct]);
       }
@@ -316,7 +343,8 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
 #pragma unroll
           for (int k = 0; k < KT; ++k)
             if (4 * tw + k < NT)
-              dxa[i] = mma16(trfrag(sm + L::wt, L::LDM, (4 * tw + k) * 16, mt * 16), trfrag(sm + L::dup, L::LDC, k * 16, ct * 16), dxa[i]);
+              dxa[i] = (NT <= 4) ? mma16(trfrag(sm + L::dup, L::LDC, k * 16, ct * 16), trfrag(sm + L::wt, L::LDM, (4 * tw + k) * 16, mt * 16), dxa[i])    // swapped: dxc^T tile
+                                 : mma16(trfrag(sm + L::wt, L::LDM, (4 * tw + k) * 16, mt * 16), trfrag(sm + L::dup, L::LDC, k * 16, ct * 16), dxa[i]);
         }
       }
       // dW[n][m] += sum_c dup[n][c] xc[m][c]   (own row tile)
@@ -333,8 +361,15 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       const int tile = wave + 4 * i;
       if (tile < MT * CT) {
         const int mt = tile / CT, ct = tile - mt * CT;
+        if (NT <= 4) {                                          // acc[r] = dxc[m = 16 mt + col][c = 16 ct + 4 q4 + r]: one 8-byte row segment
+          bf16x4 o4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dxc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)dxa[i][r];
+          for (int r = 0; r < 4; ++r) o4[r] = (bf16)dxa[i][r];
+          *reinterpret_cast<bf16x4*>(dxc + ((size_t)b * L::M + mt * 16 + col) * L::C + ct * 16 + 4 * q4) = o4;
+        } else {                                                // (the 256-token variant holds 512 registers per lane: its schedule is left alone)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dxc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)dxa[i][r];
+        }
       }
     }
   }
@@ -370,7 +405,7 @@ static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, 
                       float eps, void* o0, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, hipStream_t st) {
   using L = UpLds<NT, MT, CT>;
   if (!bwd) {
-    const size_t smem = (size_t)L::fwd_bf16 * 2;
+    const size_t smem = (size_t)(L::fwd_bf16 + 64 * L::LDC) * 2;        // + the four waves' output tiles
     if (smem > 150 * 1024) return -100;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_fwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((upmix2_fwd_kernel<NT, MT, CT>), dim3(B < 2048 ? B : 2048), dim3(256), smem, st, (const bf16*)xc, W, bias, gamma, beta, eps,
@@ -466,11 +501,15 @@ __global__ __launch_bounds__(256) void tokmix2_fwd_kernel(const bf16* scores, co
   __syncthreads();
   for (int tile = wave; tile < MT * CT; tile += 4) {
     const int mt = tile / CT, ct = tile - mt * CT;
+    // operands swapped = the transposed product: acc[r] = xc[m = 16 mt + col][c = 16 ct + 4 q4 + r] -- one 8-byte row segment per lane
+    // instead of four 2-byte elements of four rows (both operand roles have the same lane layout: idx = lane % 16, k = 4 (lane / 16) + j)
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) a = mma16(trfrag(sm + L::p, L::LDM, nt * 16, mt * 16), trfrag(sm + L::x, L::LDC, nt * 16, ct * 16), a);
+    for (int nt = 0; nt < NT; ++nt) a = mma16(trfrag(sm + L::x, L::LDC, nt * 16, ct * 16), trfrag(sm + L::p, L::LDM, nt * 16, mt * 16), a);
+    bf16x4 o4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)a[r];
+    for (int r = 0; r < 4; ++r) o4[r] = (bf16)a[r];
+    *reinterpret_cast<bf16x4*>(xc + ((size_t)b * L::M + mt * 16 + col) * L::C + ct * 16 + 4 * q4) = o4;
   }
 }
 
@@ -499,11 +538,13 @@ __global__ __launch_bounds__(256) void tokmix2_bwd_kernel(const bf16* p_in, cons
     wave_sync();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};             // operands swapped: acc[r] = dx[n = 16 nt + col][c = 16 ct + 4 q4 + r], 8-byte row segments
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a = mma16(rowfrag(sm + L::p, L::LDM, nt * 16, mt * 16), trfrag(sm + L::bg, L::LDC, mt * 16, ct * 16), a);
+      for (int mt = 0; mt < MT; ++mt) a = mma16(trfrag(sm + L::bg, L::LDC, mt * 16, ct * 16), rowfrag(sm + L::p, L::LDM, nt * 16, mt * 16), a);
+      bf16x4 o4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dx[((size_t)b * L::N + nt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)a[r];
+      for (int r = 0; r < 4; ++r) o4[r] = (bf16)a[r];
+      *reinterpret_cast<bf16x4*>(dx + ((size_t)b * L::N + nt * 16 + col) * L::C + ct * 16 + 4 * q4) = o4;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {

@@ -7,7 +7,7 @@ it is divided by 8; SIMD_NUM = 256 CUs x 4.  MFMA FLOPs executed = SQ_INSTS_VALU
 to the 16x16x16 tile included -- this is what the matrix pipe did, not the algorithmic count).
 usage: pmc_mfma.py <counter_collection.csv> <out.json> [steps-profiled]"""
 import csv, json, sys
-FAM = [("attn_fused", ("branch_fwd_kernel",)), ("attn_fused_bwd", ("branch_bwd_kernel",)), ("cga_fused", ("cga_fwd_kernel", "cga_bwd_kernel")), ("cfuse_fused", ("cfuse_fwd_kernel", "cfuse_bwd_kernel")),
+FAM = [("attn_fused", ("branch_fwd_kernel",)), ("attn_fused_bwd", ("branch_bwd_kernel",)), ("cga_fused", ("cga_fwd_kernel", "cga_bwd_kernel", "cga64_fwd_kernel", "cga64_bwd_kernel")), ("mlp2_fused", ("mlp2_fwd_kernel", "mlp2_bwd_kernel")), ("cfuse_fused", ("cfuse_fwd_kernel", "cfuse_bwd_kernel")),
        ("gemm_nt", ("gemm_nt_",)), ("gemm_tn", ("gemm_tn_",)),
        ("attn_bwd", ("true>(qavit_attn_args", "attn_bwd_kernel")), ("attn_reduce", ("attn_reduce",)),
        ("attn_fwd", ("false>(qavit_attn_args", "attn_fwd_kernel")),

@@ -5,7 +5,7 @@ gfx950 corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB; FETCH_S
 wide coalesced read at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores and float atomics.
 usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
 import csv, json, sys
-FAM = [("branch_fwd", ("branch_fwd_kernel",)), ("branch_bwd", ("branch_bwd_kernel",)), ("cga_fwd", ("cga_fwd_kernel",)), ("cga_bwd", ("cga_bwd_kernel",)), ("cfuse_fwd", ("cfuse_fwd_kernel",)), ("cfuse_bwd", ("cfuse_bwd_kernel",)), ("gemm_nt", ("gemm_nt_",)), ("gemm_tn_grouped", ("gemm_tn_",)),
+FAM = [("branch_fwd", ("branch_fwd_kernel",)), ("branch_bwd", ("branch_bwd_kernel",)), ("cga_fwd", ("cga_fwd_kernel", "cga64_fwd_kernel")), ("cga_bwd", ("cga_bwd_kernel", "cga64_bwd_kernel")), ("mlp2_fwd", ("mlp2_fwd_kernel",)), ("mlp2_bwd", ("mlp2_bwd_kernel",)), ("cfuse_fwd", ("cfuse_fwd_kernel",)), ("cfuse_bwd", ("cfuse_bwd_kernel",)), ("gemm_nt", ("gemm_nt_",)), ("gemm_tn_grouped", ("gemm_tn_",)),
        ("attn_bwd", ("true>(qavit_attn_args", "attn_bwd_kernel", "attn_reduce")), ("attn_fwd", ("false>(qavit_attn_args", "attn_fwd_kernel")),
        ("layernorm_bwd", ("layernorm_bwd",)), ("layernorm_fwd", ("layernorm_fwd",)), ("row_stats", ("row_stats",)),
        ("dwconv_bwd", ("dwconv_bwd",)), ("dwconv_fwd", ("dwconv_fwd",)), ("ccf_mid_bwd", ("ccf_bwd",)), ("ccf_mid_fwd", ("ccf_fwd",)),
