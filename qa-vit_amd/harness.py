@@ -17,6 +17,7 @@ Two recipes: ``TrainingConfig`` = HQAViT_CIFAR100.py's pre-training loop (OneCyc
 EPOCH (:384, :481-496, :520-523 -- call ``Trainer.epoch_end()``), one global clip at 1.0, label smoothing 0.1, no EMA.
 """
 import math
+import time
 from copy import deepcopy
 from dataclasses import dataclass
 from typing import Optional
@@ -459,6 +460,13 @@ class Trainer:
                     self._optim()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if self.reducer is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # The process group's watchdog thread still holds the warm-up steps' collectives and polls their end events
+            # (hipEventQuery) every 100 ms until it has seen each one complete.  Those events were recorded on the reducer's
+            # side stream; once that stream joins the capture, HIP answers such a query with hipErrorCapturedEvent and the
+            # watchdog takes the process down.  Everything is complete after the synchronize above: give the watchdog a few of
+            # its passes to retire the list before the capture begins (collectives issued DURING capture are never enqueued).
+            time.sleep(0.5)
         with torch.no_grad():
             for t, v in zip(self._state(), saved):
                 t.copy_(v)

@@ -10,8 +10,10 @@ export TMPDIR=/tmp
 python3 bench.py > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o k -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 python3 tools/kfamily.py $OUT/kt/k_kernel_stats.csv 31 > $OUT/family_summary.txt
-python3 tools/overlap_report.py $OUT/kt/k_kernel_trace.csv > $OUT/overlap.txt
-python3 tools/step_timeline.py $OUT/kt/k_kernel_trace.csv 0 100000 > $OUT/step_timeline.txt
+# stream overlap and the per-kernel timeline of one replayed step: a trace WITHOUT bench.py's instrumented eager step (its bracketing kernels are not the product)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_plain -o k -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $OUT/bench_under_rocprof_plain.json 2> $OUT/bench_under_rocprof_plain.err
+python3 tools/overlap_report.py $OUT/kt_plain/k_kernel_trace.csv > $OUT/overlap.txt
+python3 tools/step_timeline.py $OUT/kt_plain/k_kernel_trace.csv 0 100000 > $OUT/step_timeline.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 tools/prof_step.py 1024 2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 tools/prof_step.py 1024 2 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o m -- python3 tools/prof_step.py 1024 2 > $OUT/pmc_mfma.log 2>&1
@@ -34,10 +36,14 @@ python3 bench.py --config q32 --eval --variant v2 --no-cpu-baseline > $OUT/bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_q32 -o k -- python3 bench.py --config q32 --eval --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $OUT/bench_q32_under_rocprof.json 2> $OUT/bench_q32_under_rocprof.err
 python3 tools/kfamily.py $OUT/kt_q32/k_kernel_stats.csv 28 > $OUT/family_summary_q32_eval.txt
 # the data-parallel step on ONE rank over RCCL (what one GPU can show of the N-GPU step): default sync points, all seven, none
-QAVIT_FORCE_DDP=1 python3 bench.py --no-cpu-baseline --no-kernel-timing > $OUT/bench_force_ddp.json 2> $OUT/bench_force_ddp.err
-QAVIT_FORCE_DDP=1 QAVIT_DDP_TAGS=all python3 bench.py --no-cpu-baseline --no-kernel-timing > $OUT/bench_force_ddp_all_tags.json 2> $OUT/bench_force_ddp_all_tags.err
-QAVIT_FORCE_DDP=1 NCCL_DEBUG=INFO python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-graph > $OUT/bench_force_ddp_nccl_info.json 2> $OUT/bench_force_ddp_nccl_info.err
+# (librccl prints its version banner on stdout: keep the JSON line only)
+QAVIT_FORCE_DDP=1 python3 bench.py --no-cpu-baseline --no-kernel-timing 2> $OUT/bench_force_ddp.err | grep '^{' > $OUT/bench_force_ddp.json
+QAVIT_FORCE_DDP=1 QAVIT_DDP_TAGS=all python3 bench.py --no-cpu-baseline --no-kernel-timing 2> $OUT/bench_force_ddp_all_tags.err | grep '^{' > $OUT/bench_force_ddp_all_tags.json
+QAVIT_FORCE_DDP=1 QAVIT_DDP_TAGS= python3 bench.py --no-cpu-baseline --no-kernel-timing 2> $OUT/bench_force_ddp_no_tags.err | grep '^{' > $OUT/bench_force_ddp_no_tags.json
+QAVIT_FORCE_DDP=1 NCCL_DEBUG=INFO python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-graph > $OUT/bench_force_ddp_nccl_info.log 2>&1
+QAVIT_FORCE_DDP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_ddp -o k -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing > $OUT/bench_force_ddp_under_rocprof.log 2>&1
+python3 tools/kfamily.py $OUT/kt_ddp/k_kernel_stats.csv 31 > $OUT/family_summary_force_ddp.txt
 # the lateral path on its stream (default) against everything on one stream
 QAVIT_LATERAL_STREAM=0 python3 bench.py --no-cpu-baseline --no-kernel-timing > $OUT/bench_lateral_one_stream.json 2> $OUT/bench_lateral_one_stream.err
-rm -f $OUT/kt/k_kernel_trace.csv $OUT/kt_tin128/k_kernel_trace.csv $OUT/kt_tin512/k_kernel_trace.csv $OUT/kt_q32/k_kernel_trace.csv
+rm -f $OUT/kt_plain/k_kernel_trace.csv $OUT/kt_ddp/k_kernel_trace.csv $OUT/kt/k_kernel_trace.csv $OUT/kt_tin128/k_kernel_trace.csv $OUT/kt_tin512/k_kernel_trace.csv $OUT/kt_q32/k_kernel_trace.csv
 tail -n 20 $OUT/family_summary.txt $OUT/mfma_util.txt $OUT/traffic.txt $OUT/branch_mfma_pmc.txt
