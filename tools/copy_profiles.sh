@@ -20,5 +20,5 @@ cp $S/pmc_fetch/f_counter_collection.csv $P/${R}_pmc_fetch_size_eager2steps.csv
 cp $S/pmc_write/w_counter_collection.csv $P/${R}_pmc_write_size_eager2steps.csv
 gzip -c $S/pmc_mfma/m_counter_collection.csv > $P/${R}_pmc_mfma_eager2steps.csv.gz
 gzip -c $S/pmc_branch/m_counter_collection.csv > $P/${R}_pmc_branch_mfma.csv.gz
-grep -h "NCCL INFO" $S/bench_force_ddp_nccl_info.log | grep -i "algo\|proto\|channel\|ring\|tree\|Connected\|comm " | cut -c1-400 | head -60 > $P/${R}_rccl_one_rank_info.txt || true
+grep -h "NCCL INFO" $S/bench_force_ddp_nccl_info.log | grep -vi "Channel [0-9]\|Trees \[" | cut -c1-300 > $P/${R}_rccl_one_rank_info.txt || true
 [ -f $S/kt_ddp/k_kernel_stats.csv ] && cp $S/kt_ddp/k_kernel_stats.csv $P/${R}_kernel_stats_force_ddp_hipgraph.csv
