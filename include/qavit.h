@@ -606,6 +606,9 @@ typedef struct qavit_pack_desc { const float* src; void* dst; void* dstT; int ro
 int qavit_pack_weights(int dtype, const qavit_pack_desc* descs_dev, int n_desc, int max_elems, void* stream);
 /* rng[1] += 1 */
 int qavit_rng_advance(int64_t* rng, void* stream);
+/* diagnostic: *dst = the device's constant 100 MHz wall clock when `stream` reaches this launch (one lane; tools/chain_stamps.py
+ * places these at the fork / join points of a captured step to see where its two chains run without a profiler attached) */
+int qavit_stamp(uint64_t* dst, void* stream);
 /* fused AdamW over a flat fp32 buffer with a per-element group mask (skip[i] != 0: parameter never receives a
  * gradient -> untouched, as torch.optim.AdamW skips grad-is-None tensors, HQAViT_CIFAR100.py:1566-1571) and
  * global-norm clipping folded in: g *= min(1, max_norm / (*gnorm + 1e-6)) (clip_grad_norm_, :1432).

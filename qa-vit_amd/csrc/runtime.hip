@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const qavit_pack_desc* descs,
 
 __global__ void rng_advance_kernel(int64_t* rng) { rng[1] += 1; }
 
+// one 100 MHz wall-clock reading, written when the stream reaches this point (tools/chain_stamps.py: where the two chains of a step are, unprofiled)
+__global__ void stamp_kernel(uint64_t* dst) { *dst = wall_clock64(); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, int64_t n, float p, int site, const int64_t* rng) {
   const uint32_t key = rng_key(rng, site);
@@ -600,6 +603,12 @@ extern "C" int qavit_rng_advance(int64_t* rng, void* stream) {
   if (!rng) return set_error(QAVIT_EINVAL, "rng_advance: null");
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), rng);
   return check_launch("rng_advance");
+}
+
+extern "C" int qavit_stamp(uint64_t* dst, void* stream) {
+  if (!dst) return set_error(QAVIT_EINVAL, "stamp: null");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), dst);
+  return check_launch("stamp");
 }
 
 extern "C" int qavit_dropout(int dtype, const void* x, void* y, int64_t n, float p, int site, const int64_t* rng, void* stream) {

@@ -291,6 +291,7 @@ class DeferDW:
 
     @classmethod
     def finish(cls):
+        K.Stamps.mark("dw.flush")
         cls._launch()
         K.DeferredTN.enabled = False
         K.DeferredLN.enabled = False
@@ -308,6 +309,25 @@ class FlushMarkFn(Function):
     def backward(ctx, dy):
         DeferDW.flush_home()
         return dy
+
+
+class StampFn(Function):
+    """Identity that takes a wall-clock stamp ``name + ".f"`` when forward reaches it and ``name + ".b"`` when backward does (K.Stamps)."""
+
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        K.Stamps.mark(name + ".f")
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        K.Stamps.mark(ctx.name + ".b")
+        return dy, None
+
+
+def stamp(x, name):
+    return StampFn.apply(x, name) if K.Stamps.enabled else x
 
 
 class SideStream:

@@ -340,6 +340,7 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------
     def _fwd_bwd(self, x, y):
+        K.Stamps.mark("step.begin")
         self.rt.advance()
         F.pack_for(self.device).refresh()
         self.flat_g.zero_()
@@ -350,7 +351,9 @@ class Trainer:
             loss = F.cross_entropy(self.model(x), y, self.cfg.label_smoothing, y_b=y_b, lam=lam.reshape(1).float())
         else:
             loss = F.cross_entropy(self.model(x), y, self.cfg.label_smoothing)
+        K.Stamps.mark("bwd.begin")
         loss.backward()
+        K.Stamps.mark("bwd.end")
         F.SideStream.join(self.device)                     # weight-gradient GEMMs ran on the side stream
         if self.reducer is not None:
             self.reducer.finish(self.flat_g)
@@ -392,6 +395,7 @@ class Trainer:
         F.pack_for(self.device).mark_stale()            # the packed compute-dtype weights no longer match the parameters
         if self.ema_flat is not None:
             torch.lerp(self.ema_flat, self.flat_p, self.ema_w, out=self.ema_flat)
+        K.Stamps.mark("step.end")
 
     def epoch_end(self):
         """The per-epoch ``scheduler.step()`` of the transfer recipe (HQAViT_Tiny_Cifar10.py:384); no-op for OneCycle."""

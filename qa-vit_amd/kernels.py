@@ -31,6 +31,31 @@ def _require_cuda(*ts):
             raise RuntimeError("qavit HIP kernels need tensors on the GPU (there is no CPU fallback)")
 
 
+class Stamps:
+    """Diagnostic (QAVIT_STAMPS=1; tools/chain_stamps.py): named wall-clock readings taken by one-lane kernels on whatever stream is
+    current, so a captured step records where its chains are without a profiler attached.  Off: ``mark`` is a no-op."""
+    enabled = os.environ.get("QAVIT_STAMPS", "0") != "0"
+    names: list = []
+    buf = None
+
+    @classmethod
+    def mark(cls, name: str):
+        if not cls.enabled:
+            return
+        if cls.buf is None:
+            cls.buf = torch.zeros(128, dtype=torch.int64, device="cuda")
+        if name not in cls.names:
+            cls.names.append(name)
+        L.check(L.load().qavit_stamp(cls.buf.data_ptr() + 8 * cls.names.index(name), stream()), "stamp")
+
+    @classmethod
+    def read(cls):
+        """{name: microseconds since the earliest stamp} of the last pass over each mark."""
+        v = cls.buf[:len(cls.names)].cpu().tolist()
+        t0 = min(v)
+        return {n: (t - t0) / 100.0 for n, t in zip(cls.names, v)}
+
+
 class Runtime:
     """Per-device state: RNG words, NaN flags, dropout-site ids, scratch workspaces."""
     _inst = {}

@@ -216,6 +216,7 @@ _SIGS = {
     "qavit_dropout": (i32, [i32, vp, vp, i64, f32, i32, vp, vp]),
     "qavit_pack_weights": (i32, [i32, vp, i32, i32, vp]),
     "qavit_rng_advance": (i32, [vp, vp]),
+    "qavit_stamp": (i32, [vp, vp]),
     "qavit_adamw": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, f32, vp]),
     "qavit_l2norm": (i32, [vp, i64, vp, vp, vp]),
     "qavit_ce_label_smooth": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp]),

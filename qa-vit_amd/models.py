@@ -146,22 +146,27 @@ class HQAViT(_Base):
         with torch.autocast("cuda", enabled=False):
             def lateral():
                 with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    K.Stamps.mark("lat.begin")
                     feats, (fh, fw) = self.cnn_stem.forward_tokens(x, cdt)
                     R_ = {}
                     for i, f in zip((2, 3, 4), feats):
-                        a = getattr(self, f"lmfa{i}").forward_tokens(f, fh, fw)
-                        R_[i] = getattr(self, f"rrcv{i}")(a, self.H, self.W)
+                        a = getattr(self, f"lmfa{i}").forward_tokens(F.stamp(f, f"lat.feat{i}"), fh, fw)
+                        R_[i] = F.stamp(getattr(self, f"rrcv{i}")(a, self.H, self.W), f"lat.R{i}")
+                        if side is not None:                 # the token path joins scale by scale: fuse2 needs R2 only
+                            ready[i] = torch.cuda.Event()
+                            ready[i].record(side)
                 return R_
 
             def stage1():
-                T_ = self.patch_embed(x, self.pos_embed)
+                K.Stamps.mark("tok.begin")
+                T_ = F.stamp(self.patch_embed(x, self.pos_embed), "tok.embed")
                 T_ = F.dropout(T_, self.pos_drop.p, self._pos_site, self.training)
                 if _EARLY_FLUSH and side is not None and torch.is_grad_enabled() and T_.requires_grad:
                     T_ = F.FlushMarkFn.apply(T_)            # backward: the token path ends here while the lateral path's tail still runs
                 T_ = self._sync(T_, "stage1_blocks")
                 for blk in self.stage1_blocks:
                     T_ = blk(T_)
-                return T_
+                return F.stamp(T_, "tok.stage1")
 
             def lateral_steps(R_):
                 feats, (fh, fw) = yield from self.cnn_stem.forward_tokens_steps(x, cdt)
@@ -169,6 +174,8 @@ class HQAViT(_Base):
                     a = getattr(self, f"lmfa{i}").forward_tokens(f, fh, fw)
                     yield
                     R_[i] = getattr(self, f"rrcv{i}")(a, self.H, self.W)
+                    ready[i] = torch.cuda.Event()
+                    ready[i].record(side)
                     yield
 
             def stage1_steps(out):
@@ -195,6 +202,7 @@ class HQAViT(_Base):
             # numbers autograd schedules by -- the backward's: the graph executor starts a chain about when its first node's turn
             # comes in creation order, so a chain issued as one piece after the other runs mostly BEHIND it, not beside it (measured:
             # 1.4 ms of lateral-only forward and 1.8 ms of lateral-only backward per step).  2 = alternate the chains' steps.
+            ready = {}
             if _LATERAL_ORDER == 2 and side is not None:
                 R, box = {}, {}
                 gl, gm = lateral_steps(R), stage1_steps(box)
@@ -213,12 +221,14 @@ class HQAViT(_Base):
                 R = lateral()
                 T = stage1()
             for si in (2, 3, 4):
-                if si == 2 and side is not None:
-                    main.wait_stream(side)
-                    for r_ in R.values():
-                        r_.record_stream(main)
+                if side is not None:
+                    # R2 is complete ~0.5 ms before R4 (tools/chain_stamps.py): waiting for the whole lateral chain here left the
+                    # token path idle for 0.45 ms per forward.  The last event is the last work on the side stream, so the chains
+                    # are fully joined (and a capture is closed) once fuse4 has waited.
+                    main.wait_event(ready[si])
+                    R[si].record_stream(main)
                 T = self._sync(T, f"fuse{si}")
-                T = getattr(self, f"fuse{si}")(T, R[si])
+                T = F.stamp(getattr(self, f"fuse{si}")(T, R[si]), f"tok.fuse{si}")
                 T = self._sync(T, f"stage{si}_blocks")
                 for blk in getattr(self, f"stage{si}_blocks"):
                     T = blk(T)

@@ -605,7 +605,7 @@ class CNNStemModel(nn.Module):
         token path's: models.HQAViT.forward); the result is the generator's return value."""
         B, Cin, H, W = x.shape
         with torch.autocast("cuda", enabled=False):
-            t = self._conv3x3s2_tokens(x, self.stem[0], self.stem[1], (B, Cin, H, W, 3, 2, 1), cdt)
+            t = F.stamp(self._conv3x3s2_tokens(x, self.stem[0], self.stem[1], (B, Cin, H, W, 3, 2, 1), cdt), "lat.stem0")
             yield
             H1, W1 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
             t = self._conv3x3s2_tokens(t, self.stage1[0], self.stage1[1], (B, self.stem[0].out_channels, H1, W1, 3, 2, 1), cdt)
