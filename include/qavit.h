@@ -89,6 +89,8 @@ int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stream);
  * C[N,K] += A[M,N]^T . B[M,K]   (fp32 atomics, split over M);   colsum[N] += sum_m A[m,n]
  * The weight / bias gradient of every nn.Linear above (autograd of F.linear).  B may be LayerNorm-ed on
  * load with saved statistics (the fused-prologue layers).
+ * K need not be a multiple of 8 when B's rows are padded (ldb % 8 == 0, ldb >= K rounded up to 8): the pad columns are read and
+ * their products discarded.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct qavit_gemm_tn_args {
   int dtype;
@@ -105,6 +107,12 @@ int qavit_gemm_tn(const qavit_gemm_tn_args* a, void* stream);
 /* n independent problems (host array) in as few grids as possible: the weight-gradient GEMMs of a backward pass are
  * off the critical path and individually too small to fill the chip, so the autograd layer defers and batches them */
 int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* stream);
+/* The same with `ws_bytes` >= qavit_gemm_tn_ws_bytes() of 16-byte-aligned device scratch that belongs to this call until its launches
+ * have run: a tile class with more problems than one launch carries by value (24) is then ONE launch over a device-side problem
+ * table (filled by small writer launches on `stream`) instead of one launch per 24 -- fewer workgroups per problem, fewer fp32-atomic
+ * tile flushes.  ws = NULL: as qavit_gemm_tn_grouped. */
+int qavit_gemm_tn_grouped_ws(const qavit_gemm_tn_args* a, int n, void* ws, size_t ws_bytes, void* stream);
+size_t qavit_gemm_tn_ws_bytes(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * nn.LayerNorm over the last dim C (HQAViT_CIFAR100.py:1072 norm1, :1083 norm2, :1273 norm, :1029 ...).
@@ -488,6 +496,10 @@ int qavit_dwconv_bwd_ld(int dtype, const void* dy, int lddy, const void* x, cons
  * (src_nchw_f32 != 0) or channel-last tokens [B,H*W,Cin] in `dtype`; col2im scatters dcols back to tokens. */
 int qavit_im2col(int dtype, const void* src, int src_nchw_f32, void* cols, int B, int Cin, int H, int W,
                  int k, int stride, int pad, void* stream);
+/* The same with rows of `ld` >= Cin*k*k elements (pad columns written as zeros): a K of 27 (3 channels x 3x3) becomes 32-element,
+ * 64-byte rows that the GEMMs read with aligned 16-byte loads. */
+int qavit_im2col_ld(int dtype, const void* src, int src_nchw_f32, void* cols, int ld, int B, int Cin, int H, int W,
+                    int k, int stride, int pad, void* stream);
 int qavit_col2im(int dtype, const void* dcols, void* dx, int B, int Cin, int H, int W, int k, int stride, int pad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------

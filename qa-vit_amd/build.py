@@ -26,6 +26,14 @@ ALLOW_SCRATCH = (
     "bank_stats_kernel",                  # fp32 parity path of the chunked (224 px) bank statistics
     "sln_bwd_kernel",                     # spatial LayerNorm backward of the v2 stem at 64 rows per thread (fp32 / bf16): v2-stem variant only
 )
+# Step kernels allowed a BOUNDED amount of scratch, with the reason.  (name fragment, max bytes per lane)
+ALLOW_SCRATCH_UP_TO = (
+    # the one-launch weight-gradient kernel holds twenty tile-class bodies in one problem loop; three registers that live across the
+    # loop are stored when a workgroup enters the 256 x 256 class body (the one that needs all 256) and reloaded when it leaves it:
+    # 3 + 3 scratch instructions per (problem, workgroup) visit, at loop depth 1, none inside a chunk loop (read off the ISA:
+    # `hipcc -S --cuda-device-only`, the six scratch_ instructions sit between the class dispatch and the body's first barrier)
+    ("gemm_tn_uni_kernel", 16),
+)
 
 
 def _scratch_report(stderr: str):
@@ -71,7 +79,8 @@ def build(verbose: bool = False, force: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         rep = _scratch_report(r.stderr)
-        bad = [(k, b) for k, b, _ in rep if b > 0 and not any(a in k for a in ALLOW_SCRATCH)]
+        bad = [(k, b) for k, b, _ in rep if b > 0 and not any(a in k for a in ALLOW_SCRATCH)
+               and not any(a in k and b <= cap for a, cap in ALLOW_SCRATCH_UP_TO)]
         if bad:
             if "-o" in cmd and os.path.exists(cmd[cmd.index("-o") + 1]):
                 os.remove(cmd[cmd.index("-o") + 1])            # do not let a later build link the spilling object

@@ -594,12 +594,13 @@ static int dispatch_dw(int ks, bool bwd, const void* a0, const void* a1, const f
 // GEMM over rows (b, oy, ox) with K = Cin*k*k in the nn.Conv2d weight's own (c, dy, dx) order.
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool NCHW_F32, typename I>
-__global__ __launch_bounds__(256) void im2col_kernel(const void* src_, T* cols, int B, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void im2col_kernel(const void* src_, T* cols, int ld, int B, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
   const int Kc = Cin * k * k;
-  const I total = (I)B * Ho * Wo * Kc;
+  const I total = (I)B * Ho * Wo * ld;                // rows of ld >= Kc elements; the pad columns are written as zeros
   for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
-    const int col = (int)(i % (I)Kc);
-    const I row = i / (I)Kc;
+    const int col = (int)(i % (I)ld);
+    const I row = i / (I)ld;
+    if (col >= Kc) { cols[i] = from_f<T>(0.f); continue; }
     const int ox = (int)(row % (I)Wo), oy = (int)((row / (I)Wo) % (I)Ho), b = (int)(row / ((I)Wo * Ho));
     const int c = col / (k * k), r = col - c * k * k, dy = r / k, dx = r - dy * k;
     const int y = oy * stride + dy - pad, x = ox * stride + dx - pad;
@@ -644,14 +645,18 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* dcols, T* dx, int 
 using namespace qv;
 
 extern "C" int qavit_im2col(int dtype, const void* src, int src_nchw_f32, void* cols, int B, int Cin, int H, int W, int k, int stride, int pad, void* stream) {
-  if (!src || !cols || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0) return set_error(QAVIT_EINVAL, "im2col: bad arguments");
+  return qavit_im2col_ld(dtype, src, src_nchw_f32, cols, Cin * k * k, B, Cin, H, W, k, stride, pad, stream);
+}
+
+extern "C" int qavit_im2col_ld(int dtype, const void* src, int src_nchw_f32, void* cols, int ld, int B, int Cin, int H, int W, int k, int stride, int pad, void* stream) {
+  if (!src || !cols || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0 || ld < Cin * k * k) return set_error(QAVIT_EINVAL, "im2col: bad arguments");
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
-  const int64_t total = (int64_t)B * Ho * Wo * Cin * k * k;
+  const int64_t total = (int64_t)B * Ho * Wo * ld;
   int grid = (int)((total + 1023) / 1024); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool small = total < 0x7fffffffLL && (int64_t)B * Cin * H * W < 0x7fffffffLL;
-#define IM2COL(T_, N_) do { if (small) hipLaunchKernelGGL((im2col_kernel<T_, N_, uint32_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo); \
-                            else hipLaunchKernelGGL((im2col_kernel<T_, N_, int64_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, B, Cin, H, W, k, stride, pad, Ho, Wo); } while (0)
+#define IM2COL(T_, N_) do { if (small) hipLaunchKernelGGL((im2col_kernel<T_, N_, uint32_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, ld, B, Cin, H, W, k, stride, pad, Ho, Wo); \
+                            else hipLaunchKernelGGL((im2col_kernel<T_, N_, int64_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, ld, B, Cin, H, W, k, stride, pad, Ho, Wo); } while (0)
   if (dtype == QAVIT_F32) {
     if (src_nchw_f32) IM2COL(float, true); else IM2COL(float, false);
   } else if (dtype == QAVIT_BF16) {

@@ -933,9 +933,17 @@ extern "C" int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stre
   return set_error(QAVIT_EINVAL, "gemm_nt_grouped: unknown dtype");
 }
 
+extern "C" size_t qavit_gemm_tn_ws_bytes(void) { return qv::gemm_tn_wide_ws_bytes(); }
+
 extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* stream) {
+  return qavit_gemm_tn_grouped_ws(a, n, nullptr, 0, stream);
+}
+
+extern "C" int qavit_gemm_tn_grouped_ws(const qavit_gemm_tn_args* a, int n, void* ws, size_t ws_bytes, void* stream) {
   using namespace qv;
   if (!a || n <= 0) return set_error(QAVIT_EINVAL, "gemm_tn_grouped: empty group");
+  if (ws && (ws_bytes < gemm_tn_wide_ws_bytes() || (reinterpret_cast<uintptr_t>(ws) & 15)))
+    return set_error(QAVIT_EINVAL, "gemm_tn_grouped: workspace smaller than qavit_gemm_tn_ws_bytes() or not 16-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static int legacy = -1;
   if (legacy < 0) { const char* e = getenv("QAVIT_TN_LEGACY"); legacy = e ? atoi(e) : 0; }
@@ -950,7 +958,7 @@ extern "C" int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* s
     // bf16 problems: wide-tile kernel, grouped by tile class over the WHOLE list (the problems are independent, so a
     // stray fp32 problem in the queue must not cut a class group short).  fp32 problems and odd strides / alignments:
     // the single-problem path.
-    const int rc = gemm_tn_wide(a, n, st);
+    const int rc = gemm_tn_wide(a, n, st, ws);
     if (rc) return rc;
     TnGroup G;
     G.n = 0;

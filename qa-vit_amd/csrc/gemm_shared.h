@@ -9,6 +9,9 @@ namespace qv {
 int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st);
 // bf16 weight-gradient GEMMs with wide output tiles, grouped by tile class (gemm_tn_wide.hip).  Problems must be
 // validated bf16 problems; returns QAVIT_OK or an error code.
-int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st);   // launches the problems with gemm_tn_wide_ok()
+// `ws`: NULL or gemm_tn_wide_ws_bytes() of device memory private to this call (a class with more problems than a launch carries by
+// value then takes ONE launch through a device-side table).
+int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws);   // launches the problems with gemm_tn_wide_ok()
+size_t gemm_tn_wide_ws_bytes();
 bool gemm_tn_wide_ok(const qavit_gemm_tn_args& g);
 }  // namespace qv

@@ -15,9 +15,12 @@
 // leaves the tile, so a launch has no tail round (the fixed rows-per-split grid it replaces ran 576 workgroups on 512
 // slots: two rounds for 1.1 rounds of work) and the atomics stay at one or two flushes per workgroup.
 //
-// Tile classes: N side 32 / 64 / 128 / 192 columns, K side 32 / 64 / 96 / 128 columns on four waves (2 x 2), and a
-// 192-column K class on eight waves (2 x 4, 128-row chunks) so that the K = 192 layers -- most of the model -- read
-// each operand row once (two 128-wide tiles re-read A and spent a third of their MFMAs on padding).
+// Tile classes: N side 32 / 64 / 128 / 192 / 256 columns, K side 32 / 64 / 96 / 128 columns on four waves (2 x 2), and
+// 192- and 256-column K classes on eight waves (2 x 4, 128-row chunks; 64-row chunks under the 256 x 256 tile) so that
+// the K = 192 layers -- most of the model -- read each operand row once (two 128-wide tiles re-read A and spent a third
+// of their MFMAs on padding) and the lateral path's 256 <-> 1024 layers re-read 4 + 1 times instead of 8 + 2.
+//
+// With a workspace (qavit_gemm_tn_grouped_ws) ALL problems of a call share one launch whatever their class: gemm_tn_uni_kernel below.
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
@@ -42,6 +45,14 @@ __device__ __forceinline__ bf16x8 trf(const bf16* tile, int ld, int m0, int c0) 
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
 }
+
+// Operand pointers that reach the kernel through a table in memory (not as kernel arguments) are generic to the compiler, and
+// FLAT loads count on lgkmcnt as well as vmcnt: every wait for an LDS fragment would also wait for the chunk prefetch.  These say
+// "global" explicitly.
+#define QV_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ bf16x8 gload8(const bf16* p) { return *(const QV_AS1 bf16x8*)(p); }
+__device__ __forceinline__ float gloadf(const float* p) { return *(const QV_AS1 float*)(p); }
+__device__ __forceinline__ void gatomic_add(float* p, float v) { __builtin_amdgcn_global_atomic_fadd_f32((QV_AS1 float*)(p), v); }
 
 constexpr int TNW_GROUP = 24;
 
@@ -68,11 +79,41 @@ struct Stage {
 };
 
 // class geometry: waves 2 x WB, a wave owns IN x JN MFMA blocks; MC = rows of M per staged chunk
-template <int IN, int JN, int WB>
+template <int IN_, int JN_, int WB_>
 struct Cls {
+  static constexpr int IN = IN_, JN = JN_, WB = WB_;
   static constexpr int NT = 128 * WB;
-  static constexpr int MC = WB == 4 ? 128 : 64;
+  static constexpr int MC = (WB == 4 && IN < 8) ? 128 : 64;   // 256 x 256 tile: 16 staged vectors per thread at 128 rows do not fit beside 128 accumulators
   static constexpr int TNW = 32 * IN, TKW = 16 * WB * JN;
+  typedef Stage<NT, TNW, MC> SA;
+  typedef Stage<NT, TKW, MC> SB;
+};
+
+// Geometry of the ONE-LAUNCH kernel (gemm_tn_uni_kernel): every class on eight waves (2 x 4), N side 32 * IN columns (IN = 1, 2, 4, 6,
+// 8), K side 64 * JN columns (JN = 1 .. 4).  The chunk is as long as LDS and the staging registers allow -- a skinny tile moves few
+// bytes per row, and with one workgroup per CU the bytes in flight per chunk are what hides the memory latency.
+constexpr int ucls_mc(int in, int jn) {
+  const int w = 32 * in + 64 * jn, row = (w + 32) * 2;
+  if (in * jn >= 24) return 64;                      // 96+ accumulator registers: 8 + 8 staged vectors at most
+  int mc = 512;
+  while (mc * row > 150 * 1024 || (w >= 256 && mc > 128)) mc >>= 1;
+  return mc;
+}
+constexpr int ucls_lds(int in, int jn) { return ucls_mc(in, jn) * (32 * in + 64 * jn + 32) * 2; }
+constexpr int ucls_cost(int in, int jn) { return ucls_mc(in, jn) * (32 * in + 64 * jn) / 64 + 64; }   // one (tile, chunk) unit: operand elements / 64 + the chunk's fixed part
+constexpr int ucls_lds_max() {
+  int m = 0;
+  for (int in : {1, 2, 4, 6, 8})
+    for (int jn = 1; jn <= 4; ++jn) m = ucls_lds(in, jn) > m ? ucls_lds(in, jn) : m;
+  return m;
+}
+
+template <int IN_, int JN_>
+struct UCls {
+  static constexpr int IN = IN_, JN = JN_, WB = 4;
+  static constexpr int NT = 512;
+  static constexpr int MC = ucls_mc(IN, JN);
+  static constexpr int TNW = 32 * IN, TKW = 64 * JN;
   typedef Stage<NT, TNW, MC> SA;
   typedef Stage<NT, TKW, MC> SB;
 };
@@ -81,16 +122,21 @@ struct Cls {
 // lda, ldb, N, K multiples of 8.  The staging loads are UNCONDITIONAL (row / column indices are clamped into the
 // operand and the out-of-range vectors are zeroed when they are committed to LDS): a load under a lane-dependent
 // branch makes the compiler wait for it at the join, which serialises the chunk's 16 loads into 16 round trips.
-template <int IN, int JN, int WB>
+template <typename CL>
 __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* At, bf16* Bt, int bx, int by, int mbeg, int mend, int dbg) {
-  typedef Cls<IN, JN, WB> CL;
+  constexpr int IN = CL::IN, JN = CL::JN;
   constexpr int TNW = CL::TNW, TKW = CL::TKW, MC = CL::MC, NT = CL::NT;
   typedef typename CL::SA SA;
   typedef typename CL::SB SB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (mbeg >= mend) return;                            // uniform per workgroup
+  // the lane's staging / fragment geometry is recomputed per call ON PURPOSE: in the one-launch kernel twenty of these bodies sit in
+  // one problem loop, and hoisting every body's lane-invariant index registers out of that loop (they depend on threadIdx only) cost
+  // 150 spilled registers.  The empty volatile asm pins the computation to the call.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave & 1, wb = wave >> 1;
   const int n0 = bx * TNW, k0 = by * TKW;
-  if (mbeg >= mend) return;                            // uniform per workgroup
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
   const bool ln = g.ln_mean != nullptr;
@@ -109,8 +155,8 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     csum[j] = 0.f;
-    gam[j] = (ln && b_live) ? g.ln_gamma[kb + j] : 0.f;
-    bet[j] = (ln && b_live) ? g.ln_beta[kb + j] : 0.f;
+    gam[j] = (ln && b_live) ? gloadf(g.ln_gamma + kb + j) : 0.f;
+    bet[j] = (ln && b_live) ? gloadf(g.ln_beta + kb + j) : 0.f;
   }
 
   f32x4 acc[IN][JN];
@@ -126,16 +172,16 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
     for (int h = 0; h < SA::PASS; ++h) {
       int m = mc + rga + SA::RP * h;
       m = m < mend ? m : mend - 1;
-      pa[h] = *reinterpret_cast<const bf16x8*>(a_col + (size_t)m * g.lda);
+      pa[h] = gload8(a_col + (size_t)m * g.lda);
     }
 #pragma unroll
     for (int h = 0; h < SB::PASS; ++h) {
       int m = mc + rgb + SB::RP * h;
       m = m < mend ? m : mend - 1;
-      pb[h] = *reinterpret_cast<const bf16x8*>(b_col + (size_t)m * g.ldb);
+      pb[h] = gload8(b_col + (size_t)m * g.ldb);
       const int mi = ln ? m : 0;
-      pmu[h] = mean_p[mi];
-      prs[h] = rstd_p[mi];
+      pmu[h] = gloadf(mean_p + mi);
+      prs[h] = gloadf(rstd_p + mi);
     }
   };
 
@@ -174,15 +220,17 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
     if (mc + MC < mend) prefetch(mc + MC);
 #pragma unroll
     for (int kf = 0; kf < MC / 32; ++kf) {
-      bf16x8 af[IN], bfr[JN];
-#pragma unroll
-      for (int i = 0; i < IN; ++i) af[i] = trf(At, SA::LD, kf * 32, (wa * IN + i) * 16);
+      // B fragments of the k-step up front, A fragments as the MFMAs consume them (the scheduler runs them ahead as far as registers allow:
+      // holding all IN of them cost 16 registers the 256-wide classes do not have)
+      bf16x8 bfr[JN];
 #pragma unroll
       for (int j = 0; j < JN; ++j) bfr[j] = trf(Bt, SB::LD, kf * 32, (wb * JN + j) * 16);
 #pragma unroll
-      for (int i = 0; i < IN; ++i)
+      for (int i = 0; i < IN; ++i) {
+        const bf16x8 af = trf(At, SA::LD, kf * 32, (wa * IN + i) * 16);
 #pragma unroll
-        for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
   const int fr = lane & 15, fq = lane >> 4;
@@ -194,7 +242,7 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + (wa * IN + i) * 16 + fq * 4 + r, k = k0 + (wb * JN + j) * 16 + fr;
-        if (n < g.N && k < g.K) atomic_add_f(g.C + (size_t)n * g.ldc + k, acc[i][j][r]);
+        if (n < g.N && k < g.K) gatomic_add(g.C + (size_t)n * g.ldc + k, acc[i][j][r]);
       }
   if (want_csum && !(dbg & 2)) {                     // uniform per workgroup
     // lanes l and l ^ CGS, l ^ 2 CGS ... of a wave hold the same column group (other rows): fold them with shuffles, then the
@@ -215,20 +263,18 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NWV; ++w) t += red[w * RW + i];
-      if (n0 + i < g.N) atomic_add_f(g.colsum + n0 + i, t);
+      if (n0 + i < g.N) gatomic_add(g.colsum + n0 + i, t);
     }
     __syncthreads();                                 // At is staged again by the next range of this workgroup
   }
 }
 
-template <int IN, int JN, int WB>
-__global__ __launch_bounds__(128 * WB) void gemm_tn_wide_kernel(TnwGroup G) {
+template <int IN, int JN, int WB, typename Src>
+__device__ __forceinline__ void tn_wide_ranges(const Src& G, int n, int per, int dbg, bf16* At, bf16* Bt) {
   typedef Cls<IN, JN, WB> CL;
-  __shared__ __attribute__((aligned(16))) bf16 At[CL::MC * CL::SA::LD];   // [m][n]
-  __shared__ __attribute__((aligned(16))) bf16 Bt[CL::MC * CL::SB::LD];   // [m][k]
-  const int total = G.unit_start[G.n];
-  int u = blockIdx.x * G.per;
-  int uend = u + G.per;
+  const int total = G.unit_start[n];
+  int u = blockIdx.x * per;
+  int uend = u + per;
   if (uend > total) uend = total;
   int i = 0;
   while (u < uend) {                                   // every quantity here is uniform over the workgroup
@@ -242,8 +288,121 @@ __global__ __launch_bounds__(128 * WB) void gemm_tn_wide_kernel(TnwGroup G) {
     const int by = t / tn, bx = t - by * tn;
     const int M = G.p[i].M;
     const int mend = c1 * CL::MC < M ? c1 * CL::MC : M;
-    tn_wide_body<IN, JN, WB>(G.p[i], At, Bt, bx, by, c0 * CL::MC, mend, G.dbg);
+    tn_wide_body<CL>(G.p[i], At, Bt, bx, by, c0 * CL::MC, mend, dbg);
     u += c1 - c0;
+  }
+}
+
+template <int IN, int JN, int WB>
+__global__ __launch_bounds__(128 * WB) void gemm_tn_wide_kernel(TnwGroup G) {
+  typedef Cls<IN, JN, WB> CL;
+  __shared__ __attribute__((aligned(16))) bf16 At[CL::MC * CL::SA::LD];   // [m][n]
+  __shared__ __attribute__((aligned(16))) bf16 Bt[CL::MC * CL::SB::LD];   // [m][k]
+  tn_wide_ranges<IN, JN, WB>(G, G.n, G.per, G.dbg, At, Bt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE launch for every problem of a backward pass.  A launch per tile class ends each workgroup's range in a tile-sized fp32-atomic
+// flush (the chip retires about one atomic dword per L2 channel and clock: ~1.5 TB/s) and a C100 step needed 12-15 class launches
+// x 256-512 workgroups x ~1.5 flushes = ~450 MB of atomics, a fifth of the family's time, plus a ramp and a tail per launch.  Here
+// the (problem, tile, chunk) units of ALL classes form one list, weighted by the operand bytes a unit moves, cut into equal
+// contiguous ranges over one workgroup per CU: ~330 flushes per step instead of ~5000.  The class of the problem a range is in picks
+// the body (uniform switch); registers and LDS are those of the largest class, which ran at one workgroup per CU anyway.
+constexpr int TNU_MAX = 512;            // problems per launch
+constexpr int TNU_PER_WRITE = 28;       // entries a writer launch carries by value (< 4 KB of kernel arguments)
+
+struct TnuEntry {
+  qavit_gemm_tn_args p;
+  int cls;                              // IN | JN << 8
+  int tn, chunks;                       // tiles on the N side, chunks per tile
+  int cu;                               // cost of one unit
+};
+struct TnuTable {
+  int cost_start[TNU_MAX + 1];          // prefix sums of units * cu
+  TnuEntry e[TNU_MAX];
+};
+struct TnuWrite {
+  int n, off;
+  int cost_start[TNU_PER_WRITE + 1];
+  TnuEntry e[TNU_PER_WRITE];
+};
+
+__global__ __launch_bounds__(64) void tnu_table_write_kernel(TnuWrite W, TnuTable* T) {
+  const int i = threadIdx.x;
+  if (i < W.n) T->e[W.off + i] = W.e[i];
+  if (i <= W.n) T->cost_start[W.off + i] = W.cost_start[i];
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename P>
+__device__ __forceinline__ P* uni_ptr(P* p) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return reinterpret_cast<P*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int IN, int JN>
+__device__ __forceinline__ void tnu_run(const qavit_gemm_tn_args& g, char* smem, int tn, int chunks, int j0, int j1, int dbg) {
+  typedef UCls<IN, JN> CL;
+  bf16* At = reinterpret_cast<bf16*>(smem);
+  bf16* Bt = At + CL::MC * CL::SA::LD;
+  while (j0 < j1) {                                     // uniform
+    const int t = j0 / chunks, c0 = j0 - t * chunks;
+    int c1 = c0 + (j1 - j0);
+    if (c1 > chunks) c1 = chunks;
+    const int by = t / tn, bx = t - by * tn;
+    const int mend = c1 * CL::MC < g.M ? c1 * CL::MC : g.M;
+    tn_wide_body<CL>(g, At, Bt, bx, by, c0 * CL::MC, mend, dbg);
+    j0 += c1 - c0;
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_uni_kernel(const TnuTable* __restrict__ T, int n, int per, int dbg) {
+  __shared__ __attribute__((aligned(16))) char smem[ucls_lds_max()];
+  const int total = uni(T->cost_start[n]);
+  const int lo = blockIdx.x * per;
+  int hi = lo + per;
+  if (hi > total) hi = total;
+  if (lo >= hi) return;
+  int a = 0, b = n;                                      // cost_start[a] <= lo < cost_start[b]
+  while (b - a > 1) {
+    const int m = (a + b) >> 1;
+    if (uni(T->cost_start[m]) <= lo) a = m; else b = m;
+  }
+  for (int i = a; i < n; ++i) {
+    const int cs = uni(T->cost_start[i]);
+    if (cs >= hi) break;
+    const TnuEntry* e = &T->e[i];
+    const int cu = uni(e->cu), chunks = uni(e->chunks), tn = uni(e->tn), cls = uni(e->cls);
+    const int units = (uni(T->cost_start[i + 1]) - cs) / cu;
+    const int j0 = lo > cs ? (lo - cs + cu - 1) / cu : 0;
+    int j1 = (hi - cs + cu - 1) / cu;
+    if (j1 > units) j1 = units;
+    if (j0 >= j1) continue;
+    qavit_gemm_tn_args g;
+    g.dtype = QAVIT_BF16;
+    g.M = uni(e->p.M); g.N = uni(e->p.N); g.K = uni(e->p.K);
+    g.A = uni_ptr(e->p.A); g.lda = uni64(e->p.lda);
+    g.B = uni_ptr(e->p.B); g.ldb = uni64(e->p.ldb);
+    g.C = uni_ptr(e->p.C); g.ldc = uni64(e->p.ldc);
+    g.colsum = uni_ptr(e->p.colsum);
+    g.ln_gamma = uni_ptr(e->p.ln_gamma); g.ln_beta = uni_ptr(e->p.ln_beta);
+    g.ln_mean = uni_ptr(e->p.ln_mean); g.ln_rstd = uni_ptr(e->p.ln_rstd);
+    g.splits = 0;
+#define TNU_CASE(I, J) case (I | (J << 8)): tnu_run<I, J>(g, smem, tn, chunks, j0, j1, dbg); break;
+    switch (cls) {
+      TNU_CASE(1, 1) TNU_CASE(1, 2) TNU_CASE(1, 3) TNU_CASE(1, 4)
+      TNU_CASE(2, 1) TNU_CASE(2, 2) TNU_CASE(2, 3) TNU_CASE(2, 4)
+      TNU_CASE(4, 1) TNU_CASE(4, 2) TNU_CASE(4, 3) TNU_CASE(4, 4)
+      TNU_CASE(6, 1) TNU_CASE(6, 2) TNU_CASE(6, 3) TNU_CASE(6, 4)
+      TNU_CASE(8, 1) TNU_CASE(8, 2) TNU_CASE(8, 3) TNU_CASE(8, 4)
+      default: break;
+    }
+#undef TNU_CASE
   }
 }
 
@@ -262,7 +421,7 @@ int resident_wgs(int wb) {
   return cus * (per_cu > 0 ? per_cu : 2);
 }
 
-int tile_class(int n, int which = 0) {           // N side: 32-column units per tile (1, 2, 4, 6); K side: 32-column units (1, 2, 3, 4) or 6 = the 192-wide eight-wave class
+int tile_class(int n, int which = 0) {           // 32-column units per tile: N side 1, 2, 4, 6, 8; K side 1, 2, 3, 4 on four waves, 6 / 8 = the 192- / 256-wide eight-wave classes
   static int force[2] = {-1, -1};
   if (force[0] < 0) {
     const char* e = getenv("QAVIT_TN_CN"); force[0] = e ? atoi(e) : 0;
@@ -274,40 +433,54 @@ int tile_class(int n, int which = 0) {           // N side: 32-column units per 
   if (which == 1 && n <= 96) return 3;
   if (n <= 128) return 4;
   if (n <= 192) return 6;
-  const int p128 = (n + 127) / 128 * 128, p192 = (n + 191) / 192 * 192;
-  return p128 < p192 ? 4 : 6;
+  // wider than one tile: the tile width that pads least; ties go to the wider tile (fewer re-reads of the other operand)
+  int best = 4, best_pad = (n + 127) / 128 * 128;
+  const int p192 = (n + 191) / 192 * 192, p256 = (n + 255) / 256 * 256;
+  if (p192 <= best_pad) { best = 6; best_pad = p192; }
+  if (p256 <= best_pad) { best = 8; best_pad = p256; }
+  return best;
+}
+
+template <int IN, int JN, int WB>
+void fill_group(TnwGroup& G, const qavit_gemm_tn_args* const* probs, int cnt, int& units) {
+  typedef Cls<IN, JN, WB> CL;
+  G.n = cnt;
+  G.dbg = 0;
+#ifdef QAVIT_TN_FLUSH_EXPERIMENT   // diagnostic build only (QAVIT_EXTRA_HIPCC_FLAGS=-DQAVIT_TN_FLUSH_EXPERIMENT): QAVIT_TN_DBG bit 0 skips the tile flush,
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QAVIT_TN_DBG"); dbg = e ? atoi(e) : 0; } G.dbg = dbg; }   // bit 1 the column-sum flush -- WRONG results, timing only
+#endif
+  for (int i = 0; i < cnt; ++i) {
+    const qavit_gemm_tn_args& g = *probs[i];
+    G.p[i] = g;
+    G.tn[i] = (g.N + CL::TNW - 1) / CL::TNW;
+    G.chunks[i] = (g.M + CL::MC - 1) / CL::MC;
+    G.unit_start[i] = units;
+    units += G.tn[i] * ((g.K + CL::TKW - 1) / CL::TKW) * G.chunks[i];
+  }
+  for (int i = cnt; i <= TNW_GROUP; ++i) G.unit_start[i] = units;
+}
+
+// equal contiguous ranges over the resident workgroups; short launches use fewer, longer ranges (each range ends in a
+// tile-sized atomic flush)
+inline void plan_ranges(int units, int wb, int& per, int& wgs) {
+  static int min_units = -1;
+  if (min_units < 0) { const char* e = getenv("QAVIT_TN_MIN_UNITS"); min_units = e ? atoi(e) : 4; if (min_units < 1) min_units = 1; }
+  wgs = resident_wgs(wb);
+  if (units < wgs * min_units) wgs = (units + min_units - 1) / min_units;
+  per = (units + wgs - 1) / wgs;
+  wgs = (units + per - 1) / per;
 }
 
 template <int IN, int JN, int WB>
 void launch_class(const qavit_gemm_tn_args* const* probs, int n, hipStream_t st) {
   typedef Cls<IN, JN, WB> CL;
-  static int min_units = -1;
-  if (min_units < 0) { const char* e = getenv("QAVIT_TN_MIN_UNITS"); min_units = e ? atoi(e) : 4; if (min_units < 1) min_units = 1; }
   int done = 0;
   while (done < n) {
     const int cnt = (n - done < TNW_GROUP) ? (n - done) : TNW_GROUP;
     TnwGroup G;
-    G.n = cnt;
-    G.dbg = 0;
-#ifdef QAVIT_TN_FLUSH_EXPERIMENT   // diagnostic build only (QAVIT_EXTRA_HIPCC_FLAGS=-DQAVIT_TN_FLUSH_EXPERIMENT): QAVIT_TN_DBG bit 0 skips the tile flush,
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("QAVIT_TN_DBG"); dbg = e ? atoi(e) : 0; } G.dbg = dbg; }   // bit 1 the column-sum flush -- WRONG results, timing only
-#endif
-    int units = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const qavit_gemm_tn_args& g = *probs[done + i];
-      G.p[i] = g;
-      G.tn[i] = (g.N + CL::TNW - 1) / CL::TNW;
-      G.chunks[i] = (g.M + CL::MC - 1) / CL::MC;
-      G.unit_start[i] = units;
-      units += G.tn[i] * ((g.K + CL::TKW - 1) / CL::TKW) * G.chunks[i];
-    }
-    for (int i = cnt; i <= TNW_GROUP; ++i) G.unit_start[i] = units;
-    // equal contiguous ranges over the resident workgroups; short launches use fewer, longer ranges (each range
-    // ends in a tile-sized atomic flush)
-    int wgs = resident_wgs(WB);
-    if (units < wgs * min_units) wgs = (units + min_units - 1) / min_units;
-    G.per = (units + wgs - 1) / wgs;
-    wgs = (units + G.per - 1) / G.per;
+    int units = 0, wgs;
+    fill_group<IN, JN, WB>(G, probs + done, cnt, units);
+    plan_ranges(units, WB, G.per, wgs);
     hipLaunchKernelGGL((gemm_tn_wide_kernel<IN, JN, WB>), dim3(wgs), dim3(CL::NT), 0, st, G);
     done += cnt;
   }
@@ -320,7 +493,8 @@ template <int IN> class_fn pick_j(int jc) {
     case 2: return launch_class<IN, 2, 2>;
     case 3: return launch_class<IN, 3, 2>;
     case 4: return launch_class<IN, 4, 2>;
-    default: return launch_class<IN, 3, 4>;
+    case 6: return launch_class<IN, 3, 4>;
+    default: return launch_class<IN, 4, 4>;
   }
 }
 class_fn pick(int ic, int jc) {
@@ -328,7 +502,8 @@ class_fn pick(int ic, int jc) {
     case 1: return pick_j<1>(jc);
     case 2: return pick_j<2>(jc);
     case 4: return pick_j<4>(jc);
-    default: return pick_j<6>(jc);
+    case 6: return pick_j<6>(jc);
+    default: return pick_j<8>(jc);
   }
 }
 
@@ -336,15 +511,86 @@ class_fn pick(int ic, int jc) {
 
 // All problems must be bf16 and validated by the caller.  Launches them grouped by tile class.
 bool gemm_tn_wide_ok(const qavit_gemm_tn_args& g) {
-  return g.dtype == QAVIT_BF16 && g.N % 8 == 0 && g.K % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 &&
+  // K % 8 != 0 is fine when B's rows are padded to a multiple of 8 (the 16-byte loads stay inside the row; the products of the pad
+  // columns land in output columns >= K, which the flush does not write) and nothing is normalised on load
+  const bool k_ok = g.K % 8 == 0 || (!g.ln_mean && g.ldb >= (g.K + 7) / 8 * 8);
+  return g.dtype == QAVIT_BF16 && g.N % 8 == 0 && k_ok && g.lda % 8 == 0 && g.ldb % 8 == 0 &&
          ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) == 0;
 }
 
-int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st) {
-  static const int ncls[4] = {1, 2, 4, 6}, kcls[5] = {1, 2, 3, 4, 6};
+size_t gemm_tn_wide_ws_bytes() { return sizeof(TnuTable); }
+
+namespace {
+int uni_k_class(int k) {                 // 64-column units of the K-side tile (1 .. 4)
+  if (k <= 64) return 1;
+  if (k <= 128) return 2;
+  if (k <= 192) return 3;
+  if (k <= 256) return 4;
+  int best = 2, best_pad = (k + 127) / 128 * 128;
+  const int p192 = (k + 191) / 192 * 192, p256 = (k + 255) / 256 * 256;
+  if (p192 <= best_pad) { best = 3; best_pad = p192; }
+  if (p256 <= best_pad) { best = 4; best_pad = p256; }
+  return best;
+}
+
+// every wide-eligible problem of the list in one launch through the table in `ws`; returns the number of problems it took
+int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("QAVIT_TN_CLASS_LAUNCHES"); off = e ? atoi(e) : 0; }
+  if (off || !ws) return 0;
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) cnt += gemm_tn_wide_ok(a[i]) ? 1 : 0;
+  if (cnt < 2 || cnt > TNU_MAX) return 0;
+  TnuTable* T = reinterpret_cast<TnuTable*>(ws);
+  TnuWrite W;
+  W.n = 0; W.off = 0;
+  int cost = 0, done = 0;
+  auto flush = [&]() {
+    W.cost_start[W.n] = cost;
+    hipLaunchKernelGGL(tnu_table_write_kernel, dim3(1), dim3(64), 0, st, W, T);
+    W.off += W.n; W.n = 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    if (!gemm_tn_wide_ok(a[i])) continue;
+    const qavit_gemm_tn_args& g = a[i];
+    const int in = tile_class(g.N, 0), jn = uni_k_class(g.K);
+    TnuEntry& e = W.e[W.n];
+    e.p = g;
+    e.cls = in | (jn << 8);
+    e.tn = (g.N + 32 * in - 1) / (32 * in);
+    const int mc = ucls_mc(in, jn);
+    e.chunks = (g.M + mc - 1) / mc;
+    e.cu = ucls_cost(in, jn);
+    W.cost_start[W.n] = cost;
+    const long long c = (long long)e.tn * ((g.K + 64 * jn - 1) / (64 * jn)) * e.chunks * e.cu;
+    if (cost + c > 0x7fffffffLL) return -1;      // caller falls back to the class launches
+    cost += (int)c;
+    ++done;
+    if (++W.n == TNU_PER_WRITE && done < cnt) flush();
+  }
+  flush();
+  int wgs = resident_wgs(4);
+  int per = (cost + wgs - 1) / wgs;
+  const int min_cost = 4 * ucls_cost(1, 1);             // a range shorter than a few small units is all flush
+  if (per < min_cost) per = min_cost;
+  wgs = (cost + per - 1) / per;
+  int dbg = 0;
+#ifdef QAVIT_TN_FLUSH_EXPERIMENT
+  { const char* e = getenv("QAVIT_TN_DBG"); dbg = e ? atoi(e) : 0; }
+#endif
+  hipLaunchKernelGGL(gemm_tn_uni_kernel, dim3(wgs), dim3(512), 0, st, (const TnuTable*)T, cnt, per, dbg);
+  return cnt;
+}
+}  // namespace
+
+
+int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
+  static const int ncls[5] = {1, 2, 4, 6, 8}, kcls[6] = {1, 2, 3, 4, 6, 8};
+  if (gemm_tn_uni(a, n, st, ws) > 0) return check_launch("gemm_tn(one launch)");
   const qavit_gemm_tn_args* sel[256];
-  for (int ci = 0; ci < 4; ++ci)
-    for (int cj = 0; cj < 5; ++cj) {
+  // without a workspace (or with QAVIT_TN_CLASS_LAUNCHES=1): one launch per tile class and 24 problems
+  for (int ci = 0; ci < 5; ++ci)
+    for (int cj = 0; cj < 6; ++cj) {
       int cnt = 0;
       for (int i = 0; i < n; ++i) {
         if (gemm_tn_wide_ok(a[i]) && tile_class(a[i].N, 0) == ncls[ci] && tile_class(a[i].K, 1) == kcls[cj]) {

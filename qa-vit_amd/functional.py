@@ -400,6 +400,11 @@ class LinearFn(Function):
         off, n = opts.get("rows") or (0, w.shape[0])
         Kfull = w.shape[1] if w.dim() == 2 else w[0].numel()
         koff = (opts.get("cols") or (0, Kfull))[0]          # cols = (k_off, k_len): y = x @ w[rows, k_off:k_off+k_len]^T (x has k_len columns)
+        lda = Kd
+        if opts.get("xpad"):                                # x's rows carry zero columns beyond the weight's K (Im2ColFn): no gradient flows back
+            if ln_g is not None or opts.get("cols") or x.requires_grad or Kd < Kfull:
+                raise ValueError("xpad: plain Linear on a non-differentiable, zero-padded input only")
+            Kd = Kfull
         Wc, Wt = pack_for(x.device).get(w, x.dtype)
         y = torch.empty(M, n, dtype=x.dtype, device=x.device)
         act = 1 if opts.get("act") == "gelu" else 0
@@ -422,7 +427,7 @@ class LinearFn(Function):
         a = dict(a_mode=3 if ln else 0, ln=ln, ln_stats=stats, Z=Z, act=act, drop=drop, dp=dp, R=r2, ldr=n, rng=rt.rng)
         # bias pointer offset: pass a narrow view tensor to keep kernels.gemm_nt simple
         bview = None if b is None else b.detach()[off:off + n]
-        K.gemm_nt(x2, Wc, y, M, n, Kd, Kd, Kfull, n, bview, B_ptr=Wc.data_ptr() + (off * Kfull + koff) * esz, **a)
+        K.gemm_nt(x2, Wc, y, M, n, Kd, lda, Kfull, n, bview, B_ptr=Wc.data_ptr() + (off * Kfull + koff) * esz, **a)
         ctx.opts = dict(opts)
         ctx.meta = (M, n, Kd, off, act, drop, dp, x.shape, resid is not None, koff)
         ctx.save_for_backward(x2, w, b, ln_g, ln_b, Z, stats[0] if stats else None, stats[1] if stats else None)
@@ -444,16 +449,20 @@ class LinearFn(Function):
                 dx_add = dx_add.contiguous()
             dalias = None
         dx = _linear_bwd(x2, w, b, dy.reshape(M, n), off, n, ctx.needs_input_grad[0], ln_g, ln_b, Z, mean, rstd, act, drop, dp, koff,
-                         dres=dalias, dx_add=dx_add)
+                         dres=dalias, dx_add=dx_add, kd=Kd)
         dres = dy if has_res else None
         return (dx.reshape(xshape) if (dx is not None and ctx.needs_input_grad[0]) else None), None, None, None, None, dres, None
 
 
 def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, mean=None, rstd=None, act=0, drop=(0.0, 0), dp=(0.0, 0, 1), koff=0,
-                dres=None, dx_add=None):
+                dres=None, dx_add=None, kd=None):
     """Backward of y = droppath(dropout(act(LN(x2) @ w[off:off+n]^T + b[off:off+n]))) for row matrices: returns dx (or None) and
-    accumulates dW / db into the parameters' .grad (deferred grouped weight-gradient GEMMs).  Shared by LinearFn and BranchFn."""
-    M, Kd = x2.shape
+    accumulates dW / db into the parameters' .grad (deferred grouped weight-gradient GEMMs).  Shared by LinearFn and BranchFn.
+    ``kd``: the contraction length when x2's rows are zero-padded beyond it (LinearFn xpad; no dx)."""
+    M, ldx = x2.shape
+    Kd = kd or ldx
+    if Kd != ldx and (need_dx or ln_g is not None):
+        raise ValueError("padded input rows: weight / bias gradients only")
     rt = _rt(x2)
     if not dy2.is_contiguous():
         dy2 = dy2.contiguous()
@@ -496,24 +505,24 @@ def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, me
         DeferDW.arm()
         if SideStream.enabled:
             with SideStream.fork(x2.device, dz, x2, mean, rstd):
-                K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kfull, None, ln=lnarg,
+                K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, ldx, Kfull, None, ln=lnarg,
                           C_ptr=wbuf.data_ptr() + (off * Kfull + koff) * 4,
                           colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
         else:
-            K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, Kd, Kfull, None, ln=lnarg,
+            K.gemm_tn(dz, x2, wbuf, M, n, Kd, n, ldx, Kfull, None, ln=lnarg,
                       C_ptr=wbuf.data_ptr() + (off * Kfull + koff) * 4,
                       colsum_ptr=None if bbuf2 is None else bbuf2.data_ptr() + off * 4)
     return dx
 
 
-def linear(x, w, b=None, *, ln=None, act=None, drop=None, dp=None, resid=None, rows=None, cols=None, eps=1e-5, train=True, alias=False):
+def linear(x, w, b=None, *, ln=None, act=None, drop=None, dp=None, resid=None, rows=None, cols=None, eps=1e-5, train=True, alias=False, xpad=False):
     """``rows=(off, n)``: output rows off..off+n of ``w``; ``cols=(k_off, k_len)``: the K-slice w[:, k_off:k_off+k_len] (x has k_len
     columns) -- with ``resid`` it turns a Linear on a concatenation into accumulating GEMMs, no ``cat`` buffer."""
     ln_g, ln_b = ln if ln is not None else (None, None)
     # alias=True: -> (y, x_alias); the gradient that arrives on x_alias (x's other consumer) is added inside the LayerNorm-backward
     # kernel (LayerNorm-prologue Linears) or by the input-gradient GEMM's residual epilogue, instead of by an elementwise add of autograd's
     want_alias = bool(alias) and torch.is_grad_enabled() and x.requires_grad
-    opts = dict(act=act, drop=drop, dp=dp, rows=rows, cols=cols, eps=eps, train=train, alias=want_alias)
+    opts = dict(act=act, drop=drop, dp=dp, rows=rows, cols=cols, eps=eps, train=train, alias=want_alias, xpad=xpad)
     out = LinearFn.apply(x, w, b, ln_g, ln_b, resid, opts)
     if alias and not want_alias:
         return out, x
@@ -1381,7 +1390,9 @@ class Im2ColFn(Function):
         if nchw:
             src = src.float()
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        cols = torch.empty(B * Ho * Wo, Cin * k * k, dtype=dtype, device=src.device)
+        # rows padded to a multiple of 8 elements (zeros): K = 27 of the first stem convolution as 64-byte rows -- its weight-gradient GEMM over
+        # 262144 rows took the generic kernel at 0.33 TB/s on 54-byte rows.  The consumer is linear(..., xpad=True).
+        cols = torch.empty(B * Ho * Wo, (Cin * k * k + 7) // 8 * 8, dtype=dtype, device=src.device)
         K.im2col(src, nchw, cols, B, Cin, H, W, k, stride, pad)
         ctx.dims, ctx.nchw = dims, nchw
         return cols
@@ -1391,6 +1402,8 @@ class Im2ColFn(Function):
         if ctx.nchw:
             return None, None, None
         B, Cin, H, W, k, stride, pad = ctx.dims
+        if dcols.shape[1] != Cin * k * k:
+            raise NotImplementedError("col2im of padded im2col rows (Cin*k*k not a multiple of 8 with a differentiable source)")
         dcols = dcols.contiguous()
         dx = torch.empty(B, H * W, Cin, dtype=dcols.dtype, device=dcols.device)
         K.col2im(dcols, dx, B, Cin, H, W, k, stride, pad)

@@ -175,6 +175,20 @@ class DeferredTN:
     _side = {}
     _dirty = set()
 
+    _ws_bytes = None
+
+    @classmethod
+    def _grouped(cls, arr, n):
+        """qavit_gemm_tn_grouped_ws with a scratch buffer of this call's own (torch's allocator keeps it stream-ordered, also inside a
+        capture): all the problems of the call then share ONE launch through a device-side problem table."""
+        lib = L.load()
+        if n < 2:
+            return L.check(lib.qavit_gemm_tn_grouped(arr, n, stream()), "gemm_tn_grouped")
+        if cls._ws_bytes is None:
+            cls._ws_bytes = int(lib.qavit_gemm_tn_ws_bytes())
+        ws = torch.empty(cls._ws_bytes, dtype=torch.uint8, device="cuda")
+        L.check(lib.qavit_gemm_tn_grouped_ws(arr, n, ws.data_ptr(), cls._ws_bytes, stream()), "gemm_tn_grouped")
+
     @classmethod
     def _adopt_foreign(cls, q):
         """Problems queued from another stream (the lateral CNN path's backward): the launching stream waits for that stream's work
@@ -215,7 +229,7 @@ class DeferredTN:
                 if part:
                     arr = (L.GemmTnArgs * len(part))(*[a for a, _, _ in part])
                     cls._adopt_foreign(part)
-                    L.check(L.load().qavit_gemm_tn_grouped(arr, len(part), stream()), "gemm_tn_grouped")
+                    cls._grouped(arr, len(part))
             return
         arr = (L.GemmTnArgs * len(q))(*[a for a, _, _ in q])
         cls._adopt_foreign(q)
@@ -226,7 +240,7 @@ class DeferredTN:
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)                              # every operand queued so far has been produced
         with torch.cuda.stream(side):
-            L.check(L.load().qavit_gemm_tn_grouped(arr, len(q), stream()), "gemm_tn_grouped")
+            cls._grouped(arr, len(q))
         for _, keep, _ in q:                                # the caching allocator must not hand these blocks out before the side stream is done
             for t in keep:
                 if isinstance(t, torch.Tensor):
@@ -504,7 +518,8 @@ def ccf_bwd(a):
 
 
 def im2col(src, nchw_f32, cols, B, Cin, H, W, k, stride, pad):
-    L.check(L.load().qavit_im2col(dt_code(cols.dtype), src.data_ptr(), 1 if nchw_f32 else 0, cols.data_ptr(), B, Cin, H, W, k, stride, pad, stream()), "im2col")
+    L.check(L.load().qavit_im2col_ld(dt_code(cols.dtype), src.data_ptr(), 1 if nchw_f32 else 0, cols.data_ptr(), cols.shape[1], B, Cin, H, W, k, stride,
+                                     pad, stream()), "im2col")
 
 
 def col2im(dcols, dx, B, Cin, H, W, k, stride, pad):

@@ -147,6 +147,8 @@ _SIGS = {
     "qavit_gemm_nt_grouped": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "qavit_gemm_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "qavit_gemm_tn_grouped": (i32, [C.POINTER(GemmTnArgs), i32, vp]),
+    "qavit_gemm_tn_grouped_ws": (i32, [C.POINTER(GemmTnArgs), i32, vp, C.c_size_t, vp]),
+    "qavit_gemm_tn_ws_bytes": (C.c_size_t, []),
     "qavit_layernorm_fwd": (i32, [i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, i32, i32, vp]),
     "qavit_row_stats": (i32, [i32, vp, f32, i32, i32, vp, vp, vp]),
     "qavit_row_stats_multi": (i32, [i32, i32, vp, f32, i32, i32, vp, vp, vp]),
@@ -187,6 +189,7 @@ _SIGS = {
     "qavit_dwconv_fwd_ld": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_dwconv_bwd_ld": (i32, [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_im2col": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "qavit_im2col_ld": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_bank_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]),
     "qavit_bank_ws_floats": (i64, [i32, i32, i32, i32]),

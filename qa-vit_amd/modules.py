@@ -593,7 +593,7 @@ class CNNStemModel(nn.Module):
         """conv3x3/s2/p1 as im2col + MFMA GEMM, then BatchNorm + GELU, channel-last in and out."""
         B = dims[0]
         cols = F.Im2ColFn.apply(src, dims, cdt)
-        t = F.linear(cols, conv.weight, conv.bias).reshape(B, -1, conv.out_channels)
+        t = F.linear(cols, conv.weight, conv.bias, xpad=cols.shape[1] != conv.weight[0].numel()).reshape(B, -1, conv.out_channels)
         return _bn_tokens(t, bn, self.training, gelu=True)
 
     def forward_tokens(self, x, cdt):

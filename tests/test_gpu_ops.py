@@ -56,6 +56,55 @@ def test_linear_plain(F, dtype, M, K, N):
     assert rel(b.grad, br.grad) <= tol(dtype, False)
 
 
+@pytest.mark.parametrize("mode", ["one_launch", "class_launches"])
+def test_weight_gradient_gemm_tile_classes(F, Q, mode):
+    """The grouped weight-gradient GEMM on one list holding every tile class (32 .. 256 columns on either side, multi-tile N and K,
+    LayerNorm-on-load, ragged M, 74 problems = three writer launches of the device-side table) against fp32 A^T.B and column sums of
+    the bf16 operands: ``one_launch`` = qavit_gemm_tn_grouped_ws (all classes in gemm_tn_uni_kernel), ``class_launches`` =
+    qavit_gemm_tn_grouped without a workspace (a launch per class and 24 problems)."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    L = importlib.import_module("qa-vit_amd.lib")
+    g = torch.Generator().manual_seed(77)
+    shapes = [(1500, 256, 1024, False), (1500, 1024, 256, True), (900, 768, 192, False), (900, 192, 768, False), (2100, 64, 256, False),
+              (2100, 256, 64, True), (700, 512, 128, True), (700, 128, 512, False), (650, 384, 192, False), (333, 288, 64, False),
+              (1000, 256, 256, True), (520, 576, 192, False), (130, 16, 32, False), (4100, 96, 192, True)]
+    shapes += [(700 + 8 * i, 192, 192, i % 3 == 0) for i in range(60)]
+    probs = []
+    for (M, N, Kd, ln) in shapes:
+        A = (torch.randn(M, N, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+        Bm = torch.randn(M, Kd, generator=g).to(DEV).to(torch.bfloat16)
+        Cg = torch.randn(N, Kd, generator=g).to(DEV)            # the kernels ACCUMULATE into the gradient
+        cs = torch.randn(N, generator=g).to(DEV)
+        lnp = None
+        Bref = Bm.float()
+        if ln:
+            gam, bet = torch.randn(Kd, generator=g).to(DEV), torch.randn(Kd, generator=g).to(DEV)
+            mean = Bref.mean(1).contiguous()
+            rstd = (Bref.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+            lnp = (gam, bet, mean, rstd)
+            Bref = ((Bref - mean[:, None]) * rstd[:, None] * gam + bet).to(torch.bfloat16).float()   # the kernel rounds the normalised operand to bf16
+        probs.append((A, Bm, Cg, cs, lnp, Cg.clone() + A.float().t() @ Bref, cs.clone() + A.float().sum(0)))
+    K.DeferredTN.enabled = True
+    try:
+        for (A, Bm, Cg, cs, lnp, _, _) in probs:
+            M, N = A.shape
+            K.gemm_tn(A, Bm, Cg, M, N, Bm.shape[1], N, Bm.shape[1], Bm.shape[1], colsum=cs, ln=lnp)
+        assert len(K.DeferredTN.queue) == len(probs)
+        if mode == "one_launch":
+            K.DeferredTN.flush()
+        else:
+            arr = (L.GemmTnArgs * len(probs))(*[a for a, _, _ in K.DeferredTN.queue])
+            L.check(L.load().qavit_gemm_tn_grouped(arr, len(probs), K.stream()), "gemm_tn_grouped")
+    finally:
+        K.DeferredTN.enabled = False
+        K.DeferredTN.queue = []
+    torch.cuda.synchronize()
+    for (A, Bm, Cg, cs, lnp, Cref, csref), shp in zip(probs, shapes):
+        assert rel(Cg, Cref) <= 4e-3, shp
+        assert rel(cs, csref) <= 4e-3, shp
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_ln_gelu_residual(F, dtype):
     M, K, N = 2048, 192, 96
@@ -539,9 +588,16 @@ def test_conv3x3_s2_as_im2col_gemm(F, dtype):
     img = torch.randn(B, 3, 32, 32, device=DEV)
     w0, b0 = leaf(32, 3, 3, 3, scale=0.2, seed=140), leaf(32, scale=0.1, seed=141)
     cols = F.Im2ColFn.apply(img, (B, 3, 32, 32, 3, 2, 1), dtype)
-    y0 = F.linear(cols, w0, b0).reshape(B, 256, 32)
-    ref0 = TF.conv2d(img, w0.detach(), b0.detach(), stride=2, padding=1).flatten(2).transpose(1, 2)
+    assert cols.shape[1] == 32 and float(cols[:, 27:].abs().max()) == 0.0        # K = 27 padded to 64-byte rows of zeros
+    y0 = F.linear(cols, w0, b0, xpad=True).reshape(B, 256, 32)
+    w0r, b0r = w0.detach().clone().requires_grad_(True), b0.detach().clone().requires_grad_(True)
+    ref0 = TF.conv2d(img, w0r, b0r, stride=2, padding=1).flatten(2).transpose(1, 2)
     assert rel(y0, ref0) <= tol(dtype)
+    go0 = torch.randn_like(ref0)
+    y0.backward(go0.to(dtype))
+    ref0.backward(go0)
+    assert rel(w0.grad, w0r.grad) <= tol(dtype, False)
+    assert rel(b0.grad, b0r.grad) <= tol(dtype, False)
     t = leaf(B, 256, 32, seed=142).detach().to(dtype).requires_grad_(True)
     w1, b1 = leaf(64, 32, 3, 3, scale=0.1, seed=143), leaf(64, scale=0.1, seed=144)
     y1 = F.linear(F.Im2ColFn.apply(t, (B, 32, 16, 16, 3, 2, 1), dtype), w1, b1).reshape(B, 64, 64)
