@@ -280,6 +280,14 @@ int qavit_upmix_fwd(int dtype, const void* xc, const float* W, const float* bias
 int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const float* W, const float* bias,
                     const float* gamma, const float* mean, const float* rstd, void* dxc, float* dW,
                     float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, void* stream);
+/* The same with the parameter gradients left as PARTIAL ROWS: `parts` = float[qavit_upmix_bwd_parts(...)][N*M + N + 2*C], 16-byte
+ * aligned, one row [dW | dbias | dgamma | dbeta] per workgroup written with plain stores; dW / dbias / dgamma / dbeta are not
+ * touched -- fold the rows with qavit_ln_param_reduce (stride N*M + N + 2*C).  The 256-deep same-address float atomics this replaces
+ * were the larger half of the kernel.  qavit_upmix_bwd_parts() == 0: no partial-row path for this dtype / shape (pass parts = NULL). */
+int qavit_upmix_bwd_parts(int dtype, int B, int N, int M, int C);
+int qavit_upmix_bwd_p(int dtype, const void* dy, const void* xc, const float* W, const float* bias,
+                      const float* gamma, const float* mean, const float* rstd, void* dxc, float* dW,
+                      float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, float* parts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * MSDA landmark tokens (HQAViT_CIFAR100.py:499-501): dilated gathers x[:, ::d, ::d] concatenated, then

@@ -43,6 +43,17 @@ template <int W> __device__ __forceinline__ float grp_sum(float v) {
   for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// W = 16 = one DPP row: four VALU instructions (quad permutes + half-row / row mirrors) instead of four dependent ds_bpermute round
+// trips through the LDS pipe.  In-kernel stamps of the up-mix backward: the LayerNorm-backward section of a 16 x 192 tile -- three
+// such sums per row -- took 2/3 of an image's time on the bpermute form.
+template <> __device__ __forceinline__ float grp_sum<16>(float v) { return row16_sum(v); }
+template <> __device__ __forceinline__ float grp_max<16>(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
 
 
 }  // namespace qv

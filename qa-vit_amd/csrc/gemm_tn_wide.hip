@@ -570,6 +570,9 @@ int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
   }
   flush();
   int wgs = resident_wgs(4);
+  static int cap = -1;                                  // QAVIT_TN_WGS: fewer workgroups than CUs (a launch that runs BESIDE other work)
+  if (cap < 0) { const char* e = getenv("QAVIT_TN_WGS"); cap = e ? atoi(e) : 0; }
+  if (cap > 0 && cap < wgs) wgs = cap;
   int per = (cost + wgs - 1) / wgs;
   const int min_cost = 4 * ucls_cost(1, 1);             // a range shorter than a few small units is all flush
   if (per < min_cost) per = min_cost;

@@ -407,9 +407,21 @@ extern "C" int qavit_upmix_fwd(int dtype, const void* xc, const float* W, const 
   return check_launch("upmix_fwd");
 }
 
+extern "C" int qavit_upmix_bwd_parts(int dtype, int B, int N, int M, int C) {
+  return (dtype == QAVIT_BF16 && B > 0) ? qv::upmix_bf16_parts(B, N, M, C) : 0;
+}
+
 extern "C" int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma,
                                const float* mean, const float* rstd, void* dxc, float* dW, float* dbias, float* dgamma, float* dbeta,
                                int B, int N, int M, int C, void* stream) {
+  return qavit_upmix_bwd_p(dtype, dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta, B, N, M, C, nullptr, stream);
+}
+
+extern "C" int qavit_upmix_bwd_p(int dtype, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma,
+                                 const float* mean, const float* rstd, void* dxc, float* dW, float* dbias, float* dgamma, float* dbeta,
+                                 int B, int N, int M, int C, float* parts, void* stream) {
+  if (parts && (qavit_upmix_bwd_parts(dtype, B, N, M, C) == 0 || (reinterpret_cast<uintptr_t>(parts) & 15) || (reinterpret_cast<uintptr_t>(xc) & 7)))
+    return set_error(QAVIT_EINVAL, "upmix_bwd: partial rows asked for a shape / dtype / alignment without that path (qavit_upmix_bwd_parts() == 0)");
   if (!dy || !xc || !W || !bias || !gamma || !mean || !rstd || !dxc || !dW || !dgamma || !dbeta || B <= 0 || N <= 0 || M <= 0 || C <= 0)
     return set_error(QAVIT_EINVAL, "upmix_bwd: bad arguments");
   const int lds_dw = ((size_t)N * M <= 4096) ? 1 : 0;
@@ -418,9 +430,10 @@ extern "C" int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int grid = B < 512 ? B : 512;
   if (dtype == QAVIT_BF16) {
-    const int took = qv::upmix_bf16_try(true, dy, xc, W, bias, gamma, nullptr, 0.f, dxc, const_cast<float*>(mean), const_cast<float*>(rstd), dW, dbias, dgamma, dbeta, B, N, M, C, st);
+    const int took = qv::upmix_bf16_try(true, dy, xc, W, bias, gamma, nullptr, 0.f, dxc, const_cast<float*>(mean), const_cast<float*>(rstd), dW, dbias, dgamma, dbeta, B, N, M, C, st, parts);
     if (took < 0) return took;
     if (took == 1) return check_launch("upmix_bwd(bf16)");
+    if (parts) return set_error(QAVIT_EINVAL, "upmix_bwd: partial rows not available");
   }
   if (dtype == QAVIT_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix_bwd_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -8,6 +8,16 @@
 #include "launch.h"
 #include "tokens_shared.h"
 
+#ifdef QAVIT_TOKEN_STAMPS     // diagnostic build only (tools/token_stamps.py): s_memtime at phase boundaries of the up-mix backward, 32 words per workgroup
+__device__ unsigned long long qv_token_stamps[1024 * 32];
+#define TSTAMP(k) do { if (threadIdx.x == 0 && (k) < 32) qv_token_stamps[(size_t)(blockIdx.x & 1023) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int qavit_token_stamps(void* host_dst, int nwg) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(qv_token_stamps), (size_t)nwg * 32 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+
 namespace qv {
 
 // Waves of a workgroup run different trip counts here, so no workgroup barrier may sit inside the image loops: each wave
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(256) void upmix2_fwd_kernel(const bf16* xc, const f
 template <int NT, int MT, int CT>
 __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const bf16* xc, const float* W, const float* bias, const float* gamma,
                                                          const float* mean, const float* rstd, bf16* dxc, float* dW, float* dbias,
-                                                         float* dgamma, float* dbeta, int B) {
+                                                         float* dgamma, float* dbeta, int B, float* parts) {
   using L = UpLds<NT, MT, CT>;
   constexpr int NTW = (NT + 3) / 4;                           // row tiles per wave
   constexpr int DXT = (MT * CT + 3) / 4;                      // dxc tiles per wave
@@ -267,8 +277,10 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   float* dba = fl;
   float* gred = fl + L::N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q4 = lane >> 4;
+  TSTAMP(0);
   up_stage_w<NT, MT, CT>(sm + L::wt, W);
   for (int i = threadIdx.x; i < L::N; i += 256) dba[i] = 0.f;
+  int img = 0;                                               // (stamps)
   float ga[CT], pg[CT], pb[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) { ga[ct] = gamma[ct * 16 + col]; pg[ct] = 0.f; pb[ct] = 0.f; }
@@ -278,9 +290,57 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
 #pragma unroll
     for (int j = 0; j < MT; ++j) dwacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float invC = 1.f / (float)L::C;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  // Software pipeline over (image, row-tile chunk) steps: the NEXT step's dy tile (and, at an image boundary, the next image's xc
+  // tile) is requested into registers before this step's products start, and committed to LDS at the top of the next step -- with one
+  // wave per SIMD nothing else hides the two global round trips per image (they were ~4 of the ~10 us an image took).
+  constexpr int CH = L::C / 4;
+  constexpr int DYL = 16 * CH / 64;                          // 8-byte pieces of a 16-row dy tile per lane
+  constexpr int XL = (L::M * CH + 255) / 256;                // 8-byte pieces of the xc tile per thread
+  constexpr bool PIPE = NT <= 4;                             // (the 256-token variant already holds 512 registers per lane: left on the one-step schedule)
+  bf16x4 dyr[PIPE ? DYL : 1], xr[PIPE ? XL : 1];
+  float mun[4], rsn[4];                                      // the next tile's row statistics travel with its dy rows (in-stamp timeline: fetched
+                                                             // inside the row loop they were four dependent global round trips, 2/3 of an image's time)
+  auto req_dy = [&](int bb, int tw) {
+    const int nt = wave + 4 * tw;
+    if (nt < NT && bb < B) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = (size_t)bb * L::N + nt * 16 + 4 * q4 + r;
+        mun[r] = mean[row]; rsn[r] = rstd[row];
+      }
+      const bf16* dys = dy + ((size_t)bb * L::N + nt * 16) * L::C;
+#pragma unroll
+      for (int j = 0; j < DYL; ++j) {
+        const int i = lane + 64 * j, n = i / CH, ch = i - n * CH;
+        dyr[j] = *reinterpret_cast<const bf16x4*>(dys + (size_t)n * L::C + 4 * ch);
+      }
+    }
+  };
+  auto req_xc = [&](int bb) {
+    if (bb < B) {
+      const bf16* xs = xc + (size_t)bb * L::M * L::C;
+#pragma unroll
+      for (int j = 0; j < XL; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < L::M * CH) { const int m = i / CH, ch = i - m * CH; xr[j] = *reinterpret_cast<const bf16x4*>(xs + (size_t)m * L::C + 4 * ch); }
+      }
+    }
+  };
+  if (PIPE) { req_xc(blockIdx.x); req_dy(blockIdx.x, 0); }
+  TSTAMP(1);
+  for (int b = blockIdx.x; b < B; b += gridDim.x, ++img) {
     __syncthreads();
-    up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
+    TSTAMP(2 + 6 * img);
+    if (PIPE) {
+#pragma unroll
+      for (int j = 0; j < XL; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < L::M * CH) { const int m = i / CH, ch = i - m * CH; *reinterpret_cast<bf16x4*>(sm + L::xc + m * L::LDC + 4 * ch) = xr[j]; }
+      }
+      req_xc(b + gridDim.x);
+    } else {
+      up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
+    }
     f32x4 dxa[DXT];
 #pragma unroll
     for (int i = 0; i < DXT; ++i) dxa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -289,26 +349,48 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
     for (int tw = 0; tw < NTW; ++tw) {
       __syncthreads();                                           // xc staged / previous chunk consumed
       const int nt = wave + 4 * tw;
+      float muc[4], rsc[4];
       if (nt < NT) {
         // this wave's 16 dy rows: whole rows in 8-byte pieces into its slice of the dup tile (read element-wise below, then overwritten
         // in place by du) -- 48 two-byte global loads per lane were the kernel's load path
         constexpr bool STAGE_DY = NT <= 4;                       // (the 256-token variant already holds 512 registers per lane)
-        if (STAGE_DY) {
-          constexpr int CH = L::C / 4;
-          const bf16* dys = dy + ((size_t)b * L::N + nt * 16) * L::C;
+        if (PIPE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { muc[r] = mun[r]; rsc[r] = rsn[r]; }
           bf16* dtw = sm + L::dup + wave * 16 * L::LDC;
-          for (int i = lane; i < 16 * CH; i += 64) {
-            const int n = i / CH, ch = i - n * CH;
-            *reinterpret_cast<bf16x4*>(dtw + n * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(dys + (size_t)n * L::C + 4 * ch);
+#pragma unroll
+          for (int j = 0; j < DYL; ++j) {
+            const int i = lane + 64 * j, n = i / CH, ch = i - n * CH;
+            *reinterpret_cast<bf16x4*>(dtw + n * L::LDC + 4 * ch) = dyr[j];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {                          // requested before the tile's MFMAs, used after them
+            const size_t row = (size_t)b * L::N + nt * 16 + 4 * q4 + r;
+            muc[r] = mean[row]; rsc[r] = rstd[row];
+          }
+          if (STAGE_DY) {
+            const bf16* dys = dy + ((size_t)b * L::N + nt * 16) * L::C;
+            bf16* dtw = sm + L::dup + wave * 16 * L::LDC;
+            for (int i = lane; i < 16 * CH; i += 64) {
+              const int n = i / CH, ch = i - n * CH;
+              *reinterpret_cast<bf16x4*>(dtw + n * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(dys + (size_t)n * L::C + 4 * ch);
+            }
           }
         }
+      }
+      if (PIPE) { if (tw + 1 < NTW) req_dy(b, tw + 1); else req_dy(b + gridDim.x, 0); }
+      TSTAMP(3 + 6 * img);
+      if (nt < NT) {
+        constexpr bool STAGE_DY = NT <= 4;
         f32x4 acc[CT];
         up_tile<NT, MT, CT>(sm + L::wt, sm + L::xc, bias, nt, acc);
         if (STAGE_DY) wave_sync();
+        TSTAMP(4 + 6 * img);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t row = (size_t)b * L::N + nt * 16 + 4 * q4 + r;
-          const float mu = mean[row], rs = rstd[row];
+          const float mu = muc[r], rs = rsc[r];
           float g[CT];
           float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -332,7 +414,9 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc_to_lds(sm + L::dup, L::LDC, wave * 16, ct * 16, acc[ct]);
       }
+      TSTAMP(5 + 6 * img);
       __syncthreads();
+      TSTAMP(6 + 6 * img);
       // dxc[m][c] += sum_{n in chunk} W[n][m] dup[n][c]
       constexpr int KT = NT < 4 ? NT : 4;
 #pragma unroll
@@ -355,6 +439,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
           for (int ct = 0; ct < CT; ++ct)
             dwacc[tw][mt] = mma16(rowfrag(sm + L::dup, L::LDC, wave * 16, ct * 16), rowfrag(sm + L::xc, L::LDC, mt * 16, ct * 16), dwacc[tw][mt]);
       }
+      TSTAMP(7 + 6 * img);
     }
 #pragma unroll
     for (int i = 0; i < DXT; ++i) {
@@ -373,19 +458,44 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       }
     }
   }
+  TSTAMP(30);
   __syncthreads();
-  // flush: dW tiles, dbias, dgamma / dbeta
+  // flush: dW tiles, dbias, dgamma / dbeta -- as this workgroup's row [dW | dbias | dgamma | dbeta] of `parts` (plain stores; one
+  // qavit_ln_param_reduce launch folds the rows of every kernel of the pass), or with float atomics.  The atomics are 256+ deep on each
+  // of ~1.5k addresses and serialise at L2: they were the larger half of this kernel and the reason a second workgroup per CU lost.
+  // (64-token variant only: the 256-token one sits at 512 registers per lane and keeps its atomics)
+  float* prow = (NT <= 4 && parts) ? parts + (size_t)blockIdx.x * (L::N * L::M + L::N + 2 * L::C) : nullptr;
+  if constexpr (NT <= 4) {
+    float* dwdst = prow ? prow : dW;
+    const bool plain = prow != nullptr;                      // uniform
 #pragma unroll
-  for (int tw = 0; tw < NTW; ++tw) {
-    const int nt = wave + 4 * tw;
-    if (nt < NT) {
+    for (int tw = 0; tw < NTW; ++tw) {
+      const int nt = wave + 4 * tw;
+      if (nt < NT) {
+        float* rowp = dwdst + (size_t)(nt * 16 + 4 * q4) * L::M + col;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomic_add_f(dW + (size_t)(nt * 16 + 4 * q4 + r) * L::M + mt * 16 + col, dwacc[tw][mt][r]);
+          for (int r = 0; r < 4; ++r) {
+            if (plain) rowp[r * L::M + mt * 16] = dwacc[tw][mt][r]; else atomic_add_f(rowp + r * L::M + mt * 16, dwacc[tw][mt][r]);
+          }
+      }
     }
+    if (prow) { for (int i = threadIdx.x; i < L::N; i += 256) prow[L::N * L::M + i] = dba[i]; }
+    else if (dbias) for (int i = threadIdx.x; i < L::N; i += 256) atomic_add_f(dbias + i, dba[i]);
+  } else {
+#pragma unroll
+    for (int tw = 0; tw < NTW; ++tw) {
+      const int nt = wave + 4 * tw;
+      if (nt < NT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomic_add_f(dW + (size_t)(nt * 16 + 4 * q4 + r) * L::M + mt * 16 + col, dwacc[tw][mt][r]);
+      }
+    }
+    if (dbias) for (int i = threadIdx.x; i < L::N; i += 256) atomic_add_f(dbias + i, dba[i]);
   }
-  if (dbias) for (int i = threadIdx.x; i < L::N; i += 256) atomic_add_f(dbias + i, dba[i]);
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     float a = pg[ct], c = pb[ct];
@@ -395,14 +505,29 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   }
   __syncthreads();
   for (int i = threadIdx.x; i < L::C; i += 256) {
-    atomic_add_f(dgamma + i, gred[(0 * 2 + 0) * L::C + i] + gred[(1 * 2 + 0) * L::C + i] + gred[(2 * 2 + 0) * L::C + i] + gred[(3 * 2 + 0) * L::C + i]);
-    atomic_add_f(dbeta + i, gred[(0 * 2 + 1) * L::C + i] + gred[(1 * 2 + 1) * L::C + i] + gred[(2 * 2 + 1) * L::C + i] + gred[(3 * 2 + 1) * L::C + i]);
+    const float sg = gred[(0 * 2 + 0) * L::C + i] + gred[(1 * 2 + 0) * L::C + i] + gred[(2 * 2 + 0) * L::C + i] + gred[(3 * 2 + 0) * L::C + i];
+    const float sb = gred[(0 * 2 + 1) * L::C + i] + gred[(1 * 2 + 1) * L::C + i] + gred[(2 * 2 + 1) * L::C + i] + gred[(3 * 2 + 1) * L::C + i];
+    if (NT <= 4 && prow) { prow[L::N * L::M + L::N + i] = sg; prow[L::N * L::M + L::N + L::C + i] = sb; }
+    else { atomic_add_f(dgamma + i, sg); atomic_add_f(dbeta + i, sb); }
   }
+  TSTAMP(31);
+}
+
+// workgroups of the backward launch: one per CU.  With the partial-row flush a second workgroup per CU is no longer slower, and not
+// faster either (28.3 vs 31.0 us at B = 1024: the per-workgroup prologue -- W staged as bf16, first loads -- and the flush are a third of
+// a two-image workgroup's time); QAVIT_UPMIX_BWD_GRID overrides.
+template <int NT, int MT, int CT>
+static int up2_bwd_grid(int B, bool parts) {
+  (void)parts;
+  static const int bgrid = getenv("QAVIT_UPMIX_BWD_GRID") ? atoi(getenv("QAVIT_UPMIX_BWD_GRID")) : 0;
+  const int g = bgrid > 0 ? bgrid : 256;
+  return B < g ? B : g;
 }
 
 template <int NT, int MT, int CT>
 static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta,
-                      float eps, void* o0, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, hipStream_t st) {
+                      float eps, void* o0, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, hipStream_t st,
+                      float* parts = nullptr) {
   using L = UpLds<NT, MT, CT>;
   if (!bwd) {
     const size_t smem = (size_t)(L::fwd_bf16 + 64 * L::LDC) * 2;        // + the four waves' output tiles
@@ -415,18 +540,25 @@ static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, 
   const size_t smem = (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2 + (size_t)(L::N + 8 * L::C) * 4;
   if (smem > 150 * 1024) return -100;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_bwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  static const int bgrid = getenv("QAVIT_UPMIX_BWD_GRID") ? atoi(getenv("QAVIT_UPMIX_BWD_GRID")) : 256;      // one workgroup per CU: the dW / dgamma atomic flush, not the images, bounds it
-  hipLaunchKernelGGL((upmix2_bwd_kernel<NT, MT, CT>), dim3(B < bgrid ? B : bgrid), dim3(256), smem, st, (const bf16*)a0, (const bf16*)xc, W, bias, gamma,
-                     mean, rstd, (bf16*)o0, dW, dbias, dgamma, dbeta, B);
+  hipLaunchKernelGGL((upmix2_bwd_kernel<NT, MT, CT>), dim3(up2_bwd_grid<NT, MT, CT>(B, parts != nullptr)), dim3(256), smem, st, (const bf16*)a0,
+                     (const bf16*)xc, W, bias, gamma, mean, rstd, (bf16*)o0, dW, dbias, dgamma, dbeta, B, parts);
   return QAVIT_OK;
 }
 
+// partial rows the bf16 backward writes for this shape (0: the shape takes another kernel, no partial-row path)
+int upmix_bf16_parts(int B, int N, int M, int C) {
+  if (C != 192) return 0;
+  if (N == 64 && M == 16) return up2_bwd_grid<4, 1, 12>(B, true);
+  return 0;                                                  // (N == 256: atomics, see the kernel's flush)
+}
+
 int upmix_bf16_try(bool bwd, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
-                   void* out, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, hipStream_t st) {
+                   void* out, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, hipStream_t st,
+                   float* parts) {
   if ((reinterpret_cast<uintptr_t>(xc) & 7) || C != 192) return 0;
   int rc = -100;
-  if (N == 64 && M == 16) rc = up2_launch<4, 1, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st);
-  else if (N == 256 && M == 64) rc = up2_launch<16, 4, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st);
+  if (N == 64 && M == 16) rc = up2_launch<4, 1, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, parts);
+  else if (N == 256 && M == 64) rc = up2_launch<16, 4, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, nullptr);
   if (rc == -100) return 0;
   return rc == QAVIT_OK ? 1 : rc;
 }

@@ -6,6 +6,8 @@ namespace qv {
 int bank_stats_bf16_try(const void* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr, const float* Wg,
                         const float* bg, float* ws, int B, int N, int C, int S, int grid, float eps, hipStream_t st);
 int upmix_bf16_try(bool bwd, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
-                   void* out, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, hipStream_t st);
+                   void* out, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, hipStream_t st,
+                   float* parts = nullptr);      // bwd: parts != NULL -> upmix_bf16_parts() rows of [dW | dbias | dgamma | dbeta] instead of atomics
+int upmix_bf16_parts(int B, int N, int M, int C);
 int tokmix_bf16_try(bool bwd, const void* a0, const void* x, const void* dxc, void* o0, void* o1, int B, int N, int M, int C, hipStream_t st);
 }  // namespace qv

@@ -479,9 +479,23 @@ def upmix_fwd(xc, W, bias, gamma, beta, eps, y, mean, rstd, B, N, M, Cc):
 
 
 def upmix_bwd(dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta, B, N, M, Cc):
-    L.check(L.load().qavit_upmix_bwd(dt_code(xc.dtype), dy.data_ptr(), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
-                                     mean.data_ptr(), rstd.data_ptr(), dxc.data_ptr(), dW.data_ptr(), _p(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
-                                     B, N, M, Cc, stream()), "upmix_bwd")
+    lib = L.load()
+    # inside a backward pass the parameter gradients leave as one partial row per workgroup and join the pass's single reduce launch
+    n = lib.qavit_upmix_bwd_parts(dt_code(xc.dtype), B, N, M, Cc) if (DeferredLN.enabled and DeferredLN.ON and (N * M) % 8 == 0 and N % 8 == 0) else 0
+    parts = torch.empty(n, N * M + N + 2 * Cc, dtype=torch.float32, device=xc.device) if n > 0 else None
+    L.check(lib.qavit_upmix_bwd_p(dt_code(xc.dtype), dy.data_ptr(), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                                  mean.data_ptr(), rstd.data_ptr(), dxc.data_ptr(), dW.data_ptr(), _p(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
+                                  B, N, M, Cc, _p(parts), stream()), "upmix_bwd")
+    if parts is None:
+        return
+    R, base, keep = parts.shape[1], parts.data_ptr(), (parts, dW, dbias, dgamma, dbeta)
+    half = N * M // 2                                        # a reduce descriptor adds the two halves of a 2c-float slice to two destinations
+    step = min(half, 2048)
+    for o in range(0, half, step):                           # dW in slices the reduce kernel takes (c <= 2048)
+        DeferredLN.push_raw(base + 4 * 2 * o, n, step, dW.data_ptr() + 4 * 2 * o, dW.data_ptr() + 4 * (2 * o + step), R, keep)
+    if dbias is not None:
+        DeferredLN.push_raw(base + 4 * N * M, n, N // 2, dbias.data_ptr(), dbias.data_ptr() + 4 * (N // 2), R, keep)
+    DeferredLN.push_raw(base + 4 * (N * M + N), n, Cc, dgamma.data_ptr(), dbeta.data_ptr(), R, keep)
 
 
 def gather_pool_fwd(x, idx, y, B, N, NP, stride, Cc):
