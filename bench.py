@@ -509,6 +509,25 @@ def main():
             except Exception:
                 mfma_util = None
         ach, peak, unit = (tfl, peak_fl, "TFLOP/s") if mfma_bound else (gbs, PEAK_HBM_GBS, "GB/s")
+        # The same fraction from the TRACKED rocprofv3 summary (profiles/rNN_family_summary.txt = tools/kfamily.py over --kernel-trace --stats of
+        # this command): this run's algorithmic bytes / flops of the family over the profiled family time, so the line can be re-derived from
+        # files in the repository alone.  Under the profiler every kernel reads a little longer than between the event brackets above.
+        from_profiles = None
+        if default_workload:
+            import glob
+            import re
+            fams = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_family_summary.txt")))
+            if fams:
+                try:
+                    for line in open(fams[-1]):
+                        m = re.match(r"^(\S.*?)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)%\s*$", line)
+                        if m and m.group(1).strip() == name:
+                            fam_ms = float(m.group(3))
+                            p_ach = (d["flops"] / 1e12 if mfma_bound else d["bytes"] / 1e9) / (fam_ms * 1e-3)
+                            from_profiles = {"file": os.path.relpath(fams[-1], ROOT), "family": name, "kernels_per_step": float(m.group(2)),
+                                             "family_ms_per_step": fam_ms, "achieved": round(p_ach, 3), "frac": round(p_ach / peak, 5)}
+                except Exception:
+                    from_profiles = None
         out["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name, "achieved": round(ach, 3), "peak": peak,
                            "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic,
                            "launches_per_step": d["launches"], "avg_launch_us": round(avg_ms * 1e3, 2),
@@ -516,6 +535,7 @@ def main():
                            "tflops": round(tfl, 2), "gbytes_per_s": round(gbs, 1), "event_bracket_overhead_us": round(kt.empty_ms * 1e3, 2),
                            "device_ms_per_step_all_entry_points": round(sum(v["ms"] for v in fam.values()), 3),
                            "mfma_util_pct_by_family_pmc": mfma_util,
+                           "from_profiles": from_profiles,
                            "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                             "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                                             "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}

@@ -653,8 +653,6 @@ def chan_scale_add_bwd(dy, u, gamma, du, dgamma, rows, Cc, dp, rng):
 
 
 def bn_supported(dtype, Cc: int) -> bool:
-    if os.environ.get("QAVIT_BN", "1") == "0":
-        return False
     vec = 8 if dtype == torch.bfloat16 else 4
     return Cc % vec == 0 and Cc // vec <= 256 and 256 % (Cc // vec) == 0 and Cc <= 2048
 

@@ -198,10 +198,10 @@ class HQAViT(_Base):
                         yield
                 out["T"] = T_
 
-            # Issue order of the two independent chains.  It is also the hipGraph's node creation order and -- through the sequence
-            # numbers autograd schedules by -- the backward's: the graph executor starts a chain about when its first node's turn
-            # comes in creation order, so a chain issued as one piece after the other runs mostly BEHIND it, not beside it (measured:
-            # 1.4 ms of lateral-only forward and 1.8 ms of lateral-only backward per step).  2 = alternate the chains' steps.
+            # Issue order of the two independent chains (QAVIT_LATERAL_ORDER: 0 lateral first, 1 token path first, 2 alternating).  It is
+            # also the hipGraph's node creation order.  It does not matter for the free-running step: the wall-clock stamps of
+            # tools/chain_stamps.py show both chains starting within 10 us of each other whatever the order; the 1.4 ms late start a
+            # rocprofv3 kernel trace shows is the host's packet enqueue under tracing.
             ready = {}
             if _LATERAL_ORDER == 2 and side is not None:
                 R, box = {}, {}
