@@ -222,15 +222,13 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
           s[nt][r] = ok ? s[nt][r] * scale : -INFINITY;
           mx = fmaxf(mx, s[nt][r]);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows4_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float e = __expf(s[nt][r] - mx); s[nt][r] = e; sum += e; }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows4_sum(sum);
       const float inv = 1.f / sum;
 #pragma unroll
       for (int nt = 0; nt < NKT; ++nt) {
@@ -292,8 +290,7 @@ __global__ __launch_bounds__(64) void attn3_kernel(qavit_attn_args a) {
         for (int nt = 0; nt < NKT; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dot += s[nt][r] * dp[nt][r];
-        dot += __shfl_xor(dot, 16, 64);
-        dot += __shfl_xor(dot, 32, 64);
+        dot = rows4_sum(dot);
 #pragma unroll
         for (int nt = 0; nt < NKT; ++nt) {
 #pragma unroll

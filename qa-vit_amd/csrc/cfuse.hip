@@ -319,8 +319,7 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_bwd_kernel(qavit_cfuse_bwd_arg
   for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) sdz[nt][j] = row16_sum(sdz[nt][j]);
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) dsum += __shfl_xor(dsum, o, 64);
+  dsum = wave_sum(dsum);
   if (col == 0) {
 #pragma unroll
     for (int ks = 0; ks < FC / 16; ++ks)

@@ -31,16 +31,6 @@ template <> struct Vec<bf16> { static constexpr int N = 8; typedef bf16x8 type; 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 // sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane, on the VALU's data-parallel-primitive paths
 // (quad permutes, then the half-row and row mirrors): no LDS-pipe permute instructions, which all the waves of a CU share
 __device__ __forceinline__ float row16_sum(float v) {
@@ -71,19 +61,39 @@ __device__ __forceinline__ float xor32_max(float v) {
 }
 __device__ __forceinline__ float rows4_sum(float v) { return xor32_sum(xor16_sum(v)); }     // over the 4 lanes {col, col+16, col+32, col+48}
 __device__ __forceinline__ float rows4_max(float v) { return xor32_max(xor16_max(v)); }
-// reduce over a power-of-two group of `W` adjacent lanes (W <= 64)
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
+// Reductions over a power-of-two group of `W` adjacent lanes (W <= 64), result in every lane of the group, entirely on the VALU: quad
+// permutes and row mirrors (DPP) inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across rows.  The __shfl_xor butterfly these
+// replace is one ds_bpermute_b32 per step -- an LDS-pipe round trip of 100+ cycles, log2(W) of them in a dependent chain.
 template <int W> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group_sum: power of two up to 64");
+  if (W >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  if (W >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  if (W >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  if (W >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  if (W >= 32) v = xor16_sum(v);
+  if (W >= 64) v = xor32_sum(v);
   return v;
 }
 template <int W> __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group_max: power of two up to 64");
+  if (W >= 2) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  if (W >= 4) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+  if (W >= 8) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+  if (W >= 16) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+  if (W >= 32) v = xor16_max(v);
+  if (W >= 64) v = xor32_max(v);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
-// ------------------------------------------------------------------------------------------------
 // exact-erf GELU (nn.GELU() default) and its derivative
 // ------------------------------------------------------------------------------------------------
 // Exact (erf) GELU, HQAViT_CIFAR100.py nn.GELU().  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, the same size as

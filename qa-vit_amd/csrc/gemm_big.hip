@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
             for (int j = 0; j < 8; ++j) s += (float)x[j];
           }
         }
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        s = group_sum<8>(s);
         const float mean = s * invK;
         float q = 0.f;
         for (int k0 = 0; k0 < g.K; k0 += BK) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
             for (int j = 0; j < 8; ++j) { const float d = (float)x[j] - mean; q += d * d; }
           }
         }
-        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        q = group_sum<8>(q);
         const float rstd = rsqrtf(q * invK + g.ln_eps);
         mu[i] = mean; rs[i] = rstd;
         if (cb == 0 && sv == 0 && m < g.M) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }

@@ -108,15 +108,13 @@ __global__ __launch_bounds__(256) void bank_stats2_kernel(const bf16* tokens, co
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, lg[nt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows4_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float e = __expf(lg[nt][r] - mx); lg[nt][r] = e; sum += e; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows4_sum(sum);
     const float inv = 1.f / sum;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc_to_lds(wt, LDS_, nt * 16, 0, lg[nt], inv);
@@ -499,8 +497,8 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     float a = pg[ct], c = pb[ct];
-    a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-    c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+    a = rows4_sum(a);
+    c = rows4_sum(c);
     if (q4 == 0) { gred[(wave * 2 + 0) * L::C + ct * 16 + col] = a; gred[(wave * 2 + 1) * L::C + ct * 16 + col] = c; }
   }
   __syncthreads();
