@@ -137,6 +137,14 @@ int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
  * dgamma / dbeta; qavit_ln_param_reduce adds them later -- one launch for all the LayerNorms of a backward pass.  The per-workgroup
  * same-address float atomics this replaces were ~45 % of the kernel at 16k rows. */
 int qavit_layernorm_bwd_parts(int rows, int C);
+/* LayerNorm backward FUSED with the input-gradient GEMM of the narrow Linear behind the norm (TokenLearner: Linear(192, 16) on LN(x),
+ * HQAViT_CIFAR100.py:985-990): dx = LN_backward(dz . W) + dres, with dz [rows, KZ] (leading dimension ldz) the gradient of the Linear's
+ * output and W [KZ, C] (ldw) its weight in the compute dtype; the [rows, C] product never exists in memory.  bf16, KZ = 16, C % 4 == 0,
+ * C <= 256 (qavit_layernorm_bwd_lin_supported); dgamma / dbeta / part_ws as in qavit_layernorm_bwd, same partial-row count. */
+int qavit_layernorm_bwd_lin_supported(int dtype, int KZ, int C);
+int qavit_layernorm_bwd_lin(int dtype, const void* dz, int ldz, const void* W, int ldw, int KZ, const void* x, const float* gamma,
+                            const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,
+                            const void* dres, float* part_ws, void* stream);
 typedef struct qavit_ln_reduce_desc {
   const float* parts; int nparts; int C;     /* nparts rows of [2][C] (C % 4 == 0, C <= 2048) ... */
   float* dgamma; float* dbeta;               /* += the two halves of the summed row (either may be NULL) */

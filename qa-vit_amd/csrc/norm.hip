@@ -403,6 +403,106 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_multi_kernel(LnBwd4 
                                        reinterpret_cast<T*>(P.dx[i]), P.dgamma[i], P.dbeta[i], rows, C, nullptr, 0, nullptr, P.parts[i]);
 }
 
+// LayerNorm backward of a LayerNorm-prologue Linear with a NARROW output (TokenLearner's score Linear: 192 -> 16), fused with that
+// Linear's input-gradient GEMM: dxn[row][c] = sum_k dz[row][k] W[k][c] is a 16-deep dot product per element, cheaper to redo in the
+// registers of the thread that owns (row, c) than to write a [rows, C] matrix from a GEMM launch and read it back here
+// (65536 x 192: 25 MB out + 25 MB in + a launch, per block).  W's column slice of the lane (KZ x 4 values) stays in registers.
+template <int KZ, int RB, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_lin_kernel(const bf16* dz, int ldz, const bf16* W, int ldw, const bf16* x, const float* gamma,
+                                                                    const float* mean, const float* rstd, bf16* dx, float* dgamma, float* dbeta,
+                                                                    int rows, int C, const bf16* dres, float* parts) {
+  static_assert(KZ % 8 == 0, "dz rows are read as 16-byte vectors");
+  __shared__ __attribute__((aligned(16))) float wl[KZ][256];          // W as fp32, one 16-byte read per (k, lane); also the flush scratch
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  const int c = 4 * lane;
+  const bool cl = c < C;                                   // C <= 256: one 4-column slice per lane
+  for (int i = threadIdx.x; i < KZ * 256; i += 64 * NW) {
+    const int k = i >> 8, cc = i & 255;
+    wl[k][cc] = cc < C ? (float)W[(size_t)k * ldw + cc] : 0.f;
+  }
+  float pg[4], pb[4], gm[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { pg[j] = 0.f; pb[j] = 0.f; gm[j] = cl ? gamma[c + j] : 0.f; }
+  __syncthreads();
+  for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
+    bf16x4 xv[RB], rv[RB];
+    bf16x8 zv[RB][KZ / 8];
+    float mu[RB], rs[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int row = row0 + r < rows ? row0 + r : rows - 1;       // clamp: tail rows are loaded twice, stored once
+      mu[r] = mean[row]; rs[r] = rstd[row];
+#pragma unroll
+      for (int v = 0; v < KZ / 8; ++v) zv[r][v] = *reinterpret_cast<const bf16x8*>(dz + (size_t)row * ldz + 8 * v);   // same address in every lane
+      if (cl) {
+        xv[r] = *reinterpret_cast<const bf16x4*>(x + (size_t)row * C + c);
+        if (dres) rv[r] = *reinterpret_cast<const bf16x4*>(dres + (size_t)row * C + c);
+      }
+    }
+    f32x2 d2[RB][2];                                            // (d[0], d[1]), (d[2], d[3]): the dot products run as v_pk_fma_f32
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { d2[r][0] = f32x2{0.f, 0.f}; d2[r][1] = f32x2{0.f, 0.f}; }
+#pragma unroll
+    for (int k = 0; k < KZ; ++k) {                             // one weight read serves the RB rows in flight
+      const f32x4 wk = *reinterpret_cast<const f32x4*>(&wl[k][c]);
+      const f32x2 w01 = f32x2{wk[0], wk[1]}, w23 = f32x2{wk[2], wk[3]};
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const float z = (float)zv[r][k >> 3][k & 7];
+        const f32x2 zz = f32x2{z, z};
+        d2[r][0] = __builtin_elementwise_fma(zz, w01, d2[r][0]);
+        d2[r][1] = __builtin_elementwise_fma(zz, w23, d2[r][1]);
+      }
+      if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most four weight reads ahead: all sixteen hoisted cost 64 registers (spills)
+    }
+    float d[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { d[r][0] = d2[r][0][0]; d[r][1] = d2[r][0][1]; d[r][2] = d2[r][1][0]; d[r][3] = d2[r][1][1]; }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const bool live = row0 + r < rows;
+      float xh[4], g[4];
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dd = (live && cl) ? d[r][j] : 0.f;
+        xh[j] = cl ? ((float)xv[r][j] - mu[r]) * rs[r] : 0.f;
+        g[j] = dd * gm[j];
+        pg[j] += dd * xh[j];
+        pb[j] += dd;
+        c1 += g[j] * xh[j];
+        c2 += g[j];
+      }
+      c1 = wave_sum(c1) * invC;
+      c2 = wave_sum(c2) * invC;
+      if (live && cl) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(rs[r] * (g[j] - c2 - xh[j] * c1) + (dres ? (float)rv[r][j] : 0.f));
+        *reinterpret_cast<bf16x4*>(dx + (size_t)(row0 + r) * C + c) = o;
+      }
+    }
+  }
+  static_assert(KZ >= 2 * NW, "the flush folds 2 x NW rows of 256 floats in the weight tile");
+  __syncthreads();
+  float (*red)[NW][256] = reinterpret_cast<float (*)[NW][256]>(&wl[0][0]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][wave][4 * lane + j] = pg[j]; red[1][wave][4 * lane + j] = pb[j]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 512; t += 64 * NW) {
+    const int which = t >> 8, cc = t & 255;
+    float* dst = which ? dbeta : dgamma;
+    if (cc < C && (dst || parts)) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) sacc += red[which][wv][cc];
+      if (parts) parts[((size_t)blockIdx.x * 2 + which) * C + cc] = sacc;
+      else atomic_add_f(dst + cc, sacc);
+    }
+  }
+}
+
 // dgamma / dbeta += sum over the partial rows a layernorm_bwd launch left in ``parts`` ([nparts][2][C]): one workgroup per LayerNorm,
 // threads = (group, 4-float vector of the 2C-wide row), groups stride over the rows with four loads in flight, LDS fold, then ONE
 // atomic per channel (atomic because a shared parameter may collect from several LayerNorm calls).
@@ -501,6 +601,24 @@ extern "C" int qavit_layernorm_bwd_parts(int rows, int C) {
   int grid = (rows + 63) / 64;            // 16 waves x 4 rows per workgroup and pass
   if (grid > cap) grid = cap;
   return grid < 1 ? 1 : grid;
+}
+
+extern "C" int qavit_layernorm_bwd_lin_supported(int dtype, int KZ, int C) { return dtype == QAVIT_BF16 && KZ == 16 && C % 4 == 0 && C <= 256; }
+
+extern "C" int qavit_layernorm_bwd_lin(int dtype, const void* dz, int ldz, const void* W, int ldw, int KZ, const void* x, const float* gamma,
+                                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,
+                                       const void* dres, float* part_ws, void* stream) {
+  if (!dz || !W || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd_lin: bad arguments");
+  if (!qavit_layernorm_bwd_lin_supported(dtype, KZ, C)) return set_error(QAVIT_EINVAL, "layernorm_bwd_lin: bf16, 16 Linear outputs, C % 4 == 0, C <= 256 only");
+  if (ldz % 8 || ldw % 4 || ldz < KZ || ldw < C ||
+      ((reinterpret_cast<uintptr_t>(dz) & 15) | (reinterpret_cast<uintptr_t>(W) & 7) | (reinterpret_cast<uintptr_t>(x) & 7) | (reinterpret_cast<uintptr_t>(dx) & 7) |
+       (dres ? reinterpret_cast<uintptr_t>(dres) & 7 : 0) | (part_ws ? reinterpret_cast<uintptr_t>(part_ws) & 15 : 0)))
+    return set_error(QAVIT_EINVAL, "layernorm_bwd_lin: operand alignment / leading dimensions");
+  constexpr int NW = 8;                                      // four rows in flight per wave (eight measured slower: 34 vs 31.5 us at 65536 rows)
+  const int grid = qavit_layernorm_bwd_parts(rows, C);       // the same partial-row count as qavit_layernorm_bwd
+  hipLaunchKernelGGL((layernorm_bwd_lin_kernel<16, 4, NW>), dim3(grid), dim3(64 * NW), 0, reinterpret_cast<hipStream_t>(stream), (const bf16*)dz, ldz,
+                     (const bf16*)W, ldw, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, rows, C, (const bf16*)dres, part_ws);
+  return check_launch("layernorm_bwd_lin");
 }
 
 extern "C" int qavit_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,

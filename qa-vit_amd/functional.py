@@ -385,6 +385,9 @@ class SideStream:
 # ---------------------------------------------------------------------------------------------------
 # Linear (+ fused LayerNorm prologue, GELU / dropout / drop-path / residual epilogue)
 # ---------------------------------------------------------------------------------------------------
+_LN_LIN = os.environ.get("QAVIT_LN_LIN", "1") != "0"      # narrow LayerNorm-prologue Linears: dX GEMM fused into the LayerNorm-backward kernel
+
+
 class LinearFn(Function):
     """y = resid + droppath(dropout(act(LN(x) @ W[rows]^T + b[rows])))"""
 
@@ -472,7 +475,16 @@ def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, me
     esz = Wt.element_size()
     dz = dy2
     dx = None
-    if need_dx or need_t:
+    if (_LN_LIN and need_dx and not need_t and ln_g is not None and dx_add is None and koff == 0 and Kd == ldx
+            and K.layernorm_bwd_lin_ok(x2, dy2, n, Kd) and (dres is None or K.ln_dres_ok(x2, dres.reshape(M, Kd), Kd))):
+        # narrow Linear behind a LayerNorm (TokenLearner's 192 -> 16 scores): its input-gradient GEMM redone inside the LayerNorm-backward
+        # kernel -- no [M, Kd] product written by one launch and read back by the next
+        gbuf, _ = grad_sink(ln_g)
+        bbuf, _ = grad_sink(ln_b)
+        dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
+        K.layernorm_bwd_lin(dy2, Wc.data_ptr() + off * Wc.shape[1] * Wc.element_size(), Wc.shape[1], n, x2, ln_g, mean, rstd, dx, gbuf, bbuf, M, Kd,
+                            dres=None if dres is None else dres.reshape(M, Kd))
+    elif need_dx or need_t:
         dz = torch.empty_like(dy2) if (need_t and (need_dw or (b is not None and b.requires_grad))) else dy2
         dxn = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
         bwd = None

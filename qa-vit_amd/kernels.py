@@ -407,6 +407,21 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=No
         DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
 
 
+def layernorm_bwd_lin_ok(x, dz, n, Cc) -> bool:
+    return (x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and dz.is_contiguous() and dz.data_ptr() % 16 == 0 and x.data_ptr() % 8 == 0
+            and bool(L.load().qavit_layernorm_bwd_lin_supported(dt_code(x.dtype), n, Cc)))
+
+
+def layernorm_bwd_lin(dz, W_ptr, ldw, n, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dres=None):
+    """dx = LayerNorm_backward(dz @ W) + dres in one launch (qavit_layernorm_bwd_lin); W_ptr = the [n, C] compute-dtype weight rows."""
+    part = DeferredLN.parts_for(x, x, dx, rows, Cc) if (dgamma is not None or dbeta is not None) else None
+    L.check(L.load().qavit_layernorm_bwd_lin(dt_code(x.dtype), dz.data_ptr(), n, W_ptr, ldw, n, x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                             rstd.data_ptr(), dx.data_ptr(), _p(dgamma), _p(dbeta), rows, Cc, _p(dres),
+                                             part[0].data_ptr() if part else None, stream()), "layernorm_bwd_lin")
+    if part:
+        DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
+
+
 def ln_dres_ok(x, dres, Cc, dadd=None) -> bool:
     """Can qavit_layernorm_bwd add ``dres`` in its own pass?  (vector path: C % 4 == 0, aligned, same dtype / shape, no dadd)"""
     vec = 4 * x.element_size()

@@ -105,6 +105,40 @@ def test_weight_gradient_gemm_tile_classes(F, Q, mode):
         assert rel(cs, csref) <= 4e-3, shp
 
 
+@pytest.mark.parametrize("M", [4096, 1000 * 64 + 37])
+def test_linear_ln_narrow_output_fused_backward(F, M):
+    """TokenLearner's score Linear (LayerNorm -> Linear(192, 16), HQAViT_CIFAR100.py:985-990) with its input also feeding the token mix
+    (alias): in bf16 the input-gradient GEMM runs inside the LayerNorm-backward kernel (qavit_layernorm_bwd_lin).  Against fp32 torch
+    autograd, and the fused kernel against the GEMM + LayerNorm-backward pair (QAVIT_LN_LIN off)."""
+    Kd, N = 192, 16
+    x0 = leaf(M, Kd, seed=31)
+    w, b = leaf(N, Kd, scale=0.05, seed=32), leaf(N, scale=0.1, seed=33)
+    g_, be = leaf(Kd, scale=0.1, seed=34), leaf(Kd, scale=0.1, seed=35)
+    with torch.no_grad():
+        g_.add_(1.0)
+    go = torch.randn(M, N, device=DEV)
+    ga = torch.randn(M, Kd, device=DEV)
+    res = {}
+    for mode in (True, False):
+        F._LN_LIN = mode
+        for t in (w, b, g_, be):
+            t.grad = None
+        x = x0.detach().to(torch.bfloat16).requires_grad_(True)
+        y, xa = F.linear(x, w, b, ln=(g_, be), alias=True)
+        torch.autograd.backward([y, xa], [go.to(torch.bfloat16), ga.to(torch.bfloat16)])
+        res[mode] = [t.detach().float().clone() for t in (y, x.grad, w.grad, b.grad, g_.grad, be.grad)]
+    F._LN_LIN = True
+    xr = x0.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr, br, gr, ber = [t.detach().clone().requires_grad_(True) for t in (w, b, g_, be)]
+    yr = TF.linear(TF.layer_norm(xr, (Kd,), gr, ber), wr, br)
+    torch.autograd.backward([yr, xr * 1.0], [go.to(torch.bfloat16).float(), ga.to(torch.bfloat16).float()])
+    refs = [yr, xr.grad, wr.grad, br.grad, gr.grad, ber.grad]
+    for got, ref in zip(res[True], refs):
+        assert rel(got, ref) <= tol(torch.bfloat16, False)
+    for a_, b_ in zip(res[True], res[False]):
+        assert rel(a_, b_) <= 2e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_ln_gelu_residual(F, dtype):
     M, K, N = 2048, 192, 96
