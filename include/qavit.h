@@ -141,6 +141,13 @@ int qavit_layernorm_bwd_parts(int rows, int C);
  * HQAViT_CIFAR100.py:985-990): dx = LN_backward(dz . W) + dres, with dz [rows, KZ] (leading dimension ldz) the gradient of the Linear's
  * output and W [KZ, C] (ldw) its weight in the compute dtype; the [rows, C] product never exists in memory.  bf16, KZ = 16, C % 4 == 0,
  * C <= 256 (qavit_layernorm_bwd_lin_supported); dgamma / dbeta / part_ws as in qavit_layernorm_bwd, same partial-row count. */
+/* LayerNorm backward whose incoming gradient is the SUM of n_dy (1..5) same-shape tensors -- the k gradients of a normalised tensor
+ * that feeds several consumers (norm1's output and the four attention branches, HQAViT_CIFAR100.py:1072-1078) -- summed in fp32 on load
+ * instead of by a k-way sum launch.  `dy` is a HOST array of device pointers.  C % 4 == 0, C <= 256, vector-aligned operands; dres /
+ * part_ws as in qavit_layernorm_bwd (same partial-row count). */
+int qavit_layernorm_bwd_sum(int dtype, int n_dy, const void* const* dy, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C, const void* dres, float* part_ws,
+                            void* stream);
 int qavit_layernorm_bwd_lin_supported(int dtype, int KZ, int C);
 int qavit_layernorm_bwd_lin(int dtype, const void* dz, int ldz, const void* W, int ldw, int KZ, const void* x, const float* gamma,
                             const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,

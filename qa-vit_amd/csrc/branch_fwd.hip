@@ -698,6 +698,9 @@ int branch_validate(const qavit_branch_args* a) {
 // the NaN -> zeros rule's rewrite launch, shared with the fused channel-group branch (cga.hip)
 void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag,
                            int* trip, void* o_save, int64_t ldos, int Co, hipStream_t st) {
+#ifdef QAVIT_NANFIX_EXPERIMENT     // diagnostic build only: what the 32 NaN-rule launches of a step cost (QAVIT_SKIP_NANFIX=1 drops them: trip stays unset)
+  { static int skip = -1; if (skip < 0) { const char* e = getenv("QAVIT_SKIP_NANFIX"); skip = e ? atoi(e) : 0; } if (skip) return; }
+#endif
   const int64_t n = (int64_t)rows * C;
   int nb = (int)((n + 2047) / 2048);
   if (nb > 64) nb = 64;

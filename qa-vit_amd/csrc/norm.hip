@@ -292,10 +292,14 @@ static bool ln_fwd_v4_launch(int dtype, const void* x, void* y, const float* gam
   return true;
 }
 
-template <typename T, int NP, int RB, int NW>
+// More gradients of the same normalised tensor (a LayerNorm output that feeds several consumers): dy = dy + sum ex.p[q], summed in fp32 on load
+// instead of by a k-way sum launch in front of this kernel.
+struct LnDyExtra { const void* p[4]; int n; };
+
+template <typename T, int NP, int RB, int NW, bool EXTRA = false>
 __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, const float* gamma, const float* mean,
                                                       const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act,
-                                                      const T* dres = nullptr, float* parts = nullptr) {
+                                                      const T* dres = nullptr, float* parts = nullptr, LnDyExtra ex = LnDyExtra{{nullptr, nullptr, nullptr, nullptr}, 0}) {
   // RB rows per wave per iteration: all their loads are issued before the first reduction, so a wave keeps
   // 2*RB*NP vector loads in flight instead of 2 (the row loop is a pure load -> reduce -> store latency chain).
   typedef typename V4<T>::type v4;
@@ -310,6 +314,7 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
   }
   for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
     v4 xv[RB][NP], dv[RB][NP], rv[RB][NP];
+    v4 ev[EXTRA ? 4 : 1][RB][NP];
     float mu[RB], rs[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -322,6 +327,11 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
           xv[r][i] = *reinterpret_cast<const v4*>(x + (size_t)row * C + c);
           dv[r][i] = *reinterpret_cast<const v4*>(dy + (size_t)row * C + c);
           if (dres) rv[r][i] = *reinterpret_cast<const v4*>(dres + (size_t)row * C + c);      // uniform: the other gradient that meets this one at x
+          if (EXTRA) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (q < ex.n) ev[q][r][i] = *reinterpret_cast<const v4*>(reinterpret_cast<const T*>(ex.p[q]) + (size_t)row * C + c);   // uniform
+          }
         }
       }
     }
@@ -337,6 +347,11 @@ __device__ __forceinline__ void layernorm_bwd_v4_body(const T* dy, const T* x, c
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float d = live ? to_f<T>(dv[r][i][j]) : 0.f;
+            if (EXTRA) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (q < ex.n && live) d += to_f<T>(ev[q][r][i][j]);
+            }
             xh[i][j] = (to_f<T>(xv[r][i][j]) - mu[r]) * rs[r];
             if (act) d *= gelu_grad_f(xh[i][j] * gm[i][j] + bt[i][j]);
             g[i][j] = d * gm[i][j];
@@ -394,6 +409,11 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_kernel(const T* dy, 
                                                                const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const float* beta, int act,
                                                                const T* dres, float* parts) {
   layernorm_bwd_v4_body<T, NP, RB, NW>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, beta, act, dres, parts);
+}
+template <typename T, int NP, int RB, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_sum_kernel(const T* dy, LnDyExtra ex, const T* x, const float* gamma, const float* mean,
+                                                                    const float* rstd, T* dx, float* dgamma, float* dbeta, int rows, int C, const T* dres, float* parts) {
+  layernorm_bwd_v4_body<T, NP, RB, NW, true>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, nullptr, 0, dres, parts, ex);
 }
 struct LnBwd4 { const void* dy[4]; const void* x[4]; const float* gamma[4]; const float* mean[4]; const float* rstd[4]; void* dx[4]; float* dgamma[4]; float* dbeta[4]; float* parts[4]; };
 template <typename T, int NP, int RB, int NW>
@@ -601,6 +621,32 @@ extern "C" int qavit_layernorm_bwd_parts(int rows, int C) {
   int grid = (rows + 63) / 64;            // 16 waves x 4 rows per workgroup and pass
   if (grid > cap) grid = cap;
   return grid < 1 ? 1 : grid;
+}
+
+extern "C" int qavit_layernorm_bwd_sum(int dtype, int n_dy, const void* const* dy, const void* x, const float* gamma, const float* mean,
+                                       const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C, const void* dres, float* part_ws,
+                                       void* stream) {
+  if (!dy || n_dy < 1 || n_dy > 5 || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "layernorm_bwd_sum: bad arguments");
+  const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
+  if ((dtype != QAVIT_F32 && dtype != QAVIT_BF16) || C % 4 || C > 256) return set_error(QAVIT_EINVAL, "layernorm_bwd_sum: fp32 / bf16, C % 4 == 0, C <= 256");
+  uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) | (dres ? reinterpret_cast<uintptr_t>(dres) : 0);
+  LnDyExtra ex{{nullptr, nullptr, nullptr, nullptr}, n_dy - 1};
+  for (int i = 0; i < n_dy; ++i) {
+    if (!dy[i]) return set_error(QAVIT_EINVAL, "layernorm_bwd_sum: null gradient");
+    al |= reinterpret_cast<uintptr_t>(dy[i]);
+    if (i > 0) ex.p[i - 1] = dy[i];
+  }
+  if (al % (4 * esz) || (part_ws && (reinterpret_cast<uintptr_t>(part_ws) & 15))) return set_error(QAVIT_EINVAL, "layernorm_bwd_sum: vector-aligned operands");
+  constexpr int NW = 16;
+  const int grid = qavit_layernorm_bwd_parts(rows, C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == QAVIT_F32)
+    hipLaunchKernelGGL((layernorm_bwd_sum_kernel<float, 1, 2, NW>), dim3(grid), dim3(64 * NW), 0, st, (const float*)dy[0], ex, (const float*)x, gamma, mean, rstd,
+                       (float*)dx, dgamma, dbeta, rows, C, (const float*)dres, part_ws);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_sum_kernel<bf16, 1, 2, NW>), dim3(grid), dim3(64 * NW), 0, st, (const bf16*)dy[0], ex, (const bf16*)x, gamma, mean, rstd,
+                       (bf16*)dx, dgamma, dbeta, rows, C, (const bf16*)dres, part_ws);
+  return check_launch("layernorm_bwd_sum");
 }
 
 extern "C" int qavit_layernorm_bwd_lin_supported(int dtype, int KZ, int C) { return dtype == QAVIT_BF16 && KZ == 16 && C % 4 == 0 && C <= 256; }

@@ -643,6 +643,59 @@ class LayerNormFn(Function):
         return dx, None, None, None, None, None, None
 
 
+class LayerNormFanFn(Function):
+    """LayerNorm whose output feeds ``k`` consumers, plus the alias of ``x`` for the residual: -> (y_1 .. y_k, x_alias).  Backward gets
+    the k gradients and the residual's and runs ONE launch: the LayerNorm-backward kernel sums them on load (qavit_layernorm_bwd_sum)
+    instead of a k-way sum kernel in front of it (FanOutFn)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps, k):
+        Cc = x.shape[-1]
+        x2 = x.reshape(-1, Cc)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        K.layernorm_fwd(x2, y, g, b, eps, rows, Cc, mean, rstd, None, 0, act=False)
+        ctx.save_for_backward(x2, g, b, mean, rstd)
+        ctx.xshape, ctx.k = x.shape, k
+        ctx.set_materialize_grads(False)
+        y = y.reshape(x.shape)
+        return tuple(y.view_as(y) for _ in range(k)) + (x.view_as(x),)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x2, g, b, mean, rstd = ctx.saved_tensors
+        rows, Cc = x2.shape
+        dalias = grads[ctx.k]
+        dys = [t.reshape(rows, Cc) for t in grads[:ctx.k] if t is not None]
+        dys = [t if t.is_contiguous() else t.contiguous() for t in dys]
+        if not dys:
+            return dalias, None, None, None, None
+        gbuf, _ = grad_sink(g)
+        bbuf, _ = grad_sink(b)
+        dx = torch.empty_like(x2)
+        DeferDW.arm()
+        dres = None
+        if dalias is not None:
+            dres = dalias.reshape(rows, Cc)
+            if not K.ln_dres_ok(x2, dres, Cc):
+                dres = None
+        if K.layernorm_bwd_sum_ok(x2, dys, Cc):
+            K.layernorm_bwd_sum(dys, x2, g, mean, rstd, dx, gbuf, bbuf, rows, Cc, dres=dres)
+        else:
+            dy = dys[0]
+            for t in dys[1:]:
+                dy = dy + t
+            K.layernorm_bwd(dy, x2, g, mean, rstd, dx, gbuf, bbuf, rows, Cc, dres=dres)
+        dx = dx.reshape(ctx.xshape)
+        if dalias is not None and dres is None:
+            dx = dx + dalias
+        return dx, None, None, None, None
+
+
 def layer_norm(x, g, b, eps=1e-5, add=None, act=None, alias=False):
     """LayerNorm (+ pos_embed-style broadcast add); ``act="gelu"`` fuses the exact GELU that follows it.  ``alias=True`` -> (y,
     x_alias): use ``x_alias`` for the residual connection (see LayerNormFn)."""

@@ -407,6 +407,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dadd=No
         DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
 
 
+def layernorm_bwd_sum_ok(x, dys, Cc) -> bool:
+    vec = 4 * x.element_size()
+    return (1 <= len(dys) <= 5 and Cc % 4 == 0 and Cc <= 256 and x.dtype in (torch.bfloat16, torch.float32) and x.data_ptr() % vec == 0
+            and all(d.dtype == x.dtype and d.is_contiguous() and d.numel() == x.numel() and d.data_ptr() % vec == 0 for d in dys))
+
+
+def layernorm_bwd_sum(dys, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cc, dres=None):
+    """LayerNorm backward on dy = sum(dys) (qavit_layernorm_bwd_sum): the k-way gradient sum happens on load."""
+    part = DeferredLN.parts_for(x, dys[0], dx, rows, Cc) if (dgamma is not None or dbeta is not None) else None
+    L.check(L.load().qavit_layernorm_bwd_sum(dt_code(x.dtype), len(dys), _ptr_arr(dys), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             dx.data_ptr(), _p(dgamma), _p(dbeta), rows, Cc, _p(dres), part[0].data_ptr() if part else None, stream()),
+            "layernorm_bwd_sum")
+    if part:
+        DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
+
+
 def layernorm_bwd_lin_ok(x, dz, n, Cc) -> bool:
     return (x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and dz.is_contiguous() and dz.data_ptr() % 16 == 0 and x.data_ptr() % 8 == 0
             and bool(L.load().qavit_layernorm_bwd_lin_supported(dt_code(x.dtype), n, Cc)))

@@ -154,6 +154,7 @@ _SIGS = {
     "qavit_row_stats_multi": (i32, [i32, i32, vp, f32, i32, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_multi": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "qavit_layernorm_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp]),
+    "qavit_layernorm_bwd_sum": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_lin": (i32, [i32, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "qavit_layernorm_bwd_lin_supported": (i32, [i32, i32, i32]),
     "qavit_layernorm_bwd_parts": (i32, [i32, i32]),

@@ -32,6 +32,7 @@ def _drive(gen):
         return e.value
 
 
+_LN_FAN = os.environ.get("QAVIT_LN_FAN", "1") != "0"     # norm1's five-way gradient fan-in summed inside its LayerNorm-backward launch
 _BANK_PROJ2 = os.environ.get("QAVIT_BANK_PROJ2", "1") != "0"
 
 
@@ -409,10 +410,13 @@ class QuadAttentionBlock(nn.Module):
                 rt.snap = None
 
     def _forward(self, x, B, N, C, tr):
-        # xr = x again, for the residual: its gradient joins norm1's inside the LayerNorm-backward kernel
-        xn, xr = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, alias=True)
-        # norm1's output feeds four branches (MSDA twice): one k-way gradient sum instead of autograd's pairwise adds
-        xns = F.FanOutFn.apply(xn, 5) if (torch.is_grad_enabled() and xn.requires_grad) else (xn,) * 5
+        # norm1's output feeds four branches (MSDA twice); xr = x again, for the residual.  In backward the five gradients and the
+        # residual's meet inside ONE LayerNorm-backward launch (summed on load), not in a k-way sum kernel in front of it
+        if _LN_FAN and torch.is_grad_enabled() and x.requires_grad:
+            *xns, xr = F.LayerNormFanFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, 5)
+        else:
+            xn, xr = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, alias=True)
+            xns = F.FanOutFn.apply(xn, 5) if (torch.is_grad_enabled() and xn.requires_grad) else (xn,) * 5
         args = []
         for (name, branch), xb in zip((("swa", self.swa), ("msda", self.msda), ("cga", self.cga), ("cross", self.cross_attn)), xns):
             bo = branch(xb, xns[4]) if name == "msda" else branch(xb)

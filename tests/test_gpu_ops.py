@@ -281,6 +281,31 @@ def _drop_setup(drop, G, H, Nq, NK):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows", [16 * 130, 64 * 1000 + 5])
+def test_layernorm_fan_out_backward_sums_on_load(F, dtype, rows):
+    """LayerNormFanFn: a LayerNorm output with five consumers + the residual alias of its input; backward = ONE launch that sums the
+    five gradients (one of them absent) and the residual's on load (qavit_layernorm_bwd_sum), against fp32 torch autograd."""
+    C = 192
+    x0 = leaf(rows, C, seed=61)
+    g_, be = leaf(C, scale=0.1, seed=62), leaf(C, scale=0.1, seed=63)
+    with torch.no_grad():
+        g_.add_(1.0)
+    x = x0.detach().to(dtype).requires_grad_(True)
+    outs = F.LayerNormFanFn.apply(x, g_, be, 1e-5, 5)
+    ys, xa = outs[:5], outs[5]
+    gs = [torch.randn(rows, C, device=DEV).to(dtype) for _ in range(5)]
+    torch.autograd.backward([ys[0], ys[1], ys[3], ys[4], xa], [gs[0], gs[1], gs[3], gs[4], gs[2]])     # ys[2] has no consumer
+    xr = x0.detach().to(dtype).float().requires_grad_(True)
+    gr, ber = g_.detach().clone().requires_grad_(True), be.detach().clone().requires_grad_(True)
+    yr = TF.layer_norm(xr, (C,), gr, ber)
+    assert rel(ys[0], yr) <= tol(dtype)
+    torch.autograd.backward([yr, xr * 1.0], [gs[0].float() + gs[1].float() + gs[3].float() + gs[4].float(), gs[2].float()])
+    assert rel(x.grad, xr.grad) <= tol(dtype, False)
+    assert rel(g_.grad, gr.grad) <= tol(dtype, False)
+    assert rel(be.grad, ber.grad) <= tol(dtype, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("B,Hs,ws,KC", [(37, 4, 4, 32), (9, 8, 4, 32), (5, 14, 7, 64), (700, 4, 4, 32)])
 def test_attn_swa_like(F, Q, dtype, B, Hs, ws, KC, drop):
