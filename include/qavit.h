@@ -271,6 +271,10 @@ typedef struct qavit_branch_args {
   /* optional (needs nan_flag): one int written by the NaN-rule launch of this call, 1 = the rule was applied (then o_save is zeroed
    * too), 0 = not; hand it to qavit_branch_bwd, whose gradient through a tripped branch is exactly zero as the reference's is */
   int* nan_trip;
+  /* != 0 (needs nan_flag): the kernel still RAISES nan_flag but the call does not launch the rule's rewrite; the caller hands the
+   * rewrite to the consumer that reads `out` next -- qavit_bank_stats_nanfix with the matching qavit_nan_fix -- which does it for the
+   * images it visits before it reads them (one launch less per branch on the forward critical path) */
+  int nan_defer;
 } qavit_branch_args;
 
 int qavit_branch_supported(int kind, int T, int C, int H, int D, int KC, int S, int L);   /* 1 if qavit_branch_fwd covers the shape */
@@ -397,6 +401,7 @@ typedef struct qavit_cga_args {
   float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
   int* nan_flag;
   int* nan_trip;   /* optional, as in qavit_branch_args: 1 / 0 written by the NaN-rule launch; a tripped call also zeroes o_save */
+  int nan_defer;   /* as in qavit_branch_args */
 } qavit_cga_args;
 int qavit_cga_supported(int T, int C, int G, int H, int S);
 int qavit_cga_fwd(const qavit_cga_args* a, void* stream);
@@ -540,6 +545,22 @@ int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const
                      const float* g_write, const float* b_write, const float* Wg, const float* bg,
                      float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps, void* stream);
 int64_t qavit_bank_ws_floats(int B, int N, int C, int S);
+/* The NaN -> zeros rule of a fused branch call made with nan_defer, carried out by the bank write that reads the branch output next
+ * (HQAViT_CIFAR100.py:356-357, :394-395 then :296-321).  With `flag` raised, every image's rows of `tokens` are first rewritten as
+ * dropout(bias) (what proj(zeros) gives), its o_save rows zeroed, `trip` set and the flag / ticket words reset -- exactly what the
+ * rule's own launch does -- and the statistics are taken of the rewritten rows.  bf16 [B, N, 192] tokens with N = 16 or 64 do this
+ * inside the statistics kernel; every other shape runs the rule's launch first. */
+typedef struct qavit_nan_fix {
+  int* flag;                 /* int[2]: the branch call's nan_flag (flag, arrival ticket) */
+  int* trip;                 /* optional: the branch call's nan_trip */
+  const float* bias;         /* [C]: the branch's proj bias */
+  float drop_p; int drop_site; const int64_t* rng;   /* the branch's proj dropout */
+  void* o_save; int64_t ldos; int Co;                /* optional: the saved attention output [B*N, ldos], Co columns, zeroed */
+} qavit_nan_fix;
+int qavit_bank_stats_nanfix(int dtype, void* tokens, const float* g_branch, const float* b_branch,
+                            const float* g_write, const float* b_write, const float* Wg, const float* bg,
+                            float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps,
+                            const qavit_nan_fix* fix, void* stream);
 /* acc == NULL in bank_stats: the per-workgroup partials stay in ws ([nparts = ws_floats / (S*C)][S][C]) and bank_apply folds
  * them itself when given `parts` (single-GPU write = stats -> apply, fixed summation order).  With acc, stats also reduces
  * into it (the data-parallel path all-reduces acc between the two calls) and apply is called with parts = NULL.

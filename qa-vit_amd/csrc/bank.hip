@@ -311,9 +311,23 @@ extern "C" int64_t qavit_bank_ws_floats(int B, int N, int C, int S) {
   return (int64_t)bank_grid(B) * S * C;
 }
 
+namespace qv {
+void branch_nan_fix_launch(void* out, int64_t ldo, int rows, int C, const float* bias, float p, int site, const int64_t* rng, int* flag,
+                           int* trip, void* o_save, int64_t ldos, int Co, hipStream_t st);      // branch_fwd.hip
+}
+
 extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_branch, const float* b_branch,
                                 const float* g_write, const float* b_write, const float* Wg, const float* bg,
                                 float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps, void* stream) {
+  return qavit_bank_stats_nanfix(dtype, const_cast<void*>(tokens), g_branch, b_branch, g_write, b_write, Wg, bg, acc, ws, ws_floats, B, N, C, S, eps, nullptr, stream);
+}
+
+extern "C" int qavit_bank_stats_nanfix(int dtype, void* tokens, const float* g_branch, const float* b_branch,
+                                       const float* g_write, const float* b_write, const float* Wg, const float* bg,
+                                       float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps,
+                                       const qavit_nan_fix* fix, void* stream) {
+  if (fix && (!fix->flag || !fix->bias || (fix->drop_p > 0.f && !fix->rng) || fix->drop_p < 0.f || fix->drop_p >= 1.f || dtype != QAVIT_BF16))
+    return set_error(QAVIT_EINVAL, "bank_stats: the deferred NaN rule needs flag, bias, rng with dropout, bf16 tokens");
   if (!tokens || !g_branch || !b_branch || !g_write || !b_write || !Wg || !bg || !ws) return set_error(QAVIT_EINVAL, "bank_stats: null operand");
   if (B <= 0 || N <= 0 || C <= 0 || S <= 0 || S > 256 || (256 % S) != 0) return set_error(QAVIT_EINVAL, "bank_stats: bad dimensions (S must divide 256)");
   const int grid = bank_grid(B);
@@ -330,13 +344,15 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int n_acc = S * C;
   if (dtype == QAVIT_BF16) {
-    const int took = bank_stats_bf16_try(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, grid, eps, st);
+    const int took = bank_stats_bf16_try(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, grid, eps, st, fix);
     if (took < 0) return took;
     if (took == 1) {
       if (acc) hipLaunchKernelGGL(bank_reduce_kernel, dim3((n_acc + 255) / 256, (grid + 15) / 16), dim3(256), 0, st, ws, acc, grid, n_acc);
       return check_launch("bank_stats(bf16)");
     }
   }
+  if (fix)      // no kernel here carries the deferred rule for this shape: the rule's own launch first
+    qv::branch_nan_fix_launch(tokens, C, B * N, C, fix->bias, fix->drop_p, fix->drop_site, fix->rng, fix->flag, fix->trip, fix->o_save, fix->ldos, fix->Co, st);
   // one image per workgroup: a 196-token image (two chunks) gets 16 waves to share its rows and MFMA tiles
 #define BANK_LAUNCH(T_, BF_, NTH_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats_kernel<T_, BF_, NTH_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL((bank_stats_kernel<T_, BF_, NTH_>), dim3(grid), dim3(NTH_), smem, st, (const T_*)tokens, g_branch, b_branch, g_write, b_write, Wg, bg, ws, B, N, C, S, NCH, eps); }

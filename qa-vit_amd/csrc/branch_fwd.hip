@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void branch_nan_fix_kernel(bf16* out, int64_t 
   __shared__ int f_s;
   if (threadIdx.x == 0) {
     f_s = *reinterpret_cast<volatile int*>(flag);
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the read has returned before the arrival is counted (no agent-scope fence needed)
     if (atomicAdd(flag + 1, 1) == (int)gridDim.x - 1) { flag[0] = 0; flag[1] = 0; }
   }
   __syncthreads();
@@ -753,7 +753,7 @@ extern "C" int qavit_branch_fwd(const qavit_branch_args* a, void* stream) {
   else QV_BRANCH_KIND(2);
 #undef QV_BRANCH_KIND
 #undef QV_BRANCH_LAUNCH
-  if (a->nan_flag)
+  if (a->nan_flag && !a->nan_defer)
     branch_nan_fix_launch(a->out, a->ldo, a->B * a->T, BC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, a->nan_trip,
                           a->o_save, a->ldo, BC, st);
   return check_launch("branch_fwd");

@@ -522,7 +522,7 @@ extern "C" int qavit_cga_fwd(const qavit_cga_args* a, void* stream) {
     attr_done = true;
   }
   hipLaunchKernelGGL(cga_fwd_kernel, dim3((a->B + CNI - 1) / CNI), dim3(64 * CNW), SM_CGA, st, *a);
-  if (a->nan_flag)
+  if (a->nan_flag && !a->nan_defer)
     branch_nan_fix_launch(a->out, a->ldo, a->B * CT, CC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, a->nan_trip, a->o_save, CO, CO, st);
   return check_launch("cga_fwd");
 }

@@ -488,7 +488,7 @@ int cga64_fwd_launch(const qavit_cga_args* a, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL(cga64_fwd_kernel, dim3(a->B), dim3(64 * FW_WAVES), SMF_TOTAL, st, *a);
-  if (a->nan_flag)
+  if (a->nan_flag && !a->nan_defer)
     branch_nan_fix_launch(a->out, a->ldo, a->B * WT, WC, a->bproj, a->proj_drop_p, a->proj_drop_site, a->rng, a->nan_flag, a->nan_trip, a->o_save, WO, WO, st);
   return check_launch("cga_fwd");
 }

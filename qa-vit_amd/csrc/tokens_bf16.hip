@@ -29,9 +29,12 @@ namespace qv {
 // written once to a bf16 LDS tile that then feeds both products; U stays in accumulator registers across all the
 // images a wave visits.
 // ------------------------------------------------------------------------------------------------
+// `fx` (flag != NULL): the NaN -> zeros rule of the branch that produced `tokens`, deferred to this launch (qavit_nan_fix): with the flag
+// raised a wave rewrites the rows of each image it visits as dropout(bias) -- in memory, for the later readers, and in its registers --
+// and zeroes the image's saved attention output, before the statistics are taken; flag / ticket / trip are handled as the rule's own launch does.
 template <int NT, int CT>   // N = 16*NT tokens, C = 16*CT channels
-__global__ __launch_bounds__(256) void bank_stats2_kernel(const bf16* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr,
-                                                          const float* Wg, const float* bg, float* ws, int B, float eps) {
+__global__ __launch_bounds__(256) void bank_stats2_kernel(bf16* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr,
+                                                          const float* Wg, const float* bg, float* ws, int B, float eps, qavit_nan_fix fx) {
   constexpr int N = 16 * NT, C = 16 * CT, S = 16;
   constexpr int LDC = C + 4, LDS_ = S + 4;
   constexpr int CPL = C / 4;                          // channels per lane when 4 lanes share a row
@@ -44,9 +47,29 @@ __global__ __launch_bounds__(256) void bank_stats2_kernel(const bf16* tokens, co
   bf16* wt = tn + N * LDC;                                             // [N][LDS_]
   const int col = lane & 15, q4 = lane >> 4;
 
+  // (the flag's broadcast word sits behind the dynamic region: a static __shared__ object on top of the 160 KB opt-in would not fit)
+  constexpr size_t PW_B = (size_t)(N * LDC + N * LDS_) * 2;
+  constexpr size_t TAIL_B = 4 * PW_B > (size_t)4 * S * C * 4 ? 4 * PW_B : (size_t)4 * S * C * 4;
+  volatile int& f_s = *reinterpret_cast<volatile int*>(smraw + (size_t)S * LDC * 2 + 4 * C * 4 + TAIL_B);
+  if (tid == 0) {
+    int f = 0;
+    if (fx.flag) {
+      f = *reinterpret_cast<volatile int*>(fx.flag);
+      // the read has RETURNED before this workgroup's arrival is counted (no agent-scope fence: on eight XCDs that is an L2 write-back per
+      // workgroup, and all that must be ordered is this one load before this one atomic)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (atomicAdd(fx.flag + 1, 1) == (int)gridDim.x - 1) { fx.flag[0] = 0; fx.flag[1] = 0; }     // every workgroup has read the flag by then
+    }
+    f_s = f;
+  }
   for (int i = tid; i < S * C; i += 256) { const int s = i / C, c = i - s * C; WgT[s * LDC + c] = (bf16)Wg[i]; }
   for (int i = tid; i < C; i += 256) { prm[i] = gbr[i]; prm[C + i] = bbr[i]; prm[2 * C + i] = gwr[i]; prm[3 * C + i] = bwr[i]; }
   __syncthreads();
+  const bool fixit = f_s != 0;                         // uniform over the grid
+  if (fx.flag && fx.trip && blockIdx.x == 0 && tid == 0) *fx.trip = fixit ? 1 : 0;
+  const bool fdrop = fixit && fx.drop_p > 0.f && fx.rng != nullptr;
+  const uint32_t fkey = fdrop ? rng_key(fx.rng, fx.drop_site) : 0u;
+  const float finv = fdrop ? 1.f / (1.f - fx.drop_p) : 1.f;
   const float bgv = bg[col];
   f32x4 U[CT];
 #pragma unroll
@@ -58,12 +81,29 @@ __global__ __launch_bounds__(256) void bank_stats2_kernel(const bf16* tokens, co
     const int rr = lane >> 2, part = lane & 3;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const bf16* src = tokens + ((size_t)b * N + nt * 16 + rr) * C + part * CPL;
+      bf16* src = tokens + ((size_t)b * N + nt * 16 + rr) * C + part * CPL;
       float v[CPL];
+      if (fixit) {                                    // rare: the branch output is dropout(proj(0)) = dropout(bias), for this reader and the later ones
+        const uint32_t row = (uint32_t)(b * N + nt * 16 + rr);
 #pragma unroll
-      for (int j = 0; j < CPL; j += 4) {
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(src + j);
-        v[j] = (float)t[0]; v[j + 1] = (float)t[1]; v[j + 2] = (float)t[2]; v[j + 3] = (float)t[3];
+        for (int j = 0; j < CPL; j += 4) {
+          bf16x4 t;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int c = part * CPL + j + jj;
+            float val = fx.bias[c];
+            if (fdrop) val *= drop_factor(fkey, row * (uint32_t)C + (uint32_t)c, fx.drop_p, finv);
+            t[jj] = (bf16)val;
+            v[j + jj] = (float)t[jj];
+          }
+          *reinterpret_cast<bf16x4*>(src + j) = t;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPL; j += 4) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(src + j);
+          v[j] = (float)t[0]; v[j + 1] = (float)t[1]; v[j + 2] = (float)t[2]; v[j + 3] = (float)t[3];
+        }
       }
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
@@ -92,6 +132,10 @@ __global__ __launch_bounds__(256) void bank_stats2_kernel(const bf16* tokens, co
         t[0] = (bf16)v[j]; t[1] = (bf16)v[j + 1]; t[2] = (bf16)v[j + 2]; t[3] = (bf16)v[j + 3];
         *reinterpret_cast<bf16x4*>(dst + j) = t;
       }
+    }
+    if (fixit && fx.o_save) {
+      bf16* os = reinterpret_cast<bf16*>(fx.o_save) + (size_t)b * N * fx.ldos;
+      for (int i = lane; i < N * fx.Co; i += 64) { const int r = i / fx.Co, c = i - r * fx.Co; os[(size_t)r * fx.ldos + c] = (bf16)0.f; }
     }
     wave_sync();                                  // per-wave tiles: only this wave's lanes need to see the rows
     // ---- gate logits [N][S] = tn . Wg^T + bg, softmax over the N tokens of each slot ----
@@ -141,24 +185,29 @@ __global__ __launch_bounds__(256) void bank_stats2_kernel(const bf16* tokens, co
 
 template <int NT, int CT>
 static int bank2_launch(const bf16* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr, const float* Wg,
-                        const float* bg, float* ws, int B, int grid, float eps, hipStream_t st) {
+                        const float* bg, float* ws, int B, int grid, float eps, hipStream_t st, const qavit_nan_fix& fx) {
   constexpr int N = 16 * NT, C = 16 * CT, S = 16;
   size_t per_wave = (size_t)(N * (C + 4) + N * (S + 4)) * 2;
   size_t tail = 4 * per_wave;
   if (tail < (size_t)4 * S * C * 4) tail = (size_t)4 * S * C * 4;
-  const size_t smem = (size_t)S * (C + 4) * 2 + 4 * C * 4 + tail;
+  const size_t smem = (size_t)S * (C + 4) * 2 + 4 * C * 4 + tail + 16;      // + the NaN-rule flag's broadcast word
   if (smem > 160 * 1024) return -100;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bank_stats2_kernel<NT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((bank_stats2_kernel<NT, CT>), dim3(grid), dim3(256), smem, st, tokens, gbr, bbr, gwr, bwr, Wg, bg, ws, B, eps);
+  hipLaunchKernelGGL((bank_stats2_kernel<NT, CT>), dim3(grid), dim3(256), smem, st, const_cast<bf16*>(tokens), gbr, bbr, gwr, bwr, Wg, bg, ws, B, eps, fx);
   return QAVIT_OK;
 }
 
 int bank_stats_bf16_try(const void* tokens, const float* gbr, const float* bbr, const float* gwr, const float* bwr, const float* Wg,
-                        const float* bg, float* ws, int B, int N, int C, int S, int grid, float eps, hipStream_t st) {
+                        const float* bg, float* ws, int B, int N, int C, int S, int grid, float eps, hipStream_t st, const qavit_nan_fix* fix) {
   if (S != 16 || (reinterpret_cast<uintptr_t>(tokens) & 7)) return 0;
+  qavit_nan_fix fx{};
+  if (fix) {
+    fx = *fix;
+    if (fx.o_save && ((reinterpret_cast<uintptr_t>(fx.o_save) & 1) || fx.ldos < fx.Co)) return 0;
+  }
   int rc = -100;
-  if (C == 192 && N == 16) rc = bank2_launch<1, 12>((const bf16*)tokens, gbr, bbr, gwr, bwr, Wg, bg, ws, B, grid, eps, st);
-  else if (C == 192 && N == 64) rc = bank2_launch<4, 12>((const bf16*)tokens, gbr, bbr, gwr, bwr, Wg, bg, ws, B, grid, eps, st);
+  if (C == 192 && N == 16) rc = bank2_launch<1, 12>((const bf16*)tokens, gbr, bbr, gwr, bwr, Wg, bg, ws, B, grid, eps, st, fx);
+  else if (C == 192 && N == 64) rc = bank2_launch<4, 12>((const bf16*)tokens, gbr, bbr, gwr, bwr, Wg, bg, ws, B, grid, eps, st, fx);
   if (rc == -100) return 0;
   return rc == QAVIT_OK ? 1 : rc;
 }

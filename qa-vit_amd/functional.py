@@ -385,6 +385,7 @@ class SideStream:
 # ---------------------------------------------------------------------------------------------------
 # Linear (+ fused LayerNorm prologue, GELU / dropout / drop-path / residual epilogue)
 # ---------------------------------------------------------------------------------------------------
+_DEFER_FIX = os.environ.get("QAVIT_DEFER_NANFIX", "1") != "0"   # fused branches followed by a bank write: the NaN rule's rewrite rides in the bank-statistics launch
 _LN_LIN = os.environ.get("QAVIT_LN_LIN", "1") != "0"      # narrow LayerNorm-prologue Linears: dX GEMM fused into the LayerNorm-backward kernel
 
 
@@ -714,8 +715,22 @@ def _attn_drop(a, spec, rt):
         a.drop_p, a.drop_site, a.rng = float(p), int(site), rt.rng.data_ptr()
 
 
+def _defer_fix(rt, a, out, bias, proj_drop, trip, o, ldos, Co):
+    """The caller writes the bank from ``out`` next (modules._Branch._write): the NaN rule's rewrite launch is skipped and its parameters
+    wait in rt.pending_fix for bank_write, whose statistics kernel does the rewrite for the images it visits before reading them."""
+    if rt.pending_fix is not None:
+        raise RuntimeError("a deferred NaN rule was never consumed by a bank write")
+    a.nan_defer = 1
+    fx = L.NanFix()
+    fx.flag, fx.trip, fx.bias = rt.nan_flag.data_ptr(), K._p(trip), bias.data_ptr()
+    fx.drop_p, fx.drop_site = float(proj_drop[0]), int(proj_drop[1])
+    fx.rng = rt.rng.data_ptr() if proj_drop[0] > 0.0 else None
+    fx.o_save, fx.ldos, fx.Co = K._p(o), ldos, Co
+    rt.pending_fix = (fx, out, (bias, trip, o))
+
+
 def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool_idx=None, pool_stride=0, Lk=0,
-                   attn_drop=(0.0, 0), proj_drop=(0.0, 0), want_o=False, save=False):
+                   attn_drop=(0.0, 0), proj_drop=(0.0, 0), want_o=False, save=False, defer_fix=False):
     """One launch for a whole attention branch on 16- or 64-token problems (csrc/branch_fwd.hip; include/qavit.h qavit_branch_args):
     ``kind`` 0 = SWA, 1 = MSDA, 2 = cross.  ``x`` [B, 16 | 64, 192] bf16 (norm1's output); ``wqkv`` / ``wproj`` are the fp32
     parameters (read through the fragment-packed copies of the WeightPack); ``sh_k`` / ``sh_v`` fp32 [16, 192] (the bank, or
@@ -776,6 +791,8 @@ def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool
         a.rng = rt.rng.data_ptr()
     if rt.nan_guard:
         a.nan_flag = rt.nan_flag.data_ptr()
+        if defer_fix and _DEFER_FIX:
+            _defer_fix(rt, a, out, bproj, proj_drop, trip, o, Cc, Cc)
     K.branch_fwd(a)
     out = out.reshape(B, T, Cc)
     if save:
@@ -796,7 +813,7 @@ class BranchFn(Function):
         need = any(ctx.needs_input_grad)
         res = branch_forward(meta["kind"], x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k.reshape(-1, x.shape[-1]), sh_v.reshape(-1, x.shape[-1]),
                              meta.get("pool_idx"), meta.get("pool_stride", 0), meta.get("Lk", 16 if meta["kind"] == 0 else 0), meta["attn_drop"], meta["proj_drop"],
-                             want_o=need, save=need)
+                             want_o=need, save=need, defer_fix=bool(meta.get("defer_fix")))
         if not need:
             return res
         out, o, saved, trip = res
@@ -1054,6 +1071,9 @@ class CGABranchFn(Function):
             if need:
                 trip = torch.empty(1, dtype=torch.int32, device=x.device)
                 a.nan_trip = trip.data_ptr()
+            if meta.get("defer_fix") and _DEFER_FIX:
+                co = o.shape[-1] if o is not None else 0
+                _defer_fix(rt, a, out, bproj, pd, trip, o, co, co)
         L.check(L.load().qavit_cga_fwd(C.byref(a), K.stream()), "cga_fwd")
         if need:
             ctx.trip = trip
@@ -2331,8 +2351,14 @@ def bank_write(tokens, norm_g, norm_b, bank, mode, sync=None, want_snap=False):
     n_ws = K.bank_ws_floats(B, N, Cc, S)                      # = workgroups of the statistics kernel * S * C
     ws = rt.workspace("bank_ws", n_ws)
     fold_in_apply = sync is None and Cc % 4 == 0          # single GPU: apply folds the partials itself (no reduce launch)
+    fix = None
+    if rt.pending_fix is not None:                          # the branch that produced `tokens` left its NaN rule to this launch
+        fix, fout, _keep = rt.pending_fix
+        rt.pending_fix = None
+        if fout.data_ptr() != tokens.data_ptr():
+            raise RuntimeError("the deferred NaN rule belongs to another tensor than the one being written to the bank")
     K.bank_stats(tokens, norm_g, norm_b, bank.write_norm.weight, bank.write_norm.bias, bank.write_gate.weight, bank.write_gate.bias,
-                 None if fold_in_apply else acc, ws, B, N, Cc, S, 1e-5)
+                 None if fold_in_apply else acc, ws, B, N, Cc, S, 1e-5, fix=fix)
     total = B
     if sync is not None:
         total = sync(acc[: S * Cc], B)

@@ -64,6 +64,7 @@ class Runtime:
         self.device = device
         self.rng = torch.tensor([0x5EED, 0], dtype=torch.int64, device=device)
         self.nan_flag = torch.zeros(2, dtype=torch.int32, device=device)       # [flag, guard arrival ticket]
+        self.pending_fix = None        # (lib.NanFix, out tensor, keepalive): a fused branch's NaN rule waiting for the bank write that follows it
         self._ws = {}
         self._tbl = {}
         self.nan_guard = True
@@ -594,10 +595,11 @@ def dwconv_bwd(dy, x, w, dx, dw, dbias, B, H, W, Cc, ks):
 # ---------------------------------------------------------------------------------------------------
 # bank
 # ---------------------------------------------------------------------------------------------------
-def bank_stats(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, acc, ws, B, N, Cc, S, eps):
-    L.check(L.load().qavit_bank_stats(dt_code(tokens.dtype), tokens.data_ptr(), g_branch.data_ptr(), b_branch.data_ptr(), g_write.data_ptr(),
-                                      b_write.data_ptr(), Wg.data_ptr(), bg.data_ptr(), _p(acc), ws.data_ptr(), ws.numel(),
-                                      B, N, Cc, S, eps, stream()), "bank_stats")
+def bank_stats(tokens, g_branch, b_branch, g_write, b_write, Wg, bg, acc, ws, B, N, Cc, S, eps, fix=None):
+    """``fix`` (lib.NanFix): the NaN -> zeros rule a fused branch call deferred to this launch (qavit_bank_stats_nanfix)."""
+    L.check(L.load().qavit_bank_stats_nanfix(dt_code(tokens.dtype), tokens.data_ptr(), g_branch.data_ptr(), b_branch.data_ptr(), g_write.data_ptr(),
+                                             b_write.data_ptr(), Wg.data_ptr(), bg.data_ptr(), _p(acc), ws.data_ptr(), ws.numel(),
+                                             B, N, Cc, S, eps, C.byref(fix) if fix is not None else None, stream()), "bank_stats")
 
 
 def bank_ws_floats(B, N, Cc, S) -> int:

@@ -27,12 +27,17 @@ class LnReduceDesc(C.Structure):
     _fields_ = [("parts", vp), ("nparts", i32), ("C", i32), ("dgamma", vp), ("dbeta", vp), ("stride", i64)]
 
 
+class NanFix(C.Structure):                         # struct qavit_nan_fix
+    _fields_ = [("flag", vp), ("trip", vp), ("bias", vp), ("drop_p", f32), ("drop_site", i32), ("rng", vp),
+                ("o_save", vp), ("ldos", i64), ("Co", i32)]
+
+
 class CgaArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("G", i32), ("H", i32), ("D", i32), ("S", i32),
         ("x", vp), ("ldx", i64), ("wqkv_rm", vp), ("bqkv", vp), ("wproj_rm", vp), ("bproj", vp), ("sh_k", vp), ("sh_v", vp),
         ("out", vp), ("ldo", i64), ("o_save", vp),
-        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp), ("nan_flag", vp), ("nan_trip", vp),
+        ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp), ("nan_flag", vp), ("nan_trip", vp), ("nan_defer", i32),
     ]
 
 
@@ -122,7 +127,7 @@ class BranchArgs(C.Structure):
         ("out", vp), ("ldo", i64), ("o_save", vp),
         ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
         ("nan_flag", vp), ("reserved", i32),
-        ("q_save", vp), ("ldq_save", i64), ("kv_save", vp), ("ldkv_save", i64), ("pooled_save", vp), ("nan_trip", vp),
+        ("q_save", vp), ("ldq_save", i64), ("kv_save", vp), ("ldkv_save", i64), ("pooled_save", vp), ("nan_trip", vp), ("nan_defer", i32),
     ]
 
 
@@ -196,6 +201,7 @@ _SIGS = {
     "qavit_im2col": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_im2col_ld": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "qavit_bank_stats_nanfix": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, C.POINTER(NanFix), vp]),
     "qavit_bank_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]),
     "qavit_bank_ws_floats": (i64, [i32, i32, i32, i32]),
     "qavit_bank_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp, i32, vp, vp, vp]),

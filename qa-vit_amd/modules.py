@@ -83,6 +83,10 @@ class LinformerCompression(nn.Module):
 
 
 class _Branch(nn.Module):
+    def _writes(self) -> bool:
+        """Will _write() write the bank from this branch's output?  (then the fused kernels leave their NaN rule to that launch)"""
+        return bool(self.training and self._rt.bank_writes and hasattr(self, "norm"))
+
     def _write(self, out):
         rt = self._rt
         if self.training and rt.bank_writes and hasattr(self, "norm"):
@@ -136,7 +140,8 @@ class EfficientSpatialWindowAttention(_Branch):
             # branch is one launch either way (csrc/branch_fwd.hip)
             out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
                                    self.global_bank.global_k, self.global_bank.global_v,
-                                   dict(kind=0, attn_drop=(p, self._site_attn), proj_drop=(p, self._site), bank_snap=self._snap(), win_tbl=tbl))
+                                   dict(kind=0, attn_drop=(p, self._site_attn), proj_drop=(p, self._site), bank_snap=self._snap(), win_tbl=tbl,
+                                        defer_fix=self._writes()))
             self._write(out)
             return out
         qkv = F.linear(x, self.qkv.weight, self.qkv.bias).reshape(B * N, 3 * C)
@@ -195,7 +200,7 @@ class EfficientMultiScaleDilatedAttention(_Branch):
             out = F.BranchFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.linformer.E_k, self.linformer.E_v,
                                    self.global_bank.global_k, self.global_bank.global_v,
                                    dict(kind=1, pool_idx=idx, pool_stride=stride, Lk=NP, attn_drop=(p, self._site_attn), proj_drop=(p, self._site),
-                                        bank_snap=self._snap()))
+                                        bank_snap=self._snap(), defer_fix=self._writes()))
             self._write(out)
             return out
         pooled = F.GatherPoolFn.apply(x, idx, stride)
@@ -257,7 +262,7 @@ class EfficientChannelGroupAttention(_Branch):
         if fused:
             out = F.CGABranchFn.apply(x, self.q_proj.weight, self.q_proj.bias, self.k_proj.weight, self.k_proj.bias, self.v_proj.weight, self.v_proj.bias,
                                       self.proj.weight, self.proj.bias, sh_k, sh_v,
-                                      dict(G=G, H=H, spec=spec, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+                                      dict(G=G, H=H, spec=spec, attn_drop=(p, self._site_attn), proj_drop=(p, self._site), defer_fix=self._writes()))
             self._write(out)
             return out
         qkv = F.LinearStack3Fn.apply(x.reshape(B * N * G, cpg), self.q_proj.weight, self.q_proj.bias,

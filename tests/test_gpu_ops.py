@@ -1290,6 +1290,56 @@ def test_fused_branch_nan_rule(F, Q, kind, B, T):
     assert torch.equal(clean1, clean0)
 
 
+@pytest.mark.parametrize("B,T", [(9, 16), (1030, 16), (5, 64)])
+@pytest.mark.parametrize("which", ["swa", "msda", "cga"])
+def test_nan_rule_deferred_into_the_bank_write(F, Q, which, B, T):
+    """A branch module in training mode writes the bank from its output right after the fused kernel: the NaN rule's rewrite then rides
+    in the bank-statistics launch (qavit_bank_stats_nanfix) instead of a launch of its own.  With a poisoned input and dropout ON: the
+    output, the bank after the write, the trip word's effect on backward (zero gradient through the branch) and the state left for
+    the next, clean call must equal the undeferred path's (QAVIT_DEFER_NANFIX off) bit for bit."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    M = importlib.import_module("qa-vit_amd.modules")
+    rt = K.Runtime.get(0)
+    C = 192
+    cfg = Q.HQAViTConfig() if T == 16 else Q.HQAViTTinyINConfig()
+    cfg.dropout = 0.1
+    if which == "cga" and not F.cga_ok(torch.empty(1, T, C, dtype=torch.bfloat16, device=DEV), 6, 4, cfg.global_bank_size):
+        pytest.skip("fused channel-group kernel not built for this token count")
+    x0 = leaf(B, T, C, seed=900).detach().to(torch.bfloat16)
+    bad0 = x0.clone()
+    bad0[B // 2, 5, 17] = float("nan")
+    cls = {"swa": M.EfficientSpatialWindowAttention, "msda": M.EfficientMultiScaleDilatedAttention, "cga": M.EfficientChannelGroupAttention}[which]
+    torch.manual_seed(5)
+    bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+    ctx = M._Ctx("hqa")
+    mod = cls(cfg, bank, ctx).to(DEV).train()                # ONE module: dropout sites are per module instance
+    Q.fill_module(mod)
+    state = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    res = {}
+    for defer in (True, False):
+        F._DEFER_FIX = defer
+        mod.load_state_dict(state)
+        rt.seed(1234)
+        outs = []
+        for inp in (bad0, x0):                               # poisoned call, then a clean one through the same state
+            xin = inp.clone().requires_grad_(True)
+            for p_ in mod.parameters():
+                p_.grad = None
+            y = mod(xin)
+            y.float().square().sum().backward()
+            outs += [y.detach().clone(), xin.grad.detach().clone(), bank.global_k.detach().clone(), bank.global_v.detach().clone()]
+            rt.advance()
+        torch.cuda.synchronize()
+        assert rt.nan_flag.tolist() == [0, 0] and rt.pending_fix is None
+        res[defer] = outs
+    F._DEFER_FIX = True
+    assert float(res[True][1].abs().max()) == 0.0            # poisoned call: no gradient reaches x through the branch
+    assert torch.isfinite(res[True][4]).all() and float(res[True][5].abs().max()) > 0.0
+    for a_, b_ in zip(res[True], res[False]):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("B,T", [(6, 16), (3, 64)])
 @pytest.mark.parametrize("kind", [0, 1, 2, "cga"])
 def test_fused_branch_nan_rule_backward(F, Q, kind, B, T):
