@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       if (nt < NT) {
         // this wave's 16 dy rows: whole rows in 8-byte pieces into its slice of the dup tile (read element-wise below, then overwritten
         // in place by du) -- 48 two-byte global loads per lane were the kernel's load path
-        constexpr bool STAGE_DY = NT <= 4;                       // (the 256-token variant already holds 512 registers per lane)
+        constexpr bool STAGE_DY = true;                          // dy rows always reach the row loop through LDS (8-byte row pieces), never as 2-byte global loads
         if (PIPE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { muc[r] = mun[r]; rsc[r] = rsn[r]; }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       if (PIPE) { if (tw + 1 < NTW) req_dy(b, tw + 1); else req_dy(b + gridDim.x, 0); }
       TSTAMP(3 + 6 * img);
       if (nt < NT) {
-        constexpr bool STAGE_DY = NT <= 4;
+        constexpr bool STAGE_DY = true;
         f32x4 acc[CT];
         up_tile<NT, MT, CT>(sm + L::wt, sm + L::xc, bias, nt, acc);
         if (STAGE_DY) wave_sync();
