@@ -248,13 +248,38 @@ class DeferDW:
         K.DeferredTN.home_stream = K.stream()                # backward starts on the caller's stream; only its dW GEMMs are queued
         return True
 
+    _side = {}
+
     @classmethod
     def _launch(cls):
-        if DeferredBank.queue:
-            K.DeferredLN.flush()                             # the projected bank rows' gradients are among the partial rows
-            DeferredBank.run()                               # queues the projections' weight gradients
-        K.DeferredTN.flush()
-        K.DeferredLN.flush()
+        if not (_FLUSH_SIDE and torch.cuda.is_available() and K.DeferredTN.queue and not K.DeferredTN.ASYNC):
+            if DeferredBank.queue:
+                K.DeferredLN.flush()                         # the projected bank rows' gradients are among the partial rows
+                DeferredBank.run()                           # queues the projections' weight gradients
+            K.DeferredTN.flush()
+            K.DeferredLN.flush()
+            K.DeferredTN.join()
+            return
+        # End of backward: ~30 small launches (five partial-row reduces, the bank projections' sixteen skinny GEMMs and their fp32 weight
+        # gradients) used to run one after the other in front of the one-launch weight-gradient kernel -- 0.25 ms of a tail in which nothing
+        # else runs.  None of them touches what that kernel reads or writes: they go to a second stream forked HERE (before the big launch is
+        # queued) and joined after it, so they run beside its first workgroups instead of in front of them.
+        dev = torch.cuda.current_device()
+        main = torch.cuda.current_stream(dev)
+        side = cls._side.get(dev)
+        if side is None:
+            side = cls._side[dev] = torch.cuda.Stream(device=dev)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        K.DeferredTN.flush()                                 # this stream: every weight-gradient GEMM queued during the pass
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            if DeferredBank.queue:
+                K.DeferredLN.flush()
+                DeferredBank.run()                           # queues the bank projections' own (fp32, tiny) weight gradients
+                K.DeferredTN.flush()
+            K.DeferredLN.flush()
+        main.wait_stream(side)
         K.DeferredTN.join()
 
     @classmethod
@@ -385,6 +410,7 @@ class SideStream:
 # ---------------------------------------------------------------------------------------------------
 # Linear (+ fused LayerNorm prologue, GELU / dropout / drop-path / residual epilogue)
 # ---------------------------------------------------------------------------------------------------
+_FLUSH_SIDE = os.environ.get("QAVIT_FLUSH_SIDE", "1") != "0"    # end of backward: the small reduce / bank launches beside the one-launch weight-gradient kernel
 _DEFER_FIX = os.environ.get("QAVIT_DEFER_NANFIX", "1") != "0"   # fused branches followed by a bank write: the NaN rule's rewrite rides in the bank-statistics launch
 _LN_LIN = os.environ.get("QAVIT_LN_LIN", "1") != "0"      # narrow LayerNorm-prologue Linears: dX GEMM fused into the LayerNorm-backward kernel
 
