@@ -251,19 +251,38 @@ class DeferDW:
     _side = {}
 
     @classmethod
-    def _launch(cls):
-        if not (_FLUSH_SIDE and torch.cuda.is_available() and K.DeferredTN.queue and not K.DeferredTN.ASYNC):
+    def _launch(cls, rng=None):
+        """Launch what is queued.  ``rng`` = (lo, hi): a data-parallel sync point -- only the weight-gradient GEMMs whose destination lies in
+        that address range of the flat gradient buffer (the bucket prefix about to be all-reduced) and this stream's partial rows; everything
+        else waits for the end of the pass."""
+        home = rng is not None
+
+        def tn_flush():
+            if home:
+                K.DeferredTN.flush_range(*rng)
+            else:
+                K.DeferredTN.flush()
+
+        def small():
             if DeferredBank.queue:
-                K.DeferredLN.flush()                         # the projected bank rows' gradients are among the partial rows
-                DeferredBank.run()                           # queues the projections' weight gradients
-            K.DeferredTN.flush()
-            K.DeferredLN.flush()
+                K.DeferredLN.flush(home_only=home)           # the projected bank rows' gradients are among the partial rows
+                DeferredBank.run()                           # queues the projections' own (fp32, tiny) weight gradients
+                tn_flush()
+            K.DeferredLN.flush(home_only=home)
+
+        # (sync points keep the one-stream order: measured, seven forks / joins per backward cost more than the overlap returns)
+        if home or not (_FLUSH_SIDE and torch.cuda.is_available() and K.DeferredTN.queue and not K.DeferredTN.ASYNC):
+            if DeferredBank.queue:
+                K.DeferredLN.flush(home_only=home)
+                DeferredBank.run()
+            tn_flush()
+            K.DeferredLN.flush(home_only=home)
             K.DeferredTN.join()
             return
-        # End of backward: ~30 small launches (five partial-row reduces, the bank projections' sixteen skinny GEMMs and their fp32 weight
-        # gradients) used to run one after the other in front of the one-launch weight-gradient kernel -- 0.25 ms of a tail in which nothing
-        # else runs.  None of them touches what that kernel reads or writes: they go to a second stream forked HERE (before the big launch is
-        # queued) and joined after it, so they run beside its first workgroups instead of in front of them.
+        # ~30 small launches (five partial-row reduces, the bank projections' sixteen skinny GEMMs and their fp32 weight gradients) used to
+        # run one after the other in front of the one-launch weight-gradient kernel -- 0.25 ms of a tail in which nothing else runs.  None of
+        # them touches what that kernel reads or writes: they go to a second stream forked HERE (before the big launch is queued) and joined
+        # after it, so they run beside its first workgroups instead of in front of them.
         dev = torch.cuda.current_device()
         main = torch.cuda.current_stream(dev)
         side = cls._side.get(dev)
@@ -271,14 +290,15 @@ class DeferDW:
             side = cls._side[dev] = torch.cuda.Stream(device=dev)
         fork = torch.cuda.Event()
         fork.record(main)
-        K.DeferredTN.flush()                                 # this stream: every weight-gradient GEMM queued during the pass
+        tn_flush()                                           # this stream: the weight-gradient GEMMs queued during the pass (in range)
         with torch.cuda.stream(side):
             side.wait_event(fork)
-            if DeferredBank.queue:
-                K.DeferredLN.flush()
-                DeferredBank.run()                           # queues the bank projections' own (fp32, tiny) weight gradients
-                K.DeferredTN.flush()
-            K.DeferredLN.flush()
+            home_was = K.DeferredTN.home_stream
+            K.DeferredTN.home_stream = K.stream()            # what the bank projections queue here belongs to THIS pass's own stream, not to a foreign chain
+            try:
+                small()
+            finally:
+                K.DeferredTN.home_stream = home_was
         main.wait_stream(side)
         K.DeferredTN.join()
 
@@ -294,12 +314,7 @@ class DeferDW:
         launches and are run whole; weight-gradient GEMMs outside the range and everything another stream queued wait for the end."""
         if not cls._armed:
             return
-        if DeferredBank.queue:
-            K.DeferredLN.flush(home_only=True)
-            DeferredBank.run()
-        K.DeferredTN.flush_range(lo, hi)
-        K.DeferredLN.flush(home_only=True)
-        K.DeferredTN.join()
+        cls._launch((lo, hi))
 
     @classmethod
     def flush_home(cls):

@@ -179,7 +179,7 @@ class DataParallel:
     def __init__(self, model: torch.nn.Module, group=None, bucket_bytes: int = 4 << 20, bank_sync: str = "exact",
                  bank_broadcast_every: int = 50, seed: int = 0x5EED, bn_sync: str = "exact", sync_tags=None):
         """``sync_tags``: the stage boundaries at which complete buckets are all-reduced DURING backward (a tuple of tags, "all" = all
-        seven, () = none: one reduction after backward; default one sync point, see below; the environment variable QAVIT_DDP_TAGS =
+        seven, () = none: one reduction after backward -- the default, see below; the environment variable QAVIT_DDP_TAGS =
         comma-separated tags or "all" overrides).  Every sync point costs a grouped weight-gradient launch over fewer problems than the
         single end-of-backward one, so on a fast fabric fewer, larger overlapped reductions win."""
         if not dist.is_initialized():
@@ -193,11 +193,12 @@ class DataParallel:
         elif sync_tags is not None:
             self.sync_tags = None if sync_tags == "all" else tuple(sync_tags)
         else:
-            # default: ONE sync point in the middle of backward.  Measured on one MI355X (B = 1024, one rank over RCCL):
-            # 7 sync points 12.07 ms / step, 2 (stage3, stage1) 11.67, 1 (fuse3) 11.60, none of the data-parallel machinery 11.43 -- every
-            # sync point splits the end-of-backward grouped weight-gradient launch, while the 25.7 MB all-reduce it would hide is ~0.1-0.2 ms
-            # of xGMI time on 8 GPUs.
-            self.sync_tags = ("fuse3",) if not hasattr(model, "blocks") else (f"blocks.{(len(model.blocks) // 2) & ~1}",)
+            # default: NO sync point -- one bucketed all-reduce when backward (and its weight-gradient launch) has ended.  Measured on one MI355X
+            # (B = 1024, one rank over RCCL, captured): no sync point 10.26 ms / step = the step without any data-parallel
+            # machinery (10.26), one sync point (fuse3) 10.40, all seven 10.61.  Every sync point splits the single end-of-backward weight-gradient
+            # launch and puts a flush on backward's critical path, while the 25.7 MB all-reduce it would hide is ~0.1-0.2 ms of xGMI time on 8 GPUs
+            # -- so a sync point that hides half of it costs about what it saves.  sync_tags=("fuse3",) / "all" or QAVIT_DDP_TAGS bring them back.
+            self.sync_tags = ()
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=group)

@@ -62,7 +62,7 @@ def _worker(rank, world, port, out):
     par = import_module("qa-vit_amd.parallel")
     torch.manual_seed(100 + rank)                      # different init per rank: broadcast must fix it
     model = Toy()
-    dp = par.DataParallel(model, bucket_bytes=4096)     # tiny buckets -> several per stage
+    dp = par.DataParallel(model, bucket_bytes=4096, sync_tags="all")     # tiny buckets -> several per stage, reduced at every sync point of backward
     named = par.bucket_order(list(model.named_parameters()))
     names = [n for n, _ in named]
     offs = [0]

@@ -39,7 +39,7 @@ def _worker(rank, world, port, out):
     for m in model.modules():                             # SplitFusion.cat_mlp hard-wires Dropout(0.1) (HQAViT_CIFAR100.py:930)
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    dp = par.DataParallel(model)
+    dp = par.DataParallel(model, sync_tags=("fuse3", "stage1_blocks"))     # two sync points: buckets reduced during backward and after it
     tr = Q.Trainer(model, Q.TrainingConfig(batch_size=16, use_amp=False), total_steps=100, warmup_steps=10,
                    reducer=dp.reducer, compute_dtype=torch.float32, order=par.bucket_order)
     dp.bind(tr)
