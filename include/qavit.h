@@ -304,6 +304,15 @@ int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const float* W, c
  * touched -- fold the rows with qavit_ln_param_reduce (stride N*M + N + 2*C).  The 256-deep same-address float atomics this replaces
  * were the larger half of the kernel.  qavit_upmix_bwd_parts() == 0: no partial-row path for this dtype / shape (pass parts = NULL). */
 int qavit_upmix_bwd_parts(int dtype, int B, int N, int M, int C);
+/* The up-mix backward that ALSO differentiates the scale-add in front of it, xc = x + droppath(gamma * u) (the block tail,
+ * HQAViT_CIFAR100.py:1085 then :1118-1121): besides dxc (= dx) it writes du = dxc * f * gamma[0] and adds sum(dxc * f * u) to dgamma_sa
+ * (one float atomic per workgroup), f = the image's drop-path factor (dp_p, dp_site, rng; samples = images).  u, du [B*M, C].  bf16,
+ * N = 64, M = 16, C = 192 (qavit_upmix_bwd_sa_supported). */
+int qavit_upmix_bwd_sa_supported(int dtype, int N, int M, int C);
+int qavit_upmix_bwd_sa(int dtype, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma,
+                       const float* mean, const float* rstd, void* dxc, float* dW, float* dbias, float* dgamma, float* dbeta,
+                       int B, int N, int M, int C, float* parts, const void* u, void* du, const float* gamma_sa, float* dgamma_sa,
+                       float dp_p, int dp_site, const int64_t* rng, void* stream);
 int qavit_upmix_bwd_p(int dtype, const void* dy, const void* xc, const float* W, const float* bias,
                       const float* gamma, const float* mean, const float* rstd, void* dxc, float* dW,
                       float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, float* parts, void* stream);

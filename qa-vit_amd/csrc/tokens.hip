@@ -417,6 +417,26 @@ extern "C" int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const 
   return qavit_upmix_bwd_p(dtype, dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta, B, N, M, C, nullptr, stream);
 }
 
+extern "C" int qavit_upmix_bwd_sa_supported(int dtype, int N, int M, int C) { return dtype == QAVIT_BF16 && N == 64 && M == 16 && C == 192; }
+
+extern "C" int qavit_upmix_bwd_sa(int dtype, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma,
+                                  const float* mean, const float* rstd, void* dxc, float* dW, float* dbias, float* dgamma, float* dbeta,
+                                  int B, int N, int M, int C, float* parts, const void* u, void* du, const float* sa_gamma, float* sa_dgamma,
+                                  float dp_p, int dp_site, const int64_t* rng, void* stream) {
+  if (!qavit_upmix_bwd_sa_supported(dtype, N, M, C)) return set_error(QAVIT_EINVAL, "upmix_bwd_sa: bf16, 64 -> 16 tokens, C = 192 only");
+  if (!dy || !xc || !W || !bias || !gamma || !mean || !rstd || !dxc || !dW || !dgamma || !dbeta || !u || !du || B <= 0)
+    return set_error(QAVIT_EINVAL, "upmix_bwd_sa: bad arguments");
+  if (dp_p < 0.f || dp_p >= 1.f || (dp_p > 0.f && !rng)) return set_error(QAVIT_EINVAL, "upmix_bwd_sa: drop-path needs rng");
+  if (((reinterpret_cast<uintptr_t>(xc) | reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(dxc)) & 7) ||
+      (parts && (reinterpret_cast<uintptr_t>(parts) & 15)))
+    return set_error(QAVIT_EINVAL, "upmix_bwd_sa: operand alignment");
+  const int took = qv::upmix_bf16_try(true, dy, xc, W, bias, gamma, nullptr, 0.f, dxc, const_cast<float*>(mean), const_cast<float*>(rstd), dW, dbias, dgamma, dbeta,
+                                      B, N, M, C, reinterpret_cast<hipStream_t>(stream), parts, u, du, sa_gamma, sa_dgamma, dp_p, dp_site, rng);
+  if (took < 0) return took;
+  if (took != 1) return set_error(QAVIT_EINVAL, "upmix_bwd_sa: shape not covered");
+  return check_launch("upmix_bwd_sa");
+}
+
 extern "C" int qavit_upmix_bwd_p(int dtype, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma,
                                  const float* mean, const float* rstd, void* dxc, float* dW, float* dbias, float* dgamma, float* dbeta,
                                  int B, int N, int M, int C, float* parts, void* stream) {

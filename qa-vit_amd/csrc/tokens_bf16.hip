@@ -218,6 +218,11 @@ int bank_stats_bf16_try(const void* tokens, const float* gbr, const float* bbr, 
 // 16-row tile; the 192 columns of a row live in 12 accumulator tiles of ONE wave, so the LayerNorm (and, in backward,
 // its gradient) is a 16-lane register reduction -- `up` never touches memory.
 // ------------------------------------------------------------------------------------------------
+// The block tail in front of TokenUpMix, y = x + droppath(gamma * u) (HQAViT_CIFAR100.py:1085, :1118-1121), differentiated inside the up-mix
+// backward: dxc is this kernel's output anyway; with `u` given it also writes du = dxc * f * gamma and adds sum(dxc * f * u) to dgamma (f = the
+// image's drop-path factor) -- the elementwise launch that did this re-read dxc and u from memory, once per block.
+struct UpScaleAdd { const bf16* u; bf16* du; const float* gamma; float* dgamma; float dp_p; int dp_site; const int64_t* rng; };
+
 template <int NT, int MT, int CT>
 struct UpLds {
   static constexpr int N = 16 * NT, M = 16 * MT, C = 16 * CT;
@@ -314,9 +319,15 @@ __global__ __launch_bounds__(256) void upmix2_fwd_kernel(const bf16* xc, const f
 template <int NT, int MT, int CT>
 __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const bf16* xc, const float* W, const float* bias, const float* gamma,
                                                          const float* mean, const float* rstd, bf16* dxc, float* dW, float* dbias,
-                                                         float* dgamma, float* dbeta, int B, float* parts) {
+                                                         float* dgamma, float* dbeta, int B, float* parts, UpScaleAdd sa) {
   using L = UpLds<NT, MT, CT>;
   constexpr int NTW = (NT + 3) / 4;                           // row tiles per wave
+  const bool sa_on = NT <= 4 && sa.u != nullptr;              // uniform
+  const float sa_gm = sa_on ? (sa.gamma ? sa.gamma[0] : 1.f) : 0.f;
+  const bool sa_dp = sa_on && sa.dp_p > 0.f && sa.rng != nullptr;
+  const uint32_t sa_key = sa_dp ? rng_key(sa.rng, sa.dp_site) : 0u;
+  const float sa_inv = sa_dp ? 1.f / (1.f - sa.dp_p) : 1.f;
+  float sa_sum = 0.f;
   constexpr int DXT = (MT * CT + 3) / 4;                      // dxc tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   bf16* sm = reinterpret_cast<bf16*>(smraw);
@@ -391,6 +402,17 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
     f32x4 dxa[DXT];
 #pragma unroll
     for (int i = 0; i < DXT; ++i) dxa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x4 usa[NT <= 4 ? DXT : 1];                             // the scale-add's u segments of this image's dxc tiles: requested now, used after the products
+    if (sa_on) {
+#pragma unroll
+      for (int i = 0; i < DXT; ++i) {
+        const int tile = wave + 4 * i;
+        if (tile < MT * CT) {
+          const int mt = tile / CT, ct = tile - mt * CT;
+          usa[NT <= 4 ? i : 0] = *reinterpret_cast<const bf16x4*>(sa.u + ((size_t)b * L::M + mt * 16 + col) * L::C + ct * 16 + 4 * q4);
+        }
+      }
+    }
     // the row tiles go through LDS four at a time (one per wave); dxc accumulates over the chunks in registers
 #pragma unroll
     for (int tw = 0; tw < NTW; ++tw) {
@@ -497,7 +519,20 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
           bf16x4 o4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o4[r] = (bf16)dxa[i][r];
-          *reinterpret_cast<bf16x4*>(dxc + ((size_t)b * L::M + mt * 16 + col) * L::C + ct * 16 + 4 * q4) = o4;
+          const size_t off = ((size_t)b * L::M + mt * 16 + col) * L::C + ct * 16 + 4 * q4;
+          *reinterpret_cast<bf16x4*>(dxc + off) = o4;
+          if (sa_on) {                                          // the scale-add in front of the up-mix, on the rounded dxc the separate launch would read
+            const float f = sa_dp ? drop_factor(sa_key, (uint32_t)b, sa.dp_p, sa_inv) : 1.f;
+            const bf16x4 u4 = usa[NT <= 4 ? i : 0];
+            bf16x4 d4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float gv = (float)o4[r] * f;
+              d4[r] = (bf16)(gv * sa_gm);
+              sa_sum += gv * (float)u4[r];
+            }
+            *reinterpret_cast<bf16x4*>(sa.du + off) = d4;
+          }
         } else {                                                // (the 256-token variant holds 512 registers per lane: its schedule is left alone)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dxc[((size_t)b * L::M + mt * 16 + 4 * q4 + r) * L::C + ct * 16 + col] = (bf16)dxa[i][r];
@@ -507,6 +542,13 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   }
   TSTAMP(30);
   __syncthreads();
+  if (sa_on && sa.dgamma) {                                  // one atomic per workgroup (gred is free until the dgamma / dbeta fold below)
+    const float t = wave_sum(sa_sum);
+    if (lane == 0) gred[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f(sa.dgamma, gred[0] + gred[1] + gred[2] + gred[3]);
+    __syncthreads();
+  }
   // flush: dW tiles, dbias, dgamma / dbeta -- as this workgroup's row [dW | dbias | dgamma | dbeta] of `parts` (plain stores; one
   // qavit_ln_param_reduce launch folds the rows of every kernel of the pass), or with float atomics.  The atomics are 256+ deep on each
   // of ~1.5k addresses and serialise at L2: they were the larger half of this kernel and the reason a second workgroup per CU lost.
@@ -574,7 +616,7 @@ static int up2_bwd_grid(int B, bool parts) {
 template <int NT, int MT, int CT>
 static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta,
                       float eps, void* o0, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, hipStream_t st,
-                      float* parts = nullptr) {
+                      float* parts = nullptr, const UpScaleAdd* sa = nullptr) {
   using L = UpLds<NT, MT, CT>;
   if (!bwd) {
     const size_t smem = (size_t)(L::fwd_bf16 + 64 * L::LDC) * 2;        // + the four waves' output tiles
@@ -588,7 +630,8 @@ static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, 
   if (smem > 150 * 1024) return -100;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_bwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL((upmix2_bwd_kernel<NT, MT, CT>), dim3(up2_bwd_grid<NT, MT, CT>(B, parts != nullptr)), dim3(256), smem, st, (const bf16*)a0,
-                     (const bf16*)xc, W, bias, gamma, mean, rstd, (bf16*)o0, dW, dbias, dgamma, dbeta, B, parts);
+                     (const bf16*)xc, W, bias, gamma, mean, rstd, (bf16*)o0, dW, dbias, dgamma, dbeta, B, parts,
+                     sa ? *sa : UpScaleAdd{nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr});
   return QAVIT_OK;
 }
 
@@ -601,10 +644,12 @@ int upmix_bf16_parts(int B, int N, int M, int C) {
 
 int upmix_bf16_try(bool bwd, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
                    void* out, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, hipStream_t st,
-                   float* parts) {
+                   float* parts, const void* sa_u, void* sa_du, const float* sa_gamma, float* sa_dgamma, float sa_dp_p, int sa_dp_site, const int64_t* sa_rng) {
   if ((reinterpret_cast<uintptr_t>(xc) & 7) || C != 192) return 0;
   int rc = -100;
-  if (N == 64 && M == 16) rc = up2_launch<4, 1, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, parts);
+  UpScaleAdd sa{(const bf16*)sa_u, (bf16*)sa_du, sa_gamma, sa_dgamma, sa_dp_p, sa_dp_site, sa_rng};
+  if (sa_u && !(N == 64 && M == 16)) return 0;               // the fused scale-add backward exists in the 64-token variant only
+  if (N == 64 && M == 16) rc = up2_launch<4, 1, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, parts, sa_u ? &sa : nullptr);
   else if (N == 256 && M == 64) rc = up2_launch<16, 4, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, nullptr);
   if (rc == -100) return 0;
   return rc == QAVIT_OK ? 1 : rc;

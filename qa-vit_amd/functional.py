@@ -1405,6 +1405,57 @@ class UpMixFn(Function):
         return dxc, None, None, None, None, None
 
 
+class UpMixScaleAddFn(Function):
+    """TokenUpMix applied to the block tail: y = upmix(x + droppath(gamma * u)) (HQAViT_CIFAR100.py:1085, :1118-1121) as one autograd node.
+    Forward = the scale-add launch + the up-mix launch; backward = ONE launch: the up-mix backward also writes du and dgamma
+    (qavit_upmix_bwd_sa), where the separate scale-add backward re-read dxc and u from memory once per block."""
+
+    @staticmethod
+    def forward(ctx, x, u, gamma, dp, W, bias, g, b, eps):
+        rt = _rt(x)
+        B, M, Cc = x.shape
+        N = W.shape[0]
+        x = x.contiguous()
+        u = u.contiguous()
+        xc = torch.empty_like(x)
+        K.scale_add_fwd(x, u, None if gamma is None else gamma.detach(), xc, B * M, Cc, dp, rt.rng)
+        y = torch.empty(B, N, Cc, dtype=xc.dtype, device=xc.device)
+        mean = torch.empty(B * N, dtype=torch.float32, device=xc.device)
+        rstd = torch.empty(B * N, dtype=torch.float32, device=xc.device)
+        K.upmix_fwd(xc, W.detach(), bias.detach(), g.detach(), b.detach(), eps, y, mean, rstd, B, N, M, Cc)
+        ctx.save_for_backward(xc, u, gamma, W, bias, g, b, mean, rstd)
+        ctx.dp = dp
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, u, gamma, W, bias, g, b, mean, rstd = ctx.saved_tensors
+        rt = _rt(xc)
+        B, M, Cc = xc.shape
+        N = W.shape[0]
+        dy = dy.contiguous()
+        dxc = torch.empty_like(xc)
+        du = torch.empty_like(u)
+        wbuf, _ = grad_sink(W)
+        bbuf, _ = grad_sink(bias)
+        gbuf, _ = grad_sink(g)
+        bebuf, _ = grad_sink(b)
+        if wbuf is None:
+            wbuf = torch.zeros_like(W, dtype=torch.float32)
+        if gbuf is None:
+            gbuf = torch.zeros_like(g, dtype=torch.float32)
+        if bebuf is None:
+            bebuf = torch.zeros_like(b, dtype=torch.float32)
+        sgbuf, sgret = grad_sink(gamma)
+        if K.upmix_bwd_sa_ok(xc, N, M, Cc) and u.data_ptr() % 8 == 0:
+            K.upmix_bwd(dy, xc, W.detach(), bias.detach(), g.detach(), mean, rstd, dxc, wbuf, bbuf, gbuf, bebuf, B, N, M, Cc,
+                        sa=(u, du, None if gamma is None else gamma.detach(), sgbuf, ctx.dp, rt.rng))
+        else:
+            K.upmix_bwd(dy, xc, W.detach(), bias.detach(), g.detach(), mean, rstd, dxc, wbuf, bbuf, gbuf, bebuf, B, N, M, Cc)
+            K.scale_add_bwd(dxc, u, None if gamma is None else gamma.detach(), du, sgbuf, B * M, Cc, ctx.dp, rt.rng)
+        return dxc, du, sgret, None, None, None, None, None, None
+
+
 class GatherPoolFn(Function):
     @staticmethod
     def forward(ctx, x, idx, stride):

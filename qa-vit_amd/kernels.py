@@ -510,14 +510,27 @@ def upmix_fwd(xc, W, bias, gamma, beta, eps, y, mean, rstd, B, N, M, Cc):
                                      y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, M, Cc, stream()), "upmix_fwd")
 
 
-def upmix_bwd(dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta, B, N, M, Cc):
+def upmix_bwd_sa_ok(xc, N, M, Cc) -> bool:
+    return bool(L.load().qavit_upmix_bwd_sa_supported(dt_code(xc.dtype), N, M, Cc)) and xc.data_ptr() % 8 == 0
+
+
+def upmix_bwd(dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta, B, N, M, Cc, sa=None):
+    """``sa`` = (u, du, gamma_sa, dgamma_sa, (dp_p, dp_site, rows_per_sample), rng): also differentiate the scale-add in front of the up-mix
+    (qavit_upmix_bwd_sa; check upmix_bwd_sa_ok first)."""
     lib = L.load()
     # inside a backward pass the parameter gradients leave as one partial row per workgroup and join the pass's single reduce launch
     n = lib.qavit_upmix_bwd_parts(dt_code(xc.dtype), B, N, M, Cc) if (DeferredLN.enabled and DeferredLN.ON and (N * M) % 8 == 0 and N % 8 == 0) else 0
     parts = torch.empty(n, N * M + N + 2 * Cc, dtype=torch.float32, device=xc.device) if n > 0 else None
-    L.check(lib.qavit_upmix_bwd_p(dt_code(xc.dtype), dy.data_ptr(), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
-                                  mean.data_ptr(), rstd.data_ptr(), dxc.data_ptr(), dW.data_ptr(), _p(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
-                                  B, N, M, Cc, _p(parts), stream()), "upmix_bwd")
+    if sa is not None:
+        u, du, g_sa, dg_sa, dp, rng = sa
+        L.check(lib.qavit_upmix_bwd_sa(dt_code(xc.dtype), dy.data_ptr(), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                                       mean.data_ptr(), rstd.data_ptr(), dxc.data_ptr(), dW.data_ptr(), _p(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
+                                       B, N, M, Cc, _p(parts), u.data_ptr(), du.data_ptr(), _p(g_sa), _p(dg_sa), float(dp[0]), int(dp[1]),
+                                       _p(rng) if dp[0] > 0.0 else None, stream()), "upmix_bwd_sa")
+    else:
+        L.check(lib.qavit_upmix_bwd_p(dt_code(xc.dtype), dy.data_ptr(), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                                      mean.data_ptr(), rstd.data_ptr(), dxc.data_ptr(), dW.data_ptr(), _p(dbias), dgamma.data_ptr(), dbeta.data_ptr(),
+                                      B, N, M, Cc, _p(parts), stream()), "upmix_bwd")
     if parts is None:
         return
     R, base, keep = parts.shape[1], parts.data_ptr(), (parts, dW, dbias, dgamma, dbeta)

@@ -32,6 +32,7 @@ def _drive(gen):
         return e.value
 
 
+_UPMIX_SA = os.environ.get("QAVIT_UPMIX_SA", "1") != "0"   # the block's closing scale-add differentiated inside the up-mix backward launch
 _LN_FAN = os.environ.get("QAVIT_LN_FAN", "1") != "0"     # norm1's five-way gradient fan-in summed inside its LayerNorm-backward launch
 _BANK_PROJ2 = os.environ.get("QAVIT_BANK_PROJ2", "1") != "0"
 
@@ -400,7 +401,8 @@ class QuadAttentionBlock(nn.Module):
         self._dp = float(drop_path)
         self._dp1, self._dp2 = K.new_site(), K.new_site()
 
-    def forward(self, x):
+    def forward(self, x, tail=None):
+        """``tail`` (a list): skip the closing x + droppath(gamma * u) and leave (x, u, gamma, drop-path spec) in it for the caller."""
         B, N, C = x.shape
         tr = self.training
         rt = self._rt
@@ -408,13 +410,13 @@ class QuadAttentionBlock(nn.Module):
         if not rt.in_model:
             rt.snap = None
         try:
-            return self._forward(x, B, N, C, tr)
+            return self._forward(x, B, N, C, tr, tail)
         finally:
             rt.in_block = False
             if not rt.in_model:
                 rt.snap = None
 
-    def _forward(self, x, B, N, C, tr):
+    def _forward(self, x, B, N, C, tr, tail=None):
         # norm1's output feeds four branches (MSDA twice); xr = x again, for the residual.  In backward the five gradients and the
         # residual's meet inside ONE LayerNorm-backward launch (summed on load), not in a k-way sum kernel in front of it
         if _LN_FAN and torch.is_grad_enabled() and x.requires_grad:
@@ -440,6 +442,9 @@ class QuadAttentionBlock(nn.Module):
             x = F.linear(h, mlp.fc2.weight, mlp.fc2.bias, drop=(p, mlp._s2), dp=(dp, self._dp1, N), resid=xr)
         u, xr2 = self.ccf_ffn.branch(x, self.norm2)
         gamma = self.ccf_ffn.gamma if self._rt.ccf_norm else None
+        if tail is not None:                                 # the caller applies the scale-add itself (TokenUpMix: functional.UpMixScaleAddFn)
+            tail.extend((xr2, u, gamma, (dp, self._dp2, N)))
+            return None
         return F.ScaleAddFn.apply(xr2, u, gamma, (dp, self._dp2, N))
 
 
@@ -488,7 +493,16 @@ class QuadBlockWithTokenLearner(nn.Module):
     def forward(self, x):
         if not self.use_token_learner:
             return self.quad_block(x)
-        return self.token_upmix(self.quad_block(self.token_learner(x)))
+        xc = self.token_learner(x)
+        qb, up = self.quad_block, self.token_upmix
+        if _UPMIX_SA and torch.is_grad_enabled() and xc.requires_grad and not (qb._forward_hooks or qb._forward_pre_hooks or up._forward_hooks
+                                                                               or up._forward_pre_hooks):
+            # the block's closing scale-add and the up-mix as one autograd node: its backward is one launch (functional.UpMixScaleAddFn)
+            tail = []
+            qb(xc, tail)
+            xr2, u, gamma, dp = tail
+            return F.UpMixScaleAddFn.apply(xr2, u, gamma, dp, up.upsample_attn.weight, up.upsample_attn.bias, up.norm.weight, up.norm.bias, up.norm.eps)
+        return up(qb(xc))
 
 
 class PatchProj(nn.Conv2d):

@@ -281,6 +281,41 @@ def _drop_setup(drop, G, H, Nq, NK):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B", [5, 700])
+def test_upmix_with_the_block_tail_scale_add(F, Q, dtype, B):
+    """UpMixScaleAddFn = TokenUpMix(x + droppath(gamma * u)) as one node whose backward (bf16, 64 -> 16 tokens) is ONE launch that also
+    writes du and dgamma (qavit_upmix_bwd_sa): against the two separate nodes (ScaleAddFn, then UpMixFn) on the same inputs and masks."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    rt = K.Runtime.get(0)
+    N, M, C = 64, 16, 192
+    x0, u0 = leaf(B, M, C, seed=71), leaf(B, M, C, seed=72)
+    W, bias = leaf(N, M, scale=0.3, seed=73), leaf(N, scale=0.1, seed=74)
+    g_, be = leaf(C, scale=0.1, seed=75), leaf(C, scale=0.1, seed=76)
+    gam = torch.full((1,), 0.3, device=DEV, requires_grad=True)
+    with torch.no_grad():
+        g_.add_(1.0)
+    gy = torch.randn(B, N, C, device=DEV).to(dtype)
+    dp = (0.25, 4242, M)
+    res = []
+    for fused in (True, False):
+        rt.seed(99)
+        for t in (W, bias, g_, be, gam):
+            t.grad = None
+        x = x0.detach().to(dtype).requires_grad_(True)
+        u = u0.detach().to(dtype).requires_grad_(True)
+        if fused:
+            y = F.UpMixScaleAddFn.apply(x, u, gam, dp, W, bias, g_, be, 1e-5)
+        else:
+            y = F.UpMixFn.apply(F.ScaleAddFn.apply(x, u, gam, dp), W, bias, g_, be, 1e-5)
+        y.backward(gy)
+        res.append([t.detach().float().clone() for t in (y, x.grad, u.grad, gam.grad, W.grad, bias.grad, g_.grad, be.grad)])
+    for name, a_, b_ in zip(("y", "dx", "du", "dgamma", "dW", "dbias", "dg", "db"), res[0], res[1]):
+        assert rel(a_, b_) <= (2e-5 if dtype == torch.float32 else 4e-3), name
+    assert float(res[0][2].abs().max()) > 0 and float(res[0][3].abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows", [16 * 130, 64 * 1000 + 5])
 def test_layernorm_fan_out_backward_sums_on_load(F, dtype, rows):
     """LayerNormFanFn: a LayerNorm output with five consumers + the residual alias of its input; backward = ONE launch that sums the
