@@ -8,6 +8,10 @@
 
 namespace qv {
 
+template <typename T> struct V4;
+template <> struct V4<float> { typedef f32x4 type; };
+template <> struct V4<bf16> { typedef bf16x4 type; };
+
 constexpr int F_LN = 1, F_BIAS = 2, F_SCALE = 4;
 
 // row-wise LN over C of buf[N][C] in place; optional stats out
@@ -292,6 +296,8 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
   float* a = hin + N * C;          // [N][C] LN1 output
   float* raw = a + N * C;          // [N][C] conv (+bias) before scale; later d(LN1 output), then dh
   float* t = raw + N * C;          // [N][C] LN2 input, then d(conv output)
+  float* dsm = t + N * C;          // [N][C] the incoming gradient d_out
+  float* st = dsm + N * C;         // [4][N] mean1, rstd1, mean2, rstd2 of the image's rows
   const T* h = reinterpret_cast<const T*>(p.h);
   const T* dout = reinterpret_cast<const T*>(p.d_out);
   T* dh = reinterpret_cast<T*>(p.d_h);
@@ -314,14 +320,32 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
   }
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     __syncthreads();
-    for (int i = threadIdx.x; i < N * C; i += 64 * NW) hin[i] = to_f<T>(h[(size_t)b * N * C + i]);
+    // Everything the image needs from memory is requested HERE, in one round trip: its h and d_out tiles (16-byte / 8-byte vectors) and
+    // the saved statistics of its rows.  Fetched where they are used -- statistics at the top of each row iteration of three loops, a
+    // d_out row inside the LayerNorm-backward loop -- they were five or six dependent round trips per image on a workgroup whose waves
+    // have nothing else to run.
+    {
+      typedef typename V4<T>::type v4;
+      const v4* hv = reinterpret_cast<const v4*>(h + (size_t)b * N * C);
+      const v4* dv = reinterpret_cast<const v4*>(dout + (size_t)b * N * C);
+      for (int i = threadIdx.x; i < N * C / 4; i += 64 * NW) {
+        const v4 x4 = hv[i], d4 = dv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hin[4 * i + j] = to_f<T>(x4[j]); dsm[4 * i + j] = to_f<T>(d4[j]); }
+      }
+      if (ln)
+        for (int i = threadIdx.x; i < N; i += 64 * NW) {
+          st[i] = p.mean1[(size_t)b * N + i]; st[N + i] = p.rstd1[(size_t)b * N + i];
+          st[2 * N + i] = p.mean2[(size_t)b * N + i]; st[3 * N + i] = p.rstd2[(size_t)b * N + i];
+        }
+    }
     __syncthreads();
     // recompute of the forward on the same (wave = rows, lane = channels) mapping with the parameters in registers: the saved
     // statistics make LN1 elementwise, and the stencil reads one channel of the neighbour rows.  (The generic helpers above
     // fetch every tap weight from global memory inside the tap loop and divide to find (row, channel): 3/4 of this kernel's time.)
     for (int r = wave; r < N; r += NW) {
       float mu = 0.f, rs = 1.f;
-      if (ln) { mu = p.mean1[(size_t)b * N + r]; rs = p.rstd1[(size_t)b * N + r]; }
+      if (ln) { mu = st[r]; rs = st[N + r]; }
 #pragma unroll
       for (int k = 0; k < CP; ++k) {
         const int c = lane + 64 * k;
@@ -352,19 +376,19 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
     wave_sync();                                        // LN2 backward below reads only the rows this wave just wrote
     // LN2 backward, then d(conv output) = dt * scale, with dscale / dbias partials -- one pass over the owned elements
     for (int r = wave; r < N; r += NW) {
-      const T* gr = dout + ((size_t)b * N + r) * C;
+      const float* gr = dsm + r * C;
       float* tr = t + r * C;
       const float* rr = raw + r * C;
       float d[CP], xh[CP];
       float c1 = 0.f, c2 = 0.f;
       float mu = 0.f, rs = 1.f;
-      if (ln) { mu = p.mean2[(size_t)b * N + r]; rs = p.rstd2[(size_t)b * N + r]; }
+      if (ln) { mu = st[2 * N + r]; rs = st[3 * N + r]; }
 #pragma unroll
       for (int k = 0; k < CP; ++k) {
         const int c = lane + 64 * k;
         d[k] = 0.f; xh[k] = 0.f;
         if (c < C) {
-          d[k] = to_f<T>(gr[c]);
+          d[k] = gr[c];
           xh[k] = (tr[c] - mu) * rs;
           const float gg = d[k] * g2v[k];
           c1 += gg * xh[k]; c2 += gg;
@@ -416,7 +440,7 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
       const float* gr = raw + r * C;
       float d[CP], xh[CP];
       float c1 = 0.f, c2 = 0.f, mu = 0.f, rs = 1.f;
-      if (ln) { mu = p.mean1[(size_t)b * N + r]; rs = p.rstd1[(size_t)b * N + r]; }
+      if (ln) { mu = st[r]; rs = st[N + r]; }
 #pragma unroll
       for (int k = 0; k < CP; ++k) {
         const int c = lane + 64 * k;
@@ -540,7 +564,8 @@ extern "C" int qavit_ccf_bwd_parts(int B) {
 extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
   int rc = ccf_validate(a, true);
   if (rc) return rc;
-  const size_t smem = ((size_t)4 * a->Hs * a->Ws * a->C + 15 * (size_t)a->C) * sizeof(float);
+  // four image tiles + the register-partial kernel's fifth (d_out) and its row statistics + the fold scratch
+  const size_t smem = ((size_t)5 * a->Hs * a->Ws * a->C + 4 * (size_t)a->Hs * a->Ws + 15 * (size_t)a->C) * sizeof(float);
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_bwd: image tile too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = qavit_ccf_bwd_parts(a->B);
