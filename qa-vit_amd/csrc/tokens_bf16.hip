@@ -218,6 +218,28 @@ int bank_stats_bf16_try(const void* tokens, const float* gbr, const float* bbr, 
 // 16-row tile; the 192 columns of a row live in 12 accumulator tiles of ONE wave, so the LayerNorm (and, in backward,
 // its gradient) is a 16-lane register reduction -- `up` never touches memory.
 // ------------------------------------------------------------------------------------------------
+// ROWS rows of C bf16 channels from global memory into an LDS tile of row stride LD, by 256 threads, in BATCHES of loads: all the loads of
+// a batch are in flight before the first LDS store.  A plain `for (i = tid; ...) lds[i] = g[i]` with a trip count the compiler does not
+// unroll is a chain of dependent round trips -- 12 (64 x 192 tile) or 48 (256 x 192) of them at the top of every image.
+template <int ROWS, int C, int LD, int BMAX = 12>
+__device__ __forceinline__ void stage_rows_batched(bf16* dst, const bf16* src) {
+  constexpr int CH = C / 4, TOT = ROWS * CH, PER = (TOT + 255) / 256, BATCH = PER < BMAX ? PER : BMAX;
+#pragma unroll
+  for (int base = 0; base < PER; base += BATCH) {
+    bf16x4 r[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = threadIdx.x + 256 * (base + j);
+      if (base + j < PER && (TOT % 256 == 0 || i < TOT)) { const int n = i / CH, ch = i - n * CH; r[j] = *reinterpret_cast<const bf16x4*>(src + (size_t)n * C + 4 * ch); }
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = threadIdx.x + 256 * (base + j);
+      if (base + j < PER && (TOT % 256 == 0 || i < TOT)) { const int n = i / CH, ch = i - n * CH; *reinterpret_cast<bf16x4*>(dst + n * LD + 4 * ch) = r[j]; }
+    }
+  }
+}
+
 // The block tail in front of TokenUpMix, y = x + droppath(gamma * u) (HQAViT_CIFAR100.py:1085, :1118-1121), differentiated inside the up-mix
 // backward: dxc is this kernel's output anyway; with `u` given it also writes du = dxc * f * gamma and adds sum(dxc * f * u) to dgamma (f = the
 // image's drop-path factor) -- the elementwise launch that did this re-read dxc and u from memory, once per block.
@@ -234,18 +256,37 @@ struct UpLds {
   static constexpr int bwd_bf16 = dup + (N < 64 ? N : 64) * LDC;
 };
 
-template <int NT, int MT, int CT>
+template <int NT, int MT, int CT, int BMAX = 16>
 __device__ __forceinline__ void up_stage_w(bf16* Wt, const float* W) {
   using L = UpLds<NT, MT, CT>;
-  for (int i = threadIdx.x; i < L::N * L::M; i += 256) { const int n = i / L::M, m = i - n * L::M; Wt[n * L::LDM + m] = (bf16)W[i]; }
+  if constexpr (BMAX == 0) {
+    for (int i = threadIdx.x; i < L::N * L::M; i += 256) { const int n = i / L::M, m = i - n * L::M; Wt[n * L::LDM + m] = (bf16)W[i]; }
+    return;
+  }
+  constexpr int TOT = L::N * L::M, PER = (TOT + 255) / 256, BATCH = BMAX == 0 ? 1 : (PER < BMAX ? PER : BMAX);     // loads in batches: see stage_rows_batched
+#pragma unroll
+  for (int base = 0; base < PER; base += BATCH) {
+    float r[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) { const int i = threadIdx.x + 256 * (base + j); if (base + j < PER && i < TOT) r[j] = W[i]; }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = threadIdx.x + 256 * (base + j);
+      if (base + j < PER && i < TOT) { const int n = i / L::M, m = i - n * L::M; Wt[n * L::LDM + m] = (bf16)r[j]; }
+    }
+  }
 }
-template <int NT, int MT, int CT>
+template <int NT, int MT, int CT, int BMAX = 12>
 __device__ __forceinline__ void up_stage_xc(bf16* Xs, const bf16* xcb) {
   using L = UpLds<NT, MT, CT>;
-  constexpr int CH = L::C / 4;
-  for (int i = threadIdx.x; i < L::M * CH; i += 256) {
-    const int m = i / CH, ch = i - m * CH;
-    *reinterpret_cast<bf16x4*>(Xs + m * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(xcb + (size_t)m * L::C + 4 * ch);
+  if constexpr (BMAX > 0) {
+    stage_rows_batched<L::M, L::C, L::LDC, BMAX>(Xs, xcb);
+  } else {                                                   // one load in flight: for the kernel that has no registers to spare
+    constexpr int CH = L::C / 4;
+    for (int i = threadIdx.x; i < L::M * CH; i += 256) {
+      const int m = i / CH, ch = i - m * CH;
+      *reinterpret_cast<bf16x4*>(Xs + m * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(xcb + (size_t)m * L::C + 4 * ch);
+    }
   }
 }
 // accumulators of one 16-row tile: acc[ct][r] = up[nt*16 + 4q + r][ct*16 + col]
@@ -336,7 +377,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   float* gred = fl + L::N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q4 = lane >> 4;
   TSTAMP(0);
-  up_stage_w<NT, MT, CT>(sm + L::wt, W);
+  up_stage_w<NT, MT, CT, (NT <= 4 ? 16 : 0)>(sm + L::wt, W);
   for (int i = threadIdx.x; i < L::N; i += 256) dba[i] = 0.f;
   int img = 0;                                               // (stamps)
   float ga[CT], pg[CT], pb[CT];
@@ -397,7 +438,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       }
       req_xc(b + gridDim.x);
     } else {
-      up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
+      up_stage_xc<NT, MT, CT, 0>(sm + L::xc, xc + (size_t)b * L::M * L::C);     // (512 registers per lane: the plain loop)
     }
     f32x4 dxa[DXT];
 #pragma unroll
@@ -622,7 +663,10 @@ static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, 
     const size_t smem = (size_t)(L::fwd_bf16 + 64 * L::LDC) * 2;        // + the four waves' output tiles
     if (smem > 150 * 1024) return -100;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_fwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((upmix2_fwd_kernel<NT, MT, CT>), dim3(B < 2048 ? B : 2048), dim3(256), smem, st, (const bf16*)xc, W, bias, gamma, beta, eps,
+    // one image per workgroup while W is small; the 256-token variant stages 64 KB of W per workgroup (four batches of loads): a workgroup per CU,
+    // each walking its images, pays that once
+    static const int fgrid = getenv("QAVIT_UPMIX_FWD_GRID") ? atoi(getenv("QAVIT_UPMIX_FWD_GRID")) : (NT > 4 ? 256 : 2048);
+    hipLaunchKernelGGL((upmix2_fwd_kernel<NT, MT, CT>), dim3(B < fgrid ? B : fgrid), dim3(256), smem, st, (const bf16*)xc, W, bias, gamma, beta, eps,
                        (bf16*)o0, mean, rstd, B);
     return QAVIT_OK;
   }
@@ -684,14 +728,10 @@ __device__ __forceinline__ float colred(float v, float* red, int M, int parts, b
   return r;
 }
 
-template <int NT, int MT, int CT>
-__device__ __forceinline__ void mix_stage_rows(bf16* dst, const bf16* src, int rows) {
+template <int ROWS, int NT, int MT, int CT>
+__device__ __forceinline__ void mix_stage_rows(bf16* dst, const bf16* src) {
   using L = MixLds<NT, MT, CT>;
-  constexpr int CH = L::C / 4;
-  for (int i = threadIdx.x; i < rows * CH; i += 256) {
-    const int n = i / CH, ch = i - n * CH;
-    *reinterpret_cast<bf16x4*>(dst + n * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(src + (size_t)n * L::C + 4 * ch);
-  }
+  stage_rows_batched<ROWS, L::C, L::LDC>(dst, src);
 }
 
 template <int NT, int MT, int CT>
@@ -703,7 +743,7 @@ __global__ __launch_bounds__(256) void tokmix2_fwd_kernel(const bf16* scores, co
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, q4 = lane >> 4;
   constexpr int parts = 256 / L::M, RP = L::N / parts;          // rows per thread of its column
   const int m = t % L::M, part = t / L::M;
-  mix_stage_rows<NT, MT, CT>(sm + L::x, x + (size_t)b * L::N * L::C, L::N);
+  mix_stage_rows<L::N, NT, MT, CT>(sm + L::x, x + (size_t)b * L::N * L::C);
   const bf16* sc = scores + (size_t)b * L::N * L::M;
   float v[RP];
   float mx = -INFINITY;
@@ -746,19 +786,49 @@ __global__ __launch_bounds__(256) void tokmix2_bwd_kernel(const bf16* p_in, cons
   float* dP = reinterpret_cast<float*>(smraw + (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2);      // [N][M]
   float* red = dP + L::N * L::M;                                                               // [256]
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, col = lane & 15, q4 = lane >> 4;
-  mix_stage_rows<NT, MT, CT>(sm + L::bg, dxc + (size_t)b * L::M * L::C, L::M);
+  // this wave's x rows travel one tile ahead in registers: the first tile is requested with the image's dxc / P staging (one round trip
+  // instead of two), the next one before the current tile's products (the 256-token variant walks four tiles per wave)
+  constexpr int CH = L::C / 4;
+  constexpr int XL = 16 * CH / 64;
+  bf16x4 xr[XL];
+  auto req_x = [&](int nt) {
+    if (nt < NT) {
+      const bf16* xs = x + ((size_t)b * L::N + nt * 16) * L::C;
+#pragma unroll
+      for (int j = 0; j < XL; ++j) {
+        const int i = lane + 64 * j, n = i / CH, ch = i - n * CH;
+        xr[j] = *reinterpret_cast<const bf16x4*>(xs + (size_t)n * L::C + 4 * ch);
+      }
+    }
+  };
+  req_x(wave);
+  mix_stage_rows<L::M, NT, MT, CT>(sm + L::bg, dxc + (size_t)b * L::M * L::C);
   const bf16* pb = p_in + (size_t)b * L::N * L::M;
-  for (int i = t; i < L::N * L::M; i += 256) { const int n = i / L::M, m = i - n * L::M; sm[L::p + n * L::LDM + m] = pb[i]; }
+  {
+    constexpr int TOT = L::N * L::M / 4, PER = (TOT + 255) / 256, BATCH = PER < 16 ? PER : 16;      // P [N][M] as 8-byte pieces, loads in batches
+    static_assert(L::M % 4 == 0, "P rows are staged as 8-byte pieces");
+#pragma unroll
+    for (int base = 0; base < PER; base += BATCH) {
+      bf16x4 r[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) { const int i = t + 256 * (base + j); if (base + j < PER && i < TOT) r[j] = *reinterpret_cast<const bf16x4*>(pb + 4 * i); }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int i = t + 256 * (base + j);
+        if (base + j < PER && i < TOT) { const int n = (4 * i) / L::M, m = 4 * i - n * L::M; *reinterpret_cast<bf16x4*>(sm + L::p + n * L::LDM + m) = r[j]; }
+      }
+    }
+  }
   __syncthreads();
   bf16* xw = sm + L::bx + wave * 16 * L::LDC;                  // this wave's x tile
-  constexpr int CH = L::C / 4;
   for (int nt = wave; nt < NT; nt += 4) {
     wave_sync();
-    const bf16* xs = x + ((size_t)b * L::N + nt * 16) * L::C;
-    for (int i = lane; i < 16 * CH; i += 64) {
-      const int n = i / CH, ch = i - n * CH;
-      *reinterpret_cast<bf16x4*>(xw + n * L::LDC + 4 * ch) = *reinterpret_cast<const bf16x4*>(xs + (size_t)n * L::C + 4 * ch);
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+      const int i = lane + 64 * j, n = i / CH, ch = i - n * CH;
+      *reinterpret_cast<bf16x4*>(xw + n * L::LDC + 4 * ch) = xr[j];
     }
+    req_x(nt + 4);
     wave_sync();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
