@@ -12,6 +12,28 @@ template <typename T> struct V4;
 template <> struct V4<float> { typedef f32x4 type; };
 template <> struct V4<bf16> { typedef bf16x4 type; };
 
+// n elements (n % 4 == 0) of an image from global memory to an fp32 LDS tile: four vector loads per thread in flight before the first
+// store (the element-wise `for (i = tid; ...) lds[i] = g[i]` with a run-time trip count was one dependent round trip per iteration)
+template <typename T, int NTH>
+__device__ __forceinline__ void stage_image_f32(float* dst, const T* src, int n) {
+  typedef typename V4<T>::type v4;
+  const v4* sv = reinterpret_cast<const v4*>(src);
+  const int nv = n >> 2;
+  for (int base = threadIdx.x; base < nv; base += 4 * NTH) {
+    v4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = base + j * NTH; if (i < nv) r[j] = sv[i]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = base + j * NTH;
+      if (i < nv) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[4 * i + q] = to_f<T>(r[j][q]);
+      }
+    }
+  }
+}
+
 constexpr int F_LN = 1, F_BIAS = 2, F_SCALE = 4;
 
 // row-wise LN over C of buf[N][C] in place; optional stats out
@@ -101,7 +123,7 @@ __global__ __launch_bounds__(64 * NW) void ccf_fwd2_kernel(qavit_ccf_args p) {
   }
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     __syncthreads();
-    for (int i = threadIdx.x; i < N * C; i += 64 * NW) a[i] = to_f<T>(h[(size_t)b * N * C + i]);
+    stage_image_f32<T, 64 * NW>(a, h + (size_t)b * N * C, N * C);           // (C % 4 == 0 and vector-aligned images: checked by the launcher)
     __syncthreads();
     if (ln) {
       for (int r = wave; r < N; r += NW) {
@@ -328,10 +350,19 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
       typedef typename V4<T>::type v4;
       const v4* hv = reinterpret_cast<const v4*>(h + (size_t)b * N * C);
       const v4* dv = reinterpret_cast<const v4*>(dout + (size_t)b * N * C);
-      for (int i = threadIdx.x; i < N * C / 4; i += 64 * NW) {
-        const v4 x4 = hv[i], d4 = dv[i];
+      const int nv = N * C / 4;
+      for (int base = threadIdx.x; base < nv; base += 2 * 64 * NW) {      // two pieces of each tile per thread in flight before the first store
+        v4 x4[2], d4[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { hin[4 * i + j] = to_f<T>(x4[j]); dsm[4 * i + j] = to_f<T>(d4[j]); }
+        for (int j = 0; j < 2; ++j) { const int i = base + j * 64 * NW; if (i < nv) { x4[j] = hv[i]; d4[j] = dv[i]; } }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int i = base + j * 64 * NW;
+          if (i < nv) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { hin[4 * i + q] = to_f<T>(x4[j][q]); dsm[4 * i + q] = to_f<T>(d4[j][q]); }
+          }
+        }
       }
       if (ln)
         for (int i = threadIdx.x; i < N; i += 64 * NW) {
@@ -531,7 +562,8 @@ extern "C" int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream) {
   const int grid = a->B < 2048 ? a->B : 2048;
   const int threads = a->Hs * a->Ws >= 64 ? 512 : 256;    // 64-token maps fill one CU per image: 8 waves share the rows
   static const int fwd2 = getenv("QAVIT_CCF_FWD2") ? atoi(getenv("QAVIT_CCF_FWD2")) : 1;
-  if (fwd2 && a->C <= 256 && (a->dtype == QAVIT_F32 || a->dtype == QAVIT_BF16)) {
+  const size_t vecb = a->dtype == QAVIT_F32 ? 16 : 8;      // the register-partial kernels stage images with 4-element vector loads
+  if (fwd2 && a->C <= 256 && a->C % 4 == 0 && reinterpret_cast<uintptr_t>(a->h) % vecb == 0 && (a->dtype == QAVIT_F32 || a->dtype == QAVIT_BF16)) {
     const int cp = (a->C + 63) / 64;
 #define CCFF(T_, CP_) { if (threads == 512) { \
                           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_fwd2_kernel<T_, CP_, 8, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -571,7 +603,9 @@ extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
   const int grid = qavit_ccf_bwd_parts(a->B);
   if (a->parts && !(a->C <= 256 && a->Hs * a->Ws >= 15 && a->C % 8 == 0 && (reinterpret_cast<uintptr_t>(a->parts) & 15) == 0))
     return set_error(QAVIT_EINVAL, "ccf_mid_bwd: parts needs C <= 256, C % 8 == 0, >= 15 tokens and a 16-byte aligned workspace");
-  if (a->C <= 256 && a->Hs * a->Ws >= 15) {             // register-partial kernel (its wave fold needs 60*C floats of the image buffers)
+  const size_t vecb = a->dtype == QAVIT_F32 ? 16 : 8;
+  if (a->C <= 256 && a->Hs * a->Ws >= 15 && a->C % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(a->h) | reinterpret_cast<uintptr_t>(a->d_out)) % vecb == 0) {   // register-partial kernel (its wave fold needs 60*C floats of the image buffers; vector image loads)
     const int cp = (a->C + 63) / 64;
 #define CCF2(T_, CP_) { if (a->Hs * a->Ws >= 64) { \
                           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ccf_bwd2_kernel<T_, CP_, 8, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
