@@ -4,6 +4,7 @@
 // channel column (lane = channel -> conflict-free LDS, coalesced HBM) and a strip of tokens.
 // Weight / bias gradients are accumulated in registers over all images a workgroup visits, reduced through
 // LDS, and flushed with one fp32 atomic per element per workgroup.
+#include <type_traits>
 #include "common.cuh"
 #include "../../include/qavit.h"
 #include "launch.h"
@@ -640,6 +641,107 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* dcols, T* dx, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-image versions for channel-last sources: a workgroup stages the image's whole source tile (im2col) or its whole dcols block (col2im)
+// in LDS with coalesced 16-byte loads -- all of a thread's loads in flight before its first LDS store -- and then produces 16-byte pieces
+// of output rows from LDS.  The element-per-thread kernels above walk the (c, dy, dx) column order with 2-byte accesses 18 bytes apart:
+// 62 us to write 37.7 MB of im2col rows and 74 us to fold them back at B = 1024, on the lateral path's critical tail.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
+template <> struct Vec8<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+template <typename T, bool NCHW_F32>
+__global__ __launch_bounds__(256) void im2col_img_kernel(const void* src_, T* cols, int ld, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  typedef typename std::conditional<NCHW_F32, float, T>::type S;        // source element: the fp32 NCHW image or channel-last tokens in T
+  S* xs = reinterpret_cast<S*>(smraw);                         // the image as it lies in memory: [Cin][H][W] or [H*W][Cin]
+  typedef typename Vec8<S>::type svec;
+  typedef typename Vec8<T>::type vec;
+  constexpr int SN = Vec8<S>::N, VN = Vec8<T>::N;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Kc = Cin * k * k, kk = k * k;
+  const int nsrc = H * W * Cin / SN;
+  const svec* sv = reinterpret_cast<const svec*>(reinterpret_cast<const S*>(src_) + (size_t)b * H * W * Cin);
+  for (int base = tid; base < nsrc; base += 8 * 256) {
+    svec r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int i = base + 256 * j; if (i < nsrc) r[j] = sv[i]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int i = base + 256 * j; if (i < nsrc) reinterpret_cast<svec*>(xs)[i] = r[j]; }
+  }
+  __syncthreads();
+  const int ppr = ld / VN;                                     // pieces per output row
+  const int npieces = Ho * Wo * ppr;
+  T* out = cols + (size_t)b * Ho * Wo * ld;
+  for (int p = tid; p < npieces; p += 256) {
+    const int row = p / ppr, c0 = (p - row * ppr) * VN;
+    const int oy = row / Wo, ox = row - oy * Wo;
+    vec o;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      const int col = c0 + j;
+      float v = 0.f;
+      if (col < Kc) {
+        const int c = col / kk, r = col - c * kk, dy = r / k, dx = r - dy * k;
+        const int y = oy * stride + dy - pad, x = ox * stride + dx - pad;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = NCHW_F32 ? (float)xs[(c * H + y) * W + x] : to_f<S>(xs[(y * W + x) * Cin + c]);
+      }
+      o[j] = from_f<T>(v);
+    }
+    *reinterpret_cast<vec*>(out + (size_t)row * ld + c0) = o;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_img_kernel(const T* dcols, T* dx, int Cin, int H, int W, int k, int stride, int pad, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  T* ds = reinterpret_cast<T*>(smraw);                         // [Ho*Wo][Kc]
+  typedef typename Vec8<T>::type vec;
+  constexpr int VN = Vec8<T>::N;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Kc = Cin * k * k, kk = k * k;
+  const int nsrc = Ho * Wo * Kc / VN;
+  const vec* sv = reinterpret_cast<const vec*>(dcols + (size_t)b * Ho * Wo * Kc);
+  for (int base = tid; base < nsrc; base += 12 * 256) {
+    vec r[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { const int i = base + 256 * j; if (i < nsrc) r[j] = sv[i]; }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { const int i = base + 256 * j; if (i < nsrc) reinterpret_cast<vec*>(ds)[i] = r[j]; }
+  }
+  __syncthreads();
+  const int cpp = Cin / VN;                                    // pieces per pixel
+  const int npieces = H * W * cpp;
+  T* out = dx + (size_t)b * H * W * Cin;
+  for (int p = tid; p < npieces; p += 256) {
+    const int pix = p / cpp, c0 = (p - pix * cpp) * VN;
+    const int y = pix / W, x = pix - y * W;
+    float acc[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+    for (int dy = 0; dy < k; ++dy) {
+      const int ty = y + pad - dy;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= Ho) continue;
+      for (int dxx = 0; dxx < k; ++dxx) {
+        const int tx = x + pad - dxx;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= Wo) continue;
+        const T* rowp = ds + (oy * Wo + ox) * Kc + dy * k + dxx;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) acc[j] += to_f<T>(rowp[(c0 + j) * kk]);
+      }
+    }
+    vec o;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) o[j] = from_f<T>(acc[j]);
+    *reinterpret_cast<vec*>(out + (size_t)pix * Cin + c0) = o;
+  }
+}
+
 }  // namespace qv
 
 using namespace qv;
@@ -654,6 +756,21 @@ extern "C" int qavit_im2col_ld(int dtype, const void* src, int src_nchw_f32, voi
   const int64_t total = (int64_t)B * Ho * Wo * ld;
   int grid = (int)((total + 1023) / 1024); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    // an image that fits LDS: the per-image kernel (coalesced staging, 16-byte row pieces)
+    const size_t esz = dtype == QAVIT_F32 ? 4 : 2, ssz = src_nchw_f32 ? 4 : esz;
+    const int vn = dtype == QAVIT_F32 ? 4 : 8, sn = ssz == 4 ? 4 : 8;
+    const size_t smem = (size_t)H * W * Cin * ssz;
+    if ((dtype == QAVIT_F32 || dtype == QAVIT_BF16) && smem <= 96 * 1024 && (H * W * Cin) % sn == 0 && ld % vn == 0 &&
+        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(cols)) & 15) == 0 && (smem & 15) == 0 && (((size_t)ld * esz) & 15) == 0) {
+#define IM2IMG(T_, N_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_img_kernel<T_, N_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                            hipLaunchKernelGGL((im2col_img_kernel<T_, N_>), dim3(B), dim3(256), smem, st, src, (T_*)cols, ld, Cin, H, W, k, stride, pad, Ho, Wo); } while (0)
+      if (dtype == QAVIT_F32) { if (src_nchw_f32) IM2IMG(float, true); else IM2IMG(float, false); }
+      else { if (src_nchw_f32) IM2IMG(bf16, true); else IM2IMG(bf16, false); }
+#undef IM2IMG
+      return check_launch("im2col(image)");
+    }
+  }
   const bool small = total < 0x7fffffffLL && (int64_t)B * Cin * H * W < 0x7fffffffLL;
 #define IM2COL(T_, N_) do { if (small) hipLaunchKernelGGL((im2col_kernel<T_, N_, uint32_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, ld, B, Cin, H, W, k, stride, pad, Ho, Wo); \
                             else hipLaunchKernelGGL((im2col_kernel<T_, N_, int64_t>), dim3(grid), dim3(256), 0, st, src, (T_*)cols, ld, B, Cin, H, W, k, stride, pad, Ho, Wo); } while (0)
@@ -672,6 +789,22 @@ extern "C" int qavit_col2im(int dtype, const void* dcols, void* dx, int B, int C
   const int64_t total = (int64_t)B * H * W * Cin;
   int grid = (int)((total + 1023) / 1024); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
+    const int vn = dtype == QAVIT_F32 ? 4 : 8;
+    const size_t smem = (size_t)Ho * Wo * Cin * k * k * esz;
+    if ((dtype == QAVIT_F32 || dtype == QAVIT_BF16) && smem <= 128 * 1024 && Cin % vn == 0 && (Ho * Wo * Cin * k * k) % vn == 0 && (smem & 15) == 0 &&
+        ((reinterpret_cast<uintptr_t>(dcols) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 && (((size_t)H * W * Cin * esz) & 15) == 0) {
+      if (dtype == QAVIT_F32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(col2im_img_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipLaunchKernelGGL((col2im_img_kernel<float>), dim3(B), dim3(256), smem, st, (const float*)dcols, (float*)dx, Cin, H, W, k, stride, pad, Ho, Wo);
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(col2im_img_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipLaunchKernelGGL((col2im_img_kernel<bf16>), dim3(B), dim3(256), smem, st, (const bf16*)dcols, (bf16*)dx, Cin, H, W, k, stride, pad, Ho, Wo);
+      }
+      return check_launch("col2im(image)");
+    }
+  }
   const bool small = total < 0x7fffffffLL && (int64_t)B * Ho * Wo * Cin * k * k < 0x7fffffffLL;
   if (dtype == QAVIT_F32) {
     if (small) hipLaunchKernelGGL((col2im_kernel<float, uint32_t>), dim3(grid), dim3(256), 0, st, (const float*)dcols, (float*)dx, B, Cin, H, W, k, stride, pad, Ho, Wo);
