@@ -454,11 +454,16 @@ __global__ __launch_bounds__(256) void sum_k_kernel(SumPtrs P, int k, T* out, ui
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    for (int i = 0; i < k; ++i) {
-      const vec_t x = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(P.p[i]) + (size_t)v * VEC);
+    vec_t x[8];                                           // all k inputs requested before the first add (a run-time loop of load + add is k dependent round trips)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] += to_f<T>(x[j]);
-    }
+    for (int i = 0; i < 8; ++i)
+      if (i < k) x[i] = *reinterpret_cast<const vec_t*>(reinterpret_cast<const T*>(P.p[i]) + (size_t)v * VEC);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < k) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += to_f<T>(x[i][j]);
+      }
     vec_t o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o[j] = from_f<T>(acc[j]);
