@@ -855,6 +855,15 @@ extern "C" int qavit_patchify(int dtype, const float* img, void* cols, int B, in
   if (!img || !cols || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || p <= 0 || H % p || W % p)
     return set_error(QAVIT_EINVAL, "patchify: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    // patchify IS im2col with kernel = stride = p and no padding, in the same (c, dy, dx) column order: images that fit LDS take the per-image
+    // kernel of dwconv.hip (the image staged with coalesced 16-byte loads, 16-byte row pieces out) instead of one 2-byte store per element
+    const int K = Cin * p * p, vn = dtype == QAVIT_F32 ? 4 : 8;
+    const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
+    if ((dtype == QAVIT_F32 || dtype == QAVIT_BF16) && K % vn == 0 && (size_t)Cin * H * W * 4 <= 96 * 1024 && (Cin * H * W) % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(cols)) & 15) == 0 && (((size_t)K * esz) & 15) == 0)
+      return qavit_im2col_ld(dtype, img, 1, cols, K, B, Cin, H, W, p, p, 0, stream);
+  }
   const int g = blocks_for((int64_t)B * Cin * H * W, 1024);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((patchify_kernel<float>), dim3(g), dim3(256), 0, st, img, (float*)cols, B, Cin, H, W, p),
