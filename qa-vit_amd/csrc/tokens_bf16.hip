@@ -375,6 +375,11 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   float* fl = reinterpret_cast<float*>(smraw + (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2);   // [N] dbias + [4][2][C] gamma/beta partials
   float* dba = fl;
   float* gred = fl + L::N;
+  // 256-token variant: the dW accumulators of a wave's four row tiles (64 registers) live in LDS, one 16-byte slot per (tile, lane) in
+  // accumulator layout -- owned by that lane alone, so no synchronisation: read, 12 MFMAs, write back.  With them in registers the kernel
+  // sat at 512 registers per lane and its LayerNorm section ran through AGPR shuffles (stamps: 2/3 of a tile's time).
+  constexpr bool DW_LDS = NT > 4;
+  f32x4* dwl = reinterpret_cast<f32x4*>(fl + L::N + 8 * L::C);          // [NTW][MT][256 threads]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q4 = lane >> 4;
   TSTAMP(0);
   up_stage_w<NT, MT, CT, (NT <= 4 ? 16 : 0)>(sm + L::wt, W);
@@ -383,11 +388,14 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   float ga[CT], pg[CT], pb[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) { ga[ct] = gamma[ct * 16 + col]; pg[ct] = 0.f; pb[ct] = 0.f; }
-  f32x4 dwacc[NTW][MT];
+  f32x4 dwacc[DW_LDS ? 1 : NTW][DW_LDS ? 1 : MT];
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) dwacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) {
+      if (DW_LDS) dwl[(i * MT + j) * 256 + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
+      else dwacc[DW_LDS ? 0 : i][DW_LDS ? 0 : j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   const float invC = 1.f / (float)L::C;
   // Software pipeline over (image, row-tile chunk) steps: the NEXT step's dy tile (and, at an image boundary, the next image's xc
   // tile) is requested into registers before this step's products start, and committed to LDS at the top of the next step -- with one
@@ -395,8 +403,9 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   constexpr int CH = L::C / 4;
   constexpr int DYL = 16 * CH / 64;                          // 8-byte pieces of a 16-row dy tile per lane
   constexpr int XL = (L::M * CH + 255) / 256;                // 8-byte pieces of the xc tile per thread
-  constexpr bool PIPE = NT <= 4;                             // (the 256-token variant already holds 512 registers per lane: left on the one-step schedule)
-  bf16x4 dyr[PIPE ? DYL : 1], xr[PIPE ? XL : 1];
+  constexpr bool PIPE = true;                                // dy tiles (+ row statistics) one step ahead: both variants
+  constexpr bool PIPE_XC = NT <= 4;                          // the next image's xc tile too: not in the 256-token variant (24 more registers per lane: spills)
+  bf16x4 dyr[PIPE ? DYL : 1], xr[PIPE_XC ? XL : 1];
   float mun[4], rsn[4];                                      // the next tile's row statistics travel with its dy rows (in-stamp timeline: fetched
                                                              // inside the row loop they were four dependent global round trips, 2/3 of an image's time)
   auto req_dy = [&](int bb, int tw) {
@@ -425,12 +434,13 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       }
     }
   };
-  if (PIPE) { req_xc(blockIdx.x); req_dy(blockIdx.x, 0); }
+  if (PIPE_XC) req_xc(blockIdx.x);
+  if (PIPE) req_dy(blockIdx.x, 0);
   TSTAMP(1);
   for (int b = blockIdx.x; b < B; b += gridDim.x, ++img) {
     __syncthreads();
     TSTAMP(2 + 6 * img);
-    if (PIPE) {
+    if (PIPE_XC) {
 #pragma unroll
       for (int j = 0; j < XL; ++j) {
         const int i = threadIdx.x + 256 * j;
@@ -544,10 +554,13 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       // dW[n][m] += sum_c dup[n][c] xc[m][c]   (own row tile)
       if (nt < NT) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 a = DW_LDS ? dwl[(tw * MT + mt) * 256 + threadIdx.x] : dwacc[DW_LDS ? 0 : tw][DW_LDS ? 0 : mt];
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
-            dwacc[tw][mt] = mma16(rowfrag(sm + L::dup, L::LDC, wave * 16, ct * 16), rowfrag(sm + L::xc, L::LDC, mt * 16, ct * 16), dwacc[tw][mt]);
+            a = mma16(rowfrag(sm + L::dup, L::LDC, wave * 16, ct * 16), rowfrag(sm + L::xc, L::LDC, mt * 16, ct * 16), a);
+          if (DW_LDS) dwl[(tw * MT + mt) * 256 + threadIdx.x] = a; else dwacc[DW_LDS ? 0 : tw][DW_LDS ? 0 : mt] = a;
+        }
       }
       TSTAMP(7 + 6 * img);
     }
@@ -607,7 +620,7 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (plain) rowp[r * L::M + mt * 16] = dwacc[tw][mt][r]; else atomic_add_f(rowp + r * L::M + mt * 16, dwacc[tw][mt][r]);
+            if (plain) rowp[r * L::M + mt * 16] = dwacc[DW_LDS ? 0 : tw][DW_LDS ? 0 : mt][r]; else atomic_add_f(rowp + r * L::M + mt * 16, dwacc[DW_LDS ? 0 : tw][DW_LDS ? 0 : mt][r]);
           }
       }
     }
@@ -619,9 +632,11 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
       const int nt = wave + 4 * tw;
       if (nt < NT) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 a = DW_LDS ? dwl[(tw * MT + mt) * 256 + threadIdx.x] : dwacc[DW_LDS ? 0 : tw][DW_LDS ? 0 : mt];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) atomic_add_f(dW + (size_t)(nt * 16 + 4 * q4 + r) * L::M + mt * 16 + col, dwacc[tw][mt][r]);
+          for (int r = 0; r < 4; ++r) atomic_add_f(dW + (size_t)(nt * 16 + 4 * q4 + r) * L::M + mt * 16 + col, a[r]);
+        }
       }
     }
     if (dbias) for (int i = threadIdx.x; i < L::N; i += 256) atomic_add_f(dbias + i, dba[i]);
@@ -670,8 +685,9 @@ static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, 
                        (bf16*)o0, mean, rstd, B);
     return QAVIT_OK;
   }
-  const size_t smem = (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2 + (size_t)(L::N + 8 * L::C) * 4;
-  if (smem > 150 * 1024) return -100;
+  const size_t smem = (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2 + (size_t)(L::N + 8 * L::C) * 4 +
+                      (NT > 4 ? (size_t)((NT + 3) / 4) * MT * 256 * 16 : 0);          // + the 256-token variant's dW accumulators
+  if (smem > 160 * 1024) return -100;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(upmix2_bwd_kernel<NT, MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL((upmix2_bwd_kernel<NT, MT, CT>), dim3(up2_bwd_grid<NT, MT, CT>(B, parts != nullptr)), dim3(256), smem, st, (const bf16*)a0,
                      (const bf16*)xc, W, bias, gamma, mean, rstd, (bf16*)o0, dW, dbias, dgamma, dbeta, B, parts,
