@@ -313,6 +313,13 @@ int qavit_upmix_bwd_sa(int dtype, const void* dy, const void* xc, const float* W
                        const float* mean, const float* rstd, void* dxc, float* dW, float* dbias, float* dgamma, float* dbeta,
                        int B, int N, int M, int C, float* parts, const void* u, void* du, const float* gamma_sa, float* dgamma_sa,
                        float dp_p, int dp_site, const int64_t* rng, void* stream);
+/* The up-mix FORWARD with the same scale-add in front of it: forms xc = x + f * gamma_sa[0] * u (f = the image's drop-path factor; the
+ * arithmetic of qavit_scale_add_fwd) while it stages each image, writes it to `xc` [B*M, C] for the backward and up-mixes it -- one launch
+ * for the two.  bf16, C = 192, (N, M) = (64, 16) or (256, 64) (qavit_upmix_fwd_sa_supported); x, u, xc, y 8-byte aligned. */
+int qavit_upmix_fwd_sa_supported(int dtype, int N, int M, int C);
+int qavit_upmix_fwd_sa(int dtype, const void* x, const void* u, const float* gamma_sa, float dp_p, int dp_site, const int64_t* rng, void* xc,
+                       const float* W, const float* bias, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                       int B, int N, int M, int C, void* stream);
 int qavit_upmix_bwd_p(int dtype, const void* dy, const void* xc, const float* W, const float* bias,
                       const float* gamma, const float* mean, const float* rstd, void* dxc, float* dW,
                       float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, float* parts, void* stream);

@@ -417,6 +417,25 @@ extern "C" int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const 
   return qavit_upmix_bwd_p(dtype, dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta, B, N, M, C, nullptr, stream);
 }
 
+extern "C" int qavit_upmix_fwd_sa_supported(int dtype, int N, int M, int C) {
+  return dtype == QAVIT_BF16 && C == 192 && ((N == 64 && M == 16) || (N == 256 && M == 64));
+}
+
+extern "C" int qavit_upmix_fwd_sa(int dtype, const void* x, const void* u, const float* sa_gamma, float dp_p, int dp_site, const int64_t* rng, void* xc,
+                                  const float* W, const float* bias, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                                  int B, int N, int M, int C, void* stream) {
+  if (!qavit_upmix_fwd_sa_supported(dtype, N, M, C)) return set_error(QAVIT_EINVAL, "upmix_fwd_sa: bf16, 64 -> 16 or 256 -> 64 tokens, C = 192 only");
+  if (!x || !u || !xc || !W || !bias || !gamma || !beta || !y || !mean || !rstd || B <= 0) return set_error(QAVIT_EINVAL, "upmix_fwd_sa: bad arguments");
+  if (dp_p < 0.f || dp_p >= 1.f || (dp_p > 0.f && !rng)) return set_error(QAVIT_EINVAL, "upmix_fwd_sa: drop-path needs rng");
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(xc) | reinterpret_cast<uintptr_t>(y)) & 7)
+    return set_error(QAVIT_EINVAL, "upmix_fwd_sa: operand alignment");
+  const int took = qv::upmix_bf16_try(false, nullptr, x, W, bias, gamma, beta, eps, y, mean, rstd, nullptr, nullptr, nullptr, nullptr, B, N, M, C,
+                                      reinterpret_cast<hipStream_t>(stream), nullptr, u, xc, sa_gamma, nullptr, dp_p, dp_site, rng);
+  if (took < 0) return took;
+  if (took != 1) return set_error(QAVIT_EINVAL, "upmix_fwd_sa: shape not covered");
+  return check_launch("upmix_fwd_sa");
+}
+
 extern "C" int qavit_upmix_bwd_sa_supported(int dtype, int N, int M, int C) { return dtype == QAVIT_BF16 && N == 64 && M == 16 && C == 192; }
 
 extern "C" int qavit_upmix_bwd_sa(int dtype, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma,

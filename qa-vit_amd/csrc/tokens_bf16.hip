@@ -244,6 +244,39 @@ __device__ __forceinline__ void stage_rows_batched(bf16* dst, const bf16* src) {
 // backward: dxc is this kernel's output anyway; with `u` given it also writes du = dxc * f * gamma and adds sum(dxc * f * u) to dgamma (f = the
 // image's drop-path factor) -- the elementwise launch that did this re-read dxc and u from memory, once per block.
 struct UpScaleAdd { const bf16* u; bf16* du; const float* gamma; float* dgamma; float dp_p; int dp_site; const int64_t* rng; };
+// The same block tail in the forward: with `u` given the up-mix forward's `xc` operand is x, the kernel forms xc = x + f * gamma * u while it
+// stages the image (f = the image's drop-path factor) and writes it to `xc_out` for the backward -- the elementwise launch in front of it is gone.
+struct UpFwdAdd { const bf16* u; bf16* xc_out; const float* gamma; float dp_p; int dp_site; const int64_t* rng; };
+
+template <int ROWS, int C, int LD, int BMAX = 6>
+__device__ __forceinline__ void stage_rows_scale_add(bf16* dst, const bf16* x, const bf16* u, bf16* out, float f) {
+  constexpr int CH = C / 4, TOT = ROWS * CH, PER = (TOT + 255) / 256, BATCH = PER < BMAX ? PER : BMAX;
+#pragma unroll
+  for (int base = 0; base < PER; base += BATCH) {
+    bf16x4 rx[BATCH], ru[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = threadIdx.x + 256 * (base + j);
+      if (base + j < PER && (TOT % 256 == 0 || i < TOT)) {
+        const int n = i / CH, ch = i - n * CH;
+        rx[j] = *reinterpret_cast<const bf16x4*>(x + (size_t)n * C + 4 * ch);
+        ru[j] = *reinterpret_cast<const bf16x4*>(u + (size_t)n * C + 4 * ch);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = threadIdx.x + 256 * (base + j);
+      if (base + j < PER && (TOT % 256 == 0 || i < TOT)) {
+        const int n = i / CH, ch = i - n * CH;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)((float)rx[j][r] + f * (float)ru[j][r]);      // the expression of scale_add_vec_kernel
+        *reinterpret_cast<bf16x4*>(dst + n * LD + 4 * ch) = o;
+        *reinterpret_cast<bf16x4*>(out + (size_t)n * C + 4 * ch) = o;
+      }
+    }
+  }
+}
 
 template <int NT, int MT, int CT>
 struct UpLds {
@@ -308,11 +341,16 @@ __device__ __forceinline__ void up_tile(const bf16* Wt, const bf16* Xs, const fl
 
 template <int NT, int MT, int CT>
 __global__ __launch_bounds__(256) void upmix2_fwd_kernel(const bf16* xc, const float* W, const float* bias, const float* gamma, const float* beta,
-                                                         float eps, bf16* y, float* mean_o, float* rstd_o, int B) {
+                                                         float eps, bf16* y, float* mean_o, float* rstd_o, int B, UpFwdAdd fa) {
   using L = UpLds<NT, MT, CT>;
   extern __shared__ __attribute__((aligned(16))) char smraw[];
   bf16* sm = reinterpret_cast<bf16*>(smraw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, q4 = lane >> 4;
+  const bool fa_on = fa.u != nullptr;                          // uniform
+  const float fa_gm = fa_on && fa.gamma ? fa.gamma[0] : 1.f;
+  const bool fa_dp = fa_on && fa.dp_p > 0.f && fa.rng != nullptr;
+  const uint32_t fa_key = fa_dp ? rng_key(fa.rng, fa.dp_site) : 0u;
+  const float fa_inv = fa_dp ? 1.f / (1.f - fa.dp_p) : 1.f;
   up_stage_w<NT, MT, CT>(sm + L::wt, W);
   float ga[CT], be[CT];
 #pragma unroll
@@ -321,7 +359,14 @@ __global__ __launch_bounds__(256) void upmix2_fwd_kernel(const bf16* xc, const f
   bf16* yt = sm + L::dup + wave * 16 * L::LDC;                 // this wave's output tile [16][LDC]
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
-    up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
+    if (fa_on) {
+      float f = fa_gm;
+      if (fa_dp) f *= drop_factor(fa_key, (uint32_t)b, fa.dp_p, fa_inv);
+      const size_t o = (size_t)b * L::M * L::C;
+      stage_rows_scale_add<L::M, L::C, L::LDC>(sm + L::xc, xc + o, fa.u + o, fa.xc_out + o, f);
+    } else {
+      up_stage_xc<NT, MT, CT>(sm + L::xc, xc + (size_t)b * L::M * L::C);
+    }
     __syncthreads();
     for (int nt = wave; nt < NT; nt += 4) {
       f32x4 acc[CT];
@@ -672,7 +717,7 @@ static int up2_bwd_grid(int B, bool parts) {
 template <int NT, int MT, int CT>
 static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, const float* bias, const float* gamma, const float* beta,
                       float eps, void* o0, float* mean, float* rstd, float* dW, float* dbias, float* dgamma, float* dbeta, int B, hipStream_t st,
-                      float* parts = nullptr, const UpScaleAdd* sa = nullptr) {
+                      float* parts = nullptr, const UpScaleAdd* sa = nullptr, const UpFwdAdd* fa = nullptr) {
   using L = UpLds<NT, MT, CT>;
   if (!bwd) {
     const size_t smem = (size_t)(L::fwd_bf16 + 64 * L::LDC) * 2;        // + the four waves' output tiles
@@ -682,7 +727,7 @@ static int up2_launch(bool bwd, const void* a0, const void* xc, const float* W, 
     // each walking its images, pays that once
     static const int fgrid = getenv("QAVIT_UPMIX_FWD_GRID") ? atoi(getenv("QAVIT_UPMIX_FWD_GRID")) : (NT > 4 ? 256 : 2048);
     hipLaunchKernelGGL((upmix2_fwd_kernel<NT, MT, CT>), dim3(B < fgrid ? B : fgrid), dim3(256), smem, st, (const bf16*)xc, W, bias, gamma, beta, eps,
-                       (bf16*)o0, mean, rstd, B);
+                       (bf16*)o0, mean, rstd, B, fa ? *fa : UpFwdAdd{nullptr, nullptr, nullptr, 0.f, 0, nullptr});
     return QAVIT_OK;
   }
   const size_t smem = (size_t)((L::bwd_bf16 + 7) / 8 * 8) * 2 + (size_t)(L::N + 8 * L::C) * 4 +
@@ -708,9 +753,13 @@ int upmix_bf16_try(bool bwd, const void* dy, const void* xc, const float* W, con
   if ((reinterpret_cast<uintptr_t>(xc) & 7) || C != 192) return 0;
   int rc = -100;
   UpScaleAdd sa{(const bf16*)sa_u, (bf16*)sa_du, sa_gamma, sa_dgamma, sa_dp_p, sa_dp_site, sa_rng};
-  if (sa_u && !(N == 64 && M == 16)) return 0;               // the fused scale-add backward exists in the 64-token variant only
-  if (N == 64 && M == 16) rc = up2_launch<4, 1, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, parts, sa_u ? &sa : nullptr);
-  else if (N == 256 && M == 64) rc = up2_launch<16, 4, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, nullptr);
+  UpFwdAdd fa{(const bf16*)sa_u, (bf16*)sa_du, sa_gamma, sa_dp_p, sa_dp_site, sa_rng};     // forward: sa_du = where xc is written
+  const bool fwd_sa = !bwd && sa_u;
+  if (bwd && sa_u && !(N == 64 && M == 16)) return 0;        // the fused scale-add backward exists in the 64-token variant only
+  if (N == 64 && M == 16) rc = up2_launch<4, 1, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, parts,
+                                                    bwd && sa_u ? &sa : nullptr, fwd_sa ? &fa : nullptr);
+  else if (N == 256 && M == 64) rc = up2_launch<16, 4, 12>(bwd, dy, xc, W, bias, gamma, beta, eps, out, mean, rstd, dW, dbias, dgamma, dbeta, B, st, nullptr,
+                                                           nullptr, fwd_sa ? &fa : nullptr);
   if (rc == -100) return 0;
   return rc == QAVIT_OK ? 1 : rc;
 }

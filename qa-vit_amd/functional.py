@@ -427,6 +427,7 @@ class SideStream:
 # ---------------------------------------------------------------------------------------------------
 _FLUSH_SIDE = os.environ.get("QAVIT_FLUSH_SIDE", "1") != "0"    # end of backward: the small reduce / bank launches beside the one-launch weight-gradient kernel
 _DEFER_FIX = os.environ.get("QAVIT_DEFER_NANFIX", "1") != "0"   # fused branches followed by a bank write: the NaN rule's rewrite rides in the bank-statistics launch
+_UPMIX_FWD_SA = os.environ.get("QAVIT_UPMIX_FWD_SA", "1") != "0"   # block tail + up-mix forward: the scale-add formed while the up-mix stages the image
 _LN_LIN = os.environ.get("QAVIT_LN_LIN", "1") != "0"      # narrow LayerNorm-prologue Linears: dX GEMM fused into the LayerNorm-backward kernel
 
 
@@ -1407,7 +1408,7 @@ class UpMixFn(Function):
 
 class UpMixScaleAddFn(Function):
     """TokenUpMix applied to the block tail: y = upmix(x + droppath(gamma * u)) (HQAViT_CIFAR100.py:1085, :1118-1121) as one autograd node.
-    Forward = the scale-add launch + the up-mix launch; backward = ONE launch: the up-mix backward also writes du and dgamma
+    Forward = ONE launch (qavit_upmix_fwd_sa forms xc while it stages the image; else the scale-add launch + the up-mix launch); backward = ONE launch: the up-mix backward also writes du and dgamma
     (qavit_upmix_bwd_sa), where the separate scale-add backward re-read dxc and u from memory once per block."""
 
     @staticmethod
@@ -1418,11 +1419,15 @@ class UpMixScaleAddFn(Function):
         x = x.contiguous()
         u = u.contiguous()
         xc = torch.empty_like(x)
-        K.scale_add_fwd(x, u, None if gamma is None else gamma.detach(), xc, B * M, Cc, dp, rt.rng)
         y = torch.empty(B, N, Cc, dtype=xc.dtype, device=xc.device)
         mean = torch.empty(B * N, dtype=torch.float32, device=xc.device)
         rstd = torch.empty(B * N, dtype=torch.float32, device=xc.device)
-        K.upmix_fwd(xc, W.detach(), bias.detach(), g.detach(), b.detach(), eps, y, mean, rstd, B, N, M, Cc)
+        gm = None if gamma is None else gamma.detach()
+        if _UPMIX_FWD_SA and dp[2] == M and K.upmix_fwd_sa_ok(x, u, N, M, Cc):
+            K.upmix_fwd_sa(x, u, gm, dp, rt.rng, xc, W.detach(), bias.detach(), g.detach(), b.detach(), eps, y, mean, rstd, B, N, M, Cc)
+        else:
+            K.scale_add_fwd(x, u, gm, xc, B * M, Cc, dp, rt.rng)
+            K.upmix_fwd(xc, W.detach(), bias.detach(), g.detach(), b.detach(), eps, y, mean, rstd, B, N, M, Cc)
         ctx.save_for_backward(xc, u, gamma, W, bias, g, b, mean, rstd)
         ctx.dp = dp
         return y

@@ -510,6 +510,19 @@ def upmix_fwd(xc, W, bias, gamma, beta, eps, y, mean, rstd, B, N, M, Cc):
                                      y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, M, Cc, stream()), "upmix_fwd")
 
 
+def upmix_fwd_sa_ok(x, u, N, M, Cc) -> bool:
+    return (bool(L.load().qavit_upmix_fwd_sa_supported(dt_code(x.dtype), N, M, Cc)) and x.data_ptr() % 8 == 0 and u.data_ptr() % 8 == 0
+            and x.dtype == u.dtype)
+
+
+def upmix_fwd_sa(x, u, sa_gamma, dp, rng, xc, W, bias, gamma, beta, eps, y, mean, rstd, B, N, M, Cc):
+    """xc = x + droppath(sa_gamma * u) and y = upmix(xc) in one launch (qavit_upmix_fwd_sa; check upmix_fwd_sa_ok first).
+    dp = (dp_p, dp_site, rows_per_sample) with rows_per_sample == M (samples = images)."""
+    L.check(L.load().qavit_upmix_fwd_sa(dt_code(x.dtype), x.data_ptr(), u.data_ptr(), _p(sa_gamma), float(dp[0]), int(dp[1]),
+                                        _p(rng) if dp[0] > 0.0 else None, xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                                        beta.data_ptr(), eps, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, M, Cc, stream()), "upmix_fwd_sa")
+
+
 def upmix_bwd_sa_ok(xc, N, M, Cc) -> bool:
     return bool(L.load().qavit_upmix_bwd_sa_supported(dt_code(xc.dtype), N, M, Cc)) and xc.data_ptr() % 8 == 0
 

@@ -191,6 +191,8 @@ _SIGS = {
     "qavit_upmix_bwd_p": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "qavit_upmix_bwd_parts": (i32, [i32, i32, i32, i32, i32]),
     "qavit_upmix_bwd_sa_supported": (i32, [i32, i32, i32, i32]),
+    "qavit_upmix_fwd_sa_supported": (i32, [i32, i32, i32, i32]),
+    "qavit_upmix_fwd_sa": (i32, [i32, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_upmix_bwd_sa": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, i32, vp, vp]),
     "qavit_gather_pool_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_gather_pool_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -281,14 +281,15 @@ def _drop_setup(drop, G, H, Nq, NK):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B", [5, 700])
-def test_upmix_with_the_block_tail_scale_add(F, Q, dtype, B):
-    """UpMixScaleAddFn = TokenUpMix(x + droppath(gamma * u)) as one node whose backward (bf16, 64 -> 16 tokens) is ONE launch that also
+@pytest.mark.parametrize("B,N,M", [(5, 64, 16), (700, 64, 16), (300, 256, 64)])
+def test_upmix_with_the_block_tail_scale_add(F, Q, dtype, B, N, M):
+    """UpMixScaleAddFn = TokenUpMix(x + droppath(gamma * u)) as one node.  bf16: its forward is ONE launch that forms xc while it stages
+    the image (qavit_upmix_fwd_sa, both token shapes: y bit-equal to the two launches), its backward (64 -> 16 tokens) ONE launch that also
     writes du and dgamma (qavit_upmix_bwd_sa): against the two separate nodes (ScaleAddFn, then UpMixFn) on the same inputs and masks."""
     import importlib
     K = importlib.import_module("qa-vit_amd.kernels")
     rt = K.Runtime.get(0)
-    N, M, C = 64, 16, 192
+    C = 192
     x0, u0 = leaf(B, M, C, seed=71), leaf(B, M, C, seed=72)
     W, bias = leaf(N, M, scale=0.3, seed=73), leaf(N, scale=0.1, seed=74)
     g_, be = leaf(C, scale=0.1, seed=75), leaf(C, scale=0.1, seed=76)
@@ -313,6 +314,9 @@ def test_upmix_with_the_block_tail_scale_add(F, Q, dtype, B):
     for name, a_, b_ in zip(("y", "dx", "du", "dgamma", "dW", "dbias", "dg", "db"), res[0], res[1]):
         assert rel(a_, b_) <= (2e-5 if dtype == torch.float32 else 4e-3), name
     assert float(res[0][2].abs().max()) > 0 and float(res[0][3].abs().max()) > 0
+    if dtype == torch.bfloat16:
+        assert K.upmix_fwd_sa_ok(x, u, N, M, C)
+        assert torch.equal(res[0][0], res[1][0])               # same arithmetic, same rounding points
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
