@@ -110,7 +110,8 @@ int qavit_gemm_tn_grouped(const qavit_gemm_tn_args* a, int n, void* stream);
 /* The same with `ws_bytes` >= qavit_gemm_tn_ws_bytes() of 16-byte-aligned device scratch that belongs to this call until its launches
  * have run: a tile class with more problems than one launch carries by value (24) is then ONE launch over a device-side problem
  * table (filled by small writer launches on `stream`) instead of one launch per 24 -- fewer workgroups per problem, fewer fp32-atomic
- * tile flushes.  ws = NULL: as qavit_gemm_tn_grouped. */
+ * tile flushes.  ws = NULL: as qavit_gemm_tn_grouped.  While `stream` is being captured the table is filled by copy nodes from a pinned
+ * host image of the library's own (kept for the life of the process: every replay of the graph reads it) instead of writer launches. */
 int qavit_gemm_tn_grouped_ws(const qavit_gemm_tn_args* a, int n, void* ws, size_t ws_bytes, void* stream);
 size_t qavit_gemm_tn_ws_bytes(void);
 

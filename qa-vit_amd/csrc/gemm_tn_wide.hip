@@ -534,6 +534,24 @@ int uni_k_class(int k) {                 // 64-column units of the K-side tile (
 }
 
 // every wide-eligible problem of the list in one launch through the table in `ws`; returns the number of problems it took
+// Under stream capture the table is ONE copy node from a pinned host image instead of ceil(n / 28) writer launches (~6 us each, in front
+// of the one big launch at the very end of the step).  A captured graph reads the image at every replay, so an image is never reused or
+// freed; they come from a small pool allocated on a NON-capturing call (the eager warm-up steps every capture is preceded by) -- pinned
+// allocation is not legal while a capture is open -- and a capture that finds the pool empty takes the writer launches.
+constexpr int TNU_HOST_IMAGES = 16;
+struct TnuHostPool { TnuTable* img[TNU_HOST_IMAGES]; int n, used; bool tried; };
+static TnuHostPool& tnu_pool() { static TnuHostPool p{{}, 0, 0, false}; return p; }
+static void tnu_pool_fill() {
+  TnuHostPool& p = tnu_pool();
+  if (p.tried) return;
+  p.tried = true;
+  for (int i = 0; i < TNU_HOST_IMAGES; ++i) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, sizeof(TnuTable), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); break; }
+    p.img[p.n++] = reinterpret_cast<TnuTable*>(h);
+  }
+}
+
 int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
   static int off = -1;
   if (off < 0) { const char* e = getenv("QAVIT_TN_CLASS_LAUNCHES"); off = e ? atoi(e) : 0; }
@@ -542,12 +560,25 @@ int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
   for (int i = 0; i < n; ++i) cnt += gemm_tn_wide_ok(a[i]) ? 1 : 0;
   if (cnt < 2 || cnt > TNU_MAX) return 0;
   TnuTable* T = reinterpret_cast<TnuTable*>(ws);
+  static int host_img = -1;
+  if (host_img < 0) { const char* e = getenv("QAVIT_TN_HOST_TABLE"); host_img = e ? atoi(e) : 1; }
+  hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap_st) != hipSuccess) { (void)hipGetLastError(); cap_st = hipStreamCaptureStatusNone; }
+  const bool capturing = cap_st == hipStreamCaptureStatusActive;
+  if (host_img && !capturing) tnu_pool_fill();
+  TnuTable* H = nullptr;
+  if (host_img && capturing && tnu_pool().used < tnu_pool().n) H = tnu_pool().img[tnu_pool().used];
   TnuWrite W;
   W.n = 0; W.off = 0;
   int cost = 0, done = 0;
   auto flush = [&]() {
     W.cost_start[W.n] = cost;
-    hipLaunchKernelGGL(tnu_table_write_kernel, dim3(1), dim3(64), 0, st, W, T);
+    if (H) {
+      for (int i = 0; i < W.n; ++i) H->e[W.off + i] = W.e[i];
+      for (int i = 0; i <= W.n; ++i) H->cost_start[W.off + i] = W.cost_start[i];
+    } else {
+      hipLaunchKernelGGL(tnu_table_write_kernel, dim3(1), dim3(64), 0, st, W, T);
+    }
     W.off += W.n; W.n = 0;
   };
   for (int i = 0; i < n; ++i) {
@@ -569,6 +600,13 @@ int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
     if (++W.n == TNU_PER_WRITE && done < cnt) flush();
   }
   flush();
+  if (H) {
+    // cost_start[0 .. cnt] and e[0 .. cnt) are all the kernel reads: two copy nodes (the arrays are 2 KB apart in the image when cnt is small)
+    if (hipMemcpyAsync(T->cost_start, H->cost_start, sizeof(int) * (size_t)(cnt + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(T->e, H->e, sizeof(TnuEntry) * (size_t)cnt, hipMemcpyHostToDevice, st) != hipSuccess)
+      return set_error(QAVIT_ELAUNCH, "gemm_tn: copy node of the problem table");
+    ++tnu_pool().used;
+  }
   int wgs = resident_wgs(4);
   static int cap = -1;                                  // QAVIT_TN_WGS: fewer workgroups than CUs (a launch that runs BESIDE other work)
   if (cap < 0) { const char* e = getenv("QAVIT_TN_WGS"); cap = e ? atoi(e) : 0; }
@@ -589,7 +627,11 @@ int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
 
 int gemm_tn_wide(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
   static const int ncls[5] = {1, 2, 4, 6, 8}, kcls[6] = {1, 2, 3, 4, 6, 8};
-  if (gemm_tn_uni(a, n, st, ws) > 0) return check_launch("gemm_tn(one launch)");
+  {
+    const int rc = gemm_tn_uni(a, n, st, ws);
+    if (rc > 0) return check_launch("gemm_tn(one launch)");
+    if (rc < -1) return rc;
+  }
   const qavit_gemm_tn_args* sel[256];
   // without a workspace (or with QAVIT_TN_CLASS_LAUNCHES=1): one launch per tile class and 24 problems
   for (int ci = 0; ci < 5; ++ci)

@@ -264,6 +264,7 @@ def test_train_step_with_dropout_vs_oracle(Q, oracle):
     B = 24
     x = torch.randn(B, 3, 32, 32, generator=g)
     y = torch.randint(0, 100, (B,), generator=g)
+    K.Runtime.get(0).seed(20240521)          # the masks (and with them the bf16 noise of the near-zero gradients below) must not depend on which tests ran before
     seed, step = [int(v) for v in K.Runtime.get(0).rng.tolist()]
 
     mdl = Q.HQAViT(cfg).cuda().train()       # ONE module for both precisions: dropout sites are per-module ids handed out at construction
@@ -319,8 +320,10 @@ def test_train_step_with_dropout_vs_oracle(Q, oracle):
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
         ratio = float(a.norm() / b.norm())
         lo, hi = (0.4, 2.5) if a.numel() <= 2 else (0.9, 1.1)
-        if cos < 0.97 or not (lo <= ratio <= hi):
-            bad.append((n, round(cos, 4), round(ratio, 4)))
+        # gradients a few 1e-4 of the largest one are sums with heavy cancellation (a scalar layer scale: 73 k terms): the bf16 rounding of
+        # the terms is an ABSOLUTE floor of ~1e-3 * scale under them, whatever their own size
+        if (cos < 0.97 or not (lo <= ratio <= hi)) and float((a - b).norm()) > 1e-3 * scale:
+            bad.append((n, round(cos, 4), round(ratio, 4), float(a.norm()), float(b.norm()), scale))
     assert not bad, bad[:8]
 
 
