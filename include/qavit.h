@@ -142,6 +142,31 @@ int qavit_layernorm_bwd_parts(int rows, int C);
  * HQAViT_CIFAR100.py:985-990): dx = LN_backward(dz . W) + dres, with dz [rows, KZ] (leading dimension ldz) the gradient of the Linear's
  * output and W [KZ, C] (ldw) its weight in the compute dtype; the [rows, C] product never exists in memory.  bf16, KZ = 16, C % 4 == 0,
  * C <= 256 (qavit_layernorm_bwd_lin_supported); dgamma / dbeta / part_ws as in qavit_layernorm_bwd, same partial-row count. */
+/* SplitFusion's closing pair as one launch each way (HQAViT_CIFAR100.py:953-965): mixed = s0*a + s1*(t + dropout(h)), s = softmax(fw[0:2]);
+ * y = LayerNorm(mixed).  fwd writes `mixed` [rows, C] (the backward's LayerNorm input), y, mean, rstd.  bwd takes dy and writes da, dt, dh,
+ * adds the blend-weight gradient to dfw[0:2] (float atomics, one pair per workgroup; may be NULL) and the LayerNorm parameter gradients
+ * to dgamma / dbeta -- or, with part_ws = float[qavit_mix3_ln_bwd_parts(rows, C)][2][C], leaves them as partial rows in the layout of
+ * qavit_layernorm_bwd's.  Values and rounding points are those of qavit_mix3_fwd / qavit_layernorm_fwd (resp. qavit_layernorm_bwd / qavit_mix3_bwd) run
+ * one after the other.  fp32 / bf16, C % 4 == 0, C <= 256 (qavit_mix3_ln_supported), rows * C < 2^32, vector-aligned operands. */
+int qavit_mix3_ln_supported(int dtype, int C);
+int qavit_mix3_ln_bwd_parts(int rows, int C);
+int qavit_mix3_ln_fwd(int dtype, const void* a, const void* t, const void* h, const float* fw, float drop_p, int drop_site, const int64_t* rng,
+                      void* mixed, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int rows, int C,
+                      void* stream);
+int qavit_mix3_ln_bwd(int dtype, const void* dy, const void* a, const void* t, const void* h, const float* fw, float drop_p, int drop_site,
+                      const int64_t* rng, const void* mixed, const float* gamma, const float* mean, const float* rstd, void* da, void* dt,
+                      void* dh, float* dfw, float* dgamma, float* dbeta, int rows, int C, float* part_ws, void* stream);
+/* The same pair with SplitFusion's GATE in front of it (HQAViT_CIFAR100.py:945-965): a = t + sigmoid(g) * r is formed in registers (rounded
+ * where qavit_gate_mix_fwd stored it) instead of read, so the forward is one launch for gate + blend + norm and `a` never exists in
+ * memory.  bwd writes ONE gradient for t (the gate's pass-through s0 * dm plus the blend's s1 * dm, each rounded as the separate launches
+ * round them, then summed), dr and dg (qavit_gate_mix_bwd's), dh, and the parameter gradients as above. */
+int qavit_gate_mix3_ln_fwd(int dtype, const void* t, const void* r, const void* g, const void* h, const float* fw, float drop_p, int drop_site,
+                           const int64_t* rng, void* mixed, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                           int rows, int C, void* stream);
+int qavit_gate_mix3_ln_bwd(int dtype, const void* dy, const void* t, const void* r, const void* g, const void* h, const float* fw, float drop_p,
+                           int drop_site, const int64_t* rng, const void* mixed, const float* gamma, const float* mean, const float* rstd,
+                           void* dt, void* dr, void* dg, void* dh, float* dfw, float* dgamma, float* dbeta, int rows, int C, float* part_ws,
+                           void* stream);
 /* LayerNorm backward whose incoming gradient is the SUM of n_dy (1..5) same-shape tensors -- the k gradients of a normalised tensor
  * that feeds several consumers (norm1's output and the four attention branches, HQAViT_CIFAR100.py:1072-1078) -- summed in fp32 on load
  * instead of by a k-way sum launch.  `dy` is a HOST array of device pointers.  C % 4 == 0, C <= 256, vector-aligned operands; dres /

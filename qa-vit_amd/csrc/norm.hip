@@ -423,6 +423,227 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_v4_multi_kernel(LnBwd4 
                                        reinterpret_cast<T*>(P.dx[i]), P.dgamma[i], P.dbeta[i], rows, C, nullptr, 0, nullptr, P.parts[i]);
 }
 
+// SplitFusion's closing pair, blend then LayerNorm (HQAViT_CIFAR100.py:953-965): mixed = s0*a + s1*(t + dropout(h)), s = softmax(fw);
+// y = LayerNorm(mixed).  One launch each way instead of two: the forward forms `mixed` while it loads the row (and writes it for the
+// backward), the backward turns the LayerNorm input gradient into (da, dt, dh) and the two blend-weight sums in the registers that hold
+// it.  Arithmetic and rounding points are those of mix3_vec_kernel (csrc/runtime.hip) followed by the LayerNorm kernels above -- the
+// gradient of `mixed` is rounded to T where the two-launch chain stored it.
+// GATED (r, g given; a, da unused): the gate in front of the blend is formed in the same registers -- a = t + sigmoid(g) * r
+// (HQAViT_CIFAR100.py:945-949, rounded to T where gate_mix_kernel stored it) -- so `a` is never written, and the backward returns ONE gradient
+// for t (the gate's pass-through da plus the blend's dt: the two are s0 * dm and s1 * dm of the same dm) next to dr, dg, dh.
+struct LnMix3 {
+  const void* a; const void* t; const void* h; const float* fw; void* mixed;      // forward: mixed is written; backward: read (the LayerNorm input)
+  void* da; void* dt; void* dh; float* dfw;
+  float p; int site; const int64_t* rng;
+  const void* r; const void* g; void* dr; void* dg;
+};
+__device__ __forceinline__ void softmax2(const float* fw, float& w0, float& w1) {
+  const float mx = fmaxf(fw[0], fw[1]);
+  const float e0 = __expf(fw[0] - mx), e1 = __expf(fw[1] - mx), s = e0 + e1;
+  w0 = e0 / s; w1 = e1 / s;
+}
+
+template <typename T, int RB, int NW, bool GATED = false>
+__global__ __launch_bounds__(64 * NW) void mix3_ln_fwd_kernel(LnMix3 mx, T* y, const float* gamma, const float* beta, float eps, int rows, int C,
+                                                              float* mean_o, float* rstd_o) {
+  typedef typename V4<T>::type v4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  const int c = 4 * lane;
+  const bool cl = c < C;
+  float w0, w1;
+  softmax2(mx.fw, w0, w1);
+  const uint32_t key = mx.p > 0.f ? rng_key(mx.rng, mx.site) : 0u;
+  const float inv = mx.p > 0.f ? 1.f / (1.f - mx.p) : 1.f;
+  const T* a = reinterpret_cast<const T*>(mx.a);
+  const T* t = reinterpret_cast<const T*>(mx.t);
+  const T* h = reinterpret_cast<const T*>(mx.h);
+  T* mo = reinterpret_cast<T*>(mx.mixed);
+  float gm[4], bt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { gm[j] = (c + j < C) ? gamma[c + j] : 0.f; bt[j] = (c + j < C) ? beta[c + j] : 0.f; }
+  for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
+    v4 av[RB], tv[RB], hv[RB], gv[GATED ? RB : 1];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int row = row0 + r < rows ? row0 + r : rows - 1;
+      if (cl) {
+        if (GATED) {
+          av[r] = *reinterpret_cast<const v4*>(reinterpret_cast<const T*>(mx.r) + (size_t)row * C + c);
+          gv[r] = *reinterpret_cast<const v4*>(reinterpret_cast<const T*>(mx.g) + (size_t)row * C + c);
+        } else {
+          av[r] = *reinterpret_cast<const v4*>(a + (size_t)row * C + c);
+        }
+        tv[r] = *reinterpret_cast<const v4*>(t + (size_t)row * C + c);
+        hv[r] = *reinterpret_cast<const v4*>(h + (size_t)row * C + c);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const bool live = row0 + r < rows;
+      const int row = live ? row0 + r : rows - 1;
+      float v[4];
+      v4 m;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cl) {
+          const float f = mx.p > 0.f ? drop_factor(key, (uint32_t)row * (uint32_t)C + (uint32_t)(c + j), mx.p, inv) : 1.f;
+          const float b = to_f<T>(from_f<T>(to_f<T>(tv[r][j]) + to_f<T>(from_f<T>(to_f<T>(hv[r][j]) * f))));
+          float aj = to_f<T>(av[r][j]);
+          if (GATED) {
+            const float sg = 1.f / (1.f + __expf(-to_f<T>(gv[r][j])));
+            aj = to_f<T>(from_f<T>(to_f<T>(tv[r][j]) + sg * aj));
+          }
+          m[j] = from_f<T>(w0 * aj + w1 * b);
+          v[j] = to_f<T>(m[j]);
+        } else v[j] = 0.f;
+        s += v[j];
+      }
+      const float mean = wave_sum(s) * invC;
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float dlt = cl ? v[j] - mean : 0.f; s2 += dlt * dlt; }
+      const float rstd = rsqrtf(wave_sum(s2) * invC + eps);
+      if (!live) continue;                                  // uniform per wave
+      if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+      if (cl) {
+        *reinterpret_cast<v4*>(mo + (size_t)row * C + c) = m;
+        v4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = from_f<T>((v[j] - mean) * rstd * gm[j] + bt[j]);
+        *reinterpret_cast<v4*>(y + (size_t)row * C + c) = o;
+      }
+    }
+  }
+}
+
+template <typename T, int RB, int NW, bool GATED = false>
+__global__ __launch_bounds__(64 * NW) void mix3_ln_bwd_kernel(const T* dy, LnMix3 mx, const float* gamma, const float* mean, const float* rstd,
+                                                              float* dgamma, float* dbeta, int rows, int C, float* parts) {
+  typedef typename V4<T>::type v4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invC = 1.f / (float)C;
+  const int c = 4 * lane;
+  const bool cl = c < C;
+  float w0, w1;
+  softmax2(mx.fw, w0, w1);
+  const uint32_t key = mx.p > 0.f ? rng_key(mx.rng, mx.site) : 0u;
+  const float inv = mx.p > 0.f ? 1.f / (1.f - mx.p) : 1.f;
+  const T* a = reinterpret_cast<const T*>(mx.a);
+  const T* t = reinterpret_cast<const T*>(mx.t);
+  const T* h = reinterpret_cast<const T*>(mx.h);
+  const T* x = reinterpret_cast<const T*>(mx.mixed);
+  T* da = reinterpret_cast<T*>(mx.da);
+  T* dt = reinterpret_cast<T*>(mx.dt);
+  T* dh = reinterpret_cast<T*>(mx.dh);
+  float pg[4], pb[4], gm[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { pg[j] = 0.f; pb[j] = 0.f; gm[j] = (c + j < C) ? gamma[c + j] : 0.f; }
+  float p0 = 0.f, p1 = 0.f;
+  for (int row0 = (blockIdx.x * NW + wave) * RB; row0 < rows; row0 += gridDim.x * NW * RB) {
+    v4 xv[RB], dv[RB], av[RB], tv[RB], hv[RB], gv[GATED ? RB : 1];
+    float mu[RB], rs[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int row = row0 + r < rows ? row0 + r : rows - 1;       // clamp: tail rows are loaded twice, stored once
+      mu[r] = mean[row]; rs[r] = rstd[row];
+      if (cl) {
+        xv[r] = *reinterpret_cast<const v4*>(x + (size_t)row * C + c);
+        dv[r] = *reinterpret_cast<const v4*>(dy + (size_t)row * C + c);
+        if (GATED) {
+          av[r] = *reinterpret_cast<const v4*>(reinterpret_cast<const T*>(mx.r) + (size_t)row * C + c);
+          gv[r] = *reinterpret_cast<const v4*>(reinterpret_cast<const T*>(mx.g) + (size_t)row * C + c);
+        } else {
+          av[r] = *reinterpret_cast<const v4*>(a + (size_t)row * C + c);
+        }
+        tv[r] = *reinterpret_cast<const v4*>(t + (size_t)row * C + c);
+        hv[r] = *reinterpret_cast<const v4*>(h + (size_t)row * C + c);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const bool live = row0 + r < rows;
+      const int row = live ? row0 + r : rows - 1;
+      float xh[4], g[4];
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cl) {
+          const float d = live ? to_f<T>(dv[r][j]) : 0.f;
+          xh[j] = (to_f<T>(xv[r][j]) - mu[r]) * rs[r];
+          g[j] = d * gm[j];
+          pg[j] += d * xh[j];
+          pb[j] += d;
+          c1 += g[j] * xh[j];
+          c2 += g[j];
+        } else { xh[j] = 0.f; g[j] = 0.f; }
+      }
+      c1 = wave_sum(c1) * invC;
+      c2 = wave_sum(c2) * invC;
+      if (live && cl) {
+        v4 x0, x1, x2, x3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gmix = to_f<T>(from_f<T>(rs[r] * (g[j] - c2 - xh[j] * c1)));      // d(mixed), rounded where the LayerNorm-backward launch stored it
+          const float f = mx.p > 0.f ? drop_factor(key, (uint32_t)row * (uint32_t)C + (uint32_t)(c + j), mx.p, inv) : 1.f;
+          const float b = to_f<T>(from_f<T>(to_f<T>(tv[r][j]) + to_f<T>(from_f<T>(to_f<T>(hv[r][j]) * f))));
+          x0[j] = from_f<T>(gmix * w0);
+          x1[j] = from_f<T>(gmix * w1);
+          x2[j] = from_f<T>(to_f<T>(x1[j]) * f);
+          float aj = to_f<T>(av[r][j]);
+          if (GATED) {                                        // gate_mix_kernel's backward on dy = da (x0), and the one gradient of t
+            const float rj = aj, sg = 1.f / (1.f + __expf(-to_f<T>(gv[r][j]))), d = to_f<T>(x0[j]);
+            aj = to_f<T>(from_f<T>(to_f<T>(tv[r][j]) + sg * rj));
+            x1[j] = from_f<T>(d + to_f<T>(x1[j]));
+            x0[j] = from_f<T>(d * sg);
+            x3[j] = from_f<T>(d * rj * sg * (1.f - sg));
+          }
+          p0 += gmix * aj; p1 += gmix * b;
+        }
+        if (GATED) {
+          *reinterpret_cast<v4*>(reinterpret_cast<T*>(mx.dr) + (size_t)row * C + c) = x0;
+          *reinterpret_cast<v4*>(reinterpret_cast<T*>(mx.dg) + (size_t)row * C + c) = x3;
+        } else {
+          *reinterpret_cast<v4*>(da + (size_t)row * C + c) = x0;
+        }
+        *reinterpret_cast<v4*>(dt + (size_t)row * C + c) = x1;
+        *reinterpret_cast<v4*>(dh + (size_t)row * C + c) = x2;
+      }
+    }
+  }
+  __shared__ float red[2][NW][256];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][wave][4 * lane + j] = pg[j]; red[1][wave][4 * lane + j] = pb[j]; }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 512; q += 64 * NW) {            // 256 channels x {gamma, beta}
+    const int which = q >> 8, cc = q & 255;
+    float* dst = which ? dbeta : dgamma;
+    if (cc < C && (dst || parts)) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sacc += red[which][w][cc];
+      if (parts) parts[((size_t)blockIdx.x * 2 + which) * C + cc] = sacc;      // the partial-row layout of layernorm_bwd_v4_body
+      else atomic_add_f(dst + cc, sacc);
+    }
+  }
+  if (mx.dfw) {                                              // the blend weights through their softmax: one pair of atomics per workgroup
+    __syncthreads();
+    const float s0 = wave_sum(p0), s1 = wave_sum(p1);
+    if (lane == 0) { red[0][wave][0] = s0; red[1][wave][0] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { d0 += red[0][w][0]; d1 += red[1][w][0]; }
+      const float dot = d0 * w0 + d1 * w1;
+      atomic_add_f(mx.dfw + 0, w0 * (d0 - dot));
+      atomic_add_f(mx.dfw + 1, w1 * (d1 - dot));
+    }
+  }
+}
+
 // LayerNorm backward of a LayerNorm-prologue Linear with a NARROW output (TokenLearner's score Linear: 192 -> 16), fused with that
 // Linear's input-gradient GEMM: dxn[row][c] = sum_k dz[row][k] W[k][c] is a 16-deep dot product per element, cheaper to redo in the
 // registers of the thread that owns (row, c) than to write a [rows, C] matrix from a GEMM launch and read it back here
@@ -647,6 +868,99 @@ extern "C" int qavit_layernorm_bwd_sum(int dtype, int n_dy, const void* const* d
     hipLaunchKernelGGL((layernorm_bwd_sum_kernel<bf16, 1, 2, NW>), dim3(grid), dim3(64 * NW), 0, st, (const bf16*)dy[0], ex, (const bf16*)x, gamma, mean, rstd,
                        (bf16*)dx, dgamma, dbeta, rows, C, (const bf16*)dres, part_ws);
   return check_launch("layernorm_bwd_sum");
+}
+
+extern "C" int qavit_mix3_ln_supported(int dtype, int C) { return (dtype == QAVIT_BF16 || dtype == QAVIT_F32) && C % 4 == 0 && C <= 256; }
+
+static int mix3_ln_check(const char* what, int dtype, int rows, int C, float drop_p, const int64_t* rng, uintptr_t al, const float* part_ws) {
+  if (!qavit_mix3_ln_supported(dtype, C)) return set_error(QAVIT_EINVAL, "mix3_ln: fp32 / bf16, C % 4 == 0, C <= 256");
+  if (rows <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !rng)) return set_error(QAVIT_EINVAL, what);
+  if ((int64_t)rows * C > 0xffffffffll) return set_error(QAVIT_EINVAL, "mix3_ln: the dropout index is 32 bits");
+  const size_t esz = dtype == QAVIT_F32 ? 4 : 2;
+  if (al % (4 * esz) || (part_ws && (reinterpret_cast<uintptr_t>(part_ws) & 15))) return set_error(QAVIT_EINVAL, "mix3_ln: vector-aligned operands");
+  return QAVIT_OK;
+}
+
+static int mix3_ln_fwd_launch(int dtype, const LnMix3& mx, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int rows, int C,
+                              hipStream_t st, bool gated) {
+  constexpr int NW = 4, RB = 4;
+  int grid = (rows + NW * RB - 1) / (NW * RB);
+  if (grid > 2048) grid = 2048;
+#define MLF(T_, G_) hipLaunchKernelGGL((mix3_ln_fwd_kernel<T_, RB, NW, G_>), dim3(grid), dim3(64 * NW), 0, st, mx, (T_*)y, gamma, beta, eps, rows, C, mean, rstd)
+  if (dtype == QAVIT_F32) { if (gated) MLF(float, true); else MLF(float, false); }
+  else { if (gated) MLF(bf16, true); else MLF(bf16, false); }
+#undef MLF
+  return check_launch("mix3_ln_fwd");
+}
+
+// partial rows of the backward (the LayerNorm parameter gradients): 8 waves x 4 rows (fp32: 2) per workgroup and pass, two workgroups per CU
+extern "C" int qavit_mix3_ln_bwd_parts(int rows, int C) {
+  (void)C;
+  int grid = (rows + 31) / 32;
+  if (grid > 512) grid = 512;
+  return grid < 1 ? 1 : grid;
+}
+
+static int mix3_ln_bwd_launch(int dtype, const void* dy, const LnMix3& mx, const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                              int rows, int C, float* part_ws, hipStream_t st, bool gated) {
+  constexpr int NW = 8;
+  const int grid = qavit_mix3_ln_bwd_parts(rows, C);
+#define MLB(T_, RB_, G_) hipLaunchKernelGGL((mix3_ln_bwd_kernel<T_, RB_, NW, G_>), dim3(grid), dim3(64 * NW), 0, st, (const T_*)dy, mx, gamma, mean, rstd, dgamma, dbeta, rows, C, part_ws)
+  if (dtype == QAVIT_F32) { if (gated) MLB(float, 2, true); else MLB(float, 2, false); }
+  else { if (gated) MLB(bf16, 2, true); else MLB(bf16, 4, false); }
+#undef MLB
+  return check_launch("mix3_ln_bwd");
+}
+
+extern "C" int qavit_mix3_ln_fwd(int dtype, const void* a, const void* t, const void* h, const float* fw, float drop_p, int drop_site, const int64_t* rng,
+                                 void* mixed, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int rows, int C,
+                                 void* stream) {
+  if (!a || !t || !h || !fw || !mixed || !gamma || !beta || !y || !mean || !rstd) return set_error(QAVIT_EINVAL, "mix3_ln_fwd: bad arguments");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(mixed) |
+                       reinterpret_cast<uintptr_t>(y);
+  const int rc = mix3_ln_check("mix3_ln_fwd: bad arguments", dtype, rows, C, drop_p, rng, al, nullptr);
+  if (rc) return rc;
+  LnMix3 mx{a, t, h, fw, mixed, nullptr, nullptr, nullptr, nullptr, drop_p, drop_site, rng, nullptr, nullptr, nullptr, nullptr};
+  return mix3_ln_fwd_launch(dtype, mx, gamma, beta, eps, y, mean, rstd, rows, C, reinterpret_cast<hipStream_t>(stream), false);
+}
+
+extern "C" int qavit_mix3_ln_bwd(int dtype, const void* dy, const void* a, const void* t, const void* h, const float* fw, float drop_p, int drop_site,
+                                 const int64_t* rng, const void* mixed, const float* gamma, const float* mean, const float* rstd, void* da, void* dt,
+                                 void* dh, float* dfw, float* dgamma, float* dbeta, int rows, int C, float* part_ws, void* stream) {
+  if (!dy || !a || !t || !h || !fw || !mixed || !gamma || !mean || !rstd || !da || !dt || !dh) return set_error(QAVIT_EINVAL, "mix3_ln_bwd: bad arguments");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(h) |
+                       reinterpret_cast<uintptr_t>(mixed) | reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(dt) | reinterpret_cast<uintptr_t>(dh);
+  const int rc = mix3_ln_check("mix3_ln_bwd: bad arguments", dtype, rows, C, drop_p, rng, al, part_ws);
+  if (rc) return rc;
+  LnMix3 mx{a, t, h, fw, const_cast<void*>(mixed), da, dt, dh, dfw, drop_p, drop_site, rng, nullptr, nullptr, nullptr, nullptr};
+  return mix3_ln_bwd_launch(dtype, dy, mx, gamma, mean, rstd, dgamma, dbeta, rows, C, part_ws, reinterpret_cast<hipStream_t>(stream), false);
+}
+
+extern "C" int qavit_gate_mix3_ln_fwd(int dtype, const void* t, const void* r, const void* g, const void* h, const float* fw, float drop_p, int drop_site,
+                                      const int64_t* rng, void* mixed, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                                      int rows, int C, void* stream) {
+  if (!t || !r || !g || !h || !fw || !mixed || !gamma || !beta || !y || !mean || !rstd) return set_error(QAVIT_EINVAL, "gate_mix3_ln_fwd: bad arguments");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(h) |
+                       reinterpret_cast<uintptr_t>(mixed) | reinterpret_cast<uintptr_t>(y);
+  const int rc = mix3_ln_check("gate_mix3_ln_fwd: bad arguments", dtype, rows, C, drop_p, rng, al, nullptr);
+  if (rc) return rc;
+  LnMix3 mx{nullptr, t, h, fw, mixed, nullptr, nullptr, nullptr, nullptr, drop_p, drop_site, rng, r, g, nullptr, nullptr};
+  return mix3_ln_fwd_launch(dtype, mx, gamma, beta, eps, y, mean, rstd, rows, C, reinterpret_cast<hipStream_t>(stream), true);
+}
+
+extern "C" int qavit_gate_mix3_ln_bwd(int dtype, const void* dy, const void* t, const void* r, const void* g, const void* h, const float* fw, float drop_p,
+                                      int drop_site, const int64_t* rng, const void* mixed, const float* gamma, const float* mean, const float* rstd,
+                                      void* dt, void* dr, void* dg, void* dh, float* dfw, float* dgamma, float* dbeta, int rows, int C, float* part_ws,
+                                      void* stream) {
+  if (!dy || !t || !r || !g || !h || !fw || !mixed || !gamma || !mean || !rstd || !dt || !dr || !dg || !dh)
+    return set_error(QAVIT_EINVAL, "gate_mix3_ln_bwd: bad arguments");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(g) |
+                       reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(mixed) | reinterpret_cast<uintptr_t>(dt) | reinterpret_cast<uintptr_t>(dr) |
+                       reinterpret_cast<uintptr_t>(dg) | reinterpret_cast<uintptr_t>(dh);
+  const int rc = mix3_ln_check("gate_mix3_ln_bwd: bad arguments", dtype, rows, C, drop_p, rng, al, part_ws);
+  if (rc) return rc;
+  LnMix3 mx{nullptr, t, h, fw, const_cast<void*>(mixed), nullptr, dt, dh, dfw, drop_p, drop_site, rng, r, g, dr, dg};
+  return mix3_ln_bwd_launch(dtype, dy, mx, gamma, mean, rstd, dgamma, dbeta, rows, C, part_ws, reinterpret_cast<hipStream_t>(stream), true);
 }
 
 extern "C" int qavit_layernorm_bwd_lin_supported(int dtype, int KZ, int C) { return dtype == QAVIT_BF16 && KZ == 16 && C % 4 == 0 && C <= 256; }

@@ -428,6 +428,8 @@ class SideStream:
 _FLUSH_SIDE = os.environ.get("QAVIT_FLUSH_SIDE", "1") != "0"    # end of backward: the small reduce / bank launches beside the one-launch weight-gradient kernel
 _DEFER_FIX = os.environ.get("QAVIT_DEFER_NANFIX", "1") != "0"   # fused branches followed by a bank write: the NaN rule's rewrite rides in the bank-statistics launch
 _UPMIX_FWD_SA = os.environ.get("QAVIT_UPMIX_FWD_SA", "1") != "0"   # block tail + up-mix forward: the scale-add formed while the up-mix stages the image
+MIX3_LN = os.environ.get("QAVIT_MIX3_LN", "1") != "0"     # SplitFusion: blend + final LayerNorm as one launch each way
+GATE_MIX3_LN = os.environ.get("QAVIT_GATE_MIX3_LN", "1") != "0"   # ... and the gate in front of the blend with them
 _LN_LIN = os.environ.get("QAVIT_LN_LIN", "1") != "0"      # narrow LayerNorm-prologue Linears: dX GEMM fused into the LayerNorm-backward kernel
 
 
@@ -2075,6 +2077,78 @@ class Mix3Fn(Function):
         fbuf, fret = grad_sink(fw)
         K.mix3_bwd(dy, a, t, h, fw.detach(), da, dt, dh, fbuf, ctx.drop, rt.rng)
         return da, dt, dh, fret, None
+
+
+class Mix3LayerNormFn(Function):
+    """LayerNorm(s0*a + s1*(t + dropout(h))) -- SplitFusion's blend and its final norm (HQAViT_CIFAR100.py:953-965) as one autograd node and
+    one launch each way (qavit_mix3_ln_fwd / _bwd): `mixed` is written once and read once (by the backward), its gradient never leaves
+    the registers."""
+
+    @staticmethod
+    def forward(ctx, a, t, h, fw, drop, g, b, eps):
+        K._require_cuda(a, fw)
+        rt = _rt(a)
+        Cc = a.shape[-1]
+        rows = a.numel() // Cc
+        mixed = torch.empty_like(a)
+        y = torch.empty_like(a)
+        mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+        K.mix3_ln_fwd(a, t, h, fw.detach(), drop, rt.rng, mixed, g.detach(), b.detach(), eps, y, mean, rstd, rows, Cc)
+        ctx.save_for_backward(a, t, h, fw, mixed, g, b, mean, rstd)
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, t, h, fw, mixed, g, b, mean, rstd = ctx.saved_tensors
+        rt = _rt(a)
+        Cc = a.shape[-1]
+        rows = a.numel() // Cc
+        dy = dy.contiguous()
+        da, dt, dh = torch.empty_like(a), torch.empty_like(t), torch.empty_like(h)
+        fbuf, fret = grad_sink(fw)
+        gbuf, _ = grad_sink(g)
+        bbuf, _ = grad_sink(b)
+        DeferDW.arm()
+        K.mix3_ln_bwd(dy, a, t, h, fw.detach(), ctx.drop, rt.rng, mixed, g.detach(), mean, rstd, da, dt, dh, fbuf, gbuf, bbuf, rows, Cc)
+        return da, dt, dh, fret, None, None, None, None
+
+
+class GateMix3LayerNormFn(Function):
+    """LayerNorm(s0*(t + sigmoid(gl)*r) + s1*(t + dropout(h))) -- SplitFusion's gate, blend and final norm (HQAViT_CIFAR100.py:945-965) as
+    one autograd node and one launch each way (qavit_gate_mix3_ln_fwd / _bwd).  The gated sum is never written; the backward returns ONE
+    gradient for t where the separate nodes returned two (s0*dm through the gate, s1*dm from the blend) for the fan-in sum to add."""
+
+    @staticmethod
+    def forward(ctx, t, r, gl, h, fw, drop, g, b, eps):
+        K._require_cuda(t, fw)
+        rt = _rt(t)
+        Cc = t.shape[-1]
+        rows = t.numel() // Cc
+        mixed = torch.empty_like(t)
+        y = torch.empty_like(t)
+        mean = torch.empty(rows, dtype=torch.float32, device=t.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=t.device)
+        K.gate_mix3_ln_fwd(t, r, gl, h, fw.detach(), drop, rt.rng, mixed, g.detach(), b.detach(), eps, y, mean, rstd, rows, Cc)
+        ctx.save_for_backward(t, r, gl, h, fw, mixed, g, b, mean, rstd)
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, r, gl, h, fw, mixed, g, b, mean, rstd = ctx.saved_tensors
+        rt = _rt(t)
+        Cc = t.shape[-1]
+        rows = t.numel() // Cc
+        dy = dy.contiguous()
+        dt, dr, dg, dh = torch.empty_like(t), torch.empty_like(r), torch.empty_like(gl), torch.empty_like(h)
+        fbuf, fret = grad_sink(fw)
+        gbuf, _ = grad_sink(g)
+        bbuf, _ = grad_sink(b)
+        DeferDW.arm()
+        K.gate_mix3_ln_bwd(dy, t, r, gl, h, fw.detach(), ctx.drop, rt.rng, mixed, g.detach(), mean, rstd, dt, dr, dg, dh, fbuf, gbuf, bbuf, rows, Cc)
+        return dt, dr, dg, dh, fret, None, None, None, None
 
 
 class ScaleAddFn(Function):

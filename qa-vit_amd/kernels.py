@@ -688,6 +688,58 @@ def mix3_bwd(dy, a, t, h, fw, da, dt, dh, dfw, drop, rng):
                                     dh.data_ptr(), _p(dfw), a.numel(), drop[0], drop[1], rng.data_ptr(), stream()), "mix3_bwd")
 
 
+def mix3_ln_ok(a, t, h, Cc) -> bool:
+    vec = 4 * a.element_size()
+    return (bool(L.load().qavit_mix3_ln_supported(dt_code(a.dtype), Cc)) if a.dtype in (torch.bfloat16, torch.float32) else False) and \
+        a.dtype == t.dtype == h.dtype and a.numel() == t.numel() == h.numel() and a.numel() < 2 ** 32 and \
+        all(u.is_contiguous() and u.data_ptr() % vec == 0 for u in (a, t, h))
+
+
+def mix3_ln_fwd(a, t, h, fw, drop, rng, mixed, gamma, beta, eps, y, mean, rstd, rows, Cc):
+    """mixed = softmax(fw)[0]*a + softmax(fw)[1]*(t + dropout(h)); y = LayerNorm(mixed): one launch (qavit_mix3_ln_fwd; check mix3_ln_ok)."""
+    L.check(L.load().qavit_mix3_ln_fwd(dt_code(a.dtype), a.data_ptr(), t.data_ptr(), h.data_ptr(), fw.data_ptr(), float(drop[0]), int(drop[1]),
+                                       _p(rng) if drop[0] > 0.0 else None, mixed.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
+                                       mean.data_ptr(), rstd.data_ptr(), rows, Cc, stream()), "mix3_ln_fwd")
+
+
+def _mix3_ln_parts(mixed, rows, Cc, want):
+    """Partial-row workspace of the fused blend + norm backward (its own workgroup count), or None: atomics."""
+    if not (want and DeferredLN.enabled and DeferredLN.ON):
+        return None
+    n = L.load().qavit_mix3_ln_bwd_parts(rows, Cc)
+    return torch.empty(n * 2 * Cc, dtype=torch.float32, device=mixed.device), n
+
+
+def mix3_ln_bwd(dy, a, t, h, fw, drop, rng, mixed, gamma, mean, rstd, da, dt, dh, dfw, dgamma, dbeta, rows, Cc):
+    """LayerNorm backward + blend backward in one launch (qavit_mix3_ln_bwd); the LayerNorm parameter gradients as partial rows when a
+    backward pass has armed DeferredLN."""
+    part = _mix3_ln_parts(mixed, rows, Cc, dgamma is not None or dbeta is not None)
+    L.check(L.load().qavit_mix3_ln_bwd(dt_code(a.dtype), dy.data_ptr(), a.data_ptr(), t.data_ptr(), h.data_ptr(), fw.data_ptr(), float(drop[0]), int(drop[1]),
+                                       _p(rng) if drop[0] > 0.0 else None, mixed.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       da.data_ptr(), dt.data_ptr(), dh.data_ptr(), _p(dfw), _p(dgamma), _p(dbeta), rows, Cc,
+                                       part[0].data_ptr() if part else None, stream()), "mix3_ln_bwd")
+    if part:
+        DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
+
+
+def gate_mix3_ln_fwd(t, r, g, h, fw, drop, rng, mixed, gamma, beta, eps, y, mean, rstd, rows, Cc):
+    """y = LayerNorm(s0*(t + sigmoid(g)*r) + s1*(t + dropout(h))): SplitFusion's gate, blend and final norm in one launch
+    (qavit_gate_mix3_ln_fwd; operands as for mix3_ln_ok)."""
+    L.check(L.load().qavit_gate_mix3_ln_fwd(dt_code(t.dtype), t.data_ptr(), r.data_ptr(), g.data_ptr(), h.data_ptr(), fw.data_ptr(), float(drop[0]), int(drop[1]),
+                                            _p(rng) if drop[0] > 0.0 else None, mixed.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
+                                            mean.data_ptr(), rstd.data_ptr(), rows, Cc, stream()), "gate_mix3_ln_fwd")
+
+
+def gate_mix3_ln_bwd(dy, t, r, g, h, fw, drop, rng, mixed, gamma, mean, rstd, dt, dr, dg, dh, dfw, dgamma, dbeta, rows, Cc):
+    part = _mix3_ln_parts(mixed, rows, Cc, dgamma is not None or dbeta is not None)
+    L.check(L.load().qavit_gate_mix3_ln_bwd(dt_code(t.dtype), dy.data_ptr(), t.data_ptr(), r.data_ptr(), g.data_ptr(), h.data_ptr(), fw.data_ptr(),
+                                            float(drop[0]), int(drop[1]), _p(rng) if drop[0] > 0.0 else None, mixed.data_ptr(), gamma.data_ptr(),
+                                            mean.data_ptr(), rstd.data_ptr(), dt.data_ptr(), dr.data_ptr(), dg.data_ptr(), dh.data_ptr(), _p(dfw),
+                                            _p(dgamma), _p(dbeta), rows, Cc, part[0].data_ptr() if part else None, stream()), "gate_mix3_ln_bwd")
+    if part:
+        DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
+
+
 def mix2_bwd(dy, a, b, fw, da, db, dfw):
     L.check(L.load().qavit_mix2_bwd(dt_code(a.dtype), dy.data_ptr(), a.data_ptr(), b.data_ptr(), fw.data_ptr(), da.data_ptr(), db.data_ptr(),
                                     _p(dfw), a.numel(), stream()), "mix2_bwd")

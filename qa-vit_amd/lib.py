@@ -190,6 +190,12 @@ _SIGS = {
     "qavit_upmix_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_upmix_bwd_p": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "qavit_upmix_bwd_parts": (i32, [i32, i32, i32, i32, i32]),
+    "qavit_mix3_ln_supported": (i32, [i32, i32]),
+    "qavit_mix3_ln_bwd_parts": (i32, [i32, i32]),
+    "qavit_gate_mix3_ln_fwd": (i32, [i32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, vp]),
+    "qavit_gate_mix3_ln_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "qavit_mix3_ln_fwd": (i32, [i32, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, vp]),
+    "qavit_mix3_ln_bwd": (i32, [i32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "qavit_upmix_bwd_sa_supported": (i32, [i32, i32, i32, i32]),
     "qavit_upmix_fwd_sa_supported": (i32, [i32, i32, i32, i32]),
     "qavit_upmix_fwd_sa": (i32, [i32, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -791,14 +791,20 @@ class SplitFusion(nn.Module):
     def forward(self, T, R):
         gn, gf = self.gate_norm, self.gate_fc
         grad = torch.is_grad_enabled()
-        # T feeds four expressions and R three: one k-way gradient sum each instead of autograd's pairwise adds
-        T0, T1, T2, T3 = F.FanOutFn.apply(T, 4) if (grad and T.requires_grad) else (T,) * 4
+        fn = self.final_norm
+        own = isinstance(self.fusion_weights, nn.Parameter) and self.fusion_weights.numel() == 2 and (T.numel() * T.element_size()) % 16 == 0
+        # gate + blend + final norm as ONE node (functional.GateMix3LayerNormFn): T then feeds three expressions, not four (its gradient from
+        # the gate's pass-through and from the blend leave that node as one tensor)
+        tail = (own and _MIX3 and F.MIX3_LN and F.GATE_MIX3_LN and T.dtype == R.dtype and T.numel() < 2 ** 32
+                and not (fn._forward_hooks or fn._forward_pre_hooks))
+        # T feeds four (three) expressions and R three: one k-way gradient sum each instead of autograd's pairwise adds
+        if tail:
+            T0, T2, T3 = F.FanOutFn.apply(T, 3) if (grad and T.requires_grad) else (T,) * 3
+            T1 = T3
+        else:
+            T0, T1, T2, T3 = F.FanOutFn.apply(T, 4) if (grad and T.requires_grad) else (T,) * 4
         R0, R1, R2 = F.FanOutFn.apply(R, 3) if (grad and R.requires_grad) else (R,) * 3
         gl = F.linear(T0 + R0, gf.weight, gf.bias, ln=(gn.weight, gn.bias), eps=gn.eps)
-        if (T1.numel() * T1.element_size()) % 16 == 0 and T1.dtype == R1.dtype == gl.dtype:
-            t_add = F.GateMixFn.apply(T1, R1, gl)            # T + sigmoid(gate) * R in one kernel
-        else:
-            t_add = T1 + torch.sigmoid(gl) * R1
         c0, c1 = self.cat_mlp[0], self.cat_mlp[1]
         # Linear(2C -> C) on cat([T, R]) = T W[:, :C]^T + R W[:, C:]^T + b: two accumulating GEMMs, no 2C-wide cat buffer (and no
         # slice copies of its gradient)
@@ -806,11 +812,22 @@ class SplitFusion(nn.Module):
         h = F.linear(T2, c0.weight, c0.bias, cols=(0, Cc))
         h = F.linear(R2, c0.weight, None, cols=(Cc, Cc), resid=h)
         h = F.layer_norm(h, c1.weight, c1.bias, c1.eps, act="gelu")
-        fn = self.final_norm
-        own = isinstance(self.fusion_weights, nn.Parameter) and self.fusion_weights.numel() == 2 and (t_add.numel() * t_add.element_size()) % 16 == 0
+        drop = (self.cat_mlp[3].p if self.training else 0.0, self._site)
+        if tail and gl.dtype == h.dtype == T3.dtype:
+            t3, r1, g1, hh = T3.contiguous(), R1.contiguous(), gl.contiguous(), h.contiguous()
+            if K.mix3_ln_ok(t3, r1, hh, Cc) and K.mix3_ln_ok(t3, g1, hh, Cc):
+                return F.GateMix3LayerNormFn.apply(t3, r1, g1, hh, self.fusion_weights, drop, fn.weight, fn.bias, fn.eps)
+        if (T1.numel() * T1.element_size()) % 16 == 0 and T1.dtype == R1.dtype == gl.dtype:
+            t_add = F.GateMixFn.apply(T1, R1, gl)            # T + sigmoid(gate) * R in one kernel
+        else:
+            t_add = T1 + torch.sigmoid(gl) * R1
         if own and _MIX3 and T3.dtype == h.dtype == t_add.dtype and t_add.numel() < 2 ** 32:
+            ta, t3, hh = t_add.contiguous(), T3.contiguous(), h.contiguous()
+            if F.MIX3_LN and not (fn._forward_hooks or fn._forward_pre_hooks) and K.mix3_ln_ok(ta, t3, hh, ta.shape[-1]):
+                # the blend and the final norm: one launch each way (functional.Mix3LayerNormFn)
+                return F.Mix3LayerNormFn.apply(ta, t3, hh, self.fusion_weights, drop, fn.weight, fn.bias, fn.eps)
             # dropout, the add and the blend in one kernel each way
-            mixed = F.Mix3Fn.apply(t_add, T3, h, self.fusion_weights, (self.cat_mlp[3].p if self.training else 0.0, self._site))
+            mixed = F.Mix3Fn.apply(t_add, T3, h, self.fusion_weights, drop)
             return F.layer_norm(mixed, fn.weight, fn.bias, fn.eps)
         h = F.dropout(h, self.cat_mlp[3].p, self._site, self.training)
         if own:

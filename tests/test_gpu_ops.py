@@ -320,6 +320,93 @@ def test_upmix_with_the_block_tail_scale_add(F, Q, dtype, B, N, M):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,p", [(64 * 37 + 3, 192, 0.1), (4099, 192, 0.0), (777, 64, 0.1), (1000, 256, 0.1)])
+def test_blend_and_final_norm_one_launch(F, Q, dtype, rows, C, p):
+    """Mix3LayerNormFn = LayerNorm(s0*a + s1*(t + dropout(h))), SplitFusion's closing pair (HQAViT_CIFAR100.py:953-965), one launch each way
+    (qavit_mix3_ln_fwd / _bwd): against Mix3Fn followed by the LayerNorm node on the same inputs and masks -- y, da, dt, dh bit-equal (same
+    arithmetic, same rounding points), the parameter gradients to summation-order tolerance -- and against fp32 torch autograd."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    rt = K.Runtime.get(0)
+    a0, t0, h0 = leaf(rows, C, seed=81), leaf(rows, C, seed=82), leaf(rows, C, seed=83)
+    fw = torch.tensor([0.75, 0.25], device=DEV, requires_grad=True)
+    g_, be = leaf(C, scale=0.1, seed=84), leaf(C, scale=0.1, seed=85)
+    with torch.no_grad():
+        g_.add_(1.0)
+    gy = torch.randn(rows, C, device=DEV).to(dtype)
+    drop = (p, 9191)
+    res = []
+    for fused in (True, False):
+        rt.seed(77)
+        for t in (fw, g_, be):
+            t.grad = None
+        a, t, h = (v.detach().to(dtype).requires_grad_(True) for v in (a0, t0, h0))
+        assert K.mix3_ln_ok(a, t, h, C)
+        if fused:
+            y = F.Mix3LayerNormFn.apply(a, t, h, fw, drop, g_, be, 1e-5)
+        else:
+            y = F.layer_norm(F.Mix3Fn.apply(a, t, h, fw, drop), g_, be, 1e-5)
+        y.backward(gy)
+        res.append([v.detach().float().clone() for v in (y, a.grad, t.grad, h.grad, fw.grad, g_.grad, be.grad)])
+    for name, x_, y_ in zip(("y", "da", "dt", "dh"), res[0], res[1]):
+        assert torch.equal(x_, y_), name
+    for name, x_, y_ in zip(("dfw", "dgamma", "dbeta"), res[0][4:], res[1][4:]):
+        assert rel(x_, y_) <= 2e-4, name
+    # fp32 torch autograd with the kernel's mask (recovered from the fused node's dh / dt: dh = dt * mask / (1 - p))
+    keep = torch.ones(rows, C, device=DEV)
+    if p > 0:
+        dt_, dh_ = res[0][2], res[0][3]
+        keep = torch.where(dt_ != 0, (dh_ / dt_ * (1 - p)).round(), torch.ones_like(dt_))
+        frac = float(keep.mean())
+        assert abs(frac - (1 - p)) < 0.02, frac
+    ar, tr, hr = (v.detach().to(dtype).float().requires_grad_(True) for v in (a0, t0, h0))
+    fwr, gr, ber = (v.detach().clone().requires_grad_(True) for v in (fw, g_, be))
+    w = torch.softmax(fwr, 0)
+    yr = TF.layer_norm(w[0] * ar + w[1] * (tr + hr * keep / (1 - p)), (C,), gr, ber)
+    yr.backward(gy.float())
+    assert rel(res[0][0], yr) <= tol(dtype)
+    for name, x_, y_ in zip(("da", "dt", "dh", "dfw", "dgamma", "dbeta"), res[0][1:], (ar.grad, tr.grad, hr.grad, fwr.grad, gr.grad, ber.grad)):
+        assert rel(x_, y_) <= (tol(dtype, False) if name != "dfw" else 10 * tol(dtype, False)), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,p", [(64 * 37 + 3, 192, 0.1), (4099, 192, 0.0), (33000, 192, 0.1), (777, 64, 0.1)])
+def test_gate_blend_and_final_norm_one_launch(F, Q, dtype, rows, C, p):
+    """GateMix3LayerNormFn = LayerNorm(s0*(t + sigmoid(g)*r) + s1*(t + dropout(h))), SplitFusion's gate, blend and final norm
+    (HQAViT_CIFAR100.py:945-965), one launch each way (qavit_gate_mix3_ln_fwd / _bwd): against GateMixFn -> Mix3Fn -> LayerNorm on the same
+    inputs and masks.  y, dr, dg, dh bit-equal; the single t gradient against the two the separate nodes return, added; parameter gradients
+    to summation-order tolerance."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    rt = K.Runtime.get(0)
+    t0, r0, gl0, h0 = leaf(rows, C, seed=91), leaf(rows, C, seed=92), leaf(rows, C, seed=93), leaf(rows, C, seed=94)
+    fw = torch.tensor([0.6, -0.2], device=DEV, requires_grad=True)
+    g_, be = leaf(C, scale=0.1, seed=95), leaf(C, scale=0.1, seed=96)
+    with torch.no_grad():
+        g_.add_(1.0)
+    gy = torch.randn(rows, C, device=DEV).to(dtype)
+    drop = (p, 777)
+    res = []
+    for fused in (True, False):
+        rt.seed(78)
+        for v in (fw, g_, be):
+            v.grad = None
+        t, r, gl, h = (v.detach().to(dtype).requires_grad_(True) for v in (t0, r0, gl0, h0))
+        if fused:
+            y = F.GateMix3LayerNormFn.apply(t, r, gl, h, fw, drop, g_, be, 1e-5)
+        else:
+            y = F.layer_norm(F.Mix3Fn.apply(F.GateMixFn.apply(t, r, gl), t, h, fw, drop), g_, be, 1e-5)
+        y.backward(gy)
+        res.append([v.detach().float().clone() for v in (y, r.grad, gl.grad, h.grad, t.grad, fw.grad, g_.grad, be.grad)])
+    for name, x_, y_ in zip(("y", "dr", "dg", "dh"), res[0], res[1]):
+        assert torch.equal(x_, y_), name
+    assert rel(res[0][4], res[1][4]) <= (1e-6 if dtype == torch.float32 else 8e-3), "dt"
+    for name, x_, y_ in zip(("dfw", "dgamma", "dbeta"), res[0][5:], res[1][5:]):
+        assert rel(x_, y_) <= 2e-4, name
+    assert float(res[0][1].abs().max()) > 0 and float(res[0][2].abs().max()) > 0 and float(res[0][5].abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows", [16 * 130, 64 * 1000 + 5])
 def test_layernorm_fan_out_backward_sums_on_load(F, dtype, rows):
     """LayerNormFanFn: a LayerNorm output with five consumers + the residual alias of its input; backward = ONE launch that sums the

@@ -29,3 +29,30 @@ for rows, C in ((65536, 192), (16384, 192), (65536, 64), (65536, 256)):
     t_f = timeit(lambda: K.layernorm_fwd(x, y, gm, bt, 1e-5, rows, C, mean, rstd))
     mb = rows * C * 2 / 1e6
     print(f"rows={rows} C={C}: bwd {t_b:6.1f} us ({3*mb/t_b:6.0f} GB/s; without dgamma/dbeta {t_b0:6.1f} us; with dres {t_br:6.1f} us)  stats {t_s:6.1f} us ({mb/t_s:6.0f} GB/s)  fwd {t_f:6.1f} us ({2*mb/t_f:6.0f} GB/s)")
+
+# SplitFusion's closing pair (blend, then LayerNorm): one launch each way (Mix3LayerNormFn) against the two nodes
+F = importlib.import_module("qa-vit_amd.functional")
+for rows, C in ((65536, 192), (16384, 192)):
+    a, t, h = (torch.randn(rows, C, device=dev).bfloat16().requires_grad_(True) for _ in range(3))
+    fw = torch.tensor([0.75, 0.25], device=dev, requires_grad=True)
+    gm, bt = torch.ones(C, device=dev, requires_grad=True), torch.zeros(C, device=dev, requires_grad=True)
+    for p_ in (fw, gm, bt):
+        p_.grad = torch.zeros_like(p_)
+    gy = torch.randn(rows, C, device=dev).bfloat16()
+    drop = (0.1, 4321)
+    fused = lambda: F.Mix3LayerNormFn.apply(a, t, h, fw, drop, gm, bt, 1e-5)
+    split = lambda: F.layer_norm(F.Mix3Fn.apply(a, t, h, fw, drop), gm, bt, 1e-5)
+    def fb(fn):
+        def run():
+            a.grad = t.grad = h.grad = None
+            K.DeferredLN.enabled = True
+            try:
+                fn().backward(gy)
+                K.DeferredLN.flush()
+            finally:
+                K.DeferredLN.enabled = False
+        return run
+    with torch.no_grad():
+        tf, ts = timeit(fused), timeit(split)
+    tfb, tsb = timeit(fb(fused)), timeit(fb(split))
+    print(f"rows={rows} C={C}: blend + norm  fwd one launch {tf:6.1f} us / two {ts:6.1f} us;  fwd+bwd (+ the partial-row reduce) one launch each {tfb:6.1f} us / two each {tsb:6.1f} us")
