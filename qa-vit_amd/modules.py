@@ -495,9 +495,9 @@ class QuadBlockWithTokenLearner(nn.Module):
             return self.quad_block(x)
         xc = self.token_learner(x)
         qb, up = self.quad_block, self.token_upmix
-        if _UPMIX_SA and torch.is_grad_enabled() and xc.requires_grad and not (qb._forward_hooks or qb._forward_pre_hooks or up._forward_hooks
-                                                                               or up._forward_pre_hooks):
-            # the block's closing scale-add and the up-mix as one autograd node: its backward is one launch (functional.UpMixScaleAddFn)
+        if _UPMIX_SA and not (qb._forward_hooks or qb._forward_pre_hooks or up._forward_hooks or up._forward_pre_hooks):
+            # the block's closing scale-add and the up-mix as one autograd node: one launch each way (functional.UpMixScaleAddFn), also
+            # without gradients (evaluation: the forward's single launch)
             tail = []
             qb(xc, tail)
             xr2, u, gamma, dp = tail
