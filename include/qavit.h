@@ -78,9 +78,15 @@ typedef struct qavit_gemm_args {
   float dp_p; int dp_site; int dp_rows;
   const void* R; int64_t ldr;
   const int64_t* rng; /* device int64[2]: seed, step */
+  /* TWO-SOURCE A (optional, A2 != NULL): the contraction runs over the columns of [A | A2] -- columns 0 .. a2_k0 come from A (row stride
+   * lda >= a2_k0), columns a2_k0 .. K from A2 (row stride lda2 >= K - a2_k0): Linear(2C -> C) on cat([T, R]) (HQAViT_CIFAR100.py:951)
+   * without the 2C-wide cat buffer and without a second, accumulating launch.  bf16, a_mode 0, a2_k0 % 64 == 0, shapes the K-loop
+   * kernel takes (qavit_gemm_nt_a2_supported); anything else is refused. */
+  const void* A2; int64_t lda2; int a2_k0;
 } qavit_gemm_args;
 
 int qavit_gemm_nt(const qavit_gemm_args* a, void* stream);
+int qavit_gemm_nt_a2_supported(int dtype, int M, int N, int K, int a2_k0);
 /* n independent problems (host array); up to 4 of one shape / dtype / prologue / epilogue kind that take the resident-slice
  * kernel share a grid (the four compress_* Linears of a block and their input gradients), others are launched one by one */
 int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stream);

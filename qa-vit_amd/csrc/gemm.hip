@@ -858,6 +858,17 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   using namespace qv;
   if (!a || !a->A || !a->B || !a->C) return set_error(QAVIT_EINVAL, "gemm_nt: null operand");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return set_error(QAVIT_EINVAL, "gemm_nt: non-positive dimension");
+  if (a->A2) {
+    // two-source A: only the K-loop kernel stages A by 64-wide chunks with a per-chunk base -- every other route is refused, loudly
+    if (!qavit_gemm_nt_a2_supported(a->dtype, a->M, a->N, a->K, a->a2_k0) || a->a_mode != 0)
+      return set_error(QAVIT_EINVAL, "gemm_nt: two-source A needs bf16, a_mode 0, a2_k0 % 64 == 0 and a shape the K-loop kernel takes (qavit_gemm_nt_a2_supported)");
+    if (a->lda < a->a2_k0 || a->lda2 < a->K - a->a2_k0 || a->ldb < a->K || a->ldc < a->N) return set_error(QAVIT_EINVAL, "gemm_nt: leading dimension too small");
+    if ((a->drop_p > 0.f || a->dp_p > 0.f) && !a->rng) return set_error(QAVIT_EINVAL, "gemm_nt: dropout requested without rng state");
+    const int took = gemm_nt_big_try(*a, reinterpret_cast<hipStream_t>(stream));
+    if (took < 0) return took;
+    if (took == 1) return QAVIT_OK;
+    return set_error(QAVIT_EINVAL, "gemm_nt: two-source A: operand alignment / strides the K-loop kernel does not take");
+  }
   if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N) return set_error(QAVIT_EINVAL, "gemm_nt: leading dimension too small");
   if (a->a_mode == 1 && (!a->ln_gamma || !a->ln_beta || !a->ln_mean || !a->ln_rstd))
     return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm prologue needs gamma/beta and the row statistics (qavit_row_stats)");
@@ -897,9 +908,16 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   return set_error(QAVIT_EINVAL, "gemm_nt: unknown dtype");
 }
 
+extern "C" int qavit_gemm_nt_a2_supported(int dtype, int M, int N, int K, int a2_k0) {
+  // the conditions of gemm_nt_big_try (csrc/gemm_big.hip) that do not depend on pointers, plus the chunk-aligned split
+  return dtype == QAVIT_BF16 && M >= 1024 && N >= 64 && K >= 96 && (long)N * K >= 64L * 128L && K % 32 == 0 && a2_k0 > 0 && a2_k0 < K && a2_k0 % 64 == 0;
+}
+
 extern "C" int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stream) {
   using namespace qv;
   if (!a || n <= 0) return set_error(QAVIT_EINVAL, "gemm_nt_grouped: empty group");
+  for (int i = 0; i < n; ++i)
+    if (a[i].A2) { if (n == 1) return qavit_gemm_nt(a, stream); return set_error(QAVIT_EINVAL, "gemm_nt_grouped: two-source A problems are launched singly"); }
   // one grid when the problems share shape, dtype, prologue and epilogue kind and take the resident-slice kernel;
   // otherwise one launch each
   auto kind = [](const qavit_gemm_args& g) { return (g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f) ? 1 : 0; };

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
   const int fr = lane & 15, fq = lane >> 4;
 
   const bf16* A = reinterpret_cast<const bf16*>(g.A);
+  const bf16* A2 = AMODE == 0 ? reinterpret_cast<const bf16*>(g.A2) : nullptr;      // two-source A: plain prologue only
   const bf16* B = reinterpret_cast<const bf16*>(g.B);
   const bf16* Zin = reinterpret_cast<const bf16*>(g.a_Z);
   bf16* Aout = reinterpret_cast<bf16*>(g.a_out);
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
 #pragma unroll
       for (int j = 0; j < 8; ++j) { x[j] = (bf16)0.f; z[j] = (bf16)0.f; }
       if (m < g.M && k < g.K) {
-        x = *reinterpret_cast<const bf16x8*>(A + (size_t)m * g.lda + k);
+        if (A2 && k >= g.a2_k0) x = *reinterpret_cast<const bf16x8*>(A2 + (size_t)m * g.lda2 + (k - g.a2_k0));     // uniform per chunk (a2_k0 % 64 == 0)
+        else x = *reinterpret_cast<const bf16x8*>(A + (size_t)m * g.lda + k);
         if (use_z) z = *reinterpret_cast<const bf16x8*>(Zin + (size_t)m * g.a_ldz + k);
       }
       pa[i] = x;
@@ -361,6 +363,7 @@ int gemm_nt_big_try(const qavit_gemm_args& g_in, hipStream_t st) {
   if (g.K % 32) return 0;
   auto al = [](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
   if (!al(g.A, g.lda) || !al(g.B, g.ldb)) return 0;
+  if (g.A2 && (g.a_mode != 0 || g.a2_k0 % 64 || g.a2_k0 <= 0 || g.a2_k0 >= g.K || !al(g.A2, g.lda2))) return 0;
   if (g.a_mode == 2) {
     if (g.a_Z && g.a_act && !al(g.a_Z, g.a_ldz)) return 0;
     if (g.a_out && !al(g.a_out, g.a_ldo)) return 0;

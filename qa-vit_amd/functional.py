@@ -430,6 +430,7 @@ _DEFER_FIX = os.environ.get("QAVIT_DEFER_NANFIX", "1") != "0"   # fused branches
 _UPMIX_FWD_SA = os.environ.get("QAVIT_UPMIX_FWD_SA", "1") != "0"   # block tail + up-mix forward: the scale-add formed while the up-mix stages the image
 MIX3_LN = os.environ.get("QAVIT_MIX3_LN", "1") != "0"     # SplitFusion: blend + final LayerNorm as one launch each way
 GATE_MIX3_LN = os.environ.get("QAVIT_GATE_MIX3_LN", "1") != "0"   # ... and the gate in front of the blend with them
+_LINEAR_CAT = os.environ.get("QAVIT_LINEAR_CAT", "1") != "0"   # Linear on cat([T, R]): one two-source GEMM instead of a GEMM + an accumulating GEMM
 _LN_LIN = os.environ.get("QAVIT_LN_LIN", "1") != "0"      # narrow LayerNorm-prologue Linears: dX GEMM fused into the LayerNorm-backward kernel
 
 
@@ -500,6 +501,50 @@ class LinearFn(Function):
                          dres=dalias, dx_add=dx_add, kd=Kd)
         dres = dy if has_res else None
         return (dx.reshape(xshape) if (dx is not None and ctx.needs_input_grad[0]) else None), None, None, None, None, dres, None
+
+
+class LinearCatFn(Function):
+    """y = cat([x1, x2], -1) @ W^T + b without the cat: ONE GEMM whose A operand switches source at column K1 (qavit_gemm_args.A2) --
+    SplitFusion's Linear(2C -> C) on cat([T, R]) (HQAViT_CIFAR100.py:951), which was one GEMM on T and a second, accumulating one on R
+    (its output written, read back and written again).  Backward = that of the two Linears (two input-gradient GEMMs on W's column
+    halves, two deferred weight-gradient problems, one bias column sum)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b):
+        K._require_cuda(x1, w)
+        K1, K2 = x1.shape[-1], x2.shape[-1]
+        a1 = x1.reshape(-1, K1)
+        a2 = x2.reshape(-1, K2)
+        if not a1.is_contiguous():
+            a1 = a1.contiguous()
+        if not a2.is_contiguous():
+            a2 = a2.contiguous()
+        M, n = a1.shape[0], w.shape[0]
+        Wc, _ = pack_for(x1.device).get(w, x1.dtype)
+        y = torch.empty(M, n, dtype=x1.dtype, device=x1.device)
+        K.gemm_nt(a1, Wc, y, M, n, K1 + K2, K1, K1 + K2, n, None if b is None else b.detach(), A2=a2, lda2=K2, a2_k0=K1)
+        ctx.save_for_backward(a1, a2, w, b)
+        ctx.shapes = (x1.shape, x2.shape)
+        return y.reshape(*x1.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a1, a2, w, b = ctx.saved_tensors
+        M, n = a1.shape[0], w.shape[0]
+        dy2 = dy.reshape(M, n)
+        d1 = _linear_bwd(a1, w, b, dy2, 0, n, ctx.needs_input_grad[0], koff=0)
+        d2 = _linear_bwd(a2, w, None, dy2, 0, n, ctx.needs_input_grad[1], koff=a1.shape[1])
+        return (d1.reshape(ctx.shapes[0]) if (d1 is not None and ctx.needs_input_grad[0]) else None,
+                d2.reshape(ctx.shapes[1]) if (d2 is not None and ctx.needs_input_grad[1]) else None, None, None)
+
+
+def linear_cat_ok(x1, x2, w) -> bool:
+    """Can LinearCatFn take cat([x1, x2]) @ w^T?  (bf16 operands of the same row count, a split on a 64-column boundary, a shape of the K-loop GEMM)"""
+    if not (_LINEAR_CAT and x1.is_cuda and x1.dtype == x2.dtype and x1.shape[:-1] == x2.shape[:-1] and w.dim() == 2
+            and w.shape[1] == x1.shape[-1] + x2.shape[-1]):
+        return False
+    M = x1.numel() // x1.shape[-1]
+    return K.gemm_nt_a2_ok(x1, x2, M, w.shape[0], w.shape[1], x1.shape[-1]) and x1.shape[-1] % 8 == 0 and x2.shape[-1] % 8 == 0
 
 
 def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, mean=None, rstd=None, act=0, drop=(0.0, 0), dp=(0.0, 0, 1), koff=0,

@@ -114,7 +114,7 @@ def new_site() -> int:
 # ---------------------------------------------------------------------------------------------------
 def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None, ln_stats=None,
             bwd=None, Z=None, act=0, drop=(0.0, 0), scale=1.0, dp=(0.0, 0, 1), R=None, ldr=0, rng=None,
-            A_ptr=None, B_ptr=None, C_ptr=None, build_only=False):
+            A_ptr=None, B_ptr=None, C_ptr=None, build_only=False, A2=None, lda2=0, a2_k0=0):
     """C[M,N] = epi(pro(A)[M,K] @ B[N,K]^T + bias).  A/B/Cout are tensors used for dtype/liveness; *_ptr
     override the base address (column-offset views).  ``build_only`` returns the argument struct for gemm_nt_grouped."""
     a = L.GemmArgs()
@@ -149,9 +149,16 @@ def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None,
     if R is not None:
         a.R, a.ldr = R.data_ptr(), (ldr or N)
     a.rng = _p(rng)
+    if A2 is not None:                        # two-source A: columns a2_k0 .. K of the contraction come from A2 (qavit_gemm_args.A2)
+        a.A2, a.lda2, a.a2_k0 = A2.data_ptr(), lda2, a2_k0
     if build_only:
         return a
     L.check(L.load().qavit_gemm_nt(C.byref(a), stream()), "gemm_nt")
+
+
+def gemm_nt_a2_ok(x, x2, M, N, K, k0) -> bool:
+    return (x.dtype == torch.bfloat16 == x2.dtype and x.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
+            and bool(L.load().qavit_gemm_nt_a2_supported(dt_code(x.dtype), M, N, K, k0)))
 
 
 def gemm_nt_grouped(args):

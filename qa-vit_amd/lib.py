@@ -20,6 +20,7 @@ class GemmArgs(C.Structure):
         ("a_dp_p", f32), ("a_dp_site", i32), ("a_dp_rows", i32), ("a_scale", f32), ("a_out", vp), ("a_ldo", i64),
         ("Z", vp), ("ldz", i64), ("act", i32), ("drop_p", f32), ("drop_site", i32), ("scale", f32),
         ("dp_p", f32), ("dp_site", i32), ("dp_rows", i32), ("R", vp), ("ldr", i64), ("rng", vp),
+        ("A2", vp), ("lda2", i64), ("a2_k0", i32),
     ]
 
 
@@ -149,6 +150,7 @@ _SIGS = {
     "qavit_version": (i32, []),
     "qavit_last_error": (C.c_char_p, []),
     "qavit_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
+    "qavit_gemm_nt_a2_supported": (i32, [i32, i32, i32, i32, i32]),
     "qavit_gemm_nt_grouped": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "qavit_gemm_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "qavit_gemm_tn_grouped": (i32, [C.POINTER(GemmTnArgs), i32, vp]),

@@ -809,8 +809,11 @@ class SplitFusion(nn.Module):
         # Linear(2C -> C) on cat([T, R]) = T W[:, :C]^T + R W[:, C:]^T + b: two accumulating GEMMs, no 2C-wide cat buffer (and no
         # slice copies of its gradient)
         Cc = T2.shape[-1]
-        h = F.linear(T2, c0.weight, c0.bias, cols=(0, Cc))
-        h = F.linear(R2, c0.weight, None, cols=(Cc, Cc), resid=h)
+        if F.linear_cat_ok(T2, R2, c0.weight) and not (c0._forward_hooks or c0._forward_pre_hooks):
+            h = F.LinearCatFn.apply(T2, R2, c0.weight, c0.bias)      # ... and in bf16 ONE GEMM whose A operand switches source at column C
+        else:
+            h = F.linear(T2, c0.weight, c0.bias, cols=(0, Cc))
+            h = F.linear(R2, c0.weight, None, cols=(Cc, Cc), resid=h)
         h = F.layer_norm(h, c1.weight, c1.bias, c1.eps, act="gelu")
         drop = (self.cat_mlp[3].p if self.training else 0.0, self._site)
         if tail and gl.dtype == h.dtype == T3.dtype:

@@ -319,6 +319,45 @@ def test_upmix_with_the_block_tail_scale_add(F, Q, dtype, B, N, M):
         assert torch.equal(res[0][0], res[1][0])               # same arithmetic, same rounding points
 
 
+@pytest.mark.parametrize("M,C,N", [(4096 + 17, 192, 192), (1024, 128, 256), (70000, 192, 192)])
+def test_linear_on_cat_as_one_two_source_gemm(F, Q, M, C, N):
+    """LinearCatFn: cat([T, R]) @ W^T + b as ONE GEMM whose A operand switches source at column C (qavit_gemm_args.A2), SplitFusion's
+    Linear(2C -> C) (HQAViT_CIFAR100.py:951): against fp32 torch on the bf16-rounded operands (y and every gradient) and against the
+    GEMM + accumulating-GEMM pair it replaces; shapes the K-loop kernel does not take are refused, not rerouted."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    dtype = torch.bfloat16
+    t0, r0 = leaf(M, C, seed=101), leaf(M, C, seed=102)
+    W, b = leaf(N, 2 * C, scale=0.08, seed=103), leaf(N, scale=0.1, seed=104)
+    gy = torch.randn(M, N, device=DEV).to(dtype)
+    res = []
+    for one in (True, False):
+        W.grad = None; b.grad = None
+        t, r = t0.detach().to(dtype).requires_grad_(True), r0.detach().to(dtype).requires_grad_(True)
+        assert F.linear_cat_ok(t, r, W)
+        if one:
+            y = F.LinearCatFn.apply(t, r, W, b)
+        else:
+            y = F.linear(r, W, None, cols=(C, C), resid=F.linear(t, W, b, cols=(0, C)))
+        y.backward(gy)
+        res.append([v.detach().float().clone() for v in (y, t.grad, r.grad, W.grad, b.grad)])
+    tr, rr = t0.detach().to(dtype).float().requires_grad_(True), r0.detach().to(dtype).float().requires_grad_(True)
+    Wr, br = W.detach().to(dtype).float().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = torch.cat([tr, rr], -1) @ Wr.t() + br
+    yr.backward(gy.float())
+    for name, x_, y_ in zip(("y", "dT", "dR", "dW", "db"), res[0], (yr, tr.grad, rr.grad, Wr.grad, br.grad)):
+        assert rel(x_, y_) <= tol(dtype, name == "y"), name
+    for name, x_, y_ in zip(("y", "dT", "dR", "dW", "db"), res[0], res[1]):
+        assert rel(x_, y_) <= (1.2e-2 if name == "y" else 1e-5), name            # y: one rounding instead of two; the backward is the same launches
+    # refused, loudly: a split off the 64-column chunk grid, fp32 operands
+    a = torch.randn(2048, 96, device=DEV).to(dtype)
+    y = torch.empty(2048, 192, device=DEV, dtype=dtype)
+    Wb = torch.randn(192, 192, device=DEV).to(dtype)
+    with pytest.raises(RuntimeError):
+        K.gemm_nt(a, Wb, y, 2048, 192, 192, 96, 192, 192, None, A2=a, lda2=96, a2_k0=96)
+    assert not F.linear_cat_ok(t0.detach(), r0.detach(), W)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,C,p", [(64 * 37 + 3, 192, 0.1), (4099, 192, 0.0), (777, 64, 0.1), (1000, 256, 0.1)])
 def test_blend_and_final_norm_one_launch(F, Q, dtype, rows, C, p):
