@@ -883,7 +883,7 @@ static int mix3_ln_check(const char* what, int dtype, int rows, int C, float dro
 
 static int mix3_ln_fwd_launch(int dtype, const LnMix3& mx, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int rows, int C,
                               hipStream_t st, bool gated) {
-  constexpr int NW = 4, RB = 4;
+  constexpr int NW = 4, RB = 2;                              // (four rows in flight per wave: 83 registers in the gated form, 0.01 ms per step slower)
   int grid = (rows + NW * RB - 1) / (NW * RB);
   if (grid > 2048) grid = 2048;
 #define MLF(T_, G_) hipLaunchKernelGGL((mix3_ln_fwd_kernel<T_, RB, NW, G_>), dim3(grid), dim3(64 * NW), 0, st, mx, (T_*)y, gamma, beta, eps, rows, C, mean, rstd)
