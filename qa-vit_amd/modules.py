@@ -550,11 +550,12 @@ def _conv1x1_tokens(t, conv: nn.Conv2d, alias: bool = False):
     return F.linear(t, conv.weight, conv.bias, alias=alias)
 
 
-def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool, gelu: bool = False):
+def _bn_tokens(t, bn: nn.BatchNorm2d, training: bool, gelu: bool = False, bump: bool = True):
     """nn.BatchNorm2d (+ nn.GELU when ``gelu``) on channel-last tokens == batch norm over the rows of [B*H*W, C]
-    (per-rank batch statistics) -- csrc/bnorm.hip; anything it does not cover raises (no stock-op fallback)."""
+    (per-rank batch statistics) -- csrc/bnorm.hip; anything it does not cover raises (no stock-op fallback).
+    ``bump=False``: the caller has counted this batch in ``num_batches_tracked`` already (one launch for all its BatchNorms)."""
     B, N, C = t.shape
-    if training and bn.num_batches_tracked is not None:
+    if bump and training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     if not (K.bn_supported(t.dtype, C) and bn.running_mean is not None and bn.momentum is not None and bn.affine):
         # no stock-op fallback on the hot path: the reference's stems are nn.BatchNorm2d(32 | 64 | 128 | 256) with affine parameters, running
@@ -617,7 +618,7 @@ class CNNStemModel(nn.Module):
         B = dims[0]
         cols = F.Im2ColFn.apply(src, dims, cdt)
         t = F.linear(cols, conv.weight, conv.bias, xpad=cols.shape[1] != conv.weight[0].numel()).reshape(B, -1, conv.out_channels)
-        return _bn_tokens(t, bn, self.training, gelu=True)
+        return _bn_tokens(t, bn, self.training, gelu=True, bump=False)
 
     def forward_tokens(self, x, cdt):
         """-> (F2, F3, F4) as channel-last tokens [B, h*w, c] in the compute dtype, and (h, w)."""
@@ -627,6 +628,11 @@ class CNNStemModel(nn.Module):
         """``forward_tokens`` as a generator that yields between its stages (the model interleaves this chain's launches with the
         token path's: models.HQAViT.forward); the result is the generator's return value."""
         B, Cin, H, W = x.shape
+        if self.training:
+            # the four BatchNorms' num_batches_tracked in ONE launch (four 1-element adds sat between the kernels of the forward's first chain)
+            nbt = [bn.num_batches_tracked for bn in (self.stem[1], self.stage1[1], self.stage2[1], self.stage3[1]) if bn.num_batches_tracked is not None]
+            if nbt:
+                torch._foreach_add_(nbt, 1)
         with torch.autocast("cuda", enabled=False):
             t = F.stamp(self._conv3x3s2_tokens(x, self.stem[0], self.stem[1], (B, Cin, H, W, 3, 2, 1), cdt), "lat.stem0")
             yield
@@ -638,10 +644,10 @@ class CNNStemModel(nn.Module):
             yield
             # f2 / f3 also leave as lateral features: the aliases carry those consumers' gradients into the 1x1 convs' backward GEMMs
             t, f2 = _conv1x1_tokens(f2, self.stage2[0], alias=True)
-            f3 = self.stage2[2].forward_tokens(_bn_tokens(t, self.stage2[1], self.training), h, w)
+            f3 = self.stage2[2].forward_tokens(_bn_tokens(t, self.stage2[1], self.training, bump=False), h, w)
             yield
             t, f3 = _conv1x1_tokens(f3, self.stage3[0], alias=True)
-            f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training), h, w)
+            f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training, bump=False), h, w)
         return (f2, f3, f4), (h, w)
 
     def forward(self, x):                                   # NCHW surface of the reference class
