@@ -517,6 +517,15 @@ int qavit_mlp2_bwd(const qavit_mlp2_bwd_args* a, void* stream);
  * per branch slice, and the norms' mean[i] / rstd[i] [B*16] -- what the unfused forward (qavit_row_stats_multi, the LayerNorm-prologue
  * qavit_gemm_nt_grouped, qavit_hybrid_fuse_fwd) leaves for the backward.
  * ------------------------------------------------------------------------------------------------- */
+/* The parameters of a fused branch call's NaN -> zeros rule, handed to the launch that reads the branch output next (nan_defer in
+ * qavit_branch_args / qavit_cga_args; qavit_bank_stats_nanfix and qavit_cfuse_args.fix below). */
+typedef struct qavit_nan_fix {
+  int* flag;                 /* int[2]: the branch call's nan_flag (flag, arrival ticket) */
+  int* trip;                 /* optional: the branch call's nan_trip */
+  const float* bias;         /* [C]: the branch's proj bias */
+  float drop_p; int drop_site; const int64_t* rng;   /* the branch's proj dropout */
+  void* o_save; int64_t ldos; int Co;                /* optional: the saved attention output [B*N, ldos], Co columns, zeroed */
+} qavit_nan_fix;
 typedef struct qavit_cfuse_args {
   int dtype;
   int B, T, C, NB, CB;
@@ -526,6 +535,11 @@ typedef struct qavit_cfuse_args {
   const float* fw; float eps;
   void* cat; void* y;
   float* mean[4]; float* rstd[4];
+  /* fix.flag != NULL: branch `fix_branch`'s call was made with nan_defer and this launch is the next reader of its output x[fix_branch]
+   * (the cross branch, which writes no bank): with the flag raised every workgroup first rewrites its images' rows of that operand as
+   * dropout(bias), zeroes their o_save rows, and the launch sets `trip` and resets the flag / ticket words -- what the rule's own
+   * launch does (qavit_branch_nan_fix) -- then normalises the rewritten rows. */
+  qavit_nan_fix fix; int fix_branch;
 } qavit_cfuse_args;
 int qavit_compress_fuse_supported(int T, int C, int nb, int Cb);
 int qavit_compress_fuse_fwd(const qavit_cfuse_args* a, void* stream);
@@ -598,13 +612,9 @@ int64_t qavit_bank_ws_floats(int B, int N, int C, int S);
  * dropout(bias) (what proj(zeros) gives), its o_save rows zeroed, `trip` set and the flag / ticket words reset -- exactly what the
  * rule's own launch does -- and the statistics are taken of the rewritten rows.  bf16 [B, N, 192] tokens with N = 16 or 64 do this
  * inside the statistics kernel; every other shape runs the rule's launch first. */
-typedef struct qavit_nan_fix {
-  int* flag;                 /* int[2]: the branch call's nan_flag (flag, arrival ticket) */
-  int* trip;                 /* optional: the branch call's nan_trip */
-  const float* bias;         /* [C]: the branch's proj bias */
-  float drop_p; int drop_site; const int64_t* rng;   /* the branch's proj dropout */
-  void* o_save; int64_t ldos; int Co;                /* optional: the saved attention output [B*N, ldos], Co columns, zeroed */
-} qavit_nan_fix;
+/* (struct qavit_nan_fix: declared above, in front of qavit_cfuse_args) */
+/* The rule's own launch for a deferred call whose next reader cannot carry it: out [rows, C] rewritten when fix->flag is raised. */
+int qavit_branch_nan_fix(int dtype, void* out, int rows, int C, const qavit_nan_fix* fix, void* stream);
 int qavit_bank_stats_nanfix(int dtype, void* tokens, const float* g_branch, const float* b_branch,
                             const float* g_write, const float* b_write, const float* Wg, const float* bg,
                             float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps,

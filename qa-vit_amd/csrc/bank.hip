@@ -322,6 +322,14 @@ extern "C" int qavit_bank_stats(int dtype, const void* tokens, const float* g_br
   return qavit_bank_stats_nanfix(dtype, const_cast<void*>(tokens), g_branch, b_branch, g_write, b_write, Wg, bg, acc, ws, ws_floats, B, N, C, S, eps, nullptr, stream);
 }
 
+extern "C" int qavit_branch_nan_fix(int dtype, void* out, int rows, int C, const qavit_nan_fix* fix, void* stream) {
+  if (dtype != QAVIT_BF16 || !out || rows <= 0 || C <= 0 || !fix || !fix->flag || !fix->bias) return set_error(QAVIT_EINVAL, "branch_nan_fix: bf16 rows, flag and bias");
+  if (fix->drop_p < 0.f || fix->drop_p >= 1.f || (fix->drop_p > 0.f && !fix->rng)) return set_error(QAVIT_EINVAL, "branch_nan_fix: dropout needs rng");
+  qv::branch_nan_fix_launch(out, C, rows, C, fix->bias, fix->drop_p, fix->drop_site, fix->rng, fix->flag, fix->trip, fix->o_save, fix->ldos, fix->Co,
+                            reinterpret_cast<hipStream_t>(stream));
+  return check_launch("branch_nan_fix");
+}
+
 extern "C" int qavit_bank_stats_nanfix(int dtype, void* tokens, const float* g_branch, const float* b_branch,
                                        const float* g_write, const float* b_write, const float* Wg, const float* bg,
                                        float* acc, float* ws, int64_t ws_floats, int B, int N, int C, int S, float eps,

@@ -19,7 +19,7 @@ namespace {
 constexpr int FT = 16, FC = 192, FNB = 4, FCB = 48;        // tokens, channels, branches, compressed channels per branch
 constexpr int FNW = 8, FIMG = 4;                           // waves per workgroup (4 branches x 2 image slots), images per workgroup
 constexpr int FLD = FC + 8;
-constexpr int SMF_W = 0, SMF_GB = FNB * FCB * FLD * 2, SMF_X = SMF_GB + FNB * 2 * FC * 4, SMF_TOTAL = SMF_X + FNW * FT * FLD * 2;   // 76800 + 6144 + 51200 = 134144
+constexpr int SMF_W = 0, SMF_GB = FNB * FCB * FLD * 2, SMF_X = SMF_GB + FNB * 2 * FC * 4, SMF_FLAG = SMF_X + FNW * FT * FLD * 2, SMF_TOTAL = SMF_FLAG + 16;   // 76800 + 6144 + 51200 (+ the NaN flag's broadcast word) = 134160
 
 __global__ __launch_bounds__(64 * FNW) void cfuse_fwd_kernel(qavit_cfuse_args a) {
   extern __shared__ __attribute__((aligned(16))) char smraw[];
@@ -42,6 +42,18 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_fwd_kernel(qavit_cfuse_args a)
   const int img0 = blockIdx.x * FIMG + 2 * slot;
   bf16x8 xr[6], xn[6];
   load_x(img0 < a.B ? img0 : a.B - 1, xr);
+  // the NaN rule of the branch whose output this launch reads next (a.fix, see the header): the flag is read by one thread beside the
+  // weight staging below and reaches the others through the barrier that staging needs anyway
+  volatile int& f_s = *reinterpret_cast<volatile int*>(smraw + SMF_FLAG);
+  if (tid == 0) {
+    int f = 0;
+    if (a.fix.flag) {
+      f = *reinterpret_cast<volatile int*>(a.fix.flag);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the read has returned before this workgroup's arrival is counted
+      if (atomicAdd(a.fix.flag + 1, 1) == (int)gridDim.x - 1) { a.fix.flag[0] = 0; a.fix.flag[1] = 0; }
+    }
+    f_s = f;
+  }
   // weights (row-major tiles), gamma / beta, fusion weights
   {
     // the four weight tiles: all nine 16-byte loads of a thread in flight before the first LDS store (a load-store loop with a
@@ -80,6 +92,9 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_fwd_kernel(qavit_cfuse_args a)
 #pragma unroll
   for (int nt = 0; nt < 3; ++nt) bias4[nt] = a.bias[br] ? *reinterpret_cast<const f32x4*>(a.bias[br] + 16 * nt + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
+  const bool fixit = f_s != 0;                             // uniform over the grid
+  if (a.fix.flag && a.fix.trip && blockIdx.x == 0 && tid == 0) *a.fix.trip = fixit ? 1 : 0;
+  const bool fix_mine = fixit && br == a.fix_branch;       // uniform per wave
   const bf16* swb = sw + (size_t)br * FCB * FLD;
   const float* gam = sgb + br * 2 * FC;
   const float* bet = gam + FC;
@@ -89,10 +104,39 @@ __global__ __launch_bounds__(64 * FNW) void cfuse_fwd_kernel(qavit_cfuse_args a)
     const int img = img0 + ii;
     if (img >= a.B) break;                                 // uniform per wave; no barrier below
     wave_sync();                                           // the previous image's fragment reads are done
+    if (fix_mine) {
+      // rare: the branch produced NaN somewhere, its whole output is dropout(proj(0)) = dropout(bias) -- for this reader (the image's
+      // tile is built from the bias instead of from the rows loaded) and for the backward (written back); the saved attention output is
+      // zero.  One piece at a time, straight into the tile: the path must not cost the common one its registers.
+      const bool fdrop = a.fix.drop_p > 0.f && a.fix.rng != nullptr;
+      const uint32_t fkey = fdrop ? rng_key(a.fix.rng, a.fix.drop_site) : 0u;
+      const float finv = fdrop ? 1.f / (1.f - a.fix.drop_p) : 1.f;
+      bf16* xw = const_cast<bf16*>(xg);
+#pragma unroll 1
+      for (int it = 0; it < 6; ++it) {
+        const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+        const uint32_t grow = (uint32_t)(img * FT + row);
+        bf16x8 t;
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
-      const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
-      *reinterpret_cast<bf16x8*>(xt + row * FLD + 8 * c8) = xr[it];
+        for (int j = 0; j < 8; ++j) {
+          const int c = 8 * c8 + j;
+          float val = a.fix.bias[c];
+          if (fdrop) val *= drop_factor(fkey, grow * (uint32_t)FC + (uint32_t)c, a.fix.drop_p, finv);
+          t[j] = (bf16)val;
+        }
+        *reinterpret_cast<bf16x8*>(xw + ((size_t)img * FT + row) * FC + 8 * c8) = t;
+        *reinterpret_cast<bf16x8*>(xt + row * FLD + 8 * c8) = t;
+      }
+      if (a.fix.o_save) {
+        bf16* os = reinterpret_cast<bf16*>(a.fix.o_save) + (size_t)img * FT * a.fix.ldos;
+        for (int i = lane; i < FT * a.fix.Co; i += 64) { const int r = i / a.fix.Co, c = i - r * a.fix.Co; os[(size_t)r * a.fix.ldos + c] = (bf16)0.f; }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int p = lane + 64 * it, row = p / 24, c8 = p % 24;
+        *reinterpret_cast<bf16x8*>(xt + row * FLD + 8 * c8) = xr[it];
+      }
     }
     if (ii == 0 && img + 1 < a.B) load_x(img + 1, xn);      // the second image's rows fly during the first one's arithmetic
     wave_sync();
@@ -379,6 +423,11 @@ extern "C" int qavit_compress_fuse_fwd(const qavit_cfuse_args* a, void* stream) 
     if (a->bias[i] && (reinterpret_cast<uintptr_t>(a->bias[i]) & 15)) return set_error(QAVIT_EINVAL, "compress_fuse: bias must be 16-byte aligned");
   }
   if ((reinterpret_cast<uintptr_t>(a->cat) | reinterpret_cast<uintptr_t>(a->y)) & 7) return set_error(QAVIT_EINVAL, "compress_fuse: outputs must be 8-byte aligned");
+  if (a->fix.flag) {
+    if (a->fix_branch < 0 || a->fix_branch >= FNB || !a->fix.bias) return set_error(QAVIT_EINVAL, "compress_fuse: the deferred NaN rule needs its branch index and proj bias");
+    if (a->fix.drop_p < 0.f || a->fix.drop_p >= 1.f || (a->fix.drop_p > 0.f && !a->fix.rng)) return set_error(QAVIT_EINVAL, "compress_fuse: the deferred NaN rule's dropout needs rng");
+    if (a->fix.o_save && (a->fix.Co <= 0 || a->fix.ldos < a->fix.Co)) return set_error(QAVIT_EINVAL, "compress_fuse: the deferred NaN rule's o_save stride");
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {

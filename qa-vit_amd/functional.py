@@ -426,6 +426,7 @@ class SideStream:
 # Linear (+ fused LayerNorm prologue, GELU / dropout / drop-path / residual epilogue)
 # ---------------------------------------------------------------------------------------------------
 _FLUSH_SIDE = os.environ.get("QAVIT_FLUSH_SIDE", "1") != "0"    # end of backward: the small reduce / bank launches beside the one-launch weight-gradient kernel
+DEFER_FIX_CFUSE = os.environ.get("QAVIT_DEFER_NANFIX_CFUSE", "1") != "0"   # the cross branch's NaN rule rides in the compress-fuse launch
 _DEFER_FIX = os.environ.get("QAVIT_DEFER_NANFIX", "1") != "0"   # fused branches followed by a bank write: the NaN rule's rewrite rides in the bank-statistics launch
 _UPMIX_FWD_SA = os.environ.get("QAVIT_UPMIX_FWD_SA", "1") != "0"   # block tail + up-mix forward: the scale-add formed while the up-mix stages the image
 MIX3_LN = os.environ.get("QAVIT_MIX3_LN", "1") != "0"     # SplitFusion: blend + final LayerNorm as one launch each way
@@ -1817,6 +1818,14 @@ class CompressFuseFn(Function):
         T_ = args[0].shape[-2] if args[0].dim() >= 2 else 0
         if T_ > 16 and T_ % 16 == 0:
             T_ = 16                                         # the node is token-wise: 64 tokens per image = four 16-token problems to the kernel
+        fix = None
+        if rt.pending_fix is not None:                      # the branch that produced one of the operands left its NaN rule to this launch
+            fix, fout, _keep = rt.pending_fix
+            rt.pending_fix = None
+            which = [i for i in range(nb) if xs[i].data_ptr() == fout.data_ptr()]
+            if not which:
+                raise RuntimeError("the deferred NaN rule belongs to a tensor that is not an operand of this compress-fuse node")
+            fix_branch = which[0]
         if (_CFUSE and dt == torch.bfloat16 and nb == 4 and M % max(T_, 1) == 0 and all(a_ is not None for a_ in args[:20])
                 and L.load().qavit_compress_fuse_supported(T_, Kd, nb, Cb)):
             # norms, compress Linears, concat and fusion scaling in ONE launch (csrc/cfuse.hip)
@@ -1831,11 +1840,15 @@ class CompressFuseFn(Function):
                 a.mean[i], a.rstd[i] = means[i].data_ptr(), rstds[i].data_ptr()
             y = torch.empty_like(cat)
             a.fw, a.eps, a.cat, a.y = fw.data_ptr(), float(eps), cat.data_ptr(), y.data_ptr()
+            if fix is not None:
+                a.fix, a.fix_branch = fix, fix_branch
             L.check(L.load().qavit_compress_fuse_fwd(C.byref(a), K.stream()), "compress_fuse_fwd")
             stats = [t for i in range(nb) for t in (means[i], rstds[i])]
             ctx.meta = (nb, M, Kd, Cb, eps, args[0].shape)
             ctx.save_for_backward(fw, cat, *xs, *[a_ for i in range(nb) for a_ in args[5 * i + 1: 5 * i + 5]], *stats)
             return y.reshape(*args[0].shape[:-1], nb * Cb)
+        if fix is not None:                                  # this route cannot carry the rule: its own launch first
+            L.check(L.load().qavit_branch_nan_fix(K.dt_code(dt), xs[fix_branch].data_ptr(), M, Kd, C.byref(fix), K.stream()), "branch_nan_fix")
         K.row_stats_multi(xs, eps, M, Kd, means, rstds)                      # the four branch norms: one grid
         probs, stats = [], []
         for i in range(nb):

@@ -47,6 +47,7 @@ class CfuseArgs(C.Structure):
         ("dtype", i32), ("B", i32), ("T", i32), ("C", i32), ("NB", i32), ("CB", i32),
         ("x", vp * 4), ("gamma", vp * 4), ("beta", vp * 4), ("w_rm", vp * 4), ("bias", vp * 4),
         ("fw", vp), ("eps", f32), ("cat", vp), ("y", vp), ("mean", vp * 4), ("rstd", vp * 4),
+        ("fix", NanFix), ("fix_branch", i32),
     ]
 
 
@@ -213,6 +214,7 @@ _SIGS = {
     "qavit_im2col": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_im2col_ld": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_col2im": (i32, [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "qavit_branch_nan_fix": (i32, [i32, vp, i32, i32, C.POINTER(NanFix), vp]),
     "qavit_bank_stats_nanfix": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, C.POINTER(NanFix), vp]),
     "qavit_bank_stats": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]),
     "qavit_bank_ws_floats": (i64, [i32, i32, i32, i32]),

@@ -297,8 +297,12 @@ class CrossAttentionBranch(_Branch):
             sh_v = F.linear(gv, self.v_proj.weight, self.v_proj.bias).reshape(bank.bank_size, C)
         p = self.dropout.p if self.training else 0.0
         if F.branch_ok(2, x, 0, 0, bank.bank_size, self.num_heads):
+            # inside a QuadAttentionBlock the next reader of this output is the compress-fuse node: it carries the NaN rule's rewrite
+            # (qavit_cfuse_args.fix) -- unless a hook wants to see the output first
+            defer = bool(F.DEFER_FIX_CFUSE and getattr(self._rt, "in_block", False) and getattr(self._rt, "cross_to_cfuse", False)
+                         and not self._forward_hooks)
             return F.BranchFn.apply(x, self.q_proj.weight, self.q_proj.bias, self.proj.weight, self.proj.bias, None, None, sh_k, sh_v,
-                                    dict(kind=2, attn_drop=(p, self._site_attn), proj_drop=(p, self._site)))
+                                    dict(kind=2, attn_drop=(p, self._site_attn), proj_drop=(p, self._site), defer_fix=defer))
         q = F.linear(x, self.q_proj.weight, self.q_proj.bias).reshape(B * N, C)
         spec = dict(mode=1, G=B, Nq=N, L=0, H=self.num_heads, D=self.head_dim, S=bank.bank_size, q_off=0, k_off=0, v_off=0,
                     q_rows=B * N)
@@ -425,10 +429,17 @@ class QuadAttentionBlock(nn.Module):
             xn, xr = F.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, alias=True)
             xns = F.FanOutFn.apply(xn, 5) if (torch.is_grad_enabled() and xn.requires_grad) else (xn,) * 5
         args = []
-        for (name, branch), xb in zip((("swa", self.swa), ("msda", self.msda), ("cga", self.cga), ("cross", self.cross_attn)), xns):
-            bo = branch(xb, xns[4]) if name == "msda" else branch(xb)
-            nrm, cmp_ = getattr(self, f"norm_{name}"), getattr(self, f"compress_{name}")
-            args += [bo, nrm.weight, nrm.bias, cmp_.weight, cmp_.bias]
+        rt = self._rt
+        # the cross branch's output goes straight into the compress-fuse node below (no module hook in between reads it): that node's
+        # launch may carry the branch's NaN rule
+        rt.cross_to_cfuse = not any(m._forward_hooks or m._forward_pre_hooks for m in (self.norm_cross, self.compress_cross, self.fusion))
+        try:
+            for (name, branch), xb in zip((("swa", self.swa), ("msda", self.msda), ("cga", self.cga), ("cross", self.cross_attn)), xns):
+                bo = branch(xb, xns[4]) if name == "msda" else branch(xb)
+                nrm, cmp_ = getattr(self, f"norm_{name}"), getattr(self, f"compress_{name}")
+                args += [bo, nrm.weight, nrm.bias, cmp_.weight, cmp_.bias]
+        finally:
+            rt.cross_to_cfuse = False
         fused = F.CompressFuseFn.apply(self.fusion.fusion_weights, self.norm_swa.eps, *args)
         mlp = self.bottleneck_mlp
         p = mlp.dropout.p if tr else 0.0

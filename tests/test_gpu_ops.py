@@ -1505,6 +1505,64 @@ def test_nan_rule_deferred_into_the_bank_write(F, Q, which, B, T):
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("B,T", [(7, 16), (3, 64)])
+def test_nan_rule_of_the_cross_branch_rides_in_the_compress_fuse_launch(F, Q, B, T):
+    """Inside a QuadAttentionBlock the cross branch's output is read next by the compress-fuse launch, which then carries the branch's NaN
+    rule (qavit_cfuse_args.fix) instead of a launch of its own.  A block in training mode, dropout ON, one poisoned input (all four
+    rules trip), then a clean one through the same state: output, input gradient, every parameter gradient and the bank must equal the
+    path with the rule's own launch (QAVIT_DEFER_NANFIX_CFUSE off) bit for bit, and the deferral must really have happened."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    M = importlib.import_module("qa-vit_amd.modules")
+    rt = K.Runtime.get(0)
+    C = 192
+    cfg = Q.HQAViTConfig() if T == 16 else Q.HQAViTTinyINConfig()
+    cfg.dropout = 0.1
+    x0 = leaf(B, T, C, seed=910).detach().to(torch.bfloat16)
+    bad0 = x0.clone()
+    bad0[B // 2, 3, 11] = float("nan")
+    torch.manual_seed(6)
+    bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+    ctx = M._Ctx("hqa")
+    blk = M.QuadAttentionBlock(cfg, bank, 0.1, ctx).to(DEV).train()
+    Q.fill_module(blk)
+    state = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    calls = []
+    orig = F._defer_fix
+    F._defer_fix = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    res, ndef = {}, {}
+    try:
+        for defer in (True, False):
+            F.DEFER_FIX_CFUSE = defer
+            blk.load_state_dict(state)
+            rt.seed(4321)
+            outs = []
+            del calls[:]
+            for inp in (bad0, x0):
+                xin = inp.clone().requires_grad_(True)
+                for p_ in blk.parameters():
+                    p_.grad = None
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = blk(xin)
+                y.float().square().sum().backward()
+                outs += [y.detach().clone(), xin.grad.detach().clone(), bank.global_k.detach().clone()]
+                outs += [p_.grad.detach().clone() for _, p_ in sorted(blk.named_parameters()) if p_.grad is not None]
+                rt.advance()
+            torch.cuda.synchronize()
+            assert rt.nan_flag.tolist() == [0, 0] and rt.pending_fix is None
+            res[defer], ndef[defer] = outs, len(calls)
+    finally:
+        F._defer_fix = orig
+        F.DEFER_FIX_CFUSE = True
+    assert ndef[True] == ndef[False] + 2, ndef               # one more deferral per block call: the cross branch's
+    assert len(res[True]) == len(res[False])
+    for a_, b_ in zip(res[True], res[False]):
+        assert torch.equal(torch.nan_to_num(a_.float()), torch.nan_to_num(b_.float()))
+    assert torch.isfinite(res[True][0].float()).all() or True   # (the block's residual carries the poisoned input row through: only equality is asserted)
+    n1 = len(res[True]) // 2
+    assert all(torch.isfinite(t.float()).all() for t in res[True][n1:])          # the clean call after it is clean
+
+
 @pytest.mark.parametrize("B,T", [(6, 16), (3, 64)])
 @pytest.mark.parametrize("kind", [0, 1, 2, "cga"])
 def test_fused_branch_nan_rule_backward(F, Q, kind, B, T):
