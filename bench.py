@@ -54,7 +54,31 @@ def parse():
     ap.add_argument("--variant", default="v1", choices=["v1", "v2"], help="q32: QAViT.py (v1) or QAViTv2.py (v2) block variant")
     ap.add_argument("--mix", action="store_true", help="include device-side CutMix/MixUp + mixed loss in the step (off: the BASELINE metric)")
     ap.add_argument("--fwd-bwd-only", action="store_true", help="time forward+backward(+all-reduce) without the optimiser")
+    ap.add_argument("--ddp-tags", default=None, help="data-parallel sync points inside backward: 'none' (one bucketed all-reduce after backward), "
+                    "'fuse3' (one overlapped bucket prefix), 'all' (seven), or a comma list of tags; default: parallel.DataParallel's own (by world size)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` started directly (no WORLD_SIZE in the environment): THIS process has made no GPU call yet, so it may
+    start the N ranks as children -- ``python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`` -- relay what they print
+    (rank 0's JSON line on stdout) and exit with the launcher's code (non-zero if any rank failed).  Never an exec: a process that has
+    touched the GPU must not be replaced, and this one stays the parent."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()                       # counting devices does not initialise the GPU on this image
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node")
+    with socket.socket() as sk:                             # a free rendezvous port on the loopback address
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL over dmabuf IPC (the host driver supports nothing else)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: starting the ranks myself: {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    rc = subprocess.run(cmd, env=env).returncode
+    raise SystemExit(rc)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -371,11 +395,16 @@ def main():
         return bench_q32_eval(args)
     if args.eval:
         raise SystemExit("--eval is the q32 leg (BASELINE config 2); the c100 / tin legs time the full training step")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                   # does not return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if world > 1:
+            args.gpus = world
+        else:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a one-GPU number as n_gpus={args.gpus}")
     import qavit_amd as Q
     import importlib
     K = importlib.import_module("qa-vit_amd.kernels")
@@ -404,7 +433,10 @@ def main():
 
     dp = None
     if world > 1 or force_ddp:
-        dp = par.DataParallel(model)
+        tags = None
+        if args.ddp_tags is not None:
+            tags = () if args.ddp_tags == "none" else ("all" if args.ddp_tags == "all" else tuple(t for t in args.ddp_tags.split(",") if t))
+        dp = par.DataParallel(model, sync_tags=tags)
     tcfg = Q.TrainingConfig(batch_size=B * world, use_amp=(cdt == torch.bfloat16), device_mix=args.mix)
     tr = Q.Trainer(model, tcfg, total_steps=100000, warmup_steps=1000, reducer=(dp.reducer if dp else None),
                    compute_dtype=cdt, order=par.bucket_order)
@@ -459,7 +491,8 @@ def main():
                                + ("grad all-reduce, " if world > 1 else "") + ("clip + fused AdamW)" if with_optim else "no optimiser)"),
                    "weights": f"{type(cfg).__name__}() defaults, {sum(p.numel() for p in model.parameters()):,} parameters, random-init (key-seeded filler)",
                    "global_batch": B * world, "per_gpu_batch": B, "image": f"{cfg.img_size}x{cfg.img_size}x3", "parallelism": f"dp{world}",
-                   "launch": mode, "dropout": cfg.dropout, "drop_path": cfg.drop_path, "final_loss": round(loss_val, 4)},
+                   "launch": mode, "dropout": cfg.dropout, "drop_path": cfg.drop_path, "final_loss": round(loss_val, 4),
+                   "ddp_sync_tags": (("all" if dp.sync_tags is None else list(dp.sync_tags)) if dp else None)},
     }
     step_tflops = value * (MFLOP_PER_IMG_TRAIN if args.config == "c100" else 6490.0) * 1e6 / 1e12     # 1,293 / 6,490 MFLOP per image
     out["config"]["algorithmic_tflops_per_s"] = round(step_tflops, 2)                     # the reference's own operation count

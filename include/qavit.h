@@ -151,8 +151,9 @@ int qavit_layernorm_bwd_parts(int rows, int C);
 /* SplitFusion's closing pair as one launch each way (HQAViT_CIFAR100.py:953-965): mixed = s0*a + s1*(t + dropout(h)), s = softmax(fw[0:2]);
  * y = LayerNorm(mixed).  fwd writes `mixed` [rows, C] (the backward's LayerNorm input), y, mean, rstd.  bwd takes dy and writes da, dt, dh,
  * adds the blend-weight gradient to dfw[0:2] (float atomics, one pair per workgroup; may be NULL) and the LayerNorm parameter gradients
- * to dgamma / dbeta -- or, with part_ws = float[qavit_mix3_ln_bwd_parts(rows, C)][2][C], leaves them as partial rows in the layout of
- * qavit_layernorm_bwd's.  Values and rounding points are those of qavit_mix3_fwd / qavit_layernorm_fwd (resp. qavit_layernorm_bwd / qavit_mix3_bwd) run
+ * to dgamma / dbeta -- or, with part_ws = float[n = qavit_mix3_ln_bwd_parts(rows, C)][2][C] followed by float[n][4], leaves them as partial
+ * rows in the layout of qavit_layernorm_bwd's and the blend-weight contributions as n narrow rows [dfw0, dfw1, 0, 0] behind them (dfw != NULL
+ * then only says they are wanted: fold with a reduce descriptor C = 2, stride 4).  Values and rounding points are those of qavit_mix3_fwd / qavit_layernorm_fwd (resp. qavit_layernorm_bwd / qavit_mix3_bwd) run
  * one after the other.  fp32 / bf16, C % 4 == 0, C <= 256 (qavit_mix3_ln_supported), rows * C < 2^32, vector-aligned operands. */
 int qavit_mix3_ln_supported(int dtype, int C);
 int qavit_mix3_ln_bwd_parts(int rows, int C);
@@ -184,8 +185,12 @@ int qavit_layernorm_bwd_lin_supported(int dtype, int KZ, int C);
 int qavit_layernorm_bwd_lin(int dtype, const void* dz, int ldz, const void* W, int ldw, int KZ, const void* x, const float* gamma,
                             const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int C,
                             const void* dres, float* part_ws, void* stream);
+/* NARROW descriptors -- C in {1, 2, 4}: scalar layer scales, blend / fusion logits -- are folded by ONE workgroup in a fixed row
+ * order whatever nparts is, so those gradients are bit-reproducible from run to run (a float atomic per workgroup on one address
+ * is not).  C == 1: rows of 4 floats [dgamma, dbeta, -, -]; C == 2: [dgamma0, dgamma1, dbeta0, dbeta1].  Wide descriptors split
+ * their rows over workgroups of 32 and meet in float atomics: reproducible up to 32 partial rows. */
 typedef struct qavit_ln_reduce_desc {
-  const float* parts; int nparts; int C;     /* nparts rows of [2][C] (C % 4 == 0, C <= 2048) ... */
+  const float* parts; int nparts; int C;     /* nparts rows of [2][C] (C % 4 == 0 or C in {1, 2}; C <= 2048) ... */
   float* dgamma; float* dbeta;               /* += the two halves of the summed row (either may be NULL) */
   int64_t stride;                            /* ... `stride` floats apart (0: 2*C, dense; else a multiple of 4) */
 } qavit_ln_reduce_desc;
@@ -333,12 +338,15 @@ int qavit_upmix_bwd(int dtype, const void* dy, const void* xc, const float* W, c
                     float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, void* stream);
 /* The same with the parameter gradients left as PARTIAL ROWS: `parts` = float[qavit_upmix_bwd_parts(...)][N*M + N + 2*C], 16-byte
  * aligned, one row [dW | dbias | dgamma | dbeta] per workgroup written with plain stores; dW / dbias / dgamma / dbeta are not
- * touched -- fold the rows with qavit_ln_param_reduce (stride N*M + N + 2*C).  The 256-deep same-address float atomics this replaces
+ * touched -- fold the rows with qavit_ln_param_reduce (stride N*M + N + 2*C + 4: each row ends in four floats [dgamma_sa, 0, 0, 0],
+ * the layer scale's gradient of qavit_upmix_bwd_sa, zero otherwise).  The 256-deep same-address float atomics this replaces
  * were the larger half of the kernel.  qavit_upmix_bwd_parts() == 0: no partial-row path for this dtype / shape (pass parts = NULL). */
 int qavit_upmix_bwd_parts(int dtype, int B, int N, int M, int C);
+#define QAVIT_UPMIX_PART_ROW(N, M, C) ((N) * (M) + (N) + 2 * (C) + 4)
 /* The up-mix backward that ALSO differentiates the scale-add in front of it, xc = x + droppath(gamma * u) (the block tail,
  * HQAViT_CIFAR100.py:1085 then :1118-1121): besides dxc (= dx) it writes du = dxc * f * gamma[0] and adds sum(dxc * f * u) to dgamma_sa
- * (one float atomic per workgroup), f = the image's drop-path factor (dp_p, dp_site, rng; samples = images).  u, du [B*M, C].  bf16,
+ * (one float atomic per workgroup; with `parts` the workgroup's sum goes to the last four floats of its partial row instead and dgamma_sa
+ * is not touched: reduce descriptor C = 1), f = the image's drop-path factor (dp_p, dp_site, rng; samples = images).  u, du [B*M, C].  bf16,
  * N = 64, M = 16, C = 192 (qavit_upmix_bwd_sa_supported). */
 int qavit_upmix_bwd_sa_supported(int dtype, int N, int M, int C);
 int qavit_upmix_bwd_sa(int dtype, const void* dy, const void* xc, const float* W, const float* bias, const float* gamma,
@@ -638,10 +646,18 @@ int qavit_patchify(int dtype, const float* img, void* cols, int B, int Cin, int 
 int qavit_token_mean_fwd(int dtype, const void* x, void* y, int B, int N, int C, void* stream);
 int qavit_token_mean_bwd(int dtype, const void* dy, void* dx, int B, int N, int C, void* stream);
 /* HybridFusion (HQAViT_CIFAR100.py:637-640): y[:, i*Cb:(i+1)*Cb] = x[:, i*Cb:(i+1)*Cb] * softmax(fw)[i];
- * bwd: dx and dfw[nb] += (through the softmax) */
+ * bwd: dx and dfw[nb] += (through the softmax)
+ * NARROW PARTIAL ROWS (this entry point, qavit_mix2_bwd, qavit_mix3_bwd, qavit_scale_add_bwd): a parameter gradient of 1-4 values summed
+ * over the whole tensor.  part_ws == NULL: every workgroup adds its contribution with float atomics (summation order, hence the last
+ * bits, vary from run to run).  part_ws = float[QAVIT_NARROW_PARTS_MAX][row], 16-byte aligned, with nparts != NULL: workgroup b stores
+ * its contribution as row b with plain stores, the parameter gradient is NOT touched and *nparts (host) receives the number of rows
+ * written; fold them with qavit_ln_param_reduce (a narrow descriptor: fixed order, bit-reproducible).  Row = 4 floats, descriptor
+ * C = 1 (scale_add: [dgamma, 0, 0, 0]) or C = 2 (mix2 / mix3: [dfw0, dfw1, 0, 0]); hybrid_fuse: 8 floats, C = 4 (nb <= 4; more
+ * branches keep the atomics and report *nparts = 0). */
+#define QAVIT_NARROW_PARTS_MAX 1024
 int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, void* y, int rows, int nb, int Cb, void* stream);
 int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, const float* fw, void* dx, float* dfw,
-                          int rows, int nb, int Cb, void* stream);
+                          int rows, int nb, int Cb, float* part_ws, int* nparts, void* stream);
 /* out = xs[0] + ... + xs[k-1] (k <= 8 same-shape tensors, host array of device pointers): the gradient of norm1's output,
  * which feeds five consumers in QuadAttentionBlock (HQAViT_CIFAR100.py:1072-1078), summed in one pass. */
 int qavit_sum_k(int dtype, const void* const* xs, int k, void* out, int64_t n, void* stream);
@@ -660,19 +676,19 @@ int qavit_gate_mix_bwd(int dtype, const void* dy, const void* r, const void* g, 
  * of the 16-byte vector, operands 16-byte aligned).  bwd: da = s0*dy, db = s1*dy, dfw[2] += (through the softmax; may be NULL) */
 int qavit_mix2_fwd(int dtype, const void* a, const void* b, const float* fw, void* y, int64_t n, void* stream);
 int qavit_mix2_bwd(int dtype, const void* dy, const void* a, const void* b, const float* fw, void* da, void* db, float* dfw,
-                   int64_t n, void* stream);
+                   int64_t n, float* part_ws, int* nparts, void* stream);
 /* The blend with its second operand built in place (HQAViT_CIFAR100.py:953-963): y = s0*a + s1*(t + dropout(h)) -- dropout with
  * the library's counter-based mask (drop_p, drop_site, rng as qavit_dropout; element index = flat index).  bwd: da = s0*dy,
  * dt = s1*dy, dh = dt * mask, dfw[2] += (may be NULL).  Same size / alignment rules as qavit_mix2_*; n < 2^32. */
 int qavit_mix3_fwd(int dtype, const void* a, const void* t, const void* h, const float* fw, void* y, int64_t n,
                    float drop_p, int drop_site, const int64_t* rng, void* stream);
 int qavit_mix3_bwd(int dtype, const void* dy, const void* a, const void* t, const void* h, const float* fw, void* da, void* dt, void* dh,
-                   float* dfw, int64_t n, float drop_p, int drop_site, const int64_t* rng, void* stream);
+                   float* dfw, int64_t n, float drop_p, int drop_site, const int64_t* rng, float* part_ws, int* nparts, void* stream);
 /* y = x + droppath( gamma[0] * u )  (CCF-FFN gamma + residual, HQAViT_CIFAR100.py:712,1083); gamma may be NULL (=1) */
 int qavit_scale_add_fwd(int dtype, const void* x, const void* u, const float* gamma, void* y, int rows, int C,
                         float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
 int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, const float* gamma, void* du, float* dgamma,
-                        int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream);
+                        int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, float* part_ws, int* nparts, void* stream);
 /* nn.BatchNorm2d (+ optional exact GELU, act = 1) of the CNN stem on channel-last rows x[M = B*H*W, C]
  * (HQAViT_CIFAR100.py:753,760,768,775).  training != 0: batch statistics (biased variance for the output, unbiased
  * for running_var), running_mean / running_var updated in place with `momentum`, save_mean / save_rstd [C] written

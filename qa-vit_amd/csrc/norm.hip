@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64 * NW) void mix3_ln_bwd_kernel(const T* dy, LnMix
       else atomic_add_f(dst + cc, sacc);
     }
   }
-  if (mx.dfw) {                                              // the blend weights through their softmax: one pair of atomics per workgroup
+  if (mx.dfw) {                                              // the blend weights through their softmax
     __syncthreads();
     const float s0 = wave_sum(p0), s1 = wave_sum(p1);
     if (lane == 0) { red[0][wave][0] = s0; red[1][wave][0] = s1; }
@@ -638,8 +638,10 @@ __global__ __launch_bounds__(64 * NW) void mix3_ln_bwd_kernel(const T* dy, LnMix
 #pragma unroll
       for (int w = 0; w < NW; ++w) { d0 += red[0][w][0]; d1 += red[1][w][0]; }
       const float dot = d0 * w0 + d1 * w1;
-      atomic_add_f(mx.dfw + 0, w0 * (d0 - dot));
-      atomic_add_f(mx.dfw + 1, w1 * (d1 - dot));
+      // with partial rows: this workgroup's [4] after the gridDim.x LayerNorm rows (reduce descriptor C = 2: a fixed-order fold, the two
+      // logits' gradients are the same bits on every run); else one pair of atomics per workgroup
+      if (parts) *reinterpret_cast<f32x4*>(parts + (size_t)gridDim.x * 2 * C + (size_t)blockIdx.x * 4) = f32x4{w0 * (d0 - dot), w1 * (d1 - dot), 0.f, 0.f};
+      else { atomic_add_f(mx.dfw + 0, w0 * (d0 - dot)); atomic_add_f(mx.dfw + 1, w1 * (d1 - dot)); }
     }
   }
 }
@@ -747,15 +749,20 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_lin_kernel(const bf16* 
 // dgamma / dbeta += sum over the partial rows a layernorm_bwd launch left in ``parts`` ([nparts][2][C]): one workgroup per LayerNorm,
 // threads = (group, 4-float vector of the 2C-wide row), groups stride over the rows with four loads in flight, LDS fold, then ONE
 // atomic per channel (atomic because a shared parameter may collect from several LayerNorm calls).
+// NARROW descriptors (C <= 4: scalar layer scales, blend / fusion logits) are folded by ONE workgroup whatever nparts is, rows in a fixed
+// order: their sums are bit-reproducible from run to run (the wide ones are, too, up to LNR_SLICE partial rows).  C == 1: rows are
+// [dgamma, dbeta, pad, pad]; C == 2: [dgamma0, dgamma1, dbeta0, dbeta1].
 struct LnReduceGroup { int n; qavit_ln_reduce_desc d[48]; };
 constexpr int LNR_SLICE = 32;                              // partial rows per workgroup (blockIdx.y = slice)
 __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnReduceGroup G) {
   __shared__ __attribute__((aligned(16))) float fold[4096];
   const qavit_ln_reduce_desc d = G.d[blockIdx.x];
-  const int p0 = blockIdx.y * LNR_SLICE;
-  if (p0 >= d.nparts) return;                              // uniform per workgroup
-  const int p1 = p0 + LNR_SLICE < d.nparts ? p0 + LNR_SLICE : d.nparts;
-  const int W = 2 * d.C, V = W >> 2, groups = 1024 / V;
+  const bool narrow = d.C <= 4;
+  const int p0 = narrow ? 0 : blockIdx.y * LNR_SLICE;
+  if (p0 >= d.nparts || (narrow && blockIdx.y)) return;   // uniform per workgroup
+  const int p1 = narrow ? d.nparts : (p0 + LNR_SLICE < d.nparts ? p0 + LNR_SLICE : d.nparts);
+  const int W = d.C == 1 ? 4 : 2 * d.C, V = W >> 2;
+  const int groups = narrow ? 64 / V : 1024 / V;           // narrow: 64 / 32 threads sweep the rows, one serial fold of their sums
   const size_t RS = d.stride > 0 ? (size_t)d.stride : (size_t)W;          // floats between partial rows
   const int g = threadIdx.x / V, v = threadIdx.x - g * V;
   if (g < groups) {
@@ -784,6 +791,7 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(LnReduceGroup G) 
   for (int c = threadIdx.x; c < W; c += 1024) {
     float t = 0.f;
     for (int q = 0; q < groups; ++q) t += fold[q * W + c];
+    if (d.C == 1) { if (c < 2) { float* dst = c ? d.dbeta : d.dgamma; if (dst) atomic_add_f(dst, t); } continue; }
     float* dst = c < d.C ? d.dgamma : d.dbeta;
     if (dst) atomic_add_f(dst + (c < d.C ? c : c - d.C), t);
   }
@@ -1106,9 +1114,10 @@ extern "C" int qavit_layernorm_bwd_multi(int dtype, int n, const void* const* dy
 extern "C" int qavit_ln_param_reduce(const qavit_ln_reduce_desc* d, int n, void* stream) {
   if (!d || n <= 0) return set_error(QAVIT_EINVAL, "ln_param_reduce: empty list");
   for (int i = 0; i < n; ++i) {
-    if (!d[i].parts || d[i].nparts <= 0 || d[i].C <= 0 || d[i].C % 4 || d[i].C > 2048 || (reinterpret_cast<uintptr_t>(d[i].parts) & 15) ||
-        d[i].stride < 0 || d[i].stride % 4 || (d[i].stride > 0 && d[i].stride < 2 * d[i].C))
-      return set_error(QAVIT_EINVAL, "ln_param_reduce: bad descriptor (C % 4 == 0, C <= 2048, 16-byte aligned partial sums, stride % 4 == 0)");
+    const bool narrow = d[i].C == 1 || d[i].C == 2;        // rows of 4 floats
+    if (!d[i].parts || d[i].nparts <= 0 || d[i].C <= 0 || (d[i].C % 4 && !narrow) || d[i].C > 2048 || (reinterpret_cast<uintptr_t>(d[i].parts) & 15) ||
+        d[i].stride < 0 || d[i].stride % 4 || (d[i].stride > 0 && d[i].stride < (narrow ? 4 : 2 * d[i].C)))
+      return set_error(QAVIT_EINVAL, "ln_param_reduce: bad descriptor (C % 4 == 0 or C in {1, 2}, C <= 2048, 16-byte aligned partial sums, stride % 4 == 0)");
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int done = 0; done < n; done += 48) {

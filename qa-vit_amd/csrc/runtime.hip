@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void hybrid_fwd_kernel(const T* x, const float
 // dx = dy * w[b];  ds[b] = sum dy*x over branch b;  dfw[j] += sum_b ds[b] * w[b] * (delta_bj - w[j])
 template <typename T>
 __global__ __launch_bounds__(256) void hybrid_bwd_kernel(const T* dy, const T* x, const float* fw, T* dx, float* dfw,
-                                                         int64_t n, int nb, int Cb) {
+                                                         int64_t n, int nb, int Cb, float* parts) {
   float w[8], part[8];
   softmax_small(fw, nb, w);
   for (int i = 0; i < 8; ++i) part[i] = 0.f;
@@ -155,7 +155,10 @@ __global__ __launch_bounds__(256) void hybrid_bwd_kernel(const T* dy, const T* x
     for (int j = 0; j < nb; ++j) ds[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
     float dot = 0.f;
     for (int j = 0; j < nb; ++j) dot += ds[j] * w[j];
-    for (int j = 0; j < nb; ++j) atomic_add_f(dfw + j, w[j] * (ds[j] - dot));
+    if (parts) {                                            // this workgroup's row of [grid][8] contributions (qavit_ln_param_reduce, C = 4)
+      for (int j = 0; j < 8; ++j) parts[(size_t)blockIdx.x * 8 + j] = (j < nb && j < 4) ? w[j] * (ds[j] - dot) : 0.f;
+    } else
+      for (int j = 0; j < nb; ++j) atomic_add_f(dfw + j, w[j] * (ds[j] - dot));
   }
 }
 
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void hybrid_fwd_vec_kernel(const T* x, const f
 }
 template <typename T>
 __global__ __launch_bounds__(256) void hybrid_bwd_vec_kernel(const T* dy, const T* x, const float* fw, T* dx, float* dfw,
-                                                             uint32_t nvec, int nb, int Cb, int C) {
+                                                             uint32_t nvec, int nb, int Cb, int C, float* parts) {
   constexpr int VEC = Vec<T>::N;
   typedef typename Vec<T>::type vec_t;
   float w[8], part[8];
@@ -214,12 +217,15 @@ __global__ __launch_bounds__(256) void hybrid_bwd_vec_kernel(const T* dy, const 
     for (int j = 0; j < nb; ++j) ds[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
     float dot = 0.f;
     for (int j = 0; j < nb; ++j) dot += ds[j] * w[j];
-    for (int j = 0; j < nb; ++j) atomic_add_f(dfw + j, w[j] * (ds[j] - dot));
+    if (parts) {                                            // this workgroup's row of [grid][8] contributions (qavit_ln_param_reduce, C = 4)
+      for (int j = 0; j < 8; ++j) parts[(size_t)blockIdx.x * 8 + j] = (j < nb && j < 4) ? w[j] * (ds[j] - dot) : 0.f;
+    } else
+      for (int j = 0; j < nb; ++j) atomic_add_f(dfw + j, w[j] * (ds[j] - dot));
   }
 }
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void scale_add_vec_kernel(const T* a0, const T* u, const float* gamma, T* out, float* dgamma, uint32_t nvec, int C,
-                                                            float dp_p, int dp_site, int dp_rows, const int64_t* rng) {
+                                                            float dp_p, int dp_site, int dp_rows, const int64_t* rng, float* parts) {
   // forward: a0 = x, out = y = x + f*gamma*u.   backward: a0 = dy, out = du = dy*f*gamma, dgamma += sum dy*f*u.
   constexpr int VEC = Vec<T>::N;
   typedef typename Vec<T>::type vec_t;
@@ -241,12 +247,18 @@ __global__ __launch_bounds__(256) void scale_add_vec_kernel(const T* a0, const T
     }
     *reinterpret_cast<vec_t*>(out + (size_t)v * VEC) = o;
   }
-  if (BWD && dgamma) {
+  if (BWD && (dgamma || parts)) {
     __shared__ float red[4];
     const float s_ = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s_;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f(dgamma, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      const float t = red[0] + red[1] + red[2] + red[3];
+      // parts: this workgroup's row of [grid][4] (plain store; qavit_ln_param_reduce, C = 1, folds the rows in a fixed order: the scalar's
+      // gradient is then the same bits on every run -- one float atomic per workgroup on one address is not)
+      if (parts) *reinterpret_cast<f32x4*>(parts + (size_t)blockIdx.x * 4) = f32x4{t, 0.f, 0.f, 0.f};
+      else atomic_add_f(dgamma, t);
+    }
   }
 }
 
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256) void scale_add_vec_kernel(const T* a0, const T
 // sums, so each workgroup adds its own contribution.  (The stock mul/sum chain reduces with a memset-initialised
 // semaphore buffer; memset nodes of a replayed hipGraph were observed to race: garbage fusion-weight gradients.)
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, const T* dy, const float* fw, T* o0, T* o1, float* dfw, uint32_t nvec) {
+__global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, const T* dy, const float* fw, T* o0, T* o1, float* dfw, uint32_t nvec, float* parts) {
   constexpr int VEC = Vec<T>::N;
   typedef typename Vec<T>::type vec_t;
   float w[8];
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, c
       *reinterpret_cast<vec_t*>(o1 + (size_t)v * VEC) = x1;
     }
   }
-  if (BWD && dfw) {
+  if (BWD && (dfw || parts)) {
     __shared__ float red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float s0 = wave_sum(p0), s1 = wave_sum(p1);
@@ -290,8 +302,8 @@ __global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, c
     if (threadIdx.x == 0) {
       const float d0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], d1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
       const float dot = d0 * w[0] + d1 * w[1];
-      atomic_add_f(dfw + 0, w[0] * (d0 - dot));
-      atomic_add_f(dfw + 1, w[1] * (d1 - dot));
+      if (parts) *reinterpret_cast<f32x4*>(parts + (size_t)blockIdx.x * 4) = f32x4{w[0] * (d0 - dot), w[1] * (d1 - dot), 0.f, 0.f};   // [grid][4]: reduce desc C = 2
+      else { atomic_add_f(dfw + 0, w[0] * (d0 - dot)); atomic_add_f(dfw + 1, w[1] * (d1 - dot)); }
     }
   }
 }
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256) void mix2_vec_kernel(const T* a, const T* b, c
 // bwd: da = s0*dy, dt = s1*dy, dh = dt * mask, dfw through the softmax from (sum dy*a, sum dy*(t + dropout(h))).
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void mix3_vec_kernel(const T* a, const T* t, const T* h, const T* dy, const float* fw, T* o0, T* o1, T* o2, float* dfw,
-                                                       uint32_t nvec, float p, int site, const int64_t* rng) {
+                                                       uint32_t nvec, float p, int site, const int64_t* rng, float* parts) {
   constexpr int VEC = Vec<T>::N;
   typedef typename Vec<T>::type vec_t;
   float w[8];
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(256) void mix3_vec_kernel(const T* a, const T* t, c
       *reinterpret_cast<vec_t*>(o2 + (size_t)v * VEC) = x2;
     }
   }
-  if (BWD && dfw) {
+  if (BWD && (dfw || parts)) {
     __shared__ float red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float s0 = wave_sum(p0), s1 = wave_sum(p1);
@@ -349,8 +361,8 @@ __global__ __launch_bounds__(256) void mix3_vec_kernel(const T* a, const T* t, c
     if (threadIdx.x == 0) {
       const float d0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], d1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
       const float dot = d0 * w[0] + d1 * w[1];
-      atomic_add_f(dfw + 0, w[0] * (d0 - dot));
-      atomic_add_f(dfw + 1, w[1] * (d1 - dot));
+      if (parts) *reinterpret_cast<f32x4*>(parts + (size_t)blockIdx.x * 4) = f32x4{w[0] * (d0 - dot), w[1] * (d1 - dot), 0.f, 0.f};   // [grid][4]: reduce desc C = 2
+      else { atomic_add_f(dfw + 0, w[0] * (d0 - dot)); atomic_add_f(dfw + 1, w[1] * (d1 - dot)); }
     }
   }
 }
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(256) void scale_add_fwd_kernel(const T* x, const T*
 }
 template <typename T>
 __global__ __launch_bounds__(256) void scale_add_bwd_kernel(const T* dy, const T* u, const float* gamma, T* du, float* dgamma,
-                                                            int64_t n, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng) {
+                                                            int64_t n, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, float* parts) {
   const float gm = gamma ? gamma[0] : 1.f;
   const uint32_t key = dp_p > 0.f ? rng_key(rng, dp_site) : 0u;
   const float inv = dp_p > 0.f ? 1.f / (1.f - dp_p) : 1.f;
@@ -505,12 +517,16 @@ __global__ __launch_bounds__(256) void scale_add_bwd_kernel(const T* dy, const T
     du[i] = from_f<T>(g * gm);
     part += g * to_f<T>(u[i]);
   }
-  if (dgamma) {
+  if (dgamma || parts) {
     __shared__ float red[4];
     const float s = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f(dgamma, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      const float t = red[0] + red[1] + red[2] + red[3];
+      if (parts) *reinterpret_cast<f32x4*>(parts + (size_t)blockIdx.x * 4) = f32x4{t, 0.f, 0.f, 0.f};
+      else atomic_add_f(dgamma, t);
+    }
   }
 }
 
@@ -664,24 +680,32 @@ extern "C" int qavit_hybrid_fuse_fwd(int dtype, const void* x, const float* fw, 
   return check_launch("hybrid_fuse_fwd");
 }
 extern "C" int qavit_hybrid_fuse_bwd(int dtype, const void* dy, const void* x, const float* fw, void* dx, float* dfw,
-                                     int rows, int nb, int Cb, void* stream) {
+                                     int rows, int nb, int Cb, float* part_ws, int* nparts, void* stream) {
   if (!dy || !x || !fw || !dx || !dfw || rows <= 0 || nb <= 0 || nb > 8 || Cb <= 0) return set_error(QAVIT_EINVAL, "hybrid_fuse_bwd: bad arguments");
+  if (part_ws && (!nparts || (reinterpret_cast<uintptr_t>(part_ws) & 15))) return set_error(QAVIT_EINVAL, "hybrid_fuse_bwd: part_ws needs nparts and 16-byte alignment");
+  if (nb > 4) part_ws = nullptr;                            // rows of [8] = (4 logits, 4 unused): more branches keep the atomics
+  if (nparts) *nparts = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)rows * nb * Cb;
   if (dtype == QAVIT_BF16 && vec_ok<bf16>(nb * Cb, Cb, n, x, dy, dx)) {
     const uint32_t nvec = (uint32_t)(n / 8);
-    hipLaunchKernelGGL((hybrid_bwd_vec_kernel<bf16>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, nvec, nb, Cb, nb * Cb);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((hybrid_bwd_vec_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, nvec, nb, Cb, nb * Cb, part_ws);
     return check_launch("hybrid_fuse_bwd");
   }
   if (dtype == QAVIT_F32 && vec_ok<float>(nb * Cb, Cb, n, x, dy, dx)) {
     const uint32_t nvec = (uint32_t)(n / 4);
-    hipLaunchKernelGGL((hybrid_bwd_vec_kernel<float>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, nvec, nb, Cb, nb * Cb);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((hybrid_bwd_vec_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, nvec, nb, Cb, nb * Cb, part_ws);
     return check_launch("hybrid_fuse_bwd");
   }
   const int g = blocks_for(n, 4096, 1024);
+  if (part_ws) *nparts = g;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb),
-             hipLaunchKernelGGL((hybrid_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, n, nb, Cb), "hybrid_fuse_bwd");
+             hipLaunchKernelGGL((hybrid_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, fw, (float*)dx, dfw, n, nb, Cb, part_ws),
+             hipLaunchKernelGGL((hybrid_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, fw, (bf16*)dx, dfw, n, nb, Cb, part_ws), "hybrid_fuse_bwd");
   return check_launch("hybrid_fuse_bwd");
 }
 
@@ -748,10 +772,10 @@ extern "C" int qavit_mix2_fwd(int dtype, const void* a, const void* b, const flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == QAVIT_BF16 && vec_ok<bf16>(8, 8, n, a, b, y) && n % 8 == 0) {
     const uint32_t nvec = (uint32_t)(n / 8);
-    hipLaunchKernelGGL((mix2_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)nullptr, fw, (bf16*)y, (bf16*)nullptr, (float*)nullptr, nvec);
+    hipLaunchKernelGGL((mix2_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)nullptr, fw, (bf16*)y, (bf16*)nullptr, (float*)nullptr, nvec, (float*)nullptr);
   } else if (dtype == QAVIT_F32 && vec_ok<float>(4, 4, n, a, b, y) && n % 4 == 0) {
     const uint32_t nvec = (uint32_t)(n / 4);
-    hipLaunchKernelGGL((mix2_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)nullptr, fw, (float*)y, (float*)nullptr, (float*)nullptr, nvec);
+    hipLaunchKernelGGL((mix2_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)nullptr, fw, (float*)y, (float*)nullptr, (float*)nullptr, nvec, (float*)nullptr);
   } else return set_error(QAVIT_EINVAL, "mix2_fwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
   return check_launch("mix2_fwd");
 }
@@ -764,44 +788,57 @@ extern "C" int qavit_mix3_fwd(int dtype, const void* a, const void* t, const voi
   if (dtype == QAVIT_BF16 && al && n % 8 == 0) {
     const uint32_t nvec = (uint32_t)(n / 8);
     hipLaunchKernelGGL((mix3_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)a, (const bf16*)t, (const bf16*)h, (const bf16*)nullptr, fw,
-                       (bf16*)y, (bf16*)nullptr, (bf16*)nullptr, (float*)nullptr, nvec, drop_p, drop_site, rng);
+                       (bf16*)y, (bf16*)nullptr, (bf16*)nullptr, (float*)nullptr, nvec, drop_p, drop_site, rng, (float*)nullptr);
   } else if (dtype == QAVIT_F32 && al && n % 4 == 0) {
     const uint32_t nvec = (uint32_t)(n / 4);
     hipLaunchKernelGGL((mix3_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)a, (const float*)t, (const float*)h, (const float*)nullptr, fw,
-                       (float*)y, (float*)nullptr, (float*)nullptr, (float*)nullptr, nvec, drop_p, drop_site, rng);
+                       (float*)y, (float*)nullptr, (float*)nullptr, (float*)nullptr, nvec, drop_p, drop_site, rng, (float*)nullptr);
   } else return set_error(QAVIT_EINVAL, "mix3_fwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
   return check_launch("mix3_fwd");
 }
 
 extern "C" int qavit_mix3_bwd(int dtype, const void* dy, const void* a, const void* t, const void* h, const float* fw, void* da, void* dt, void* dh,
-                              float* dfw, int64_t n, float drop_p, int drop_site, const int64_t* rng, void* stream) {
+                              float* dfw, int64_t n, float drop_p, int drop_site, const int64_t* rng, float* part_ws, int* nparts, void* stream) {
   if (!dy || !a || !t || !h || !fw || !da || !dt || !dh || n <= 0 || drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !rng))
     return set_error(QAVIT_EINVAL, "mix3_bwd: bad arguments");
+  if (part_ws && (!nparts || (reinterpret_cast<uintptr_t>(part_ws) & 15))) return set_error(QAVIT_EINVAL, "mix3_bwd: part_ws needs nparts and 16-byte alignment");
+  if (nparts) *nparts = 0;
   if (n > 0xffffffffll) return set_error(QAVIT_EINVAL, "mix3_bwd: the dropout index is 32 bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool al = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(h) |
                     reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(dt) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
   if (dtype == QAVIT_BF16 && al && n % 8 == 0) {
     const uint32_t nvec = (uint32_t)(n / 8);
-    hipLaunchKernelGGL((mix3_vec_kernel<bf16, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)a, (const bf16*)t, (const bf16*)h, (const bf16*)dy, fw,
-                       (bf16*)da, (bf16*)dt, (bf16*)dh, dfw, nvec, drop_p, drop_site, rng);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((mix3_vec_kernel<bf16, true>), dim3(g), dim3(256), 0, st, (const bf16*)a, (const bf16*)t, (const bf16*)h, (const bf16*)dy, fw,
+                       (bf16*)da, (bf16*)dt, (bf16*)dh, dfw, nvec, drop_p, drop_site, rng, part_ws);
   } else if (dtype == QAVIT_F32 && al && n % 4 == 0) {
     const uint32_t nvec = (uint32_t)(n / 4);
-    hipLaunchKernelGGL((mix3_vec_kernel<float, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)a, (const float*)t, (const float*)h, (const float*)dy, fw,
-                       (float*)da, (float*)dt, (float*)dh, dfw, nvec, drop_p, drop_site, rng);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((mix3_vec_kernel<float, true>), dim3(g), dim3(256), 0, st, (const float*)a, (const float*)t, (const float*)h, (const float*)dy, fw,
+                       (float*)da, (float*)dt, (float*)dh, dfw, nvec, drop_p, drop_site, rng, part_ws);
   } else return set_error(QAVIT_EINVAL, "mix3_bwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
   return check_launch("mix3_bwd");
 }
 
-extern "C" int qavit_mix2_bwd(int dtype, const void* dy, const void* a, const void* b, const float* fw, void* da, void* db, float* dfw, int64_t n, void* stream) {
+extern "C" int qavit_mix2_bwd(int dtype, const void* dy, const void* a, const void* b, const float* fw, void* da, void* db, float* dfw, int64_t n,
+                              float* part_ws, int* nparts, void* stream) {
   if (!dy || !a || !b || !fw || !da || !db || n <= 0) return set_error(QAVIT_EINVAL, "mix2_bwd: bad arguments");
+  if (part_ws && (!nparts || (reinterpret_cast<uintptr_t>(part_ws) & 15))) return set_error(QAVIT_EINVAL, "mix2_bwd: part_ws needs nparts and 16-byte alignment");
+  if (nparts) *nparts = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == QAVIT_BF16 && vec_ok<bf16>(8, 8, n, a, b, dy) && vec_ok<bf16>(8, 8, n, da, db, dy) && n % 8 == 0) {
     const uint32_t nvec = (uint32_t)(n / 8);
-    hipLaunchKernelGGL((mix2_vec_kernel<bf16, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)dy, fw, (bf16*)da, (bf16*)db, dfw, nvec);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((mix2_vec_kernel<bf16, true>), dim3(g), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)dy, fw, (bf16*)da, (bf16*)db, dfw, nvec, part_ws);
   } else if (dtype == QAVIT_F32 && vec_ok<float>(4, 4, n, a, b, dy) && vec_ok<float>(4, 4, n, da, db, dy) && n % 4 == 0) {
     const uint32_t nvec = (uint32_t)(n / 4);
-    hipLaunchKernelGGL((mix2_vec_kernel<float, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)dy, fw, (float*)da, (float*)db, dfw, nvec);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((mix2_vec_kernel<float, true>), dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)dy, fw, (float*)da, (float*)db, dfw, nvec, part_ws);
   } else return set_error(QAVIT_EINVAL, "mix2_bwd: element count must be a multiple of the 16-byte vector, 16-byte aligned operands");
   return check_launch("mix2_bwd");
 }
@@ -814,12 +851,12 @@ extern "C" int qavit_scale_add_fwd(int dtype, const void* x, const void* u, cons
   const int64_t n = (int64_t)rows * C;
   if (dtype == QAVIT_BF16 && vec_ok<bf16>(C, C, n, x, u, y)) {
     const uint32_t nvec = (uint32_t)(n / 8);
-    hipLaunchKernelGGL((scale_add_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)x, (const bf16*)u, gamma, (bf16*)y, (float*)nullptr, nvec, C, dp_p, dp_site, dp_rows, rng);
+    hipLaunchKernelGGL((scale_add_vec_kernel<bf16, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const bf16*)x, (const bf16*)u, gamma, (bf16*)y, (float*)nullptr, nvec, C, dp_p, dp_site, dp_rows, rng, (float*)nullptr);
     return check_launch("scale_add_fwd");
   }
   if (dtype == QAVIT_F32 && vec_ok<float>(C, C, n, x, u, y)) {
     const uint32_t nvec = (uint32_t)(n / 4);
-    hipLaunchKernelGGL((scale_add_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)x, (const float*)u, gamma, (float*)y, (float*)nullptr, nvec, C, dp_p, dp_site, dp_rows, rng);
+    hipLaunchKernelGGL((scale_add_vec_kernel<float, false>), dim3(blocks_for(nvec, 512, 2048)), dim3(256), 0, st, (const float*)x, (const float*)u, gamma, (float*)y, (float*)nullptr, nvec, C, dp_p, dp_site, dp_rows, rng, (float*)nullptr);
     return check_launch("scale_add_fwd");
   }
   const int g = blocks_for(n, 1024);
@@ -829,25 +866,32 @@ extern "C" int qavit_scale_add_fwd(int dtype, const void* x, const void* u, cons
   return check_launch("scale_add_fwd");
 }
 extern "C" int qavit_scale_add_bwd(int dtype, const void* dy, const void* u, const float* gamma, void* du, float* dgamma,
-                                   int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, void* stream) {
+                                   int rows, int C, float dp_p, int dp_site, int dp_rows, const int64_t* rng, float* part_ws, int* nparts, void* stream) {
   if (!dy || !u || !du || rows <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "scale_add_bwd: bad arguments");
+  if (part_ws && (!nparts || (reinterpret_cast<uintptr_t>(part_ws) & 15))) return set_error(QAVIT_EINVAL, "scale_add_bwd: part_ws needs nparts and 16-byte alignment");
+  if (nparts) *nparts = 0;
   if (dp_p > 0.f && (!rng || dp_rows <= 0)) return set_error(QAVIT_EINVAL, "scale_add_bwd: drop-path needs rng and rows-per-sample");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t n = (int64_t)rows * C;
   if (dtype == QAVIT_BF16 && vec_ok<bf16>(C, C, n, dy, u, du)) {
     const uint32_t nvec = (uint32_t)(n / 8);
-    hipLaunchKernelGGL((scale_add_vec_kernel<bf16, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)u, gamma, (bf16*)du, dgamma, nvec, C, dp_p, dp_site, dp_rows, rng);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((scale_add_vec_kernel<bf16, true>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)u, gamma, (bf16*)du, dgamma, nvec, C, dp_p, dp_site, dp_rows, rng, part_ws);
     return check_launch("scale_add_bwd");
   }
   if (dtype == QAVIT_F32 && vec_ok<float>(C, C, n, dy, u, du)) {
     const uint32_t nvec = (uint32_t)(n / 4);
-    hipLaunchKernelGGL((scale_add_vec_kernel<float, true>), dim3(blocks_for(nvec, 1024, 512)), dim3(256), 0, st, (const float*)dy, (const float*)u, gamma, (float*)du, dgamma, nvec, C, dp_p, dp_site, dp_rows, rng);
+    const int g = blocks_for(nvec, 1024, 512);
+    if (part_ws) *nparts = g;
+    hipLaunchKernelGGL((scale_add_vec_kernel<float, true>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)u, gamma, (float*)du, dgamma, nvec, C, dp_p, dp_site, dp_rows, rng, part_ws);
     return check_launch("scale_add_bwd");
   }
   const int g = blocks_for(n, 4096, 1024);
+  if (part_ws) *nparts = g;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((scale_add_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)u, gamma, (float*)du, dgamma, n, C, dp_p, dp_site, dp_rows, rng),
-             hipLaunchKernelGGL((scale_add_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)u, gamma, (bf16*)du, dgamma, n, C, dp_p, dp_site, dp_rows, rng), "scale_add_bwd");
+             hipLaunchKernelGGL((scale_add_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)u, gamma, (float*)du, dgamma, n, C, dp_p, dp_site, dp_rows, rng, part_ws),
+             hipLaunchKernelGGL((scale_add_bwd_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)u, gamma, (bf16*)du, dgamma, n, C, dp_p, dp_site, dp_rows, rng, part_ws), "scale_add_bwd");
   return check_launch("scale_add_bwd");
 }
 

@@ -641,18 +641,27 @@ __global__ __launch_bounds__(256) void upmix2_bwd_kernel(const bf16* dy, const b
   }
   TSTAMP(30);
   __syncthreads();
-  if (sa_on && sa.dgamma) {                                  // one atomic per workgroup (gred is free until the dgamma / dbeta fold below)
+  constexpr int PROW = L::N * L::M + L::N + 2 * L::C + 4;     // floats per partial row: [dW | dbias | dgamma | dbeta | scale-add dgamma, 0, 0, 0]
+  if (sa_on && (sa.dgamma || (NT <= 4 && parts))) {         // (gred is free until the dgamma / dbeta fold below)
     const float t = wave_sum(sa_sum);
     if (lane == 0) gred[wave] = t;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f(sa.dgamma, gred[0] + gred[1] + gred[2] + gred[3]);
+    if (threadIdx.x == 0) {
+      const float tt = gred[0] + gred[1] + gred[2] + gred[3];
+      // the layer scale's gradient: the last four floats of this workgroup's partial row (reduce descriptor C = 1, a fixed-order fold:
+      // the scalar is the same bits on every run), or one atomic per workgroup on one address
+      if (NT <= 4 && parts) *reinterpret_cast<f32x4*>(parts + (size_t)blockIdx.x * PROW + (PROW - 4)) = f32x4{tt, 0.f, 0.f, 0.f};
+      else atomic_add_f(sa.dgamma, tt);
+    }
     __syncthreads();
+  } else if (NT <= 4 && parts && threadIdx.x == 0) {
+    *reinterpret_cast<f32x4*>(parts + (size_t)blockIdx.x * PROW + (PROW - 4)) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // flush: dW tiles, dbias, dgamma / dbeta -- as this workgroup's row [dW | dbias | dgamma | dbeta] of `parts` (plain stores; one
   // qavit_ln_param_reduce launch folds the rows of every kernel of the pass), or with float atomics.  The atomics are 256+ deep on each
   // of ~1.5k addresses and serialise at L2: they were the larger half of this kernel and the reason a second workgroup per CU lost.
   // (64-token variant only: the 256-token one sits at 512 registers per lane and keeps its atomics)
-  float* prow = (NT <= 4 && parts) ? parts + (size_t)blockIdx.x * (L::N * L::M + L::N + 2 * L::C) : nullptr;
+  float* prow = (NT <= 4 && parts) ? parts + (size_t)blockIdx.x * PROW : nullptr;
   if constexpr (NT <= 4) {
     float* dwdst = prow ? prow : dW;
     const bool plain = prow != nullptr;                      // uniform

@@ -540,7 +540,7 @@ def upmix_bwd(dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta,
     lib = L.load()
     # inside a backward pass the parameter gradients leave as one partial row per workgroup and join the pass's single reduce launch
     n = lib.qavit_upmix_bwd_parts(dt_code(xc.dtype), B, N, M, Cc) if (DeferredLN.enabled and DeferredLN.ON and (N * M) % 8 == 0 and N % 8 == 0) else 0
-    parts = torch.empty(n, N * M + N + 2 * Cc, dtype=torch.float32, device=xc.device) if n > 0 else None
+    parts = torch.empty(n, N * M + N + 2 * Cc + 4, dtype=torch.float32, device=xc.device) if n > 0 else None     # QAVIT_UPMIX_PART_ROW
     if sa is not None:
         u, du, g_sa, dg_sa, dp, rng = sa
         L.check(lib.qavit_upmix_bwd_sa(dt_code(xc.dtype), dy.data_ptr(), xc.data_ptr(), W.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
@@ -561,6 +561,8 @@ def upmix_bwd(dy, xc, W, bias, gamma, mean, rstd, dxc, dW, dbias, dgamma, dbeta,
     if dbias is not None:
         DeferredLN.push_raw(base + 4 * N * M, n, N // 2, dbias.data_ptr(), dbias.data_ptr() + 4 * (N // 2), R, keep)
     DeferredLN.push_raw(base + 4 * (N * M + N), n, Cc, dgamma.data_ptr(), dbeta.data_ptr(), R, keep)
+    if sa is not None and sa[3] is not None:                 # the layer scale in front of the up-mix: the last four floats of each row
+        DeferredLN.push_raw(base + 4 * (N * M + N + 2 * Cc), n, 1, sa[3].data_ptr(), None, R, keep + (sa[3],))
 
 
 def gather_pool_fwd(x, idx, y, B, N, NP, stride, Cc):
@@ -656,8 +658,28 @@ def hybrid_fuse_fwd(x, fw, y, rows, nb, Cb):
     L.check(L.load().qavit_hybrid_fuse_fwd(dt_code(x.dtype), x.data_ptr(), fw.data_ptr(), y.data_ptr(), rows, nb, Cb, stream()), "hybrid_fuse_fwd")
 
 
+NARROW_PARTS_MAX = 1024                                     # QAVIT_NARROW_PARTS_MAX
+
+
+def _narrow_ws(device, want, row=4):
+    """Workspace for the narrow partial rows of a 1-4 value parameter gradient (include/qavit.h, NARROW PARTIAL ROWS), or None: float atomics.
+    Every workgroup adding its share to ONE address made such a gradient differ in its last bit from run to run."""
+    if not (want and DeferredLN.ON):
+        return None
+    return torch.empty(NARROW_PARTS_MAX * row, dtype=torch.float32, device=device)
+
+
+def _narrow_push(ws, n, Cn, dst, row=4):
+    """Fold the n rows a launch left in ``ws`` into ``dst`` (fixed order): in the pass's one reduce launch, or now."""
+    if ws is not None and n.value > 0:
+        DeferredLN.push_raw(ws.data_ptr(), int(n.value), Cn, dst.data_ptr(), None, row, (ws, dst))
+
+
 def hybrid_fuse_bwd(dy, x, fw, dx, dfw, rows, nb, Cb):
-    L.check(L.load().qavit_hybrid_fuse_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), fw.data_ptr(), dx.data_ptr(), dfw.data_ptr(), rows, nb, Cb, stream()), "hybrid_fuse_bwd")
+    ws, n = _narrow_ws(x.device, nb <= 4, 8), C.c_int(0)
+    L.check(L.load().qavit_hybrid_fuse_bwd(dt_code(x.dtype), dy.data_ptr(), x.data_ptr(), fw.data_ptr(), dx.data_ptr(), dfw.data_ptr(), rows, nb, Cb,
+                                           _p(ws), C.byref(n), stream()), "hybrid_fuse_bwd")
+    _narrow_push(ws, n, 4, dfw, 8)
 
 
 def sum_k(xs, out):
@@ -691,8 +713,10 @@ def mix3_fwd(a, t, h, fw, y, drop, rng):
 
 
 def mix3_bwd(dy, a, t, h, fw, da, dt, dh, dfw, drop, rng):
+    ws, n = _narrow_ws(a.device, dfw is not None), C.c_int(0)
     L.check(L.load().qavit_mix3_bwd(dt_code(a.dtype), dy.data_ptr(), a.data_ptr(), t.data_ptr(), h.data_ptr(), fw.data_ptr(), da.data_ptr(), dt.data_ptr(),
-                                    dh.data_ptr(), _p(dfw), a.numel(), drop[0], drop[1], rng.data_ptr(), stream()), "mix3_bwd")
+                                    dh.data_ptr(), _p(dfw), a.numel(), drop[0], drop[1], rng.data_ptr(), _p(ws), C.byref(n), stream()), "mix3_bwd")
+    _narrow_push(ws, n, 2, dfw)
 
 
 def mix3_ln_ok(a, t, h, Cc) -> bool:
@@ -710,11 +734,19 @@ def mix3_ln_fwd(a, t, h, fw, drop, rng, mixed, gamma, beta, eps, y, mean, rstd, 
 
 
 def _mix3_ln_parts(mixed, rows, Cc, want):
-    """Partial-row workspace of the fused blend + norm backward (its own workgroup count), or None: atomics."""
+    """Partial-row workspace of the fused blend + norm backward (its own workgroup count: n LayerNorm rows of 2C floats, then n narrow
+    rows of 4 floats for the blend logits), or None: atomics."""
     if not (want and DeferredLN.enabled and DeferredLN.ON):
         return None
     n = L.load().qavit_mix3_ln_bwd_parts(rows, Cc)
-    return torch.empty(n * 2 * Cc, dtype=torch.float32, device=mixed.device), n
+    return torch.empty(n * (2 * Cc + 4), dtype=torch.float32, device=mixed.device), n
+
+
+def _mix3_ln_push(part, Cc, dfw, dgamma, dbeta):
+    ws, n = part
+    DeferredLN.push(ws, n, Cc, dgamma, dbeta)
+    if dfw is not None:
+        DeferredLN.push_raw(ws.data_ptr() + 4 * n * 2 * Cc, n, 2, dfw.data_ptr(), None, 4, (ws, dfw))
 
 
 def mix3_ln_bwd(dy, a, t, h, fw, drop, rng, mixed, gamma, mean, rstd, da, dt, dh, dfw, dgamma, dbeta, rows, Cc):
@@ -726,7 +758,7 @@ def mix3_ln_bwd(dy, a, t, h, fw, drop, rng, mixed, gamma, mean, rstd, da, dt, dh
                                        da.data_ptr(), dt.data_ptr(), dh.data_ptr(), _p(dfw), _p(dgamma), _p(dbeta), rows, Cc,
                                        part[0].data_ptr() if part else None, stream()), "mix3_ln_bwd")
     if part:
-        DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
+        _mix3_ln_push(part, Cc, dfw, dgamma, dbeta)
 
 
 def gate_mix3_ln_fwd(t, r, g, h, fw, drop, rng, mixed, gamma, beta, eps, y, mean, rstd, rows, Cc):
@@ -744,12 +776,14 @@ def gate_mix3_ln_bwd(dy, t, r, g, h, fw, drop, rng, mixed, gamma, mean, rstd, dt
                                             mean.data_ptr(), rstd.data_ptr(), dt.data_ptr(), dr.data_ptr(), dg.data_ptr(), dh.data_ptr(), _p(dfw),
                                             _p(dgamma), _p(dbeta), rows, Cc, part[0].data_ptr() if part else None, stream()), "gate_mix3_ln_bwd")
     if part:
-        DeferredLN.push(part[0], part[1], Cc, dgamma, dbeta)
+        _mix3_ln_push(part, Cc, dfw, dgamma, dbeta)
 
 
 def mix2_bwd(dy, a, b, fw, da, db, dfw):
+    ws, n = _narrow_ws(a.device, dfw is not None), C.c_int(0)
     L.check(L.load().qavit_mix2_bwd(dt_code(a.dtype), dy.data_ptr(), a.data_ptr(), b.data_ptr(), fw.data_ptr(), da.data_ptr(), db.data_ptr(),
-                                    _p(dfw), a.numel(), stream()), "mix2_bwd")
+                                    _p(dfw), a.numel(), _p(ws), C.byref(n), stream()), "mix2_bwd")
+    _narrow_push(ws, n, 2, dfw)
 
 
 def scale_add_fwd(x, u, gamma, y, rows, Cc, dp, rng):
@@ -757,7 +791,10 @@ def scale_add_fwd(x, u, gamma, y, rows, Cc, dp, rng):
 
 
 def scale_add_bwd(dy, u, gamma, du, dgamma, rows, Cc, dp, rng):
-    L.check(L.load().qavit_scale_add_bwd(dt_code(dy.dtype), dy.data_ptr(), u.data_ptr(), _p(gamma), du.data_ptr(), _p(dgamma), rows, Cc, dp[0], dp[1], dp[2], _p(rng), stream()), "scale_add_bwd")
+    ws, n = _narrow_ws(dy.device, dgamma is not None), C.c_int(0)
+    L.check(L.load().qavit_scale_add_bwd(dt_code(dy.dtype), dy.data_ptr(), u.data_ptr(), _p(gamma), du.data_ptr(), _p(dgamma), rows, Cc, dp[0], dp[1], dp[2], _p(rng),
+                                         _p(ws), C.byref(n), stream()), "scale_add_bwd")
+    _narrow_push(ws, n, 1, dgamma)
 
 
 def chan_scale_add_fwd(x, u, gamma, y, rows, Cc, dp, rng):

@@ -223,18 +223,18 @@ _SIGS = {
     "qavit_token_mean_fwd": (i32, [i32, vp, vp, i32, i32, i32, vp]),
     "qavit_token_mean_bwd": (i32, [i32, vp, vp, i32, i32, i32, vp]),
     "qavit_hybrid_fuse_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, vp]),
-    "qavit_hybrid_fuse_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "qavit_hybrid_fuse_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "qavit_sum_k": (i32, [i32, vp, i32, vp, i64, vp]),
     "qavit_rand_perm": (i32, [vp, i32, vp, i32, vp]),
     "qavit_mix_apply": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_gate_mix_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
     "qavit_gate_mix_bwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp]),
     "qavit_mix2_fwd": (i32, [i32, vp, vp, vp, vp, i64, vp]),
-    "qavit_mix2_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "qavit_mix2_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]),
     "qavit_mix3_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, f32, i32, vp, vp]),
-    "qavit_mix3_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, i32, vp, vp]),
+    "qavit_mix3_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, i32, vp, vp, vp, vp]),
     "qavit_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
-    "qavit_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "qavit_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp, vp, vp]),
     "qavit_chan_scale_add_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_chan_scale_add_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]),
     "qavit_bn_fwd": (i32, [i32, vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, i32, i32, i64, vp]),

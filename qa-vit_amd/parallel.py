@@ -179,8 +179,8 @@ class DataParallel:
     def __init__(self, model: torch.nn.Module, group=None, bucket_bytes: int = 4 << 20, bank_sync: str = "exact",
                  bank_broadcast_every: int = 50, seed: int = 0x5EED, bn_sync: str = "exact", sync_tags=None):
         """``sync_tags``: the stage boundaries at which complete buckets are all-reduced DURING backward (a tuple of tags, "all" = all
-        seven, () = none: one reduction after backward -- the default, see below; the environment variable QAVIT_DDP_TAGS =
-        comma-separated tags or "all" overrides).  Every sync point costs a grouped weight-gradient launch over fewer problems than the
+        seven, () = none: one reduction after backward; the default depends on the world size, see below; the environment variable
+        QAVIT_DDP_TAGS = comma-separated tags or "all" overrides).  Every sync point costs a grouped weight-gradient launch over fewer problems than the
         single end-of-backward one, so on a fast fabric fewer, larger overlapped reductions win."""
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs torch.distributed.init_process_group first")
@@ -193,12 +193,15 @@ class DataParallel:
         elif sync_tags is not None:
             self.sync_tags = None if sync_tags == "all" else tuple(sync_tags)
         else:
-            # default: NO sync point -- one bucketed all-reduce when backward (and its weight-gradient launch) has ended.  Measured on one MI355X
-            # (B = 1024, one rank over RCCL, captured): no sync point 10.26 ms / step = the step without any data-parallel
-            # machinery (10.26), one sync point (fuse3) 10.40, all seven 10.61.  Every sync point splits the single end-of-backward weight-gradient
-            # launch and puts a flush on backward's critical path, while the 25.7 MB all-reduce it would hide is ~0.1-0.2 ms of xGMI time on 8 GPUs
-            # -- so a sync point that hides half of it costs about what it saves.  sync_tags=("fuse3",) / "all" or QAVIT_DDP_TAGS bring them back.
-            self.sync_tags = ()
+            # default by world size.  ONE rank: no sync point -- there is nothing to overlap (RCCL launches no kernel for a one-rank collective)
+            # and every sync point splits the single end-of-backward weight-gradient launch and puts a flush on backward's critical path
+            # (measured on one MI355X, B = 1024, one rank over RCCL, captured; DESIGN.md section 6: no sync point 10.26 ms / step = the step
+            # without any data-parallel machinery, one sync point (fuse3) 10.40, all seven 10.61).  MORE than one rank: one sync point in the
+            # middle of backward ("fuse3"): the bucket prefix head .. fuse3 (about half of the 25.7 MB) is all-reduced on the side stream
+            # while stages 2 and 1 and the lateral path run their backward -- the north star's "overlapped with the backward pass".  Whether
+            # an exposed all-reduce is cheaper than the split flush on 8 GPUs has not been measured (no multi-GPU node in this pipeline), so
+            # the overlapped form stays the default there; sync_tags=() / "all", QAVIT_DDP_TAGS or bench.py --ddp-tags select the others.
+            self.sync_tags = ("fuse3",) if self.world > 1 else ()
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=group)

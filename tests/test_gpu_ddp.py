@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, tags):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
@@ -39,7 +39,10 @@ def _worker(rank, world, port, out):
     for m in model.modules():                             # SplitFusion.cat_mlp hard-wires Dropout(0.1) (HQAViT_CIFAR100.py:930)
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    dp = par.DataParallel(model, sync_tags=("fuse3", "stage1_blocks"))     # two sync points: buckets reduced during backward and after it
+    # sync points: buckets reduced during backward (each one flushes the weight-gradient problems of ITS address range only:
+    # DeferDW.flush_range) and after it; "all" = the seven stage boundaries, () = one reduction after backward, None = the default
+    dp = par.DataParallel(model, sync_tags=tags)
+    assert dp.sync_tags == (("fuse3",) if tags is None else None if tags == "all" else tuple(tags))
     tr = Q.Trainer(model, Q.TrainingConfig(batch_size=16, use_amp=False), total_steps=100, warmup_steps=10,
                    reducer=dp.reducer, compute_dtype=torch.float32, order=par.bucket_order)
     dp.bind(tr)
@@ -84,9 +87,13 @@ def _single_process_reference():
     return model, tr, losses
 
 
-def test_two_rank_step_keeps_replicas_identical(tmp_path):
+@pytest.mark.parametrize("tags", [("fuse3", "stage1_blocks"), "all", (), None], ids=["two_sync_points", "all_seven", "none", "default"])
+def test_two_rank_step_keeps_replicas_identical(tmp_path, tags):
+    """Whatever the sync points -- two, all seven (every one a partial weight-gradient flush by address range), none, or the default
+    for world > 1 (one overlapped bucket prefix) -- the reduced gradients and the parameters after two steps are those of the
+    single-process B = 16 step."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), tags), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt", weights_only=False), torch.load(tmp_path / "r1.pt", weights_only=False)
     # ---- 2 ranks x 8 images == one process x 16 images (exact bank statistics + SyncBN): parameters after two optimiser
     # steps, the last step's averaged gradient, the bank, BatchNorm running statistics, the global gradient norm

@@ -1545,8 +1545,8 @@ def test_nan_rule_of_the_cross_branch_rides_in_the_compress_fuse_launch(F, Q, B,
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     y = blk(xin)
                 y.float().square().sum().backward()
-                outs += [y.detach().clone(), xin.grad.detach().clone(), bank.global_k.detach().clone()]
-                outs += [p_.grad.detach().clone() for _, p_ in sorted(blk.named_parameters()) if p_.grad is not None]
+                outs += [("y", y.detach().clone()), ("dx", xin.grad.detach().clone()), ("bank", bank.global_k.detach().clone())]
+                outs += [(n_, p_.grad.detach().clone()) for n_, p_ in sorted(blk.named_parameters()) if p_.grad is not None]
                 rt.advance()
             torch.cuda.synchronize()
             assert rt.nan_flag.tolist() == [0, 0] and rt.pending_fix is None
@@ -1556,11 +1556,63 @@ def test_nan_rule_of_the_cross_branch_rides_in_the_compress_fuse_launch(F, Q, B,
         F.DEFER_FIX_CFUSE = True
     assert ndef[True] == ndef[False] + 2, ndef               # one more deferral per block call: the cross branch's
     assert len(res[True]) == len(res[False])
-    for a_, b_ in zip(res[True], res[False]):
-        assert torch.equal(torch.nan_to_num(a_.float()), torch.nan_to_num(b_.float()))
-    assert torch.isfinite(res[True][0].float()).all() or True   # (the block's residual carries the poisoned input row through: only equality is asserted)
+    # Bit equality where the arithmetic ORDER is fixed: activations, the input gradient, the bank, and the narrow parameter gradients that
+    # leave as partial rows folded in a fixed order (the layer scale ccf_ffn.gamma, the fusion logits).  Every other parameter gradient of
+    # this un-armed backward is summed with float atomics from several workgroups (LayerNorm / CCF partials, weight-gradient tile flushes):
+    # their last bits depend on arrival order, run to run, so they are compared to summation-order tolerance (round 3 asserted bit equality
+    # on all of them and failed on a 1-ulp difference in ccf_ffn.gamma, then still five atomics on one address).
+    fixed = ("y", "dx", "bank", "ccf_ffn.gamma", "fusion.fusion_weights")
+    for (na, a_), (nb_, b_) in zip(res[True], res[False]):
+        assert na == nb_
+        a_, b_ = torch.nan_to_num(a_.float()), torch.nan_to_num(b_.float())
+        if na in fixed:
+            assert torch.equal(a_, b_), na
+        else:
+            assert float((a_ - b_).abs().max()) <= 2e-6 * float(b_.abs().max()) + 1e-30, na
+    # (the block's residual carries the poisoned input row through the first call: only equality is asserted there)
     n1 = len(res[True]) // 2
-    assert all(torch.isfinite(t.float()).all() for t in res[True][n1:])          # the clean call after it is clean
+    assert all(torch.isfinite(t.float()).all() for _, t in res[True][n1:])       # the clean call after it is clean
+
+
+def test_narrow_parameter_gradients_are_bit_reproducible(F, Q):
+    """Scalar layer scales and two-logit blends are summed over the whole tensor.  One float atomic per workgroup on ONE address gave a
+    last-bit difference from run to run (the red test of round 3: ccf_ffn.gamma, 265.3792 vs 265.3793).  They now leave as narrow partial
+    rows folded in a fixed order by qavit_ln_param_reduce: the same launch repeated gives the same bits, at grids of hundreds of workgroups,
+    with the reduce launched at once (eager) -- and the sum matches fp32 torch."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    rt = K.Runtime.get(0)
+    rows, C = 16384, 192                                    # 384 workgroups in the vector kernels
+    for dtype in (torch.bfloat16, torch.float32):
+        dy = torch.randn(rows, C, device=DEV).to(dtype)
+        u = torch.randn(rows, C, device=DEV).to(dtype)
+        a = torch.randn(rows, C, device=DEV).to(dtype)
+        gam = torch.full((1,), 0.3, device=DEV)
+        fw = torch.tensor([0.4, -0.3], device=DEV)
+        seen = {"scale_add": [], "mix2": [], "mix3": []}
+        for _ in range(4):
+            dg = torch.zeros(1, device=DEV)
+            K.scale_add_bwd(dy, u, gam, torch.empty_like(dy), dg, rows, C, (0.1, 77, 16), rt.rng)
+            seen["scale_add"].append(dg.clone())
+            d2 = torch.zeros(2, device=DEV)
+            K.mix2_bwd(dy, a, u, fw, torch.empty_like(dy), torch.empty_like(dy), d2)
+            seen["mix2"].append(d2.clone())
+            d3 = torch.zeros(2, device=DEV)
+            K.mix3_bwd(dy, a, u, u, fw, torch.empty_like(dy), torch.empty_like(dy), torch.empty_like(dy), d3, (0.0, 5), rt.rng)
+            seen["mix3"].append(d3.clone())
+        torch.cuda.synchronize()
+        for name, vals in seen.items():
+            assert all(torch.equal(vals[0], v) for v in vals[1:]), (name, [v.tolist() for v in vals])
+            assert float(vals[0].abs().max()) > 0, name
+        # value check (drop-path off for the reference): dgamma = sum dy * u
+        dg = torch.zeros(1, device=DEV)
+        K.scale_add_bwd(dy, u, gam, torch.empty_like(dy), dg, rows, C, (0.0, 0, 16), rt.rng)
+        ref = (dy.double() * u.double()).sum()
+        assert abs(float(dg) - float(ref)) <= 1e-3 * math.sqrt(rows * C), (float(dg), float(ref))      # |sum| ~ sqrt(n); fp32 partial sums
+        w = torch.softmax(fw.double(), 0)
+        ds = torch.stack([(dy.double() * a.double()).sum(), (dy.double() * u.double()).sum()])
+        ref2 = w * (ds - (ds * w).sum())
+        assert rel(seen["mix2"][0], ref2.float()) <= 1e-3
 
 
 @pytest.mark.parametrize("B,T", [(6, 16), (3, 64)])
