@@ -419,7 +419,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        par.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # flight recorder on: Trainer.capture drains the watchdog by it
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg = Q.HQAViTConfig() if args.config == "c100" else Q.HQAViTTinyINConfig()
@@ -503,6 +503,8 @@ def main():
         out["config"]["needed_mfma_frac"] = round(need / (PEAK_BF16_TFLOPS * world), 5)
     if capture_error is not None:
         out["config"]["graph_capture_error"] = capture_error
+    if getattr(tr, "watchdog_drain", None):
+        out["config"]["watchdog_drain"] = tr.watchdog_drain
 
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         # one instrumented eager step of the same workload: per-call HIP-event timing of every C-ABI entry point

@@ -466,11 +466,13 @@ class Trainer:
         torch.cuda.synchronize()
         if self.reducer is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
             # The process group's watchdog thread still holds the warm-up steps' collectives and polls their end events
-            # (hipEventQuery) every 100 ms until it has seen each one complete.  Those events were recorded on the reducer's
-            # side stream; once that stream joins the capture, HIP answers such a query with hipErrorCapturedEvent and the
-            # watchdog takes the process down.  Everything is complete after the synchronize above: give the watchdog a few of
-            # its passes to retire the list before the capture begins (collectives issued DURING capture are never enqueued).
-            time.sleep(0.5)
+            # (hipEventQuery) until it has seen each one complete.  Those events were recorded on the reducer's side stream; once
+            # that stream joins the capture, HIP answers such a query with hipErrorCapturedEvent and the watchdog takes the process
+            # down.  Everything is complete on the device after the synchronize above: wait until the watchdog has RETIRED its list
+            # (read from the flight recorder; raises on a timeout) before the capture begins -- collectives issued DURING capture are
+            # never put on that list.
+            from . import parallel
+            self.watchdog_drain = parallel.drain_watchdog()
         with torch.no_grad():
             for t, v in zip(self._state(), saved):
                 t.copy_(v)

@@ -76,6 +76,13 @@ class Runtime:
             cls._inst[key] = Runtime(torch.device("cuda", key))
         return cls._inst[key]
 
+    @classmethod
+    def drop_pending_fix(cls):
+        """A call failed between a fused branch deferring its NaN rule and the launch that would have consumed it (an OOM, a refused
+        operand, an interrupt): forget the deferral on every device, or every later forward raises 'never consumed'."""
+        for r in cls._inst.values():
+            r.pending_fix = None
+
     def seed(self, s: int):
         self.rng[0] = int(s)
         self.rng[1] = 0

@@ -84,6 +84,15 @@ class LinformerCompression(nn.Module):
 
 
 class _Branch(nn.Module):
+    def __call__(self, *args, **kwargs):
+        try:
+            return super().__call__(*args, **kwargs)
+        except BaseException:
+            # a NaN rule deferred by the fused kernel (kernels.Runtime.pending_fix, per-device state) must not outlive the call that failed
+            # between the deferral and the launch that would have consumed it: every later forward would raise "never consumed"
+            K.Runtime.drop_pending_fix()
+            raise
+
     def _writes(self) -> bool:
         """Will _write() write the bank from this branch's output?  (then the fused kernels leave their NaN rule to that launch)"""
         return bool(self.training and self._rt.bank_writes and hasattr(self, "norm"))
@@ -415,6 +424,9 @@ class QuadAttentionBlock(nn.Module):
             rt.snap = None
         try:
             return self._forward(x, B, N, C, tr, tail)
+        except BaseException:
+            K.Runtime.drop_pending_fix()                    # (see _Branch.__call__: the cross branch's rule waits for the compress-fuse launch)
+            raise
         finally:
             rt.in_block = False
             if not rt.in_model:

@@ -20,10 +20,62 @@ Design (SURVEY.md sections 5 and 8e):
     keeps per-rank statistics (stock DDP semantics).  Buffers are broadcast from rank 0 at construction.
   * dropout / drop-path RNG streams differ per rank (seed + rank).
 """
+import os
+import pickle
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def init_process_group(backend: str = "nccl", **kw):
+    """``dist.init_process_group`` with the process group's flight recorder ON (TORCH_FR_BUFFER_SIZE, read when the NCCL / RCCL group
+    is created): ``drain_watchdog`` reads from it which collectives the watchdog thread has retired."""
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")            # (older builds read TORCH_NCCL_TRACE_BUFFER_SIZE)
+    if "TORCH_NCCL_TRACE_BUFFER_SIZE" not in os.environ and not hasattr(torch._C._distributed_c10d, "_dump_fr_trace"):
+        os.environ["TORCH_NCCL_TRACE_BUFFER_SIZE"] = "2000"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL over dmabuf IPC
+    return dist.init_process_group(backend, **kw)
+
+
+def _active_collectives() -> Optional[int]:
+    """Number of collectives still on the watchdog thread's list, from the flight recorder: entries whose ``retired`` flag the watchdog
+    has not set yet.  (``state == completed`` is NOT that: the dump itself marks an entry completed as soon as its end event has
+    fired, while the watchdog keeps polling the work until its own next pass -- measured on MI355X: completed at once, retired 81 ms
+    later, tools/watchdog_probe.py.)  None when the recorder is off or this build has none: nothing can be observed."""
+    try:
+        from torch._C import _distributed_c10d as c10d
+        entries = pickle.loads(c10d._dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries")
+        if not entries or "retired" not in entries[0]:
+            return None                                     # recorder off (or no collective was ever issued: nothing to drain either)
+        return sum(0 if e.get("retired") else 1 for e in entries)
+    except Exception:
+        return None
+
+
+def drain_watchdog(timeout_s: float = 20.0, poll_s: float = 0.02) -> str:
+    """Block until the process group's watchdog thread has RETIRED every collective issued so far.  Call after a device
+    synchronize, before hipGraph capture: the watchdog polls the end events of the collectives on its list (hipEventQuery, one pass
+    per 100 ms) until it has seen each complete; if the stream such an event was recorded on joins a capture meanwhile, HIP answers
+    the query with hipErrorCapturedEvent and the watchdog takes the process down.  Round 3 slept 0.5 s here and hoped; this reads the
+    list's state from the flight recorder and waits for it to be empty -- or raises after ``timeout_s``.  Returns how it decided."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+        return "no nccl group"
+    n = _active_collectives()
+    if n is None:
+        # nothing observable: the one fallback left is the watchdog's own period -- several passes, and say so
+        time.sleep(1.0)
+        return "flight recorder off: slept 1.0 s (start the group with parallel.init_process_group to make this deterministic)"
+    t0 = time.monotonic()
+    while n:
+        if time.monotonic() - t0 > timeout_s:
+            raise RuntimeError(f"drain_watchdog: {n} collective(s) still on the watchdog's list after {timeout_s} s; refusing to capture")
+        time.sleep(poll_s)
+        n = _active_collectives()
+        if n is None:
+            raise RuntimeError("drain_watchdog: the flight recorder stopped answering")
+    return f"watchdog list empty after {time.monotonic() - t0:.3f} s"
 
 
 def bucket_order(named: Sequence[Tuple[str, torch.nn.Parameter]]):

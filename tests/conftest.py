@@ -57,6 +57,13 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_r3():
+    """bf16 envelope of the reference itself (tests/golden/make_golden_r3.py): per-tensor deviation of its autocast(bfloat16) step from
+    its fp32 step."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_r3.npz"))
+
+
+@pytest.fixture(scope="session")
 def Q():
     import qavit_amd
     return qavit_amd

@@ -712,6 +712,117 @@ def test_bf16_train_step_vs_reference(tag, golden, Q):
     assert np.isfinite(got).all()
 
 
+def _hip_step(Q, tag, x, y, dtype, tap_names):
+    """One train-mode step (dropout = drop-path = 0) of the HIP model in ``dtype``: logits, loss, taps, bank, parameter gradients."""
+    model = build(Q, tag, dropout=0.0, drop_path=0.0).train()
+    zero_dropout(model)
+    model.compute_dtype = dtype
+    taps, hooks = {}, []
+    mods = dict(model.named_modules())
+    for n in tap_names:
+        hooks.append(mods[n].register_forward_hook(lambda m, i, o, n=n: taps.__setitem__(n, (o[0] if isinstance(o, tuple) else o).detach().float().clone())))
+    logits = model(x)
+    loss = torch.nn.functional.cross_entropy(logits.float(), y, label_smoothing=MODELS[tag][3])
+    loss.backward()
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+    return dict(logits=logits.detach().float(), loss=float(loss), taps=taps, grads=grads,
+                bank_k=model.global_bank.global_k.detach().float().clone(), bank_v=model.global_bank.global_v.detach().float().clone())
+
+
+@pytest.mark.parametrize("tag", ["c100", "tin"])
+def test_bf16_step_within_the_references_own_bf16_envelope(tag, golden, golden_r3, Q):
+    """The benchmarked arithmetic is bf16 and most fused kernels exist in bf16 only, while the reference-held fixtures are fp32.  This test
+    pins the bf16 path on an envelope RECORDED FROM THE REFERENCE (tests/golden/make_golden_r3.py): how far the reference's own
+    autocast(bfloat16) step (HQAViT_CIFAR100.py:1402-1410) drifts from its fp32 step, per tensor, on nine seeded batches of eight images (the test runs the first).  The HIP
+    bf16 step's drift from the HIP fp32 step (which test_train_step_vs_reference pins to the reference's fp32 numbers) is measured the same
+    way and must stay within 1.5 x that envelope: logits, loss, every forward tap, the bank after the in-forward writes and the global gradient
+    norm; EVERY parameter gradient (L2-relative) is held to the envelope as a distribution (median, 90 %, 99 % <= 1.5 x) and individually to
+    2 x -- see the comment at the gates for why the per-tensor bound is not 1.5."""
+    g = torch.Generator().manual_seed(int(golden_r3["batch_seeds"][0]))   # make_golden_r3.batch(): row 0 of the fixture
+    S, classes = golden[f"{tag}/x"].shape[-1], (100 if tag == "c100" else 200)
+    x = torch.randn(int(golden_r3["batch_size"]), 3, S, S, generator=g).cuda()
+    y = torch.randint(0, classes, (int(golden_r3["batch_size"]),), generator=g).cuda()
+    tap_names = [k[len(f"{tag}/dev/tap/"):] for k in golden_r3.files if k.startswith(f"{tag}/dev/tap/")]
+    ref = _hip_step(Q, tag, x, y, torch.float32, tap_names)
+    low = _hip_step(Q, tag, x, y, torch.bfloat16, tap_names)
+
+    def mrel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    K_ = 1.5
+    env = lambda key: float(golden_r3[f"{tag}/dev/{key}"].max())          # noqa: E731  (the per-tensor maximum over the recorded batches)
+    report = {}
+    report["logits"] = (mrel(low["logits"], ref["logits"]), env("logits"))
+    report["loss"] = (abs(low["loss"] - ref["loss"]) / abs(ref["loss"]), env("loss"))
+    report["bank_k"] = (mrel(low["bank_k"], ref["bank_k"]), env("bank_k"))
+    report["bank_v"] = (mrel(low["bank_v"], ref["bank_v"]), env("bank_v"))
+    for n in tap_names:
+        if n in low["taps"]:
+            t_low, t_ref = low["taps"][n], ref["taps"][n]
+            if n == "patch_embed":                          # here the module's output already holds + pos_embed (fused into its LayerNorm)
+                pe = dict(build(Q, tag).named_parameters())["pos_embed"].detach().float()
+                t_low, t_ref = t_low - pe, t_ref - pe
+            report["tap/" + n] = (mrel(t_low, t_ref), env("tap/" + n))
+    names = golden_r3[f"{tag}/grad_names"].tolist()
+    assert set(names) == set(ref["grads"]) == set(low["grads"])
+    gl = float(torch.sqrt(sum(low["grads"][n].double().pow(2).sum() for n in names)))
+    gr = float(torch.sqrt(sum(ref["grads"][n].double().pow(2).sum() for n in names)))
+    report["gnorm"] = (abs(gl / gr - 1.0), env("gnorm"))
+    for k_, (got, e) in report.items():
+        print(f"{tag}: {k_:48s} hip bf16-vs-fp32 {got:.3e}   reference envelope {e:.3e}   ratio {got / max(e, 1e-30):.2f}")
+    bad = [(k_, got, e) for k_, (got, e) in report.items() if got > K_ * e + (2e-4 if k_ in ("loss", "gnorm") else 0.0)]
+    assert not bad, bad
+    # ---- every parameter gradient
+    import re
+    l2_rows = golden_r3[f"{tag}/dev/grad_l2"]
+    nrm = golden_r3[f"{tag}/grad_norm_fp32"][0]
+    big = nrm.max()
+    live = [i for i, n in enumerate(names) if not (zero_by_construction(n) or nrm[i] <= 1e-6 * big)]   # the rest: identically zero in exact arithmetic
+    # A tensor's L2-relative drift averages the round-off of its elements: for a wide tensor it is a stable number and the reference's
+    # value on nine batches bounds it well; for a scalar or a 2-4 logit vector it is ONE draw of |noise| and nine draws say little about
+    # the tail.  Narrow parameters (< 32 elements) are therefore bounded by the envelope of their KIND -- the same parameter over all blocks
+    # (the 8 ccf_ffn.gamma, the 3 rrcv*.beta, ...: name with the digits removed), 9 x (blocks of that kind) draws instead of 9.
+    numel = {n: int(ref["grads"][n].numel()) for n in names}
+    kind = lambda n: re.sub(r"\d+", "#", n)                # noqa: E731
+    env_kind = {}
+    for i in live:
+        if numel[names[i]] < 32:
+            env_kind[kind(names[i])] = max(env_kind.get(kind(names[i]), 0.0), float(l2_rows[:, i].max()))
+    wide, narrow, unresolved = [], [], []
+    for i in live:
+        n = names[i]
+        d = float((low["grads"][n] - ref["grads"][n]).norm() / ref["grads"][n].norm().clamp_min(1e-30))
+        e = env_kind[kind(n)] if numel[n] < 32 else float(l2_rows[:, i].max())
+        rec = (round(d / e, 3), n, numel[n], round(d, 5), round(e, 5))
+        if e >= 0.25:
+            unresolved.append(rec)                          # the reference's own bf16 does not resolve this gradient (a near-cancelled sum:
+        elif numel[n] < 32:                                 # rrcv*.beta, envelope 0.41): reported, nothing to hold the HIP path to
+            narrow.append(rec)
+        else:
+            wide.append(rec)
+    ratios = np.array([w[0] for w in wide])
+    for grp in (wide, narrow, unresolved):
+        grp.sort(reverse=True)
+    print(f"{tag}: {len(wide)} wide parameter gradients, L2-relative bf16 drift / reference envelope: median {np.median(ratios):.2f}, "
+          f"90 % {np.quantile(ratios, 0.9):.2f}, 99 % {np.quantile(ratios, 0.99):.2f}, max {ratios.max():.2f}; {len(narrow)} narrow (max "
+          f"{narrow[0][0] if narrow else 0:.2f}), {len(unresolved)} unresolved in the reference's own bf16")
+    for w in wide[:6] + narrow[:3] + unresolved[:3]:
+        print(f"{tag}:    ratio {w[0]:5.2f}  {w[1]:60s} numel {w[2]:7d}  drift {w[3]:.4f}  envelope {w[4]:.4f}")
+    # The HIP step is not bit-reproducible (float atomics in the bank write and the parameter-gradient flushes), so its drift is a fresh
+    # draw on every run: over six runs on MI355X the LARGEST of the ~700 / ~930 per-tensor ratios read 1.27-1.49 while the distribution
+    # stayed put (median 0.62-0.74, 90 % 0.85-0.99).  Gates: the distribution against the envelope itself, 99 % of the tensors within
+    # 1.5 x their envelope, and no tensor beyond 2 x -- unless its drift is under half a bf16 ulp (2^-9) of its own norm (head.bias:
+    # 7e-4 against 4e-4: exact to the arithmetic's resolution whatever the ratio says).
+    assert np.median(ratios) <= 1.0, np.median(ratios)
+    assert np.quantile(ratios, 0.9) <= 1.25, np.quantile(ratios, 0.9)
+    assert np.quantile(ratios, 0.99) <= K_, (np.quantile(ratios, 0.99), wide[:8])
+    over = [w for w in wide + narrow if w[0] > 2.0 and w[3] > 2.0 ** -9]
+    assert not over, over[:8]
+    assert all(np.isfinite(w[3]) and w[3] <= 4.0 for w in unresolved), unresolved      # noise of the gradient's own size, not garbage
+
+
 def test_weight_pack_follows_the_optimizer(Q, golden):
     """Evaluation right after Trainer.step() / replay() must read the UPDATED weights (the fused AdamW writes through raw
     pointers, so torch's version counters do not move): bf16 and fp32 logits equal those of a fresh model loaded from

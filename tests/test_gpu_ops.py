@@ -1505,6 +1505,37 @@ def test_nan_rule_deferred_into_the_bank_write(F, Q, which, B, T):
         assert torch.equal(a_, b_)
 
 
+def test_a_failed_call_does_not_leave_a_deferred_nan_rule_behind(F, Q):
+    """The deferred NaN rule is per-device state between the fused branch launch and the bank write that consumes it.  A call that fails
+    in between (here: the bank write raises) must drop it, or every later forward would raise 'never consumed'."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    M = importlib.import_module("qa-vit_amd.modules")
+    rt = K.Runtime.get(0)
+    cfg = Q.HQAViTConfig()
+    bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+    mod = M.EfficientSpatialWindowAttention(cfg, bank, M._Ctx("hqa")).to(DEV).train()
+    Q.fill_module(mod)
+    x = leaf(4, 16, 192, seed=77).detach().to(torch.bfloat16)
+    orig = F.bank_write
+    seen = []
+
+    def boom(*a, **k):
+        seen.append(rt.pending_fix is not None)
+        raise RuntimeError("injected failure between the deferral and its consumer")
+    F.bank_write = boom
+    try:
+        with pytest.raises(RuntimeError, match="injected"):
+            mod(x)
+    finally:
+        F.bank_write = orig
+    assert seen == [True]                                   # the rule WAS deferred when the failure hit
+    assert rt.pending_fix is None
+    y = mod(x)                                              # and the next call runs
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all() and rt.pending_fix is None and rt.nan_flag.tolist() == [0, 0]
+
+
 @pytest.mark.parametrize("B,T", [(7, 16), (3, 64)])
 def test_nan_rule_of_the_cross_branch_rides_in_the_compress_fuse_launch(F, Q, B, T):
     """Inside a QuadAttentionBlock the cross branch's output is read next by the compress-fuse launch, which then carries the branch's NaN
