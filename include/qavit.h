@@ -365,6 +365,33 @@ int qavit_upmix_bwd_p(int dtype, const void* dy, const void* xc, const float* W,
                       float* dbias, float* dgamma, float* dbeta, int B, int N, int M, int C, float* parts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * TokenLearner (HQAViT_CIFAR100.py:971-1002) as ONE launch each way: scores = Linear(LayerNorm(x)) [B, N, M], P = softmax over the N
+ * tokens, xc = P^T x [B, M, C].  It replaces the LayerNorm-prologue qavit_gemm_nt + qavit_tokmix_fwd forward and qavit_tokmix_bwd +
+ * qavit_layernorm_bwd_lin + the score Linear's deferred qavit_gemm_tn problem backward: an image's N x C token tile is read once per
+ * direction.  bf16, (N, M, C) = (64, 16, 192) (qavit_tl_supported).  x 16-byte aligned; W = the [M, C] compute-dtype copy of the score
+ * weight (row-major), bias fp32 [M] or NULL.
+ * fwd writes p (bf16 [B, N, M], saved), xc, and the row statistics mean / rstd [B * N] (saved).
+ * bwd takes dxc and writes dx = dx(LayerNorm path) + dx(mixing path) and ONE partial row per workgroup,
+ *   parts = float[qavit_tl_bwd_parts(B, N, M)][M*C + M + 2*C] = [dW (M x C) | dbias (M) | dgamma (C) | dbeta (C)], 16-byte aligned,
+ * to be folded into the parameter gradients by qavit_ln_param_reduce (stride M*C + M + 2*C); no gradient buffer is touched here. */
+typedef struct qavit_tl_args {
+  const void* x; const float* ln_g; const float* ln_b; float eps;
+  const void* W; const float* bias;
+  void* p; void* xc; float* mean; float* rstd;
+  int B, N, M, C;
+} qavit_tl_args;
+typedef struct qavit_tl_bwd_args {
+  const void* dxc; const void* x; const void* p; const float* mean; const float* rstd;
+  const float* ln_g; const float* ln_b; const void* W;
+  void* dx; float* parts;
+  int B, N, M, C;
+} qavit_tl_bwd_args;
+int qavit_tl_supported(int dtype, int N, int M, int C);
+int qavit_tl_fwd(const qavit_tl_args* a, void* stream);
+int qavit_tl_bwd_parts(int B, int N, int M);
+int qavit_tl_bwd(const qavit_tl_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * MSDA landmark tokens (HQAViT_CIFAR100.py:499-501): dilated gathers x[:, ::d, ::d] concatenated, then
  * AvgPool1d(stride, stride) over the token axis.  idx[NP*stride] are source-token indices (host-built,
  * device-resident): pooled[b,j,:] = mean_s x[b, idx[j*stride+s], :].

@@ -1420,6 +1420,53 @@ class TokMixFn(Function):
         return ds, dx
 
 
+_TL_FUSED = os.environ.get("QAVIT_FUSED_TL", "1") != "0"
+
+
+def tl_ok(x, w) -> bool:
+    """TokenLearner as the fused node (TokenLearnerFn)?  bf16 [B, 64, 192] tokens, 16 learned tokens."""
+    return bool(_TL_FUSED and x.is_cuda and x.dim() == 3 and w.dim() == 2 and w.shape[1] == x.shape[-1]
+                and K.tl_ok(x if x.is_contiguous() else x.contiguous(), x.shape[1], w.shape[0], x.shape[2]))
+
+
+class TokenLearnerFn(Function):
+    """xc = softmax_N(Linear(LayerNorm(x)))^T x  (HQAViT_CIFAR100.py:971-1002) as ONE autograd node, one launch each way (qavit_tl_fwd /
+    qavit_tl_bwd).  It replaces LinearFn (LayerNorm-prologue GEMM with 16 outputs) + TokMixFn forward and tokmix_bwd + layernorm_bwd_lin +
+    the score Linear's deferred weight-gradient GEMM backward: the [B*N, C] token matrix is read once per direction, and the parameter
+    gradients (score weight / bias, LayerNorm gamma / beta) leave the backward kernel as partial rows for the pass's reduce launch."""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, w, b, eps):
+        K._require_cuda(x, w)
+        B, N, Cc = x.shape
+        M = w.shape[0]
+        x = x.contiguous()
+        Wc, _ = pack_for(x.device).get(w, x.dtype)
+        p = torch.empty(B, N, M, dtype=x.dtype, device=x.device)
+        xc = torch.empty(B, M, Cc, dtype=x.dtype, device=x.device)
+        mean = torch.empty(B * N, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(B * N, dtype=torch.float32, device=x.device)
+        K.tl_fwd(x, ln_g, ln_b, eps, Wc, None if b is None else b.detach(), p, xc, mean, rstd, B, N, M, Cc)
+        ctx.save_for_backward(x, ln_g, ln_b, w, b, p, mean, rstd)
+        return xc
+
+    @staticmethod
+    def backward(ctx, dxc):
+        x, ln_g, ln_b, w, b, p, mean, rstd = ctx.saved_tensors
+        B, N, Cc = x.shape
+        M = w.shape[0]
+        dxc = dxc.contiguous()
+        Wc, _ = pack_for(x.device).get(w, x.dtype)
+        dx = torch.empty_like(x)
+        wbuf, wret = grad_sink(w)
+        bbuf, bret = grad_sink(b)
+        gbuf, gret = grad_sink(ln_g)
+        bebuf, beret = grad_sink(ln_b)
+        DeferDW.arm()
+        K.tl_bwd(dxc, x, p, mean, rstd, ln_g, ln_b, Wc, dx, wbuf, bbuf, gbuf, bebuf, B, N, M, Cc)
+        return dx, _ret(gret, ln_g), _ret(beret, ln_b), _ret(wret, w), (None if b is None else _ret(bret, b)), None
+
+
 class UpMixFn(Function):
     @staticmethod
     def forward(ctx, xc, W, bias, g, b, eps):

@@ -511,6 +511,48 @@ def nan_guard(x, flag):
 # ---------------------------------------------------------------------------------------------------
 # token kernels
 # ---------------------------------------------------------------------------------------------------
+def tl_ok(x, N, M, Cc) -> bool:
+    """Can the fused TokenLearner kernels (qavit_tl_fwd / qavit_tl_bwd) take this problem?"""
+    return (x.dtype == torch.bfloat16 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and bool(L.load().qavit_tl_supported(dt_code(x.dtype), N, M, Cc)))
+
+
+def tl_fwd(x, ln_g, ln_b, eps, Wc, bias, p, xc, mean, rstd, B, N, M, Cc):
+    """TokenLearner forward in one launch (qavit_tl_fwd): p = softmax_N(Linear(LN(x))), xc = p^T x; Wc = the [M, C] compute-dtype weight."""
+    a = L.TlArgs()
+    a.x, a.ln_g, a.ln_b, a.eps = x.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(eps)
+    a.W, a.bias = Wc.data_ptr(), _p(bias)
+    a.p, a.xc, a.mean, a.rstd = p.data_ptr(), xc.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    a.B, a.N, a.M, a.C = B, N, M, Cc
+    L.check(L.load().qavit_tl_fwd(C.byref(a), stream()), "tl_fwd")
+
+
+def tl_bwd(dxc, x, p, mean, rstd, ln_g, ln_b, Wc, dx, dW, dbias, dgamma, dbeta, B, N, M, Cc):
+    """TokenLearner backward in one launch (qavit_tl_bwd): dx, and the score Linear's / LayerNorm's parameter gradients as one partial
+    row per workgroup, folded by the pass's reduce launch (DeferredLN) or at once when no backward pass has armed the queue."""
+    lib = L.load()
+    n = int(lib.qavit_tl_bwd_parts(B, N, M))
+    R = M * Cc + M + 2 * Cc
+    parts = torch.empty(n, R, dtype=torch.float32, device=x.device)
+    a = L.TlBwdArgs()
+    a.dxc, a.x, a.p, a.mean, a.rstd = dxc.data_ptr(), x.data_ptr(), p.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    a.ln_g, a.ln_b, a.W, a.dx, a.parts = ln_g.data_ptr(), ln_b.data_ptr(), Wc.data_ptr(), dx.data_ptr(), parts.data_ptr()
+    a.B, a.N, a.M, a.C = B, N, M, Cc
+    L.check(lib.qavit_tl_bwd(C.byref(a), stream()), "tl_bwd")
+    base, keep = parts.data_ptr(), (parts, dW, dbias, dgamma, dbeta)
+    if dW is not None:
+        half = M * Cc // 2
+        step = min(half, 2048)
+        while half % step or step % 4:
+            step -= 4
+        for o in range(0, half, step):                       # a reduce descriptor adds the two halves of a 2c-float slice to two destinations (c <= 2048)
+            DeferredLN.push_raw(base + 4 * 2 * o, n, step, dW.data_ptr() + 4 * 2 * o, dW.data_ptr() + 4 * (2 * o + step), R, keep)
+    if dbias is not None:
+        DeferredLN.push_raw(base + 4 * M * Cc, n, M // 2, dbias.data_ptr(), dbias.data_ptr() + 4 * (M // 2), R, keep)
+    if dgamma is not None or dbeta is not None:
+        DeferredLN.push_raw(base + 4 * (M * Cc + M), n, Cc, _p(dgamma), _p(dbeta), R, keep)
+
+
 def tokmix_fwd(scores, x, p, xc, B, N, M, Cc):
     L.check(L.load().qavit_tokmix_fwd(dt_code(x.dtype), scores.data_ptr(), x.data_ptr(), p.data_ptr(), xc.data_ptr(), B, N, M, Cc, stream()), "tokmix_fwd")
 

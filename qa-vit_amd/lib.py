@@ -120,6 +120,16 @@ class AttnArgs(C.Structure):
     ]
 
 
+class TlArgs(C.Structure):                          # struct qavit_tl_args
+    _fields_ = [("x", vp), ("ln_g", vp), ("ln_b", vp), ("eps", f32), ("W", vp), ("bias", vp),
+                ("p", vp), ("xc", vp), ("mean", vp), ("rstd", vp), ("B", i32), ("N", i32), ("M", i32), ("C", i32)]
+
+
+class TlBwdArgs(C.Structure):                       # struct qavit_tl_bwd_args
+    _fields_ = [("dxc", vp), ("x", vp), ("p", vp), ("mean", vp), ("rstd", vp), ("ln_g", vp), ("ln_b", vp), ("W", vp),
+                ("dx", vp), ("parts", vp), ("B", i32), ("N", i32), ("M", i32), ("C", i32)]
+
+
 class BranchArgs(C.Structure):
     _fields_ = [
         ("dtype", i32), ("kind", i32),
@@ -187,6 +197,10 @@ _SIGS = {
     "qavit_nan_guard": (i32, [i32, vp, i64, vp, vp]),
     "qavit_branch_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "qavit_branch_fwd": (i32, [C.POINTER(BranchArgs), vp]),
+    "qavit_tl_supported": (i32, [i32, i32, i32, i32]),
+    "qavit_tl_fwd": (i32, [C.POINTER(TlArgs), vp]),
+    "qavit_tl_bwd_parts": (i32, [i32, i32, i32]),
+    "qavit_tl_bwd": (i32, [C.POINTER(TlBwdArgs), vp]),
     "qavit_tokmix_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_tokmix_bwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "qavit_upmix_fwd": (i32, [i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp]),

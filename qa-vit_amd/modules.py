@@ -481,6 +481,8 @@ class TokenLearner(nn.Module):
 
     def forward(self, x):
         ln, fc = self.attention[0], self.attention[1]
+        if F.tl_ok(x, fc.weight) and not (ln._forward_hooks or fc._forward_hooks or ln._forward_pre_hooks or fc._forward_pre_hooks):
+            return F.TokenLearnerFn.apply(x, ln.weight, ln.bias, fc.weight, fc.bias, ln.eps)      # one launch each way (csrc/tokens_tl.hip)
         scores, xa = F.linear(x, fc.weight, fc.bias, ln=(ln.weight, ln.bias), eps=ln.eps, alias=True)
         return F.TokMixFn.apply(scores, xa)
 

@@ -45,7 +45,8 @@ def test_ctypes_structs_match_header(Q):
     pairs = [("qavit_gemm_args", Q.lib.GemmArgs), ("qavit_gemm_tn_args", Q.lib.GemmTnArgs), ("qavit_attn_args", Q.lib.AttnArgs),
              ("qavit_ccf_args", Q.lib.CcfArgs), ("qavit_pack_desc", Q.lib.PackDesc), ("qavit_branch_args", Q.lib.BranchArgs),
              ("qavit_branch_bwd_args", Q.lib.BranchBwdArgs), ("qavit_ln_reduce_desc", Q.lib.LnReduceDesc), ("qavit_cga_args", Q.lib.CgaArgs), ("qavit_cga_bwd_args", Q.lib.CgaBwdArgs), ("qavit_cfuse_args", Q.lib.CfuseArgs), ("qavit_cfuse_bwd_args", Q.lib.CfuseBwdArgs),
-             ("qavit_mlp2_args", Q.lib.Mlp2Args), ("qavit_mlp2_bwd_args", Q.lib.Mlp2BwdArgs)]
+             ("qavit_mlp2_args", Q.lib.Mlp2Args), ("qavit_mlp2_bwd_args", Q.lib.Mlp2BwdArgs),
+             ("qavit_tl_args", Q.lib.TlArgs), ("qavit_tl_bwd_args", Q.lib.TlBwdArgs)]
     for cname, st in pairs:
         assert [f[0] for f in st._fields_] == _struct_fields(cname), cname
 

@@ -681,6 +681,67 @@ def test_tokmix_upmix(F, dtype, N, M, B):
         assert rel(a.grad, rr.grad) <= tol(dtype, False) * 2, nme
 
 
+@pytest.mark.parametrize("B", [3, 260, 1500])
+def test_fused_token_learner(F, Q, B):
+    """TokenLearnerFn = softmax_N(Linear(LayerNorm(x)))^T x (HQAViT_CIFAR100.py:971-1002) as one launch each way (qavit_tl_fwd / qavit_tl_bwd,
+    bf16, 64 -> 16 tokens): against fp32 torch autograd on the bf16-rounded operands -- xc, dx and the four parameter gradients the
+    backward kernel leaves as partial rows (score weight / bias, LayerNorm gamma / beta) -- and against the chain it replaces (LayerNorm-
+    prologue GEMM + TokMixFn; tokmix_bwd + layernorm_bwd_lin + the deferred weight-gradient GEMM).  B = 260 / 1500: more images than the
+    backward's 256 workgroups (partial rows span images), B = 3: fewer."""
+    import importlib
+    M_ = importlib.import_module("qa-vit_amd.modules")
+    N, M, C = 64, 16, 192
+    dtype = torch.bfloat16
+    tl = M_.TokenLearner(C, M).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        tl.attention[0].weight.copy_(1.0 + 0.2 * torch.randn(C, generator=g))
+        tl.attention[0].bias.copy_(0.2 * torch.randn(C, generator=g))
+        tl.attention[1].weight.copy_(0.3 * torch.randn(M, C, generator=g))
+        tl.attention[1].bias.copy_(0.3 * torch.randn(M, generator=g))
+    x0 = (leaf(B, N, C, seed=610).detach() * 1.5 + 0.3).to(dtype)
+    go = torch.randn(B, M, C, device=DEV).to(dtype)
+    res = []
+    for fused in (True, False):
+        F._TL_FUSED = fused
+        try:
+            for p_ in tl.parameters():
+                p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            assert F.tl_ok(x, tl.attention[1].weight) == fused
+            xc = tl(x)
+            xc.backward(go)
+            torch.cuda.synchronize()
+        finally:
+            F._TL_FUSED = True
+        res.append(dict(xc=xc.detach().float(), dx=x.grad.float(), dW=tl.attention[1].weight.grad.clone(), db=tl.attention[1].bias.grad.clone(),
+                        dg=tl.attention[0].weight.grad.clone(), dbeta=tl.attention[0].bias.grad.clone()))
+    # fp32 torch on the operands the kernels see (bf16 tokens, bf16-rounded score weight)
+    xr = x0.float().requires_grad_(True)
+    gr, br = (t.detach().clone().requires_grad_(True) for t in (tl.attention[0].weight, tl.attention[0].bias))
+    Wr = tl.attention[1].weight.detach().to(dtype).float().requires_grad_(True)
+    b2 = tl.attention[1].bias.detach().clone().requires_grad_(True)
+    sc = TF.linear(TF.layer_norm(xr, (C,), gr, br), Wr, b2)
+    ref = torch.bmm(torch.softmax(sc, 1).transpose(1, 2), xr)
+    ref.backward(go.float())
+    refs = dict(xc=ref, dx=xr.grad, dW=Wr.grad, db=b2.grad, dg=gr.grad, dbeta=br.grad)
+    # d/dbias is identically zero in exact arithmetic (a softmax over the tokens ignores a per-column constant): what either path holds is the
+    # sum of its bf16 score-gradient roundings -- bounded against the weight gradient's size and against the unfused path's own residue
+    wmax = float(refs["dW"].abs().max())
+    assert float(res[0]["db"].abs().max()) <= max(3.0 * float(res[1]["db"].abs().max()), 2e-2 * wmax), (res[0]["db"].abs().max(), res[1]["db"].abs().max(), wmax)
+    # ... and so is d/dbeta of the LayerNorm: dbeta = W^T . (column sums of the score gradient) = W^T . 0
+    gmax = float(refs["dg"].abs().max())
+    assert float(res[0]["dbeta"].abs().max()) <= max(3.0 * float(res[1]["dbeta"].abs().max()), 2e-2 * gmax), (res[0]["dbeta"].abs().max(), res[1]["dbeta"].abs().max(), gmax)
+    for k_ in ("xc", "dx", "dW", "dg"):
+        t_ = tol(dtype, k_ == "xc")
+        assert rel(res[0][k_], refs[k_]) <= t_, (k_, "fused vs fp32 torch", rel(res[0][k_], refs[k_]))
+        assert rel(res[1][k_], refs[k_]) <= t_ * 1.5, (k_, "unfused vs fp32 torch")
+        assert rel(res[0][k_], res[1][k_]) <= t_, (k_, "fused vs unfused")
+    # the forward keeps the unfused chain's rounding points (bf16 LayerNorm output, scores, P); the row statistics are summed in another
+    # order (4 lanes x 48 channels here, 8 lanes x 24 in the GEMM prologue), so a few normalised values round the other way: within 2 bf16 ulps
+    assert rel(res[0]["xc"], res[1]["xc"]) <= 2.0 ** -6
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Hs,dil", [(4, (1, 2)), (8, (1, 2)), (14, (1, 2, 3)), (4, (1, 1, 1, 1, 1, 2))])
 def test_gather_pool(F, dtype, Hs, dil):
