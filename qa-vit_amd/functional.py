@@ -734,6 +734,79 @@ class LayerNormFn(Function):
         return dx, None, None, None, None, None, None
 
 
+_DX_CAT = os.environ.get("QAVIT_DX_CAT", "1") != "0"
+
+
+class FanGroup:
+    """The fused attention branches that read ONE LayerNormFanFn output (norm1 of a QuadAttentionBlock: cross q_proj, SWA qkv, MSDA's
+    q) each end their backward in an input-gradient GEMM of the same [M, C] shape whose results the fan node then sums.  Instead the
+    branch backward kernels write dq (| dk | dv) into column slices of ONE [M, 5C] matrix and return no gradient; the fan node's backward
+    runs ONE GEMM over the concatenated contraction axis against the row-stack [Wq_cross; Wqkv_swa; Wqkv_msda] (its transposed pack,
+    K = the first 5C columns) -- the sum of the three products is what the contraction computes -- with the landmark-path gradient of MSDA
+    as its residual addend (dx = dq_c Wq_c + [dq dk dv]_s Wqkv_s + dq_m Wq_m + dx_pool; HQAViT_CIFAR100.py:448, :523, :613 backward).
+    Two launches, two [M, C] round trips and two addends of the fan-in sum fewer per block."""
+    registry = {}                                           # data_ptr of the fan-out tensor -> weakref(FanGroup)
+
+    def __init__(self, M, Cc, dtype, device):
+        self.M, self.C, self.dtype, self.device = M, Cc, dtype, device
+        self.buf = None
+        self.entries = {}                                   # kind -> weight parameter
+        self.resid = None
+
+    # column offset / width of a branch kind's slice: cross q | SWA q k v | MSDA q
+    def slot(self, kind):
+        Cc = self.C
+        return {2: (0, Cc), 0: (Cc, 3 * Cc), 1: (4 * Cc, Cc)}[kind]
+
+    def slice_ptr(self, kind):
+        if self.buf is None:
+            self.buf = torch.empty(self.M, 5 * self.C, dtype=self.dtype, device=self.device)
+        return self.buf.data_ptr() + self.slot(kind)[0] * self.buf.element_size()
+
+    @classmethod
+    def create(cls, y, rows, Cc):
+        if not (_DX_CAT and y.is_cuda and y.dtype == torch.bfloat16 and rows >= 16 and Cc % 64 == 0):
+            return None
+        grp = cls(rows, Cc, y.dtype, y.device)
+        cls.registry[y.data_ptr()] = weakref.ref(grp)
+        return grp
+
+    @classmethod
+    def lookup(cls, x):
+        """The live group whose fan-out tensor ``x`` is a view of (called in a branch's FORWARD, while that tensor is alive)."""
+        ref = cls.registry.get(x.data_ptr())
+        grp = ref() if ref is not None else None
+        if grp is None or grp.M != x.numel() // x.shape[-1] or grp.C != x.shape[-1] or grp.dtype != x.dtype:
+            return None
+        return grp
+
+    def run(self):
+        """-> the summed input gradient [M, C] of the registered branches, or None."""
+        if not self.entries:
+            return None
+        M, Cc = self.M, self.C
+        out = torch.empty(M, Cc, dtype=self.dtype, device=self.device)
+        order = (2, 0, 1)
+        ld = 5 * Cc
+        esz = self.buf.element_size()
+        if all(k in self.entries for k in order):
+            _, Wt = pack_for(self.device).get([self.entries[2], self.entries[0], self.entries[1]], self.dtype)      # [C, C + 3C + 3C]
+            K.gemm_nt(self.buf, Wt, out, M, Cc, 5 * Cc, ld, Wt.shape[1], Cc, None, R=self.resid, ldr=Cc)
+            return out
+        first = True                                        # a branch without a gradient this pass: a GEMM per registered slice
+        for k in order:
+            if k not in self.entries:
+                continue
+            off, width = self.slot(k)
+            _, Wt = pack_for(self.device).get(self.entries[k], self.dtype)
+            R = self.resid if first else out
+            K.gemm_nt(self.buf, Wt, out, M, Cc, width, ld, Wt.shape[1], Cc, None, R=R, ldr=Cc, A_ptr=self.buf.data_ptr() + off * esz)
+            first = False
+        if first:
+            return None
+        return out
+
+
 class LayerNormFanFn(Function):
     """LayerNorm whose output feeds ``k`` consumers, plus the alias of ``x`` for the residual: -> (y_1 .. y_k, x_alias).  Backward gets
     the k gradients and the residual's and runs ONE launch: the LayerNorm-backward kernel sums them on load (qavit_layernorm_bwd_sum)
@@ -753,6 +826,8 @@ class LayerNormFanFn(Function):
         ctx.save_for_backward(x2, g, b, mean, rstd)
         ctx.xshape, ctx.k = x.shape, k
         ctx.set_materialize_grads(False)
+        # the consumers' qkv input-gradient GEMMs, deferred to this node's backward (grad mode is off inside Function.forward: ask the ctx)
+        ctx.group = FanGroup.create(y, rows, Cc) if ctx.needs_input_grad[0] else None
         y = y.reshape(x.shape)
         return tuple(y.view_as(y) for _ in range(k)) + (x.view_as(x),)
 
@@ -763,6 +838,12 @@ class LayerNormFanFn(Function):
         dalias = grads[ctx.k]
         dys = [t.reshape(rows, Cc) for t in grads[:ctx.k] if t is not None]
         dys = [t if t.is_contiguous() else t.contiguous() for t in dys]
+        grp = getattr(ctx, "group", None)
+        if grp is not None:
+            dcat = grp.run()                                # ONE GEMM for the branches that left their dq / dk / dv in the group's matrix
+            if dcat is not None:
+                dys.insert(0, dcat)
+            ctx.group = None
         if not dys:
             return dalias, None, None, None, None
         gbuf, _ = grad_sink(g)
@@ -917,6 +998,7 @@ class BranchFn(Function):
             sk_s, sv_s = snap if snap is not None else K.copy2(sh_k, sh_v)
         ctx.sh_alias = (sh_k, sh_v)
         ctx.meta = meta
+        ctx.fan = FanGroup.lookup(x) if ctx.needs_input_grad[0] else None      # x is one output of a LayerNormFanFn: see FanGroup
         ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj, E_k, E_v, sk_s, sv_s, o, *saved)
         return out
 
@@ -1001,28 +1083,41 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
         a.nan_trip = ctx.trip.data_ptr()
     esz = 2
     dkv = None
+    # the qkv input-gradient GEMM deferred to the fan node that produced x (FanGroup): dq (| dk | dv) go into its [M, 5C] matrix
+    grp = getattr(ctx, "fan", None) if (ctx.needs_input_grad[0] and wqkv.requires_grad) else None
+    if grp is not None and (grp.M != M or grp.C != Cc or kind in grp.entries):
+        grp = None
+    dq_ptr, dq_ld = None, None
+    if grp is not None:
+        dq_ptr, dq_ld = grp.slice_ptr(kind), 5 * Cc
     if kind == 0:
         qkv = saved[0]
-        dq = torch.empty_like(qkv)
+        dq = torch.empty_like(qkv) if grp is None else None
         a.q, a.ldq = qkv.data_ptr(), 3 * Cc
         a.k_tok, a.v_tok, a.ldkv, a.kv_rows = qkv.data_ptr() + Cc * esz, qkv.data_ptr() + 2 * Cc * esz, 3 * Cc, 16
-        a.dq, a.lddq = dq.data_ptr(), 3 * Cc
-        a.dk_tok, a.dv_tok, a.lddkv = dq.data_ptr() + Cc * esz, dq.data_ptr() + 2 * Cc * esz, 3 * Cc
+        if grp is None:
+            dq_ptr, dq_ld = dq.data_ptr(), 3 * Cc
+        a.dq, a.lddq = dq_ptr, dq_ld
+        a.dk_tok, a.dv_tok, a.lddkv = dq_ptr + Cc * esz, dq_ptr + 2 * Cc * esz, dq_ld
         a.KC, a.L = E_k.shape[1], 16
     elif kind == 1:
         q, kv, p2 = saved
         Lk = m["Lk"]
-        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        dq, dkv = (torch.empty_like(q) if grp is None else None), torch.empty_like(kv)
         a.q, a.ldq = q.data_ptr(), Cc
         a.k_tok, a.v_tok, a.ldkv, a.kv_rows = kv.data_ptr(), kv.data_ptr() + Cc * esz, 2 * Cc, Lk
-        a.dq, a.lddq = dq.data_ptr(), Cc
+        if grp is None:
+            dq_ptr, dq_ld = dq.data_ptr(), Cc
+        a.dq, a.lddq = dq_ptr, dq_ld
         a.dk_tok, a.dv_tok, a.lddkv = dkv.data_ptr(), dkv.data_ptr() + Cc * esz, 2 * Cc
         a.KC, a.L = E_k.shape[1], Lk
     else:
         q = saved[0]
-        dq = torch.empty_like(q)
+        dq = torch.empty_like(q) if grp is None else None
         a.q, a.ldq = q.data_ptr(), Cc
-        a.dq, a.lddq = dq.data_ptr(), Cc
+        if grp is None:
+            dq_ptr, dq_ld = dq.data_ptr(), Cc
+        a.dq, a.lddq = dq_ptr, dq_ld
     if kind != 2:
         a.E_k, a.E_v = E_k.data_ptr(), E_v.data_ptr()
     nparts = K.branch_bwd_parts(B, T)
@@ -1080,7 +1175,25 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
     # ---- the projections' own backward
     need_dx = ctx.needs_input_grad[0]
     with torch.no_grad():
-        if kind == 0:
+        if grp is not None:
+            # input gradient: the fan node's ONE GEMM over every registered slice; here only the weight / bias gradients, whose dz operand
+            # is this branch's column slice of the group's matrix (leading dimension 5C)
+            nq = 3 * Cc if kind == 0 else Cc
+            dxp = None
+            if kind == 1:
+                idx, stride = m["pool_idx"], m["pool_stride"]
+                NP = idx.numel() // stride
+                dpool = _linear_bwd(saved[2], wqkv, bqkv, dkv, Cc, 2 * Cc, need_dx)
+                dxp = torch.empty(M, Cc, dtype=x.dtype, device=x.device)
+                K.gather_pool_bwd(dpool.reshape(B, NP, Cc).contiguous(), idx, dxp, B, T, NP, stride, Cc)
+                grp.resid = dxp
+            wq_buf, _ = grad_sink(wqkv)
+            bq_buf, _ = grad_sink(bqkv)
+            K.gemm_tn(grp.buf, x2, wq_buf, M, nq, Cc, 5 * Cc, Cc, Cc, None, A_ptr=dq_ptr, C_ptr=wq_buf.data_ptr(),
+                      colsum_ptr=None if bq_buf is None else bq_buf.data_ptr())
+            grp.entries[kind] = wqkv
+            dx = None
+        elif kind == 0:
             dx = _linear_bwd(x2, wqkv, bqkv, dq, 0, 3 * Cc, need_dx)
         elif kind == 1:
             idx, stride = m["pool_idx"], m["pool_stride"]

@@ -1566,6 +1566,61 @@ def test_nan_rule_deferred_into_the_bank_write(F, Q, which, B, T):
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("B,T", [(70, 16), (5, 16), (20, 64)])
+def test_qkv_input_gradients_as_one_gemm_in_the_fan_node(F, Q, B, T):
+    """FanGroup: the three fused attention branches that read norm1's output (cross q_proj, SWA qkv, MSDA q) leave dq | dk | dv in column
+    slices of one [M, 5C] matrix and the fan node's backward runs ONE input-gradient GEMM over the concatenated contraction axis (K = 5C,
+    MSDA's landmark-path gradient as the residual addend) instead of three GEMMs whose results it then summed.  A QuadAttentionBlock in
+    training mode, dropout on, bf16: output bit-equal (the forward is untouched), input gradient and EVERY parameter gradient against the
+    three-GEMM path (QAVIT_DX_CAT off) -- the weight gradients read the same dq bits through a leading dimension of 5C -- and the group
+    must really have been used."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    M = importlib.import_module("qa-vit_amd.modules")
+    rt = K.Runtime.get(0)
+    C = 192
+    cfg = Q.HQAViTConfig() if T == 16 else Q.HQAViTTinyINConfig()
+    cfg.dropout = 0.1
+    x0 = leaf(B, T, C, seed=930).detach().to(torch.bfloat16)
+    torch.manual_seed(7)
+    bank = M.GlobalTokenBank(cfg.global_bank_size, cfg.embed_dim).to(DEV)
+    blk = M.QuadAttentionBlock(cfg, bank, 0.1, M._Ctx("hqa")).to(DEV).train()
+    Q.fill_module(blk)
+    state = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    gy = torch.randn(B, T, C, device=DEV).to(torch.bfloat16)
+    runs = []
+    orig = F.FanGroup.run
+    F.FanGroup.run = lambda self: (runs.append(sorted(self.entries)), orig(self))[1]
+    res = {}
+    try:
+        for cat in (True, False):
+            F._DX_CAT = cat
+            blk.load_state_dict(state)
+            rt.seed(2468)
+            del runs[:]
+            for p_ in blk.parameters():
+                p_.grad = None
+            xin = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(xin)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[cat] = dict(y=y.detach().float().clone(), dx=xin.grad.float().clone(),
+                            **{n_: p_.grad.detach().clone() for n_, p_ in blk.named_parameters() if p_.grad is not None})
+            assert runs == ([[0, 1, 2]] if cat else []), runs        # one group run holding cross (2), SWA (0) and MSDA (1) -- or none
+    finally:
+        F.FanGroup.run = orig
+        F._DX_CAT = True
+    assert torch.equal(res[True]["y"], res[False]["y"])
+    assert set(res[True]) == set(res[False])
+    for k_ in res[True]:
+        if k_ == "y":
+            continue
+        a_, b_ = res[True][k_], res[False][k_]
+        # one rounding of the summed input gradient instead of three roundings and a sum: bf16-level differences downstream of norm1
+        assert rel(a_, b_) <= (2e-2 if k_ == "dx" or k_.startswith("norm1") else 1e-5 if ".qkv." in k_ or "cross_attn.q_proj" in k_ else 2e-2), (k_, rel(a_, b_))
+
+
 def test_a_failed_call_does_not_leave_a_deferred_nan_rule_behind(F, Q):
     """The deferred NaN rule is per-device state between the fused branch launch and the bank write that consumes it.  A call that fails
     in between (here: the bank write raises) must drop it, or every later forward would raise 'never consumed'."""
