@@ -83,10 +83,24 @@ typedef struct qavit_gemm_args {
    * without the 2C-wide cat buffer and without a second, accumulating launch.  bf16, a_mode 0, a2_k0 % 64 == 0, shapes the K-loop
    * kernel takes (qavit_gemm_nt_a2_supported); anything else is refused. */
   const void* A2; int64_t lda2; int a2_k0;
+  /* LAYERNORM-BACKWARD EPILOGUE (optional, e_x != NULL): the product is the gradient of a LayerNorm's OUTPUT (the input-gradient GEMM of
+   * the Linear behind the LayerNorm: HQAViT_CIFAR100.py:1072-1082 norm1 -> qkv, :704 norm2 -> fc1, :945 gate_norm -> gate_fc) and the
+   * call writes the gradient of the LayerNorm's INPUT instead:  dy = acc (+ e_add0 + e_add1: the same output's gradients from other
+   * consumers, [M, N] contiguous);  C = rstd * (dy * gamma - mean_N(dy * gamma) - xhat * mean_N(dy * gamma * xhat)) + R,  xhat =
+   * (e_x - e_mean) * e_rstd -- one launch and no [M, N] round trip where a GEMM and qavit_layernorm_bwd ran.  The LayerNorm parameter
+   * gradients dgamma = colsum(dy * xhat), dbeta = colsum(dy) are ADDED to e_dgamma / e_dbeta with float atomics, or, with e_parts =
+   * float[qavit_gemm_nt_lnbwd_parts(M, N)][2][N], left as partial rows in qavit_layernorm_bwd's layout (fold with
+   * qavit_ln_param_reduce).  bf16, N in {128, 192, 256} = the LayerNorm width = one column block, a_mode 0 or 2, no other epilogue term
+   * than R (qavit_gemm_nt_lnbwd_supported); e_x / e_add* rows of N elements, 16-byte aligned. */
+  const void* e_x; const float* e_mean; const float* e_rstd; const float* e_gamma;
+  const void* e_add0; const void* e_add1;
+  float* e_dgamma; float* e_dbeta; float* e_parts;
 } qavit_gemm_args;
 
 int qavit_gemm_nt(const qavit_gemm_args* a, void* stream);
 int qavit_gemm_nt_a2_supported(int dtype, int M, int N, int K, int a2_k0);
+int qavit_gemm_nt_lnbwd_supported(int dtype, int M, int N, int K, int a_mode);
+int qavit_gemm_nt_lnbwd_parts(int M, int N);
 /* n independent problems (host array); up to 4 of one shape / dtype / prologue / epilogue kind that take the resident-slice
  * kernel share a grid (the four compress_* Linears of a block and their input gradients), others are launched one by one */
 int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stream);

@@ -858,6 +858,14 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   using namespace qv;
   if (!a || !a->A || !a->B || !a->C) return set_error(QAVIT_EINVAL, "gemm_nt: null operand");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return set_error(QAVIT_EINVAL, "gemm_nt: non-positive dimension");
+  if (a->e_x) {
+    // LayerNorm-backward epilogue: only the K-loop kernel has it -- every other route is refused, loudly
+    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N) return set_error(QAVIT_EINVAL, "gemm_nt: leading dimension too small");
+    if ((a->a_drop_p > 0.f || a->a_dp_p > 0.f) && !a->rng) return set_error(QAVIT_EINVAL, "gemm_nt: dropout requested without rng state");
+    if (a->a_dp_p > 0.f && a->a_dp_rows <= 0) return set_error(QAVIT_EINVAL, "gemm_nt: drop-path needs rows-per-sample");
+    const int took = gemm_nt_big_lnbwd(*a, reinterpret_cast<hipStream_t>(stream));
+    return took == 1 ? QAVIT_OK : (took < 0 ? took : set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue not applicable"));
+  }
   if (a->A2) {
     // two-source A: only the K-loop kernel stages A by 64-wide chunks with a per-chunk base -- every other route is refused, loudly
     if (!qavit_gemm_nt_a2_supported(a->dtype, a->M, a->N, a->K, a->a2_k0) || a->a_mode != 0)
@@ -907,6 +915,9 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
   }
   return set_error(QAVIT_EINVAL, "gemm_nt: unknown dtype");
 }
+
+extern "C" int qavit_gemm_nt_lnbwd_supported(int dtype, int M, int N, int K, int a_mode) { return qv::gemm_nt_lnbwd_shape_ok(dtype, M, N, K, a_mode) ? 1 : 0; }
+extern "C" int qavit_gemm_nt_lnbwd_parts(int M, int N) { return (M > 0 && (N == 128 || N == 192 || N == 256)) ? qv::gemm_nt_lnbwd_parts(M, N) : 0; }
 
 extern "C" int qavit_gemm_nt_a2_supported(int dtype, int M, int N, int K, int a2_k0) {
   // the conditions of gemm_nt_big_try (csrc/gemm_big.hip) that do not depend on pointers, plus the chunk-aligned split

@@ -295,6 +295,102 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
     }
   }
   __syncthreads();                                    // As/Bs are dead: reuse them as per-wave epilogue scratch
+  if constexpr (EPI == 2) {
+    // LAYERNORM-BACKWARD EPILOGUE (qavit_gemm_args.e_x): the tile holds whole rows of dy = the gradient of a LayerNorm's output (BN_ ==
+    // N, one column block).  32 rows at a time -- the two row groups the 2 x 2 wave grid holds per step -- go through an fp32 LDS tile;
+    // 8 threads share a row (BN_ / 8 consecutive columns each), so the two row means are in-lane sums + one DPP reduction over 8
+    // adjacent lanes.  A thread keeps the same columns for every row group: its dgamma / dbeta column partials stay in registers until
+    // the end, where they meet in the LDS tile and leave as this row tile's partial row (or as float atomics).
+    constexpr int SLD = BN_ + 4, CPT = BN_ / 8, NV = CPT / 8;
+    static_assert(BN_ % 64 == 0 && (BN_ == 128 || BN_ == 192 || BN_ == 256), "LayerNorm width = one column block of 128, 192 or 256");
+    float* S = reinterpret_cast<float*>(smem);                 // [32][SLD]
+    float* Gl = S + 32 * SLD;                                   // [BN_] gamma
+    for (int c = tid; c < BN_; c += 256) Gl[c] = g.e_gamma[c];
+    const int srow = tid >> 3, seg = tid & 7, c0 = seg * CPT;
+    const bf16* X = reinterpret_cast<const bf16*>(g.e_x);
+    const bf16* A0 = reinterpret_cast<const bf16*>(g.e_add0);
+    const bf16* A1 = reinterpret_cast<const bf16*>(g.e_add1);
+    const bf16* Rr = reinterpret_cast<const bf16*>(g.R);
+    bf16* Cc = reinterpret_cast<bf16*>(g.C);
+    float pg[CPT], pb[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) { pg[q] = 0.f; pb[q] = 0.f; }
+    const float invN = 1.f / (float)BN_;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(wm * 16 + fq * 4 + r) * SLD + wn * WN + j * 16 + fr] = acc[i][j][r];
+      __syncthreads();
+      const int m = m0 + ((srow >> 4) * TM + i) * 16 + (srow & 15);
+      const bool live = m < g.M;
+      const size_t mc = (size_t)(live ? m : g.M - 1);
+      const float mu = g.e_mean[mc], rs = g.e_rstd[mc];
+      float d[CPT], xh[CPT];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = c0 + 8 * v;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(S + srow * SLD + c), t1 = *reinterpret_cast<const f32x4*>(S + srow * SLD + c + 4);
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(X + mc * BN_ + c);
+        float dd[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if (A0) { const bf16x8 av = *reinterpret_cast<const bf16x8*>(A0 + mc * BN_ + c);
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) dd[q] += (float)av[q]; }
+        if (A1) { const bf16x8 av = *reinterpret_cast<const bf16x8*>(A1 + mc * BN_ + c);
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) dd[q] += (float)av[q]; }
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gl + c), g1 = *reinterpret_cast<const f32x4*>(Gl + c + 4);
+        const float gm[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float dy = live ? dd[q] : 0.f, xx = ((float)xv[q] - mu) * rs, gg = dy * gm[q];
+          d[8 * v + q] = gg;                                   // dy * gamma
+          xh[8 * v + q] = xx;
+          s1 += gg * xx;
+          s2 += gg;
+          pg[8 * v + q] += dy * xx;
+          pb[8 * v + q] += dy;
+        }
+      }
+      s1 = group_sum<8>(s1) * invN;
+      s2 = group_sum<8>(s2) * invN;
+      if (live) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int c = c0 + 8 * v;
+          float o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = rs * (d[8 * v + q] - s2 - xh[8 * v + q] * s1);
+          if (Rr) { const bf16x8 rv = *reinterpret_cast<const bf16x8*>(Rr + mc * g.ldr + c);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] += (float)rv[q]; }
+          bf16x8 ov;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) ov[q] = (bf16)o[q];
+          *reinterpret_cast<bf16x8*>(Cc + mc * g.ldc + c) = ov;
+        }
+      }
+      __syncthreads();                                        // the tile is free for the next row group
+    }
+    // column sums of the partials over the 32 row-threads of each segment, one array at a time through the LDS tile
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) S[srow * SLD + c0 + q] = which ? pb[q] : pg[q];
+      __syncthreads();
+      for (int c = tid; c < BN_; c += 256) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) t += S[r * SLD + c];
+        if (g.e_parts) g.e_parts[((size_t)tm * 2 + which) * BN_ + c] = t;
+        else { float* dst = which ? g.e_dbeta : g.e_dgamma; if (dst) atomic_add_f(dst + c, t); }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   float* Ws = reinterpret_cast<float*>(smem) + wave * 16 * WLD;
   constexpr int CG = WN / 16;
 #pragma unroll
@@ -326,7 +422,7 @@ template <int BM_, int BN_, int AMODE, int EPI>
 int big_launch(const qavit_gemm_args& g, hipStream_t st) {
   const int n_tiles_m = (g.M + BM_ - 1) / BM_, ncb = (g.N + BN_ - 1) / BN_;
   size_t smem = (size_t)(BM_ + BN_) * LDT * 2 + (AMODE == 1 ? (size_t)2 * g.K * 4 : 0);
-  const size_t scratch = (size_t)4 * 16 * (BN_ / 2 + 4) * 4;
+  const size_t scratch = EPI == 2 ? (size_t)(32 * (BN_ + 4) + BN_) * 4 : (size_t)4 * 16 * (BN_ / 2 + 4) * 4;
   if (smem < scratch) smem = scratch;
   if (smem > 150 * 1024) return -100;
   static bool attr_done = false;
@@ -339,6 +435,21 @@ int big_launch(const qavit_gemm_args& g, hipStream_t st) {
   return QAVIT_OK;
 }
 
+// row-tile height the dispatch below picks for a problem of M rows and `ncb` column blocks (also the partial-row count of the
+// LayerNorm-backward epilogue: one row per row tile)
+int big_bm(int M, int ncb, int bn) {
+  static const int bm32_below = getenv("QAVIT_BIG_BM32") ? atoi(getenv("QAVIT_BIG_BM32")) : 448;
+  if (bn == 256) return 128;
+  if ((long)((M + 127) / 128) * ncb >= 448) return 128;
+  return (long)((M + 63) / 64) * ncb < bm32_below ? 32 : 64;
+}
+
+template <int BM_, int BN_>
+int big_lnbwd(const qavit_gemm_args& g, hipStream_t st) {
+  if constexpr (BN_ == 256 && BM_ != 128) return -100;
+  else return g.a_mode == 2 ? big_launch<BM_, BN_, 2, 2>(g, st) : big_launch<BM_, BN_, 0, 2>(g, st);
+}
+
 template <int BM_, int BN_>
 int big_modes(const qavit_gemm_args& g, hipStream_t st) {
   const bool full = g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.R || g.scale != 1.f;
@@ -348,6 +459,34 @@ int big_modes(const qavit_gemm_args& g, hipStream_t st) {
 }
 
 }  // namespace
+
+bool gemm_nt_lnbwd_shape_ok(int dtype, int M, int N, int K, int a_mode) {
+  return dtype == QAVIT_BF16 && M >= 1024 && (N == 128 || N == 192 || N == 256) && K >= 96 && K % 32 == 0 && (a_mode == 0 || a_mode == 2);
+}
+int gemm_nt_lnbwd_parts(int M, int N) { return (M + big_bm(M, 1, N) - 1) / big_bm(M, 1, N); }
+
+// the LayerNorm-backward epilogue (qavit_gemm_args.e_x): only this kernel has it.  1 = launched, < 0 error (never "not applicable":
+// the caller asked qavit_gemm_nt_lnbwd_supported first)
+int gemm_nt_big_lnbwd(const qavit_gemm_args& g, hipStream_t st) {
+  if (!gemm_nt_lnbwd_shape_ok(g.dtype, g.M, g.N, g.K, g.a_mode)) return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: bf16, M >= 1024, N in {128, 192, 256}, K % 32 == 0, a_mode 0 or 2");
+  auto al = [](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
+  if (!g.e_mean || !g.e_rstd || !g.e_gamma || g.A2 || g.bias || g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.scale != 1.f)
+    return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue takes no bias / activation / dropout / scale and needs mean, rstd, gamma");
+  if (!al(g.A, g.lda) || !al(g.B, g.ldb) || !al(g.C, g.ldc) || !al(g.e_x, 8) || (g.e_add0 && !al(g.e_add0, 8)) || (g.e_add1 && !al(g.e_add1, 8)) ||
+      (g.R && !al(g.R, g.ldr)) || (g.e_parts && (reinterpret_cast<uintptr_t>(g.e_parts) & 15)))
+    return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: 16-byte aligned operands, leading dimensions % 8");
+  if (g.a_mode == 2 && ((g.a_Z && g.a_act && !al(g.a_Z, g.a_ldz)) || (g.a_out && !al(g.a_out, g.a_ldo))))
+    return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: a_Z / a_out alignment");
+  const int bm = big_bm(g.M, 1, g.N);
+  int rc;
+  if (g.N == 256) rc = big_lnbwd<128, 256>(g, st);
+  else if (g.N == 192) rc = bm == 128 ? big_lnbwd<128, 192>(g, st) : (bm == 32 ? big_lnbwd<32, 192>(g, st) : big_lnbwd<64, 192>(g, st));
+  else rc = bm == 128 ? big_lnbwd<128, 128>(g, st) : (bm == 32 ? big_lnbwd<32, 128>(g, st) : big_lnbwd<64, 128>(g, st));
+  if (rc == -100) return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: tile does not fit LDS");
+  if (rc != QAVIT_OK) return rc;
+  rc = check_launch("gemm_nt(big, LayerNorm backward)");
+  return rc == QAVIT_OK ? 1 : rc;
+}
 
 // returns 1 = launched, 0 = not applicable (caller falls back to the resident-slice kernel), < 0 error
 int gemm_nt_big_try(const qavit_gemm_args& g_in, hipStream_t st) {

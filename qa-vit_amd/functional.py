@@ -577,10 +577,23 @@ def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, me
                             dres=None if dres is None else dres.reshape(M, Kd))
     elif need_dx or need_t:
         dz = torch.empty_like(dy2) if (need_t and (need_dw or (b is not None and b.requires_grad))) else dy2
-        dxn = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
         bwd = None
         if need_t:
             bwd = dict(Z=Z, ldz=n, act=act, drop=drop, dp=dp, out=dz if dz is not dy2 else None, ldo=n)
+        r2 = None if dres is None else dres.reshape(M, Kd)
+        if (_LN_EPI and ln_g is not None and need_dx and dx_add is None and koff == 0 and Kd == ldx
+                and K.gemm_nt_lnbwd_ok(x2, M, Kd, n, 2 if need_t else 0, r2) and dy2.data_ptr() % 16 == 0):
+            # the LayerNorm backward in the input-gradient GEMM's epilogue (the K-loop kernel's column block is the whole LayerNorm row):
+            # no [M, Kd] product written by one launch and read back by the next
+            gbuf, _ = grad_sink(ln_g)
+            bbuf, _ = grad_sink(ln_b)
+            dx = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
+            DeferDW.arm()
+            K.gemm_nt(dy2, Wt, dx, M, Kd, n, n, Wt.shape[1], Kd, None, a_mode=2 if need_t else 0, bwd=bwd, rng=rt.rng,
+                      B_ptr=Wt.data_ptr() + (koff * Wt.shape[1] + off) * esz, R=r2, ldr=Kd,
+                      lnbwd=dict(x=x2, mean=mean, rstd=rstd, gamma=ln_g, dgamma=gbuf, dbeta=bbuf))
+            return _linear_bwd_weights(x2, w, b, dz, off, n, Kd, ldx, koff, ln_g, ln_b, mean, rstd, need_dw, dx)
+        dxn = torch.empty(M, Kd, dtype=x2.dtype, device=x2.device)
         # dx_add [M, Kd]: another gradient of the same x, added in this GEMM's residual epilogue (no LayerNorm behind it)
         K.gemm_nt(dy2, Wt, dxn, M, Kd, n, n, Wt.shape[1], Kd, None, a_mode=2 if need_t else 0, bwd=bwd, rng=rt.rng,
                   B_ptr=Wt.data_ptr() + (koff * Wt.shape[1] + off) * esz, R=dx_add if ln_g is None else None, ldr=Kd)
@@ -598,6 +611,15 @@ def _linear_bwd(x2, w, b, dy2, off, n, need_dx, ln_g=None, ln_b=None, Z=None, me
                 dx = dx + dres.reshape(M, Kd)
         else:
             dx = dxn if dres is None else dxn + dres.reshape(M, Kd)
+    return _linear_bwd_weights(x2, w, b, dz, off, n, Kd, ldx, koff, ln_g, ln_b, mean, rstd, need_dw, dx)
+
+
+_LN_EPI = os.environ.get("QAVIT_LN_EPILOGUE", "1") != "0"   # LayerNorm backward as the input-gradient GEMM's epilogue (csrc/gemm_big.hip, EPI 2)
+
+
+def _linear_bwd_weights(x2, w, b, dz, off, n, Kd, ldx, koff, ln_g, ln_b, mean, rstd, need_dw, dx):
+    """The weight / bias gradient half of _linear_bwd (deferred grouped GEMMs); returns ``dx`` unchanged."""
+    M = x2.shape[0]
     if need_dw or (b is not None and b.requires_grad):
         wbuf, _ = grad_sink(w)
         bbuf2, _ = grad_sink(b)
@@ -780,8 +802,13 @@ class FanGroup:
             return None
         return grp
 
-    def run(self):
-        """-> the summed input gradient [M, C] of the registered branches, or None."""
+    def complete(self) -> bool:
+        return all(k in self.entries for k in (2, 0, 1))
+
+    def run(self, lnbwd=None, dres=None):
+        """-> the summed input gradient [M, C] of the registered branches, or None.  ``lnbwd`` (all three branches registered only): the
+        fan node's LayerNorm backward as the GEMM's epilogue -- the result is then the gradient of the LayerNorm's INPUT, with ``dres``
+        (the residual path's gradient) added behind it and the landmark-path gradient in front of it."""
         if not self.entries:
             return None
         M, Cc = self.M, self.C
@@ -789,10 +816,15 @@ class FanGroup:
         order = (2, 0, 1)
         ld = 5 * Cc
         esz = self.buf.element_size()
-        if all(k in self.entries for k in order):
+        if self.complete():
             _, Wt = pack_for(self.device).get([self.entries[2], self.entries[0], self.entries[1]], self.dtype)      # [C, C + 3C + 3C]
-            K.gemm_nt(self.buf, Wt, out, M, Cc, 5 * Cc, ld, Wt.shape[1], Cc, None, R=self.resid, ldr=Cc)
+            if lnbwd is not None:
+                lnbwd = dict(lnbwd, adds=[self.resid] + list(lnbwd.get("adds") or ()))
+                K.gemm_nt(self.buf, Wt, out, M, Cc, 5 * Cc, ld, Wt.shape[1], Cc, None, R=dres, ldr=Cc, lnbwd=lnbwd)
+            else:
+                K.gemm_nt(self.buf, Wt, out, M, Cc, 5 * Cc, ld, Wt.shape[1], Cc, None, R=self.resid, ldr=Cc)
             return out
+        assert lnbwd is None
         first = True                                        # a branch without a gradient this pass: a GEMM per registered slice
         for k in order:
             if k not in self.entries:
@@ -839,22 +871,32 @@ class LayerNormFanFn(Function):
         dys = [t.reshape(rows, Cc) for t in grads[:ctx.k] if t is not None]
         dys = [t if t.is_contiguous() else t.contiguous() for t in dys]
         grp = getattr(ctx, "group", None)
+        ctx.group = None
+        dres = None
+        if dalias is not None:
+            dres = dalias.reshape(rows, Cc)
+            if not K.ln_dres_ok(x2, dres, Cc):
+                dres = None
+        if grp is not None and grp.complete() and _LN_EPI and (dalias is None or dres is not None) and \
+                len(dys) + (grp.resid is not None) <= 2 and K.gemm_nt_lnbwd_ok(x2, rows, Cc, 5 * Cc, 0, grp.resid, dres, *dys):
+            # ONE launch for the whole node: the branches' input-gradient GEMM (K = 5C) with this LayerNorm's backward as its epilogue
+            # -- the remaining consumers' gradients (the channel-group branch) and MSDA's landmark-path gradient are added to the
+            # product on load, the residual path's gradient behind the LayerNorm backward
+            gbuf, _ = grad_sink(g)
+            bbuf, _ = grad_sink(b)
+            DeferDW.arm()
+            dx = grp.run(lnbwd=dict(x=x2, mean=mean, rstd=rstd, gamma=g, dgamma=gbuf, dbeta=bbuf, adds=dys), dres=dres)
+            return dx.reshape(ctx.xshape), None, None, None, None
         if grp is not None:
             dcat = grp.run()                                # ONE GEMM for the branches that left their dq / dk / dv in the group's matrix
             if dcat is not None:
                 dys.insert(0, dcat)
-            ctx.group = None
         if not dys:
             return dalias, None, None, None, None
         gbuf, _ = grad_sink(g)
         bbuf, _ = grad_sink(b)
         dx = torch.empty_like(x2)
         DeferDW.arm()
-        dres = None
-        if dalias is not None:
-            dres = dalias.reshape(rows, Cc)
-            if not K.ln_dres_ok(x2, dres, Cc):
-                dres = None
         if K.layernorm_bwd_sum_ok(x2, dys, Cc):
             K.layernorm_bwd_sum(dys, x2, g, mean, rstd, dx, gbuf, bbuf, rows, Cc, dres=dres)
         else:

@@ -121,9 +121,12 @@ def new_site() -> int:
 # ---------------------------------------------------------------------------------------------------
 def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None, ln_stats=None,
             bwd=None, Z=None, act=0, drop=(0.0, 0), scale=1.0, dp=(0.0, 0, 1), R=None, ldr=0, rng=None,
-            A_ptr=None, B_ptr=None, C_ptr=None, build_only=False, A2=None, lda2=0, a2_k0=0):
+            A_ptr=None, B_ptr=None, C_ptr=None, build_only=False, A2=None, lda2=0, a2_k0=0, lnbwd=None):
     """C[M,N] = epi(pro(A)[M,K] @ B[N,K]^T + bias).  A/B/Cout are tensors used for dtype/liveness; *_ptr
-    override the base address (column-offset views).  ``build_only`` returns the argument struct for gemm_nt_grouped."""
+    override the base address (column-offset views).  ``build_only`` returns the argument struct for gemm_nt_grouped.
+    ``lnbwd`` = dict(x, mean, rstd, gamma, dgamma, dbeta[, adds]): the LayerNorm-backward epilogue (qavit_gemm_args.e_x; check
+    gemm_nt_lnbwd_ok first) -- the product is the gradient of LayerNorm(x)'s output, Cout receives the gradient of x (+ R); the
+    LayerNorm parameter gradients leave as partial rows when a backward pass has armed DeferredLN, else as float atomics."""
     a = L.GemmArgs()
     a.dtype = dt_code(A.dtype)
     a.M, a.N, a.K = M, N, K
@@ -158,9 +161,36 @@ def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None,
     a.rng = _p(rng)
     if A2 is not None:                        # two-source A: columns a2_k0 .. K of the contraction come from A2 (qavit_gemm_args.A2)
         a.A2, a.lda2, a.a2_k0 = A2.data_ptr(), lda2, a2_k0
+    ln_parts = None
+    if lnbwd is not None:
+        a.e_x, a.e_mean, a.e_rstd, a.e_gamma = lnbwd["x"].data_ptr(), lnbwd["mean"].data_ptr(), lnbwd["rstd"].data_ptr(), lnbwd["gamma"].data_ptr()
+        adds = [t for t in (lnbwd.get("adds") or ()) if t is not None]
+        if len(adds) > 2:
+            raise ValueError("gemm_nt: the LayerNorm-backward epilogue takes at most two addends")
+        if adds:
+            a.e_add0 = adds[0].data_ptr()
+        if len(adds) > 1:
+            a.e_add1 = adds[1].data_ptr()
+        dg, db = lnbwd.get("dgamma"), lnbwd.get("dbeta")
+        if (dg is not None or db is not None) and DeferredLN.enabled and DeferredLN.ON:
+            n_ = int(L.load().qavit_gemm_nt_lnbwd_parts(M, N))
+            ln_parts = (torch.empty(n_ * 2 * N, dtype=torch.float32, device=A.device), n_)
+            a.e_parts = ln_parts[0].data_ptr()
+        else:
+            a.e_dgamma, a.e_dbeta = _p(dg), _p(db)
     if build_only:
         return a
     L.check(L.load().qavit_gemm_nt(C.byref(a), stream()), "gemm_nt")
+    if ln_parts is not None:
+        DeferredLN.push(ln_parts[0], ln_parts[1], N, lnbwd.get("dgamma"), lnbwd.get("dbeta"), keep=(lnbwd["x"],))
+
+
+def gemm_nt_lnbwd_ok(x, M, N, K, a_mode, *others) -> bool:
+    """Can qavit_gemm_nt run its LayerNorm-backward epilogue on this input-gradient GEMM?  (x = the LayerNorm's input [M, N]; ``others``:
+    the addends / residual, same shape and dtype)"""
+    return (x.dtype == torch.bfloat16 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and all(t is None or (t.dtype == x.dtype and t.is_contiguous() and t.numel() == x.numel() and t.data_ptr() % 16 == 0) for t in others)
+            and bool(L.load().qavit_gemm_nt_lnbwd_supported(dt_code(x.dtype), M, N, K, a_mode)))
 
 
 def gemm_nt_a2_ok(x, x2, M, N, K, k0) -> bool:

@@ -21,6 +21,8 @@ class GemmArgs(C.Structure):
         ("Z", vp), ("ldz", i64), ("act", i32), ("drop_p", f32), ("drop_site", i32), ("scale", f32),
         ("dp_p", f32), ("dp_site", i32), ("dp_rows", i32), ("R", vp), ("ldr", i64), ("rng", vp),
         ("A2", vp), ("lda2", i64), ("a2_k0", i32),
+        ("e_x", vp), ("e_mean", vp), ("e_rstd", vp), ("e_gamma", vp), ("e_add0", vp), ("e_add1", vp),
+        ("e_dgamma", vp), ("e_dbeta", vp), ("e_parts", vp),
     ]
 
 
@@ -162,6 +164,8 @@ _SIGS = {
     "qavit_last_error": (C.c_char_p, []),
     "qavit_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "qavit_gemm_nt_a2_supported": (i32, [i32, i32, i32, i32, i32]),
+    "qavit_gemm_nt_lnbwd_supported": (i32, [i32, i32, i32, i32, i32]),
+    "qavit_gemm_nt_lnbwd_parts": (i32, [i32, i32]),
     "qavit_gemm_nt_grouped": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "qavit_gemm_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "qavit_gemm_tn_grouped": (i32, [C.POINTER(GemmTnArgs), i32, vp]),

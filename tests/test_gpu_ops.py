@@ -139,6 +139,65 @@ def test_linear_ln_narrow_output_fused_backward(F, M):
         assert rel(a_, b_) <= 2e-2
 
 
+@pytest.mark.parametrize("M,Kd,N,act,alias", [(4096, 192, 96, "gelu", True), (1024 + 37, 192, 96, None, False), (70000, 192, 192, None, True),
+                                              (20000, 192, 576, None, False), (5000, 128, 512, "gelu", False), (66000, 256, 1024, "gelu", True),
+                                              (30000, 128, 96, None, True)])
+def test_layernorm_backward_in_the_input_gradient_gemm_epilogue(F, Q, M, Kd, N, act, alias):
+    """LayerNorm -> Linear (norm2 -> CCF fc1 with GELU, gate_norm -> gate_fc, the ConvNeXt blocks' norm -> pwconv1; HQAViT_CIFAR100.py:704,
+    :945, :728): in bf16 the Linear's input-gradient GEMM runs the LayerNorm backward as its epilogue (qavit_gemm_args.e_x: the K-loop
+    kernel's column block is the whole LayerNorm row of 128 / 192 / 256) -- dx, the residual alias' gradient added behind it, dgamma /
+    dbeta as partial rows or atomics.  Against fp32 torch autograd and against the GEMM + LayerNorm-backward pair (QAVIT_LN_EPILOGUE off);
+    every row-tile height (32 / 64 / 128 rows), ragged M, a_mode 0 and 2."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    x0 = leaf(M, Kd, seed=41) * 1.3 + 0.2
+    w, b = leaf(N, Kd, scale=0.05, seed=42), leaf(N, scale=0.1, seed=43)
+    g_, be = leaf(Kd, scale=0.1, seed=44), leaf(Kd, scale=0.1, seed=45)
+    with torch.no_grad():
+        g_.add_(1.0)
+    go = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    ga = torch.randn(M, Kd, device=DEV).to(torch.bfloat16)
+    calls = []
+    orig = K.gemm_nt
+    K.gemm_nt = lambda *a, **k: (calls.append(k.get("lnbwd") is not None), orig(*a, **k))[1]
+    res = {}
+    try:
+        for mode in (True, False):
+            F._LN_EPI = mode
+            del calls[:]
+            for t in (w, b, g_, be):
+                t.grad = None
+            x = x0.detach().to(torch.bfloat16).requires_grad_(True)
+            if alias:
+                y, xa = F.linear(x, w, b, ln=(g_, be), act=act, alias=True)
+                torch.autograd.backward([y, xa], [go, ga])
+            else:
+                y = F.linear(x, w, b, ln=(g_, be), act=act)
+                y.backward(go)
+            torch.cuda.synchronize()
+            assert any(calls) == mode, (mode, calls)            # the epilogue really ran (and only when asked)
+            res[mode] = [t.detach().float().clone() for t in (y, x.grad, w.grad, b.grad, g_.grad, be.grad)]
+    finally:
+        K.gemm_nt = orig
+        F._LN_EPI = True
+    xr = x0.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br, gr, ber = [t.detach().clone().requires_grad_(True) for t in (b, g_, be)]
+    yr = TF.linear(TF.layer_norm(xr, (Kd,), gr, ber), wr, br)
+    if act == "gelu":
+        yr = TF.gelu(yr)
+    if alias:
+        torch.autograd.backward([yr, xr * 1.0], [go.float(), ga.float()])
+    else:
+        yr.backward(go.float())
+    refs = [yr, xr.grad, wr.grad, br.grad, gr.grad, ber.grad]
+    for name, got, ref in zip(("y", "dx", "dW", "db", "dgamma", "dbeta"), res[True], refs):
+        assert rel(got, ref) <= tol(torch.bfloat16, name == "y"), (name, rel(got, ref))
+    for name, a_, b_ in zip(("y", "dx", "dW", "db", "dgamma", "dbeta"), res[True], res[False]):
+        assert rel(a_, b_) <= 2e-2, (name, rel(a_, b_))
+    assert torch.equal(res[True][0], res[False][0])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_ln_gelu_residual(F, dtype):
     M, K, N = 2048, 192, 96
@@ -1590,7 +1649,7 @@ def test_qkv_input_gradients_as_one_gemm_in_the_fan_node(F, Q, B, T):
     gy = torch.randn(B, T, C, device=DEV).to(torch.bfloat16)
     runs = []
     orig = F.FanGroup.run
-    F.FanGroup.run = lambda self: (runs.append(sorted(self.entries)), orig(self))[1]
+    F.FanGroup.run = lambda self, *a_, **k_: (runs.append((sorted(self.entries), k_.get("lnbwd") is not None)), orig(self, *a_, **k_))[1]
     res = {}
     try:
         for cat in (True, False):
@@ -1607,7 +1666,9 @@ def test_qkv_input_gradients_as_one_gemm_in_the_fan_node(F, Q, B, T):
             torch.cuda.synchronize()
             res[cat] = dict(y=y.detach().float().clone(), dx=xin.grad.float().clone(),
                             **{n_: p_.grad.detach().clone() for n_, p_ in blk.named_parameters() if p_.grad is not None})
-            assert runs == ([[0, 1, 2]] if cat else []), runs        # one group run holding cross (2), SWA (0) and MSDA (1) -- or none
+            # one group run holding cross (2), SWA (0) and MSDA (1), with norm1's backward as the GEMM's epilogue where the K-loop kernel
+            # takes the shape (M >= 1024 rows) -- or none
+            assert runs == ([([0, 1, 2], B * T >= 1024)] if cat else []), runs
     finally:
         F.FanGroup.run = orig
         F._DX_CAT = True
