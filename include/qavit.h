@@ -89,7 +89,7 @@ typedef struct qavit_gemm_args {
    * consumers, [M, N] contiguous);  C = rstd * (dy * gamma - mean_N(dy * gamma) - xhat * mean_N(dy * gamma * xhat)) + R,  xhat =
    * (e_x - e_mean) * e_rstd -- one launch and no [M, N] round trip where a GEMM and qavit_layernorm_bwd ran.  The LayerNorm parameter
    * gradients dgamma = colsum(dy * xhat), dbeta = colsum(dy) are ADDED to e_dgamma / e_dbeta with float atomics, or, with e_parts =
-   * float[qavit_gemm_nt_lnbwd_parts(M, N)][2][N], left as partial rows in qavit_layernorm_bwd's layout (fold with
+   * float[qavit_gemm_nt_lnbwd_parts(M, N, K)][2][N], left as partial rows in qavit_layernorm_bwd's layout (fold with
    * qavit_ln_param_reduce).  bf16, N in {128, 192, 256} = the LayerNorm width = one column block, a_mode 0 or 2, no other epilogue term
    * than R (qavit_gemm_nt_lnbwd_supported); e_x / e_add* rows of N elements, 16-byte aligned. */
   const void* e_x; const float* e_mean; const float* e_rstd; const float* e_gamma;
@@ -100,7 +100,7 @@ typedef struct qavit_gemm_args {
 int qavit_gemm_nt(const qavit_gemm_args* a, void* stream);
 int qavit_gemm_nt_a2_supported(int dtype, int M, int N, int K, int a2_k0);
 int qavit_gemm_nt_lnbwd_supported(int dtype, int M, int N, int K, int a_mode);
-int qavit_gemm_nt_lnbwd_parts(int M, int N);
+int qavit_gemm_nt_lnbwd_parts(int M, int N, int K);
 /* n independent problems (host array); up to 4 of one shape / dtype / prologue / epilogue kind that take the resident-slice
  * kernel share a grid (the four compress_* Linears of a block and their input gradients), others are launched one by one */
 int qavit_gemm_nt_grouped(const qavit_gemm_args* a, int n, void* stream);
@@ -314,7 +314,8 @@ typedef struct qavit_branch_args {
   void* o_save;
   float attn_drop_p; int attn_drop_site; float proj_drop_p; int proj_drop_site; const int64_t* rng;
   int* nan_flag;
-  int reserved;   /* must be 0 */
+  int drain_waits;   /* 0; != 0 (diagnostic): every weight-ring step first waits for ALL outstanding memory operations of the wave, so the
+                      * counted s_waitcnt vmcnt(N) arithmetic of the q / k / v / O save bursts holds trivially -- same bits, slower */
   /* optional saves for the backward pass (q_save == NULL: none): q rows [B*T, ldq_save] at column 0; k at column 0 and v at
    * column C of kv_save [B*rows, ldkv_save], rows = T per image (SWA; kv_save = q_save + C elements gives the usual [B*T, 3C]
    * qkv matrix) or L landmark rows per image (MSDA); pooled_save [B*L, C] = MSDA's pooled landmarks.  kind 2 saves q only. */

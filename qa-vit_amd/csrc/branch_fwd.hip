@@ -257,14 +257,25 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
   constexpr int B1 = KST, B2 = (SAVE && KIND == 0) ? 2 * KST : -100, B3 = NQKV;
   constexpr int N1 = (KIND == 2) ? 0 : 3, N2 = 3, N3 = (KIND == 0) ? 6 : (KIND == 2 ? 6 : 3);      // stores per burst (cross: q and O rows both at step NQKV = KST)
   auto burst_extra = [](int c, int b, int n) { return (c > b && c <= b + AHEAD) ? n : 0; };
+  // a.drain_waits (diagnostic, uniform): every ring step waits for ALL of this wave's outstanding memory operations first -- the counted
+  // waits below then hold trivially.  tests/test_gpu_ops.py compares the two forms bit for bit: a miscounted burst would show there.
+  const bool drain_waits = a.drain_waits != 0;
 #define QV_RING_STEP(c)                                                                         \
   do {                                                                                          \
+    if (drain_waits) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
     ring_wait((NCH - 1 - (c)) < (AHEAD - 1) ? (NCH - 1 - (c)) : (AHEAD - 1),                    \
               SAVE ? burst_extra((c), B1, N1) + burst_extra((c), B2, N2) + burst_extra((c), B3, N3) : 0);   \
     if ((c) + AHEAD < NCH) issue((c) + AHEAD);                                                  \
   } while (0)
   // the burst: wave w stores rows 8 (w & 1) .. + 8 of sub-image w >> 1 from its staging tile
+  // The wait arithmetic counts these stores by POSITION: exactly three dwordx4 stores per burst, issued after the ring step's LDS-DMA
+  // (issue(c + AHEAD)) and before the next ring step.  Nothing else enforces that, so the burst is fenced for the compiler on both sides:
+  // a scheduling barrier (no instruction moves across it) and an empty asm with a memory clobber (no memory operation is hoisted, sunk,
+  // split or merged across it) -- a store that slid above the DMA or below the next counted wait would let a wave read a ring slot that
+  // has not landed: wrong numbers, no fault.
   auto store_rows = [&](const bf16* stage, bf16* gdst, int64_t ld) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       const int p = lane + 64 * it, row = 8 * (wave & 1) + p / 24, c8 = p % 24;
@@ -272,6 +283,8 @@ __global__ __launch_bounds__(512) void branch_fwd_kernel(qavit_branch_args a) {
       *reinterpret_cast<bf16x8*>(gdst + (size_t)tile_row<TT, WIN>(tile, wave >> 1, row, a.B) * ld + 8 * c8) = v8;
       if (KSH) asm volatile("" ::: "memory");              // one piece at a time: this variant has no registers for three pieces in flight
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
   bf16* qstage = (KIND == 2) ? sp_all_q : so_all;           // cross: the O quads follow the q phase directly, its q rows stage in a region of their own
 

@@ -917,7 +917,7 @@ extern "C" int qavit_gemm_nt(const qavit_gemm_args* a, void* stream) {
 }
 
 extern "C" int qavit_gemm_nt_lnbwd_supported(int dtype, int M, int N, int K, int a_mode) { return qv::gemm_nt_lnbwd_shape_ok(dtype, M, N, K, a_mode) ? 1 : 0; }
-extern "C" int qavit_gemm_nt_lnbwd_parts(int M, int N) { return (M > 0 && (N == 128 || N == 192 || N == 256)) ? qv::gemm_nt_lnbwd_parts(M, N) : 0; }
+extern "C" int qavit_gemm_nt_lnbwd_parts(int M, int N, int K) { return (M > 0 && (N == 128 || N == 192 || N == 256)) ? qv::gemm_nt_lnbwd_parts(M, N, K) : 0; }
 
 extern "C" int qavit_gemm_nt_a2_supported(int dtype, int M, int N, int K, int a2_k0) {
   // the conditions of gemm_nt_big_try (csrc/gemm_big.hip) that do not depend on pointers, plus the chunk-aligned split

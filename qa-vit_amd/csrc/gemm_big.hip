@@ -275,6 +275,30 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // LayerNorm-backward epilogue (EPI 2): what its first row group reads from memory -- the LayerNorm input, up to two addends, the
+  // residual, the row statistics: 4 x the output's bytes -- is requested HERE, before the K loop, and the next group's while the current
+  // one is worked on: as the epilogue's own loads they stood alone at the end of every workgroup (K = 960, M = 16384: 22.6 us without
+  // the epilogue, 36 us with it).  Row tiles of 128 rows keep the plain form (their accumulators leave no registers for it).
+  constexpr bool LNPRE = EPI == 2 && BM_ <= 64;
+  constexpr int LN_NV = (EPI == 2) ? BN_ / 64 : 1;
+  bf16x8 lx[LN_NV], la0[LN_NV], la1[LN_NV], lr[LN_NV];
+  float lmu = 0.f, lrs = 0.f;
+  auto ln_request = [&](int i) {
+    const int srow = tid >> 3, c0 = (tid & 7) * (BN_ / 8);
+    const int m = m0 + ((srow >> 4) * TM + i) * 16 + (srow & 15);
+    const size_t mc = (size_t)(m < g.M ? m : g.M - 1);
+    lmu = g.e_mean[mc]; lrs = g.e_rstd[mc];
+#pragma unroll
+    for (int v = 0; v < LN_NV; ++v) {
+      const int c = c0 + 8 * v;
+      lx[v] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(g.e_x) + mc * BN_ + c);
+      if (g.e_add0) la0[v] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(g.e_add0) + mc * BN_ + c);
+      if (g.e_add1) la1[v] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(g.e_add1) + mc * BN_ + c);
+      if (g.R) lr[v] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(g.R) + mc * g.ldr + c);
+    }
+  };
+  if (LNPRE) ln_request(0);
+
   prefetch(0);
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     __syncthreads();                                  // previous chunk's MFMAs are done with As/Bs (and Gs is staged)
@@ -326,19 +350,22 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
       const int m = m0 + ((srow >> 4) * TM + i) * 16 + (srow & 15);
       const bool live = m < g.M;
       const size_t mc = (size_t)(live ? m : g.M - 1);
-      const float mu = g.e_mean[mc], rs = g.e_rstd[mc];
+      if (!LNPRE) ln_request(i);
+      const float mu = lmu, rs = lrs;
+      bf16x8 rres[NV];
       float d[CPT], xh[CPT];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = c0 + 8 * v;
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(S + srow * SLD + c), t1 = *reinterpret_cast<const f32x4*>(S + srow * SLD + c + 4);
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(X + mc * BN_ + c);
+        const bf16x8 xv = lx[v];
+        rres[v] = lr[v];
         float dd[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-        if (A0) { const bf16x8 av = *reinterpret_cast<const bf16x8*>(A0 + mc * BN_ + c);
+        if (A0) { const bf16x8 av = la0[v];
 #pragma unroll
                   for (int q = 0; q < 8; ++q) dd[q] += (float)av[q]; }
-        if (A1) { const bf16x8 av = *reinterpret_cast<const bf16x8*>(A1 + mc * BN_ + c);
+        if (A1) { const bf16x8 av = la1[v];
 #pragma unroll
                   for (int q = 0; q < 8; ++q) dd[q] += (float)av[q]; }
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gl + c), g1 = *reinterpret_cast<const f32x4*>(Gl + c + 4);
@@ -354,6 +381,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
           pb[8 * v + q] += dy;
         }
       }
+      if (LNPRE && i + 1 < TM) ln_request(i + 1);             // the next row group's operands travel while this one is finished
       s1 = group_sum<8>(s1) * invN;
       s2 = group_sum<8>(s2) * invN;
       if (live) {
@@ -363,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_nt_big_kernel(qavit_gemm_args g, int
           float o[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) o[q] = rs * (d[8 * v + q] - s2 - xh[8 * v + q] * s1);
-          if (Rr) { const bf16x8 rv = *reinterpret_cast<const bf16x8*>(Rr + mc * g.ldr + c);
+          if (Rr) { const bf16x8 rv = rres[v];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) o[q] += (float)rv[q]; }
           bf16x8 ov;
@@ -437,10 +465,13 @@ int big_launch(const qavit_gemm_args& g, hipStream_t st) {
 
 // row-tile height the dispatch below picks for a problem of M rows and `ncb` column blocks (also the partial-row count of the
 // LayerNorm-backward epilogue: one row per row tile)
-int big_bm(int M, int ncb, int bn) {
+int big_bm(int M, int ncb, int bn, int K = 0) {
   static const int bm32_below = getenv("QAVIT_BIG_BM32") ? atoi(getenv("QAVIT_BIG_BM32")) : 448;
   if (bn == 256) return 128;
   if ((long)((M + 127) / 128) * ncb >= 448) return 128;
+  // a long contraction re-reads the whole weight once per row tile: from K = 768 the 64-row tile wins although it leaves one workgroup per
+  // CU (the fan node's K = 960 GEMM at 16384 rows: 22.6 -> 21.8 us plain, 30.0 -> 26.4 us with the LayerNorm-backward epilogue)
+  if (K >= 768) return 64;
   return (long)((M + 63) / 64) * ncb < bm32_below ? 32 : 64;
 }
 
@@ -463,7 +494,7 @@ int big_modes(const qavit_gemm_args& g, hipStream_t st) {
 bool gemm_nt_lnbwd_shape_ok(int dtype, int M, int N, int K, int a_mode) {
   return dtype == QAVIT_BF16 && M >= 1024 && (N == 128 || N == 192 || N == 256) && K >= 96 && K % 32 == 0 && (a_mode == 0 || a_mode == 2);
 }
-int gemm_nt_lnbwd_parts(int M, int N) { return (M + big_bm(M, 1, N) - 1) / big_bm(M, 1, N); }
+int gemm_nt_lnbwd_parts(int M, int N, int K) { return (M + big_bm(M, 1, N, K) - 1) / big_bm(M, 1, N, K); }
 
 // the LayerNorm-backward epilogue (qavit_gemm_args.e_x): only this kernel has it.  1 = launched, < 0 error (never "not applicable":
 // the caller asked qavit_gemm_nt_lnbwd_supported first)
@@ -477,7 +508,7 @@ int gemm_nt_big_lnbwd(const qavit_gemm_args& g, hipStream_t st) {
     return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: 16-byte aligned operands, leading dimensions % 8");
   if (g.a_mode == 2 && ((g.a_Z && g.a_act && !al(g.a_Z, g.a_ldz)) || (g.a_out && !al(g.a_out, g.a_ldo))))
     return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: a_Z / a_out alignment");
-  const int bm = big_bm(g.M, 1, g.N);
+  const int bm = big_bm(g.M, 1, g.N, g.K);
   int rc;
   if (g.N == 256) rc = big_lnbwd<128, 256>(g, st);
   else if (g.N == 192) rc = bm == 128 ? big_lnbwd<128, 192>(g, st) : (bm == 32 ? big_lnbwd<32, 192>(g, st) : big_lnbwd<64, 192>(g, st));
@@ -524,12 +555,11 @@ int gemm_nt_big_try(const qavit_gemm_args& g_in, hipStream_t st) {
     if (rc0) return rc0;
     g.a_mode = 1;
   }
-  const bool bm128 = (long)((g.M + 127) / 128) * ncb >= 448;
   int rc;
   // fewer than ~1.75 workgroups per CU at 64-row tiles (rows = B*16 learned tokens): 32-row tiles put two workgroups on a
-  // CU so one's global-load latency hides behind the other's MFMAs
-  static const int bm32_below = getenv("QAVIT_BIG_BM32") ? atoi(getenv("QAVIT_BIG_BM32")) : 448;
-  const bool bm32 = !bm128 && (long)((g.M + 63) / 64) * ncb < bm32_below;
+  // CU so one's global-load latency hides behind the other's MFMAs (big_bm)
+  const int bm_pick = big_bm(g.M, ncb, bn, g.K);
+  const bool bm128 = bm_pick == 128, bm32 = bm_pick == 32;
   if (bn == 256) rc = big_modes<128, 256>(g, st);                      // 64-row tiles would starve the MFMA pipe here
   else if (bn == 192) rc = bm128 ? big_modes<128, 192>(g, st) : (bm32 ? big_modes<32, 192>(g, st) : big_modes<64, 192>(g, st));
   else rc = bm128 ? big_modes<128, 128>(g, st) : (bm32 ? big_modes<32, 128>(g, st) : big_modes<64, 128>(g, st));

@@ -10,7 +10,7 @@ int gemm_nt_big_try(const qavit_gemm_args& g, hipStream_t st);
 // the same kernel with the LayerNorm-backward epilogue (qavit_gemm_args.e_x): 1 = launched, < 0 = error code
 int gemm_nt_big_lnbwd(const qavit_gemm_args& g, hipStream_t st);
 bool gemm_nt_lnbwd_shape_ok(int dtype, int M, int N, int K, int a_mode);
-int gemm_nt_lnbwd_parts(int M, int N);
+int gemm_nt_lnbwd_parts(int M, int N, int K);
 // bf16 weight-gradient GEMMs with wide output tiles, grouped by tile class (gemm_tn_wide.hip).  Problems must be
 // validated bf16 problems; returns QAVIT_OK or an error code.
 // `ws`: NULL or gemm_tn_wide_ws_bytes() of device memory private to this call (a class with more problems than a launch carries by

@@ -942,6 +942,9 @@ def _defer_fix(rt, a, out, bias, proj_drop, trip, o, ldos, Co):
     rt.pending_fix = (fx, out, (bias, trip, o))
 
 
+_BRANCH_DRAIN = os.environ.get("QAVIT_BRANCH_DRAIN", "0") != "0"
+
+
 def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool_idx=None, pool_stride=0, Lk=0,
                    attn_drop=(0.0, 0), proj_drop=(0.0, 0), want_o=False, save=False, defer_fix=False):
     """One launch for a whole attention branch on 16- or 64-token problems (csrc/branch_fwd.hip; include/qavit.h qavit_branch_args):
@@ -957,6 +960,7 @@ def branch_forward(kind, x, wqkv, bqkv, wproj, bproj, E_k, E_v, sh_k, sh_v, pool
     pack = pack_for(x.device)
     a = L.BranchArgs()
     a.dtype, a.kind = K.dt_code(x.dtype), kind
+    a.drain_waits = 1 if _BRANCH_DRAIN else 0               # diagnostic: the ring's counted waits replaced by full drains (same bits)
     a.B, a.T, a.C, a.H, a.D = B, T, Cc, 4, Cc // 4
     a.KC, a.S, a.L = (E_k.shape[1] if E_k is not None else 0), sh_k.shape[-2], Lk
     a.x, a.ldx = x2.data_ptr(), Cc

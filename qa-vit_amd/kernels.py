@@ -173,7 +173,7 @@ def gemm_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, *, a_mode=0, ln=None,
             a.e_add1 = adds[1].data_ptr()
         dg, db = lnbwd.get("dgamma"), lnbwd.get("dbeta")
         if (dg is not None or db is not None) and DeferredLN.enabled and DeferredLN.ON:
-            n_ = int(L.load().qavit_gemm_nt_lnbwd_parts(M, N))
+            n_ = int(L.load().qavit_gemm_nt_lnbwd_parts(M, N, K))
             ln_parts = (torch.empty(n_ * 2 * N, dtype=torch.float32, device=A.device), n_)
             a.e_parts = ln_parts[0].data_ptr()
         else:

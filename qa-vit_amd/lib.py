@@ -140,7 +140,7 @@ class BranchArgs(C.Structure):
         ("E_k", vp), ("E_v", vp), ("sh_k", vp), ("sh_v", vp), ("pool_idx", vp), ("pool_stride", i32),
         ("out", vp), ("ldo", i64), ("o_save", vp),
         ("attn_drop_p", f32), ("attn_drop_site", i32), ("proj_drop_p", f32), ("proj_drop_site", i32), ("rng", vp),
-        ("nan_flag", vp), ("reserved", i32),
+        ("nan_flag", vp), ("drain_waits", i32),
         ("q_save", vp), ("ldq_save", i64), ("kv_save", vp), ("ldkv_save", i64), ("pooled_save", vp), ("nan_trip", vp), ("nan_defer", i32),
     ]
 
@@ -165,7 +165,7 @@ _SIGS = {
     "qavit_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "qavit_gemm_nt_a2_supported": (i32, [i32, i32, i32, i32, i32]),
     "qavit_gemm_nt_lnbwd_supported": (i32, [i32, i32, i32, i32, i32]),
-    "qavit_gemm_nt_lnbwd_parts": (i32, [i32, i32]),
+    "qavit_gemm_nt_lnbwd_parts": (i32, [i32, i32, i32]),
     "qavit_gemm_nt_grouped": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "qavit_gemm_tn": (i32, [C.POINTER(GemmTnArgs), vp]),
     "qavit_gemm_tn_grouped": (i32, [C.POINTER(GemmTnArgs), i32, vp]),

@@ -1254,6 +1254,48 @@ def _attn_keep(seed, step, site, kind, B, T, H, NK, drop):
     return torch.from_numpy(attn_keep_mask(seed, step, site, G, H, Nq, NK, drop)).to(DEV)
 
 
+@pytest.mark.parametrize("B,T", [(1030, 16), (130, 64)])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_fused_branch_counted_waits_equal_draining_waits(F, Q, kind, B, T):
+    """The fused branch forward streams its weights through an LDS ring behind COUNTED s_waitcnt vmcnt(N) waits; the q / k / v / O saves of
+    the training form put global stores between the ring's loads, and the wait arithmetic counts those stores by position (three per
+    burst).  qavit_branch_args.drain_waits makes every ring step wait for everything instead: the training form's output and every saved
+    tensor must be the same BITS either way -- a miscounted burst (a wave reading a ring slot that has not landed) would show here, on
+    more tiles than one round of workgroups."""
+    import importlib
+    K = importlib.import_module("qa-vit_amd.kernels")
+    C, S, KC = 192, 16, 32
+    x = leaf(B, T, C, seed=320).detach().to(torch.bfloat16)
+    n_qkv = C if kind == 2 else 3 * C
+    wqkv, bqkv = leaf(n_qkv, C, scale=0.08, seed=321).detach(), leaf(n_qkv, scale=0.1, seed=322).detach()
+    wproj, bproj = leaf(C, C, scale=0.08, seed=323).detach(), leaf(C, scale=0.1, seed=324).detach()
+    Ek = Ev = idx = None
+    stride, Lk = 0, 0
+    if kind != 2:
+        rows = 16 if kind == 0 else 128
+        Ek, Ev = leaf(rows, KC, scale=0.3, seed=325).detach(), leaf(rows, KC, scale=0.3, seed=326).detach()
+        Lk = 16
+    if kind == 1:
+        stride = 2
+        idx, Lk = _msda_idx(T, stride)
+    bk, bv = leaf(S, C, scale=0.5, seed=327).detach(), leaf(S, C, scale=0.5, seed=328).detach()
+    sa, sp = K.new_site(), K.new_site()
+    res = []
+    for drain in (False, True):
+        F._BRANCH_DRAIN = drain
+        try:
+            out, o, saved, _trip = F.branch_forward(kind, x, wqkv, bqkv, wproj, bproj, Ek, Ev, bk, bv, idx, stride, Lk,
+                                                    attn_drop=(0.1, sa), proj_drop=(0.1, sp), want_o=True, save=True)
+            torch.cuda.synchronize()
+        finally:
+            F._BRANCH_DRAIN = False
+        res.append([t.clone() for t in (out, o) + tuple(saved)])
+    assert len(res[0]) == len(res[1]) >= 3
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_, b_)
+    assert float(res[0][0].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("drop", [0.0, 0.1])
 @pytest.mark.parametrize("B,T", [(5, 16), (64, 16), (1030, 16), (3, 64), (130, 64)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
