@@ -492,14 +492,14 @@ int big_modes(const qavit_gemm_args& g, hipStream_t st) {
 }  // namespace
 
 bool gemm_nt_lnbwd_shape_ok(int dtype, int M, int N, int K, int a_mode) {
-  return dtype == QAVIT_BF16 && M >= 1024 && (N == 128 || N == 192 || N == 256) && K >= 96 && K % 32 == 0 && (a_mode == 0 || a_mode == 2);
+  return dtype == QAVIT_BF16 && M >= 1024 && (N == 128 || N == 192 || N == 256) && K >= 64 && K % 32 == 0 && (a_mode == 0 || a_mode == 2);
 }
 int gemm_nt_lnbwd_parts(int M, int N, int K) { return (M + big_bm(M, 1, N, K) - 1) / big_bm(M, 1, N, K); }
 
 // the LayerNorm-backward epilogue (qavit_gemm_args.e_x): only this kernel has it.  1 = launched, < 0 error (never "not applicable":
 // the caller asked qavit_gemm_nt_lnbwd_supported first)
 int gemm_nt_big_lnbwd(const qavit_gemm_args& g, hipStream_t st) {
-  if (!gemm_nt_lnbwd_shape_ok(g.dtype, g.M, g.N, g.K, g.a_mode)) return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: bf16, M >= 1024, N in {128, 192, 256}, K % 32 == 0, a_mode 0 or 2");
+  if (!gemm_nt_lnbwd_shape_ok(g.dtype, g.M, g.N, g.K, g.a_mode)) return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue: bf16, M >= 1024, N in {128, 192, 256}, K >= 64, K % 32 == 0, a_mode 0 or 2");
   auto al = [](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 8 == 0; };
   if (!g.e_mean || !g.e_rstd || !g.e_gamma || g.A2 || g.bias || g.Z || g.act || g.drop_p > 0.f || g.dp_p > 0.f || g.scale != 1.f)
     return set_error(QAVIT_EINVAL, "gemm_nt: LayerNorm-backward epilogue takes no bias / activation / dropout / scale and needs mean, rstd, gamma");

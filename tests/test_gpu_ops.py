@@ -141,7 +141,7 @@ def test_linear_ln_narrow_output_fused_backward(F, M):
 
 @pytest.mark.parametrize("M,Kd,N,act,alias", [(4096, 192, 96, "gelu", True), (1024 + 37, 192, 96, None, False), (70000, 192, 192, None, True),
                                               (20000, 192, 576, None, False), (5000, 128, 512, "gelu", False), (66000, 256, 1024, "gelu", True),
-                                              (30000, 128, 96, None, True)])
+                                              (30000, 128, 96, None, True), (40000, 192, 64, None, True)])
 def test_layernorm_backward_in_the_input_gradient_gemm_epilogue(F, Q, M, Kd, N, act, alias):
     """LayerNorm -> Linear (norm2 -> CCF fc1 with GELU, gate_norm -> gate_fc, the ConvNeXt blocks' norm -> pwconv1; HQAViT_CIFAR100.py:704,
     :945, :728): in bf16 the Linear's input-gradient GEMM runs the LayerNorm backward as its epilogue (qavit_gemm_args.e_x: the K-loop

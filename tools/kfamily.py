@@ -10,7 +10,7 @@ if _adamw:
     n = float(sum(_adamw))
 FAM = [("branch_fwd", ("branch_fwd_kernel", "branch_nan_fix")), ("branch_bwd", ("branch_bwd_kernel",)), ("cga (fused)", ("cga_fwd_kernel", "cga_bwd_kernel", "cga64_fwd_kernel", "cga64_bwd_kernel")), ("compress-fuse (fused)", ("cfuse_fwd_kernel", "cfuse_bwd_kernel")), ("mlp2 (fused)", ("mlp2_fwd_kernel", "mlp2_bwd_kernel")), ("gemm_nt", ("gemm_nt_",)), ("gemm_tn", ("gemm_tn_", "tnu_table_write")), ("attn_bwd", ("attn2_kernel<", "attn3_kernel<", "attn4_kernel<", "attn_bwd_kernel", "attn_reduce")),
        ("layernorm_bwd", ("layernorm_bwd", "mix3_ln_bwd")), ("layernorm_fwd", ("layernorm_fwd", "mix3_ln_fwd")), ("row_stats", ("row_stats",)), ("dwconv", ("dwconv",)),
-       ("ccf", ("ccf_",)), ("bank", ("bank_",)), ("bn", ("bn_",)), ("tokmix/upmix", ("tokmix", "upmix")), ("elementwise (own)", ("hybrid_", "scale_add", "mix2_", "mix3_", "dropout_kernel", "gather_pool", "token_mean", "patchify", "im2col", "col2im", "nan_", "zero_f32", "pack_kernel", "adamw", "l2_", "rng_", "ce_ls_kernel", "sum_k_kernel", "copy2_kernel", "gate_mix", "local_clip", "chan_scale", "sln_", "ln_param_reduce", "ln_dadd")), ("bench harness", ("spin_kernel",)), ("torch/other", ("",))]
+       ("ccf", ("ccf_",)), ("bank", ("bank_",)), ("bn", ("bn_",)), ("tokmix/upmix/tl", ("tokmix", "upmix", "tl_fwd_kernel", "tl_bwd_kernel")), ("elementwise (own)", ("hybrid_", "scale_add", "mix2_", "mix3_", "dropout_kernel", "gather_pool", "token_mean", "patchify", "im2col", "col2im", "nan_", "zero_f32", "pack_kernel", "adamw", "l2_", "rng_", "ce_ls_kernel", "sum_k_kernel", "copy2_kernel", "gate_mix", "local_clip", "chan_scale", "sln_", "ln_param_reduce", "ln_dadd")), ("bench harness", ("spin_kernel",)), ("torch/other", ("",))]
 agg = {}
 for r in rows:
     nm = r["Name"]
