@@ -65,7 +65,7 @@ class _Base(nn.Module):
 
 
 _LATERAL_STREAM = os.environ.get("QAVIT_LATERAL_STREAM", "1") != "0"
-_LATERAL_ORDER = int(os.environ.get("QAVIT_LATERAL_ORDER", "0"))
+_LATERAL_ORDER = int(os.environ.get("QAVIT_LATERAL_ORDER", "4"))
 _EARLY_FLUSH = os.environ.get("QAVIT_EARLY_FLUSH", "0") != "0"   # deferred weight-gradient work of the token path launched when ITS backward ends
 _DONE = object()
 _SIDE = {}
@@ -203,7 +203,42 @@ class HQAViT(_Base):
             # tools/chain_stamps.py show both chains starting within 10 us of each other whatever the order; the 1.4 ms late start a
             # rocprofv3 kernel trace shows is the host's packet enqueue under tracing.
             ready = {}
-            if _LATERAL_ORDER == 2 and side is not None:
+            scales = None
+            if _LATERAL_ORDER in (3, 4) and side is not None and hasattr(self.cnn_stem, "forward_tokens_scales"):
+                # Scale by scale: the lateral work of scale i + 1 (stem stage, LMFAdapter, RRCV) is BUILT after the token path's stage i.
+                # The side stream runs the same kernels in the same order as with order 0 -- what changes is the age of the autograd
+                # nodes: the engine runs the youngest ready node first, so with the whole lateral chain built up front every stem node
+                # was older than every block and the stem's backward (0.8 ms at B = 1024) queued up at the very end of the pass, where
+                # since round 4 it, not the token path, ended the step (tools/chain_stamps.py: stem reached at 8.10 ms, patch embedding
+                # at 7.91 ms).  Built per scale, stem stage i + 1's backward follows LMFAdapter i + 1's at once, beside the token path's
+                # stage-i backward.
+                gen = self.cnn_stem.forward_tokens_scales(x, cdt)
+                R, fhw = {}, {}
+
+                def lateral_scale(i):
+                    with torch.cuda.stream(side):
+                        if i == 2:
+                            K.Stamps.mark("lat.begin")
+                            f, fhw["hw"] = next(gen)
+                        else:
+                            f = next(gen)
+                        fh, fw = fhw["hw"]
+                        a = getattr(self, f"lmfa{i}").forward_tokens(F.stamp(f, f"lat.feat{i}"), fh, fw)
+                        R[i] = F.stamp(getattr(self, f"rrcv{i}")(a, self.H, self.W), f"lat.R{i}")
+                        ready[i] = torch.cuda.Event()
+                        ready[i].record(side)
+                scales = lateral_scale
+                if _LATERAL_ORDER == 4:
+                    # the token path's first stage is built BEFORE the lateral chain's first scale.  With the lateral scale first (order 3)
+                    # the replayed graph started the token path only when the lateral chain had finished scale 3 (stamps: tok.begin at
+                    # 0.95 ms instead of 0.05 ms, step 9.72 ms against 9.37): the hipGraph executor's schedule follows node creation
+                    # order more than the round-3 probe suggested when a branch is extended after its sibling was built
+                    T = stage1()
+                    lateral_scale(2)
+                else:
+                    lateral_scale(2)
+                    T = stage1()
+            elif _LATERAL_ORDER == 2 and side is not None:
                 R, box = {}, {}
                 gl, gm = lateral_steps(R), stage1_steps(box)
                 live_l = live_m = True
@@ -232,6 +267,8 @@ class HQAViT(_Base):
                 T = self._sync(T, f"stage{si}_blocks")
                 for blk in getattr(self, f"stage{si}_blocks"):
                     T = blk(T)
+                if scales is not None and si < 4:
+                    scales(si + 1)
             return self._head(T)
 
 

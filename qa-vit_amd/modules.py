@@ -675,6 +675,33 @@ class CNNStemModel(nn.Module):
             f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training, bump=False), h, w)
         return (f2, f3, f4), (h, w)
 
+    def forward_tokens_scales(self, x, cdt):
+        """``forward_tokens`` one lateral feature at a time: a generator that yields (F2, (h, w)), then F3, then F4, running each stem
+        stage only when its feature is asked for.  The model asks for scale i + 1 AFTER it has built the token path's stage i
+        (models.HQAViT: QAVIT_LATERAL_ORDER 3), so the autograd nodes of stem stage i + 1 are younger than that stage's blocks and
+        the engine -- which runs the youngest ready node first -- takes their backward right after LMFAdapter i + 1's, beside the
+        token path's stage-i backward, instead of at the very end of the pass where every stem node used to queue up."""
+        B, Cin, H, W = x.shape
+        if self.training:
+            nbt = [bn.num_batches_tracked for bn in (self.stem[1], self.stage1[1], self.stage2[1], self.stage3[1]) if bn.num_batches_tracked is not None]
+            if nbt:
+                torch._foreach_add_(nbt, 1)
+        with torch.autocast("cuda", enabled=False):
+            t = F.stamp(self._conv3x3s2_tokens(x, self.stem[0], self.stem[1], (B, Cin, H, W, 3, 2, 1), cdt), "lat.stem0")
+            H1, W1 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            t = self._conv3x3s2_tokens(t, self.stage1[0], self.stage1[1], (B, self.stem[0].out_channels, H1, W1, 3, 2, 1), cdt)
+            h, w = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+            f2 = self.stage1[3].forward_tokens(t, h, w)
+            t, f2 = _conv1x1_tokens(f2, self.stage2[0], alias=True)      # (the alias carries F2's lateral gradient into this conv's backward GEMM)
+        yield f2, (h, w)
+        with torch.autocast("cuda", enabled=False):
+            f3 = self.stage2[2].forward_tokens(_bn_tokens(t, self.stage2[1], self.training, bump=False), h, w)
+            t, f3 = _conv1x1_tokens(f3, self.stage3[0], alias=True)
+        yield f3
+        with torch.autocast("cuda", enabled=False):
+            f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training, bump=False), h, w)
+        yield f4
+
     def forward(self, x):                                   # NCHW surface of the reference class
         (f2, f3, f4), (h, w) = self.forward_tokens(x, x.dtype)
         B = x.shape[0]
