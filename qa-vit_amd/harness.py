@@ -16,6 +16,7 @@ Two recipes: ``TrainingConfig`` = HQAViT_CIFAR100.py's pre-training loop (OneCyc
 ``head`` at base_lr * head_lr_multiplier, :327-342), LinearLR(0.1 -> 1) warm-up then CosineAnnealingLR stepped once per
 EPOCH (:384, :481-496, :520-523 -- call ``Trainer.epoch_end()``), one global clip at 1.0, label smoothing 0.1, no EMA.
 """
+import os
 import math
 import time
 from copy import deepcopy

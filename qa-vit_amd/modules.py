@@ -627,6 +627,18 @@ class ConvNeXtBlock(nn.Module):
         return self.forward_tokens(_to_tokens(x), H, W).transpose(1, 2).reshape(B, C, H, W)
 
 
+_STEM3_STREAM = os.environ.get("QAVIT_STEM3_STREAM", "0") != "0"      # diagnostic only: see CNNStemModel.forward_tokens_scales
+_STEM3 = {}
+
+
+def _stem3_stream(device):
+    key = torch.device(device).index or 0
+    st = _STEM3.get(key)
+    if st is None:
+        st = _STEM3[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class CNNStemModel(nn.Module):
     """HQAViT_CIFAR100.py:742-793, channel-last throughout: the two strided 3x3 convolutions are im2col + MFMA GEMM,
     the 1x1 convolutions are GEMMs, the depthwise 7x7 is csrc/dwconv.hip, BatchNorm(+GELU) is csrc/bnorm.hip."""
@@ -699,7 +711,22 @@ class CNNStemModel(nn.Module):
             t, f3 = _conv1x1_tokens(f3, self.stage3[0], alias=True)
         yield f3
         with torch.autocast("cuda", enabled=False):
-            f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training, bump=False), h, w)
+            s3 = _stem3_stream(x.device) if (_STEM3_STREAM and x.is_cuda and torch.is_grad_enabled() and t.requires_grad) else None
+            if s3 is None:
+                f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training, bump=False), h, w)
+            else:
+                # DIAGNOSTIC (QAVIT_STEM3_STREAM=1, off by default): the stem's last stage on a THIRD stream (so that its backward, replayed
+                # on the forward stream, is a graph branch of its own).  Eager it runs; under hipGraph capture of the training step the
+                # process dies of a segmentation fault INSIDE hipStreamEndCapture (python -X faulthandler: torch/cuda/graphs.py capture_end),
+                # also when the stream is joined explicitly before the capture ends -- the reproducer of the "three-stream capture crash"
+                # DESIGN.md section 6 carries since round 2.
+                cur = torch.cuda.current_stream(x.device)
+                s3.wait_stream(cur)
+                with torch.cuda.stream(s3):
+                    f4 = self.stage3[2].forward_tokens(_bn_tokens(t, self.stage3[1], self.training, bump=False), h, w)
+                cur.wait_stream(s3)
+                t.record_stream(s3)
+                f4.record_stream(cur)
         yield f4
 
     def forward(self, x):                                   # NCHW surface of the reference class
