@@ -28,11 +28,12 @@ ALLOW_SCRATCH = (
 )
 # Step kernels allowed a BOUNDED amount of scratch, with the reason.  (name fragment, max bytes per lane)
 ALLOW_SCRATCH_UP_TO = (
-    # the one-launch weight-gradient kernel holds twenty tile-class bodies in one problem loop; three registers that live across the
-    # loop are stored when a workgroup enters the 256 x 256 class body (the one that needs all 256) and reloaded when it leaves it:
-    # 3 + 3 scratch instructions per (problem, workgroup) visit, at loop depth 1, none inside a chunk loop (read off the ISA:
-    # `hipcc -S --cuda-device-only`, the six scratch_ instructions sit between the class dispatch and the body's first barrier)
-    ("gemm_tn_uni_kernel", 16),
+    # the one-launch weight-gradient kernel holds twenty tile-class bodies in one problem loop; twelve lane-invariant registers (thread
+    # geometry that lives across the loop) are stored ONCE when a workgroup enters the problem loop (ten scratch stores, loop depth 1) and
+    # a class body reloads the one to four it needs in its prologue (loop depth 2 = once per (problem, tile) segment, ~2 segments per
+    # workgroup and launch); none inside a chunk loop (depth 3).  Read off the ISA: `hipcc -S --cuda-device-only`, every scratch_
+    # instruction of the kernel sits in a block the compiler annotates Depth=1 or Depth=2.
+    ("gemm_tn_uni_kernel", 48),
 )
 
 

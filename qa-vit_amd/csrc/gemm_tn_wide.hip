@@ -32,6 +32,7 @@ namespace qv {
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 __device__ __forceinline__ bf16x8 trf(const bf16* tile, int ld, int m0, int c0) {
   // lane l: rows m0 + 8*(l>>4) + j (j = 0..7), column c0 + (l & 15)
@@ -83,7 +84,7 @@ template <int IN_, int JN_, int WB_>
 struct Cls {
   static constexpr int IN = IN_, JN = JN_, WB = WB_;
   static constexpr int NT = 128 * WB;
-  static constexpr int MC = (WB == 4 && IN < 8) ? 128 : 64;   // 256 x 256 tile: 16 staged vectors per thread at 128 rows do not fit beside 128 accumulators
+  static constexpr int MC = (WB == 4 && IN * JN < 24) ? 128 : 64;   // 256 x 256 tile: 16 staged vectors per thread at 128 rows do not fit beside 128 accumulators
   static constexpr int TNW = 32 * IN, TKW = 16 * WB * JN;
   typedef Stage<NT, TNW, MC> SA;
   typedef Stage<NT, TKW, MC> SB;
@@ -100,7 +101,17 @@ constexpr int ucls_mc(int in, int jn) {
   return mc;
 }
 constexpr int ucls_lds(int in, int jn) { return ucls_mc(in, jn) * (32 * in + 64 * jn + 32) * 2; }
-constexpr int ucls_cost(int in, int jn) { return ucls_mc(in, jn) * (32 * in + 64 * jn) / 64 + 64; }   // one (tile, chunk) unit: operand elements / 64 + the chunk's fixed part
+// one (tile, chunk) unit: operand elements / 64 + the chunk's fixed part, times what the class was MEASURED to take per such unit inside the
+// one launch (tools/tn_stamps.py, C100 step at B = 1024: the 192-column K classes run 11-22 % over the byte model, the skinniest class 16 %
+// under) -- the launch lasts as long as its slowest range, and ranges made of one class only were 19 % over the mean
+constexpr int ucls_adj_pct(int in, int jn) {
+  if (jn == 3) return in == 2 ? 122 : in == 4 ? 111 : in == 6 ? 120 : 115;
+  if (in == 1) return jn == 1 ? 84 : 95;
+  if (in == 8 && jn == 4) return 111;
+  if (jn == 4 && in <= 4) return 97;
+  return 100;
+}
+constexpr int ucls_cost(int in, int jn) { return (ucls_mc(in, jn) * (32 * in + 64 * jn) / 64 + 64) * ucls_adj_pct(in, jn) / 100; }
 constexpr int ucls_lds_max() {
   int m = 0;
   for (int in : {1, 2, 4, 6, 8})
@@ -118,12 +129,28 @@ struct UCls {
   typedef Stage<NT, TKW, MC> SB;
 };
 
+#ifdef QAVIT_TN_STAMPS         // diagnostic build only (tools/tn_stamps.py): per workgroup s_memtime at start / end, segments run, and time + cost per tile class
+}  // namespace
+}  // namespace qv
+__device__ unsigned long long qv_tn_stamps[512 * 48];
+extern "C" int qavit_tn_stamps(void* host_dst, int nwg) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(qv_tn_stamps), (size_t)nwg * 48 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+namespace qv {
+namespace {
+#define TNSTAMP_SET(k, v) do { if (threadIdx.x == 0) qv_tn_stamps[(size_t)(blockIdx.x & 511) * 48 + (k)] = (v); } while (0)
+#define TNSTAMP_ADD(k, v) do { if (threadIdx.x == 0) qv_tn_stamps[(size_t)(blockIdx.x & 511) * 48 + (k)] += (v); } while (0)
+#else
+#define TNSTAMP_SET(k, v) do { } while (0)
+#define TNSTAMP_ADD(k, v) do { } while (0)
+#endif
+
 // Preconditions (gemm_tn_wide checks them, other problems take the generic kernel): A, B 16-byte aligned,
 // lda, ldb, N, K multiples of 8.  The staging loads are UNCONDITIONAL (row / column indices are clamped into the
 // operand and the out-of-range vectors are zeroed when they are committed to LDS): a load under a lane-dependent
 // branch makes the compiler wait for it at the join, which serialises the chunk's 16 loads into 16 round trips.
 template <typename CL>
-__device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* At, bf16* Bt, int bx, int by, int mbeg, int mend, int dbg) {
+__device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* At, bf16* Bt, float* gb, int bx, int by, int mbeg, int mend, int dbg) {
   constexpr int IN = CL::IN, JN = CL::JN;
   constexpr int TNW = CL::TNW, TKW = CL::TKW, MC = CL::MC, NT = CL::NT;
   typedef typename CL::SA SA;
@@ -151,12 +178,17 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
   const bf16* a_col = A + (a_live ? na : 0);
   const bf16* b_col = B + (b_live ? kb : 0);
 
-  float gam[8], bet[8], csum[8];
+  // LayerNorm-on-load: the tile's gamma / beta live in LDS (gb[0 .. 255] / gb[256 .. 511]), read back per staged vector -- sixteen
+  // registers per lane that every body (normalising or not) used to carry through its MFMA loop
+  float csum[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    csum[j] = 0.f;
-    gam[j] = (ln && b_live) ? gloadf(g.ln_gamma + kb + j) : 0.f;
-    bet[j] = (ln && b_live) ? gloadf(g.ln_beta + kb + j) : 0.f;
+  for (int j = 0; j < 8; ++j) csum[j] = 0.f;
+  if (ln && rgb == 0 && cgb < SB::CG) {                // visible after the first chunk's barrier; the previous body read gb before ITS last barrier
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      gb[8 * cgb + j] = b_live ? gloadf(g.ln_gamma + kb + j) : 0.f;
+      gb[256 + 8 * cgb + j] = b_live ? gloadf(g.ln_beta + kb + j) : 0.f;
+    }
   }
 
   f32x4 acc[IN][JN];
@@ -167,7 +199,28 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
 
   bf16x8 pa[SA::PASS], pb[SB::PASS];
   float pmu[SB::PASS], prs[SB::PASS];
+  // lane offsets inside a chunk (elements, 32 bits): a whole chunk's loads are then  uniform row pointer + lane offset  -- scalar address
+  // arithmetic, no 64-bit multiply per load -- and need no row clamp; only a range's last, partial chunk takes the clamped form below
+  const uint32_t offa = 2u * ((uint32_t)rga * (uint32_t)g.lda + (uint32_t)(a_live ? na : 0));      // BYTES: (uniform pointer) + zext(32-bit lane
+  const uint32_t offb = 2u * ((uint32_t)rgb * (uint32_t)g.ldb + (uint32_t)(b_live ? kb : 0));      // offset) is the scalar-base load form
   auto prefetch = [&](int mc) {
+    if (mc + MC <= mend) {                               // uniform
+      const char* Ab = reinterpret_cast<const char*>(A + (size_t)mc * g.lda);
+      const char* Bb = reinterpret_cast<const char*>(B + (size_t)mc * g.ldb);
+#pragma unroll
+      for (int h = 0; h < SA::PASS; ++h) pa[h] = *(const QV_AS1 bf16x8*)(Ab + (size_t)(SA::RP * h) * g.lda * 2 + offa);
+#pragma unroll
+      for (int h = 0; h < SB::PASS; ++h) pb[h] = *(const QV_AS1 bf16x8*)(Bb + (size_t)(SB::RP * h) * g.ldb * 2 + offb);
+      if (ln) {                                          // uniform
+        const uint32_t offs = 4u * (uint32_t)rgb;
+#pragma unroll
+        for (int h = 0; h < SB::PASS; ++h) {
+            pmu[h] = *(const QV_AS1 float*)(reinterpret_cast<const char*>(mean_p + mc + SB::RP * h) + offs);
+            prs[h] = *(const QV_AS1 float*)(reinterpret_cast<const char*>(rstd_p + mc + SB::RP * h) + offs);
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < SA::PASS; ++h) {
       int m = mc + rga + SA::RP * h;
@@ -187,7 +240,47 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
 
   prefetch(mbeg);
   for (int mc = mbeg; mc < mend; mc += MC) {
+#ifdef QAVIT_TN_STAMPS
+    const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long s1 = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+#else
+    __syncthreads();
+#endif
+    // A whole chunk is committed as loaded: no row of it is past the range, and a column past N or K only feeds output rows / columns the
+    // flush does not write (its lane loaded column group 0: finite values).  The per-element selects this path leaves out, with the
+    // 64-bit address multiplies of the clamped prefetch, were 3/4 of the staging phase's VALU work, and staging was 37 % + 19 % (waiting
+    // for the slowest wave of it) of the 192 x 192 class's time against 2 % waiting for memory (tools/tn_phases.py).
+    const bool whole = mc + MC <= mend;                  // uniform
+    if (whole) {
+      if (cga < SA::CG) {
+#pragma unroll
+        for (int h = 0; h < SA::PASS; ++h) {
+          *reinterpret_cast<bf16x8*>(At + (rga + SA::RP * h) * SA::LD + 8 * cga) = pa[h];
+          if (want_csum) {
+            const u32x4 u = __builtin_bit_cast(u32x4, pa[h]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              csum[2 * q] += __uint_as_float(u[q] << 16);
+              csum[2 * q + 1] += __uint_as_float(u[q] & 0xffff0000u);
+            }
+          }
+        }
+      }
+      if (cgb < SB::CG) {
+#pragma unroll
+        for (int h = 0; h < SB::PASS; ++h) {
+          bf16x8 v = pb[h];
+          if (ln) {                                      // uniform
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)(((float)v[j] - pmu[h]) * prs[h] * gb[8 * cgb + j] + gb[256 + 8 * cgb + j]);
+          }
+          *reinterpret_cast<bf16x8*>(Bt + (rgb + SB::RP * h) * SB::LD + 8 * cgb) = v;
+        }
+      }
+    } else {
     if (cga < SA::CG) {
 #pragma unroll
       for (int h = 0; h < SA::PASS; ++h) {
@@ -209,15 +302,27 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
         bf16x8 v = pb[h];
         if (ln) {                                        // uniform
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (bf16)(((float)v[j] - pmu[h]) * prs[h] * gam[j] + bet[j]);
+          for (int j = 0; j < 8; ++j) v[j] = (bf16)(((float)v[j] - pmu[h]) * prs[h] * gb[8 * cgb + j] + gb[256 + 8 * cgb + j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : (bf16)0.f;
         *reinterpret_cast<bf16x8*>(Bt + (rgb + SB::RP * h) * SB::LD + 8 * cgb) = v;
       }
     }
-    __syncthreads();
+    }
+    // the next chunk's loads go out as soon as the staging registers are free, BEFORE the barrier (a __syncthreads would drain them: the
+    // barrier below waits for the LDS stores only) -- 3 % of the launch against prefetching behind the barrier.  (Spread over the k-steps
+    // of the MFMA phase instead -- a chunk's 128 load instructions are ~2000 clocks of issue on the CU's 64 B/clock vector memory path --
+    // they arrive too late: the mixed list of a step 1.28 ms against 1.10.)
     if (mc + MC < mend) prefetch(mc + MC);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef QAVIT_TN_STAMPS
+    const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+#endif
+    __builtin_amdgcn_s_barrier();
+#ifdef QAVIT_TN_STAMPS
+    const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int kf = 0; kf < MC / 32; ++kf) {
       // B fragments of the k-step up front, A fragments as the MFMAs consume them (the scheduler runs them ahead as far as registers allow:
@@ -232,6 +337,10 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
         for (int j = 0; j < JN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
       }
     }
+#ifdef QAVIT_TN_STAMPS        // wave 0's view: load wait | barrier A | staging (+ prefetch issue, LDS stores landed) | barrier B | MFMA phase (issue)
+    TNSTAMP_ADD(44, s1 - s0); TNSTAMP_ADD(45, s2 - s1); TNSTAMP_ADD(46, s3 - s2); TNSTAMP_ADD(47, s4 - s3);
+    TNSTAMP_ADD(3, (unsigned long long)__builtin_amdgcn_s_memtime() - s4);
+#endif
   }
   const int fr = lane & 15, fq = lane >> 4;
   if (!(dbg & 1))
@@ -270,7 +379,7 @@ __device__ __forceinline__ void tn_wide_body(const qavit_gemm_tn_args& g, bf16* 
 }
 
 template <int IN, int JN, int WB, typename Src>
-__device__ __forceinline__ void tn_wide_ranges(const Src& G, int n, int per, int dbg, bf16* At, bf16* Bt) {
+__device__ __forceinline__ void tn_wide_ranges(const Src& G, int n, int per, int dbg, bf16* At, bf16* Bt, float* gb) {
   typedef Cls<IN, JN, WB> CL;
   const int total = G.unit_start[n];
   int u = blockIdx.x * per;
@@ -288,7 +397,7 @@ __device__ __forceinline__ void tn_wide_ranges(const Src& G, int n, int per, int
     const int by = t / tn, bx = t - by * tn;
     const int M = G.p[i].M;
     const int mend = c1 * CL::MC < M ? c1 * CL::MC : M;
-    tn_wide_body<CL>(G.p[i], At, Bt, bx, by, c0 * CL::MC, mend, dbg);
+    tn_wide_body<CL>(G.p[i], At, Bt, gb, bx, by, c0 * CL::MC, mend, dbg);
     u += c1 - c0;
   }
 }
@@ -298,7 +407,8 @@ __global__ __launch_bounds__(128 * WB) void gemm_tn_wide_kernel(TnwGroup G) {
   typedef Cls<IN, JN, WB> CL;
   __shared__ __attribute__((aligned(16))) bf16 At[CL::MC * CL::SA::LD];   // [m][n]
   __shared__ __attribute__((aligned(16))) bf16 Bt[CL::MC * CL::SB::LD];   // [m][k]
-  tn_wide_ranges<IN, JN, WB>(G, G.n, G.per, G.dbg, At, Bt);
+  __shared__ __attribute__((aligned(16))) float gb[512];
+  tn_wide_ranges<IN, JN, WB>(G, G.n, G.per, G.dbg, At, Bt, gb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -316,6 +426,7 @@ struct TnuEntry {
   int cls;                              // IN | JN << 8
   int tn, chunks;                       // tiles on the N side, chunks per tile
   int cu;                               // cost of one unit
+  int tiles, cb;                        // tiles of the problem; chunks per block (multi-tile problems, see tnu_run), 0 = one tile
 };
 struct TnuTable {
   int cost_start[TNU_MAX + 1];          // prefix sums of units * cu
@@ -327,6 +438,7 @@ struct TnuWrite {
   TnuEntry e[TNU_PER_WRITE];
 };
 
+static_assert(sizeof(TnuWrite) <= 4096, "a writer launch carries its entries as kernel arguments");
 __global__ __launch_bounds__(64) void tnu_table_write_kernel(TnuWrite W, TnuTable* T) {
   const int i = threadIdx.x;
   if (i < W.n) T->e[W.off + i] = W.e[i];
@@ -345,28 +457,47 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Unit order inside a problem.  One tile: its chunks in order.  Several tiles (an operand wider than the widest tile -- the lateral
+// path's 256 <-> 1024 layers, the 768-column fuse, the 576-column qkv): BLOCKS of `cb` chunks, and inside a block tile after tile over the
+// same rows, with cb chunks priced at one workgroup's range.  The workgroups that hold the tiles of one row block then walk the same rows at
+// the same time: the operand every tile re-reads comes out of the Infinity Cache instead of HBM a second, third, fourth time, and the
+// column slices the tiles take from one wide row are fetched together (tile after tile over ALL rows, as before, the slices of a row were
+// read a quarter of a launch apart: 1.2x the algorithmic bytes by the counters, and those ranges were the slowest of the launch).
 template <int IN, int JN>
-__device__ __forceinline__ void tnu_run(const qavit_gemm_tn_args& g, char* smem, int tn, int chunks, int j0, int j1, int dbg) {
+__device__ __forceinline__ void tnu_run(const qavit_gemm_tn_args& g, char* smem, int tn, int chunks, int tiles, int cb, int j0, int j1, int dbg) {
   typedef UCls<IN, JN> CL;
   bf16* At = reinterpret_cast<bf16*>(smem);
   bf16* Bt = At + CL::MC * CL::SA::LD;
   while (j0 < j1) {                                     // uniform
-    const int t = j0 / chunks, c0 = j0 - t * chunks;
+    int t, c0, cend;
+    if (cb > 0) {
+      const int blku = tiles * cb, blk = j0 / blku, rem = j0 - blk * blku, cbase = blk * cb;
+      const int cbl = chunks - cbase < cb ? chunks - cbase : cb;      // the last block is the short one
+      t = rem / cbl; c0 = cbase + rem - t * cbl; cend = cbase + cbl;
+    } else {
+      t = j0 / chunks; c0 = j0 - t * chunks; cend = chunks;
+    }
     int c1 = c0 + (j1 - j0);
-    if (c1 > chunks) c1 = chunks;
+    if (c1 > cend) c1 = cend;
     const int by = t / tn, bx = t - by * tn;
     const int mend = c1 * CL::MC < g.M ? c1 * CL::MC : g.M;
-    tn_wide_body<CL>(g, At, Bt, bx, by, c0 * CL::MC, mend, dbg);
+    tn_wide_body<CL>(g, At, Bt, reinterpret_cast<float*>(smem + ucls_lds_max()), bx, by, c0 * CL::MC, mend, dbg);
     j0 += c1 - c0;
   }
 }
 
+
 __global__ __launch_bounds__(512) void gemm_tn_uni_kernel(const TnuTable* __restrict__ T, int n, int per, int dbg) {
-  __shared__ __attribute__((aligned(16))) char smem[ucls_lds_max()];
+  __shared__ __attribute__((aligned(16))) char smem[ucls_lds_max() + 2048];        // + gamma / beta of the tile (tn_wide_body)
+  static_assert(ucls_lds_max() % 16 == 0 && ucls_lds_max() + 2048 <= 160 * 1024, "LDS budget");
   const int total = uni(T->cost_start[n]);
   const int lo = blockIdx.x * per;
   int hi = lo + per;
   if (hi > total) hi = total;
+#ifdef QAVIT_TN_STAMPS
+  for (int k = 0; k < 48; ++k) TNSTAMP_SET(k, 0ull);
+  TNSTAMP_SET(0, (unsigned long long)__builtin_amdgcn_s_memtime());
+#endif
   if (lo >= hi) return;
   int a = 0, b = n;                                      // cost_start[a] <= lo < cost_start[b]
   while (b - a > 1) {
@@ -377,7 +508,7 @@ __global__ __launch_bounds__(512) void gemm_tn_uni_kernel(const TnuTable* __rest
     const int cs = uni(T->cost_start[i]);
     if (cs >= hi) break;
     const TnuEntry* e = &T->e[i];
-    const int cu = uni(e->cu), chunks = uni(e->chunks), tn = uni(e->tn), cls = uni(e->cls);
+    const int cu = uni(e->cu), chunks = uni(e->chunks), tn = uni(e->tn), cls = uni(e->cls), tiles = uni(e->tiles), cb = uni(e->cb);
     const int units = (uni(T->cost_start[i + 1]) - cs) / cu;
     const int j0 = lo > cs ? (lo - cs + cu - 1) / cu : 0;
     int j1 = (hi - cs + cu - 1) / cu;
@@ -393,7 +524,10 @@ __global__ __launch_bounds__(512) void gemm_tn_uni_kernel(const TnuTable* __rest
     g.ln_gamma = uni_ptr(e->p.ln_gamma); g.ln_beta = uni_ptr(e->p.ln_beta);
     g.ln_mean = uni_ptr(e->p.ln_mean); g.ln_rstd = uni_ptr(e->p.ln_rstd);
     g.splits = 0;
-#define TNU_CASE(I, J) case (I | (J << 8)): tnu_run<I, J>(g, smem, tn, chunks, j0, j1, dbg); break;
+#define TNU_CASE(I, J) case (I | (J << 8)): tnu_run<I, J>(g, smem, tn, chunks, tiles, cb, j0, j1, dbg); break;
+#ifdef QAVIT_TN_STAMPS
+    const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+#endif
     switch (cls) {
       TNU_CASE(1, 1) TNU_CASE(1, 2) TNU_CASE(1, 3) TNU_CASE(1, 4)
       TNU_CASE(2, 1) TNU_CASE(2, 2) TNU_CASE(2, 3) TNU_CASE(2, 4)
@@ -403,7 +537,17 @@ __global__ __launch_bounds__(512) void gemm_tn_uni_kernel(const TnuTable* __rest
       default: break;
     }
 #undef TNU_CASE
+#ifdef QAVIT_TN_STAMPS
+    {
+      const int in = cls & 255, jn = cls >> 8;
+      const int ci = (in == 1 ? 0 : in == 2 ? 1 : in == 4 ? 2 : in == 6 ? 3 : 4) * 4 + (jn - 1);
+      TNSTAMP_ADD(4 + ci, (unsigned long long)__builtin_amdgcn_s_memtime() - t_in);
+      TNSTAMP_ADD(24 + ci, (unsigned long long)((j1 - j0) * cu));
+      TNSTAMP_ADD(2, 1ull);
+    }
+#endif
   }
+  TNSTAMP_SET(1, (unsigned long long)__builtin_amdgcn_s_memtime());
 }
 
 // workgroups the chip holds at once, per class (two 4-wave workgroups or one 8-wave workgroup per CU)
@@ -568,6 +712,24 @@ int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
   if (host_img && !capturing) tnu_pool_fill();
   TnuTable* H = nullptr;
   if (host_img && capturing && tnu_pool().used < tnu_pool().n) H = tnu_pool().img[tnu_pool().used];
+  // pass 1: the launch's total cost -> the range one workgroup gets (the block length of the multi-tile problems is priced at it)
+  int wgs = resident_wgs(4);
+  static int cap = -1;                                  // QAVIT_TN_WGS: fewer workgroups than CUs (a launch that runs BESIDE other work)
+  if (cap < 0) { const char* e = getenv("QAVIT_TN_WGS"); cap = e ? atoi(e) : 0; }
+  if (cap > 0 && cap < wgs) wgs = cap;
+  static int blocked = -1;                              // QAVIT_TN_BLOCKED=0: tile after tile over all rows (the round-3 order)
+  if (blocked < 0) { const char* e = getenv("QAVIT_TN_BLOCKED"); blocked = e ? atoi(e) : 1; }
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!gemm_tn_wide_ok(a[i])) continue;
+    const qavit_gemm_tn_args& g = a[i];
+    const int in = tile_class(g.N, 0), jn = uni_k_class(g.K), mc = ucls_mc(in, jn);
+    total += (long long)((g.N + 32 * in - 1) / (32 * in)) * ((g.K + 64 * jn - 1) / (64 * jn)) * ((g.M + mc - 1) / mc) * ucls_cost(in, jn);
+  }
+  if (total > 0x7fffffffLL) return -1;                  // caller falls back to the class launches
+  const int min_cost = 4 * ucls_cost(1, 1);             // a range shorter than a few small units is all flush
+  int per = (int)((total + wgs - 1) / wgs);
+  if (per < min_cost) per = min_cost;
   TnuWrite W;
   W.n = 0; W.off = 0;
   int cost = 0, done = 0;
@@ -592,10 +754,15 @@ int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
     const int mc = ucls_mc(in, jn);
     e.chunks = (g.M + mc - 1) / mc;
     e.cu = ucls_cost(in, jn);
+    e.tiles = e.tn * ((g.K + 64 * jn - 1) / (64 * jn));
+    e.cb = 0;
+    if (e.tiles > 1 && blocked) {
+      e.cb = (per + e.cu / 2) / e.cu;
+      if (e.cb < 1) e.cb = 1;
+      if (e.cb >= e.chunks) e.cb = e.chunks;             // one block: tile after tile, as before
+    }
     W.cost_start[W.n] = cost;
-    const long long c = (long long)e.tn * ((g.K + 64 * jn - 1) / (64 * jn)) * e.chunks * e.cu;
-    if (cost + c > 0x7fffffffLL) return -1;      // caller falls back to the class launches
-    cost += (int)c;
+    cost += e.tiles * e.chunks * e.cu;
     ++done;
     if (++W.n == TNU_PER_WRITE && done < cnt) flush();
   }
@@ -607,13 +774,6 @@ int gemm_tn_uni(const qavit_gemm_tn_args* a, int n, hipStream_t st, void* ws) {
       return set_error(QAVIT_ELAUNCH, "gemm_tn: copy node of the problem table");
     ++tnu_pool().used;
   }
-  int wgs = resident_wgs(4);
-  static int cap = -1;                                  // QAVIT_TN_WGS: fewer workgroups than CUs (a launch that runs BESIDE other work)
-  if (cap < 0) { const char* e = getenv("QAVIT_TN_WGS"); cap = e ? atoi(e) : 0; }
-  if (cap > 0 && cap < wgs) wgs = cap;
-  int per = (cost + wgs - 1) / wgs;
-  const int min_cost = 4 * ucls_cost(1, 1);             // a range shorter than a few small units is all flush
-  if (per < min_cost) per = min_cost;
   wgs = (cost + per - 1) / per;
   int dbg = 0;
 #ifdef QAVIT_TN_FLUSH_EXPERIMENT

@@ -5,7 +5,7 @@ import glob, os, subprocess, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "branch_fwd"
 macro = sys.argv[2] if len(sys.argv) > 2 else "QAVIT_BRANCH_STAMPS"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qa-vit_amd")
-flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result", "-D" + macro]
+flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result"] + ["-D" + m for m in macro.split(",")]
 os.makedirs("/tmp/stampbuild", exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", f"{root}/csrc/{src}.hip", "-o", f"/tmp/stampbuild/{src}.o"])
 objs = [o for o in glob.glob(root + "/build/*.o") if not o.endswith(f"/{src}.o")] + [f"/tmp/stampbuild/{src}.o"]
