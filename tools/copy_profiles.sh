@@ -7,7 +7,7 @@ for f in bench_default_run bench_under_rocprof bench_tin_b128 bench_tin_b512 ben
          bench_force_ddp bench_force_ddp_all_tags bench_force_ddp_no_tags bench_lateral_one_stream; do
   [ -f $S/$f.json ] && cp $S/$f.json $P/${R}_$f.json
 done
-for f in family_summary family_summary_tin_b128 family_summary_tin_b512 family_summary_q32_eval family_summary_force_ddp overlap step_timeline mfma_util traffic bench_branch branch_mfma_pmc; do
+for f in family_summary family_summary_tin_b128 family_summary_tin_b512 family_summary_q32_eval family_summary_force_ddp overlap step_timeline mfma_util traffic bench_branch branch_mfma_pmc tn_census tn_stream bench_tl chain_stamps; do
   [ -f $S/$f.txt ] && cp $S/$f.txt $P/${R}_$f.txt
 done
 cp $S/kt/k_kernel_stats.csv $P/${R}_kernel_stats_bench_hipgraph_B1024.csv

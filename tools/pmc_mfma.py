@@ -12,7 +12,7 @@ FAM = [("attn_fused", ("branch_fwd_kernel",)), ("attn_fused_bwd", ("branch_bwd_k
        ("attn_bwd", ("true>(qavit_attn_args", "attn_bwd_kernel")), ("attn_reduce", ("attn_reduce",)),
        ("attn_fwd", ("false>(qavit_attn_args", "attn_fwd_kernel")),
        ("layernorm", ("layernorm_", "row_stats")), ("dwconv", ("dwconv",)), ("ccf", ("ccf_",)), ("bank", ("bank_",)),
-       ("bn", ("bn_",)), ("tokmix/upmix", ("tokmix", "upmix")), ("other", ("",))]
+       ("bn", ("bn_",)), ("tokmix/upmix/tl", ("tokmix", "upmix", "tl_fwd_kernel", "tl_bwd_kernel")), ("other", ("",))]
 SIMD_NUM, XCDS = 1024, 8
 steps = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 agg = {}

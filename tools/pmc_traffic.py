@@ -9,7 +9,7 @@ FAM = [("branch_fwd", ("branch_fwd_kernel",)), ("branch_bwd", ("branch_bwd_kerne
        ("attn_bwd", ("true>(qavit_attn_args", "attn_bwd_kernel", "attn_reduce")), ("attn_fwd", ("false>(qavit_attn_args", "attn_fwd_kernel")),
        ("layernorm_bwd", ("layernorm_bwd",)), ("layernorm_fwd", ("layernorm_fwd",)), ("row_stats", ("row_stats",)),
        ("dwconv_bwd", ("dwconv_bwd",)), ("dwconv_fwd", ("dwconv_fwd",)), ("ccf_mid_bwd", ("ccf_bwd",)), ("ccf_mid_fwd", ("ccf_fwd",)),
-       ("bank_stats", ("bank_stats", "bank_reduce")), ("bn", ("bn_",))]
+       ("bank_stats", ("bank_stats", "bank_reduce")), ("bn", ("bn_",)), ("tl_fwd", ("tl_fwd_kernel",)), ("tl_bwd", ("tl_bwd_kernel",))]
 def fold(path):
     agg = {}
     for r in csv.DictReader(open(path)):

@@ -45,5 +45,11 @@ QAVIT_FORCE_DDP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 python3 tools/kfamily.py $OUT/kt_ddp/k_kernel_stats.csv 31 > $OUT/family_summary_force_ddp.txt
 # the lateral path on its stream (default) against everything on one stream
 QAVIT_LATERAL_STREAM=0 python3 bench.py --no-cpu-baseline --no-kernel-timing > $OUT/bench_lateral_one_stream.json 2> $OUT/bench_lateral_one_stream.err
+# the one-launch weight-gradient kernel: the step's own problem list in isolation, homogeneous streaming sets per tile class; the fused TokenLearner;
+# the step's chain stamps (host-recorded events at the phase boundaries of one eager step)
+python3 tools/tn_census.py > $OUT/tn_census.txt 2>&1
+python3 tools/bench_tn_stream.py > $OUT/tn_stream.txt 2>&1
+python3 tools/bench_tl.py > $OUT/bench_tl.txt 2>&1
+python3 tools/chain_stamps.py > $OUT/chain_stamps.txt 2>&1
 rm -f $OUT/kt_plain/k_kernel_trace.csv $OUT/kt_ddp/k_kernel_trace.csv $OUT/kt/k_kernel_trace.csv $OUT/kt_tin128/k_kernel_trace.csv $OUT/kt_tin512/k_kernel_trace.csv $OUT/kt_q32/k_kernel_trace.csv
 tail -n 20 $OUT/family_summary.txt $OUT/mfma_util.txt $OUT/traffic.txt $OUT/branch_mfma_pmc.txt
