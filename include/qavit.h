@@ -628,6 +628,10 @@ int qavit_dwconv_bwd(int dtype, const void* dy, const void* x, const float* w, v
  * gradient that meets this one at x and is added into dx.  Strides in elements, >= C; needs H and W multiples of 8 when they differ from C. */
 int qavit_dwconv_fwd_ld(int dtype, const void* x, const float* w, const float* bias, void* y, int ldy,
                         int B, int H, int W, int C, int ks, void* stream);
+/* ... and x itself copied into a third column slice by the same launch (xcopy rows ldc apart; the cat's pass-through member, :834): one launch
+ * fewer per LMFAdapter.  H and W multiples of 8. */
+int qavit_dwconv_fwd_ld2(int dtype, const void* x, const float* w, const float* bias, void* y, int ldy, void* xcopy, int ldc,
+                         int B, int H, int W, int C, int ks, void* stream);
 int qavit_dwconv_bwd_ld(int dtype, const void* dy, int lddy, const void* x, const float* w, void* dx, const void* dadd, int lddadd,
                         float* dw, float* dbias, int B, int H, int W, int C, int ks, void* stream);
 

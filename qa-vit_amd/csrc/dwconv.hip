@@ -358,7 +358,8 @@ __device__ __forceinline__ void dw_load_tile8(const T* src, float (&tl)[8][8], i
 
 // ONE8: the map IS one 8x8 tile (H = W = 8 known at compile time: out-of-map rows / columns and their loads fold away)
 template <typename T, int KS, bool ONE8>
-__global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H_, int W_, int C, int ldy) {
+__global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const float* w, const float* bias, T* y, int B, int H_, int W_, int C, int ldy,
+                                                          T* xc, int ldc) {
   constexpr int TS = 8, R = KS / 2, KK = KS * KS;
   const int H = ONE8 ? 8 : H_, W = ONE8 ? 8 : W_;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -389,6 +390,15 @@ __global__ __launch_bounds__(256) void dwconv_fwdt_kernel(const T* x, const floa
       for (int yy = 0; yy < TS; ++yy)
 #pragma unroll
         for (int xx = 0; xx < TS; ++xx) y[(((size_t)b * H + ty * TS + yy) * W + tx * TS + xx) * ldy + c] = from_f<T>(o[yy][xx >> 1][xx & 1]);
+    }
+    if (xc && cok) {                                         // uniform: the tile's input cells once more, into another column slice (qavit_dwconv_fwd_ld2)
+#pragma unroll
+      for (int yy = 0; yy < TS; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < TS; ++xx) {
+          const size_t cell = ((size_t)b * H + ty * TS + yy) * W + tx * TS + xx;
+          xc[cell * ldc + c] = x[cell * C + c];
+        }
     }
   }
 }
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(256) void dwconv_bwdt_kernel(const T* dy, const T* 
 }
 
 // Row strides (in elements) of the operands that may be column slices of a wider buffer: y forward, dy and the addend backward.
-struct DwStrides { int ldy; int lddy; const void* dadd; int lddadd; };
+struct DwStrides { int ldy; int lddy; const void* dadd; int lddadd; void* xc = nullptr; int ldc = 0; };
 static inline bool tiled_ok(int H, int W) { return H % 8 == 0 && W % 8 == 0; }
 
 template <typename T, int KS>
@@ -517,7 +527,7 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
                      int B, int H, int W, int C, hipStream_t st, const DwStrides& S) {
   const int N = H * W;
   const int ld0 = bwd ? S.lddy : S.ldy;                      // the strided operand: y forward, dy backward
-  const bool plain = ld0 == C && !S.dadd;
+  const bool plain = ld0 == C && !S.dadd && !S.xc;
   const int chunks = (C + DW_CH - 1) / DW_CH;
   static const int pk8 = getenv("QAVIT_DW8_PK") ? atoi(getenv("QAVIT_DW8_PK")) : 1;      // 8x8 maps on the packed-FMA tile kernels (0: the scalar-FMA dwconv_fwd8 / bwd8)
   if ((pk8 || !plain) && H == 8 && W == 8) {
@@ -525,7 +535,7 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
     static const int w8 = getenv("QAVIT_DWT8_BWD_WGS") ? atoi(getenv("QAVIT_DWT8_BWD_WGS")) : 512;
     const int cap = (bwd ? w8 : 1024) / chunks > 0 ? (bwd ? w8 : 1024) / chunks : 1;
     if (gy > cap) gy = cap;
-    if (!bwd) hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C, S.ldy);
+    if (!bwd) hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C, S.ldy, (T*)S.xc, S.ldc);
     else hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, true>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C,
                             S.lddy, (const T*)S.dadd, S.lddadd);
     return check_launch("dwconv8(pk)");
@@ -546,7 +556,7 @@ static int launch_dw(bool bwd, const void* a0, const void* a1, const float* w, c
     const int cap = (bwd ? wt_ : 2048) / chunks > 0 ? (bwd ? wt_ : 2048) / chunks : 1;
     if (gy > cap) gy = cap;
     if (!bwd) {
-      hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C, S.ldy);
+      hipLaunchKernelGGL((dwconv_fwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, w, bias, (T*)o0, B, H, W, C, S.ldy, (T*)S.xc, S.ldc);
       return check_launch("dwconv_fwdt");
     }
     hipLaunchKernelGGL((dwconv_bwdt_kernel<T, KS, false>), dim3(chunks, gy), dim3(256), 0, st, (const T*)a0, (const T*)a1, w, (T*)o0, dw, dbias, B, H, W, C,
@@ -823,6 +833,18 @@ extern "C" int qavit_dwconv_fwd_ld(int dtype, const void* x, const float* w, con
   if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st, S);
   if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st, S);
   return set_error(QAVIT_EINVAL, "dwconv_fwd: unknown dtype");
+}
+
+extern "C" int qavit_dwconv_fwd_ld2(int dtype, const void* x, const float* w, const float* bias, void* y, int ldy, void* xcopy, int ldc,
+                                    int B, int H, int W, int C, int ks, void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldy < C || !xcopy || ldc < C) return set_error(QAVIT_EINVAL, "dwconv_fwd_ld2: bad arguments");
+  if (!tiled_ok(H, W)) return set_error(QAVIT_EINVAL, "dwconv_fwd_ld2: map sides must be multiples of 8");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DwStrides S{ldy, C, nullptr, 0};
+  S.xc = xcopy; S.ldc = ldc;
+  if (dtype == QAVIT_F32) return dispatch_dw<float>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st, S);
+  if (dtype == QAVIT_BF16) return dispatch_dw<bf16>(ks, false, x, nullptr, w, bias, y, nullptr, nullptr, B, H, W, C, st, S);
+  return set_error(QAVIT_EINVAL, "dwconv_fwd_ld2: unknown dtype");
 }
 
 extern "C" int qavit_dwconv_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int ks, void* stream) {

@@ -551,7 +551,17 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* img, T* cols
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2_partial_kernel(const float* g, int64_t n, float* partial) {
   float s = 0.f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += g[i] * g[i];
+  const bool vec = (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+  const int64_t n4 = vec ? (n >> 2) : 0;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i + step < n4; i += 2 * step) {
+    const f32x4 a = g4[i], b = g4[i + step];
+    s += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+  }
+  for (; i < n4; i += step) { const f32x4 a = g4[i]; s += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]); }
+  for (int64_t j = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += step) s += g[j] * g[j];
   __shared__ float red[4];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -933,7 +943,20 @@ __global__ __launch_bounds__(256) void local_clip_norm_kernel(const float* g, co
   const float* p = g + seg[2 * blockIdx.x];
   const int64_t n = seg[2 * blockIdx.x + 1];
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) { const float v = p[i]; s += v * v; }
+  // 16-byte loads, four in flight per thread (segments start on 256-byte boundaries of the flat buffer): as a scalar loop the 262 k-element
+  // segments were 64 dependent-looking iterations per thread and the launch took 26 us at the very end of the step
+  const bool vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  const int64_t n4 = vec ? (n >> 2) : 0;
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(p);
+  const int64_t step = (int64_t)gridDim.y * 256;
+  int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  for (; i + 3 * step < n4; i += 4 * step) {
+    const f32x4 a = p4[i], b = p4[i + step], c = p4[i + 2 * step], d = p4[i + 3 * step];
+    s += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]) +
+         (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]) + (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+  }
+  for (; i < n4; i += step) { const f32x4 a = p4[i]; s += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]); }
+  for (int64_t j = (n4 << 2) + (int64_t)blockIdx.y * 256 + threadIdx.x; j < n; j += step) { const float v = p[j]; s += v * v; }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -943,8 +966,13 @@ __global__ __launch_bounds__(256) void local_clip_scale_kernel(float* g, const i
   float* p = g + seg[2 * blockIdx.x];
   const int64_t n = seg[2 * blockIdx.x + 1];
   const float sc = fminf(clip / (sqrtf(ws[blockIdx.x]) + 1e-6f), 1.f);
-  if (sc < 1.f)
-    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) p[i] *= sc;
+  if (sc < 1.f) {
+    const bool vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    const int64_t n4 = vec ? (n >> 2) : 0;
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.y * 256) { f32x4 a = p4[i]; a[0] *= sc; a[1] *= sc; a[2] *= sc; a[3] *= sc; p4[i] = a; }
+    for (int64_t j = (n4 << 2) + (int64_t)blockIdx.y * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.y * 256) p[j] *= sc;
+  }
   __syncthreads();                                         // every thread of this chunk has read ws[seg]
   if (threadIdx.x == 0) {
     int* ticket = reinterpret_cast<int*>(ws + nseg) + blockIdx.x;

@@ -695,6 +695,13 @@ def dwconv_fwd_ld(x, w, bias, y, ldy, B, H, W, Cc, ks):
     L.check(L.load().qavit_dwconv_fwd_ld(dt_code(x.dtype), x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), ldy, B, H, W, Cc, ks, stream()), "dwconv_fwd_ld")
 
 
+def dwconv_fwd_ld2(x, w, bias, y, ldy, xcopy, ldc, B, H, W, Cc, ks):
+    """As dwconv_fwd_ld, and the same launch copies ``x`` into the column slice ``xcopy`` (row stride ``ldc``): the pass-through member of
+    LMFAdapter's cat.  Map sides multiples of 8."""
+    L.check(L.load().qavit_dwconv_fwd_ld2(dt_code(x.dtype), x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), ldy, xcopy.data_ptr(), ldc,
+                                          B, H, W, Cc, ks, stream()), "dwconv_fwd_ld2")
+
+
 def dwconv_bwd_ld(dy, lddy, x, w, dx, dadd, lddadd, dw, dbias, B, H, W, Cc, ks):
     """``dy`` is a column slice (row stride ``lddy``); ``dadd`` (None, or row stride ``lddadd``; may be ``dx``) is added into ``dx``."""
     L.check(L.load().qavit_dwconv_bwd_ld(dt_code(x.dtype), dy.data_ptr(), lddy, x.data_ptr(), w.data_ptr(), dx.data_ptr(), _p(dadd), lddadd,

@@ -228,6 +228,7 @@ _SIGS = {
     "qavit_dwconv_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_dwconv_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_dwconv_fwd_ld": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "qavit_dwconv_fwd_ld2": (i32, [i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_dwconv_bwd_ld": (i32, [i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_im2col": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_im2col_ld": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
