@@ -790,6 +790,9 @@ class FanGroup:
         if not (_DX_CAT and y.is_cuda and y.dtype == torch.bfloat16 and rows >= 16 and Cc % 64 == 0):
             return None
         grp = cls(rows, Cc, y.dtype, y.device)
+        if len(cls.registry) > 256:                         # addresses of groups long gone (an eager run over many shapes): drop the dead references
+            for key in [k_ for k_, r in cls.registry.items() if r() is None]:
+                del cls.registry[key]
         cls.registry[y.data_ptr()] = weakref.ref(grp)
         return grp
 
