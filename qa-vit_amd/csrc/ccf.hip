@@ -537,6 +537,220 @@ __global__ __launch_bounds__(64 * NW) void ccf_bwd2_kernel(qavit_ccf_args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 4 x 4 maps (the 16 learned tokens of every C100 block), C <= 128 even: ONE WAVE PER IMAGE, EVERYTHING IN REGISTERS.  Lane l owns the
+// channel pair (2l, 2l + 1) at all 16 positions: the depthwise 3 x 3 stencil and its backward are per-lane arithmetic on 32 registers (no
+// LDS, no barrier), a LayerNorm row is a wave sum over the lanes, and the parameter-gradient partials are registers of the lane that owns
+// the channel.  The LDS kernels above walk the image five times through fp32 LDS tiles with a barrier between the phases: 37 us backward and
+// 16 us forward for 3 MB of activations at B = 1024 (one image per SIMD), VALU- and LDS-issue bound.
+template <typename T> struct V2;
+template <> struct V2<float> { typedef f32x2 type; };
+template <> struct V2<bf16> { typedef __attribute__((ext_vector_type(2))) __bf16 type; };
+
+template <typename T>
+__device__ __forceinline__ void ccf3_load_rows(const T* src, int C, int c0, bool act, float (&v)[16][2]) {
+  typedef typename V2<T>::type v2;
+  v2 raw[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) raw[r] = *reinterpret_cast<const v2*>(src + (size_t)r * C + c0);      // inactive lanes read the pair at c0 = 0
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { v[r][0] = act ? to_f<T>(raw[r][0]) : 0.f; v[r][1] = act ? to_f<T>(raw[r][1]) : 0.f; }
+}
+
+struct Ccf3Par { float g1[2], b1[2], g2[2], b2[2], cb[2], cs[2], wt[2][9]; };
+__device__ __forceinline__ void ccf3_params(const qavit_ccf_args& p, int c0, bool act, Ccf3Par& q) {
+  const bool ln = p.flags & F_LN, hb = p.flags & F_BIAS, hs = p.flags & F_SCALE;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = c0 + k;
+    q.g1[k] = (act && ln) ? p.g1[c] : 0.f; q.b1[k] = (act && ln) ? p.b1[c] : 0.f;
+    q.g2[k] = (act && ln) ? p.g2[c] : 0.f; q.b2[k] = (act && ln) ? p.b2[c] : 0.f;
+    q.cb[k] = (act && hb) ? p.cbias[c] : 0.f;
+    q.cs[k] = (act && hs) ? p.cscale[c] : (act ? 1.f : 0.f);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) q.wt[k][t] = act ? p.w[c * 9 + t] : 0.f;
+  }
+}
+// conv(+bias) of the 4 x 4 map held per lane: raw[r][k] = sum_taps wt * a[neighbour] + cb
+__device__ __forceinline__ void ccf3_conv(const float (&a)[16][2], const Ccf3Par& q, float (&raw)[16][2]) {
+#pragma unroll
+  for (int y = 0; y < 4; ++y)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int yy = y + dy - 1, xx = x + dx - 1;
+            if (yy >= 0 && yy < 4 && xx >= 0 && xx < 4) sacc += q.wt[k][dy * 3 + dx] * a[yy * 4 + xx][k];
+          }
+        raw[y * 4 + x][k] = sacc + q.cb[k];
+      }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ccf_fwd3_kernel(qavit_ccf_args p) {
+  const int C = p.C, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool act = 2 * lane < C, ln = p.flags & F_LN;
+  const int c0 = act ? 2 * lane : 0;
+  const float invC = 1.f / (float)C;
+  Ccf3Par q;
+  ccf3_params(p, c0, act, q);
+  const T* h = reinterpret_cast<const T*>(p.h);
+  T* out = reinterpret_cast<T*>(p.out);
+  typedef typename V2<T>::type v2;
+  for (int b = blockIdx.x + (int)gridDim.x * wave; b < p.B; b += (int)gridDim.x * 4) {
+    float a[16][2];
+    ccf3_load_rows<T>(h + (size_t)b * 16 * C, C, c0, act, a);
+    if (ln) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float mean = wave_sum(a[r][0] + a[r][1]) * invC;
+        const float d0 = act ? a[r][0] - mean : 0.f, d1 = act ? a[r][1] - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * invC + p.eps);
+        a[r][0] = act ? d0 * rstd * q.g1[0] + q.b1[0] : 0.f;
+        a[r][1] = act ? d1 * rstd * q.g1[1] + q.b1[1] : 0.f;
+        if (lane == 0) { p.mean1[(size_t)b * 16 + r] = mean; p.rstd1[(size_t)b * 16 + r] = rstd; }
+      }
+    }
+    float v[16][2];
+    ccf3_conv(a, q, v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v0 = v[r][0] * q.cs[0], v1 = v[r][1] * q.cs[1];
+      if (ln) {
+        const float mean = wave_sum(v0 + v1) * invC;
+        const float d0 = act ? v0 - mean : 0.f, d1 = act ? v1 - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * invC + p.eps);
+        v0 = d0 * rstd * q.g2[0] + q.b2[0]; v1 = d1 * rstd * q.g2[1] + q.b2[1];
+        if (lane == 0) { p.mean2[(size_t)b * 16 + r] = mean; p.rstd2[(size_t)b * 16 + r] = rstd; }
+      }
+      if (act) { v2 o; o[0] = from_f<T>(v0); o[1] = from_f<T>(v1); *reinterpret_cast<v2*>(out + ((size_t)b * 16 + r) * C + c0) = o; }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ccf_bwd3_kernel(qavit_ccf_args p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // [4 waves][15 C]: the fold of the parameter-gradient partials
+  const int C = p.C, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool act = 2 * lane < C, ln = p.flags & F_LN, hb = p.flags & F_BIAS, hs = p.flags & F_SCALE;
+  const int c0 = act ? 2 * lane : 0;
+  const float invC = 1.f / (float)C;
+  Ccf3Par q;
+  ccf3_params(p, c0, act, q);
+  const T* h = reinterpret_cast<const T*>(p.h);
+  const T* dout = reinterpret_cast<const T*>(p.d_out);
+  T* dh = reinterpret_cast<T*>(p.d_h);
+  typedef typename V2<T>::type v2;
+  float rg1[2] = {0.f, 0.f}, rb1[2] = {0.f, 0.f}, rg2[2] = {0.f, 0.f}, rb2[2] = {0.f, 0.f}, rcb[2] = {0.f, 0.f}, rcs[2] = {0.f, 0.f}, rw[2][9];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) rw[k][t] = 0.f;
+  for (int b = blockIdx.x + (int)gridDim.x * wave; b < p.B; b += (int)gridDim.x * 4) {
+    float hv[16][2], d[16][2];
+    ccf3_load_rows<T>(h + (size_t)b * 16 * C, C, c0, act, hv);
+    ccf3_load_rows<T>(dout + (size_t)b * 16 * C, C, c0, act, d);
+    // recompute of the forward from the saved row statistics (uniform per wave: scalar loads)
+    float a[16][2], raw[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float mu = 0.f, rs = 1.f;
+      if (ln) { mu = p.mean1[(size_t)b * 16 + r]; rs = p.rstd1[(size_t)b * 16 + r]; }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) a[r][k] = !act ? 0.f : ln ? (hv[r][k] - mu) * rs * q.g1[k] + q.b1[k] : hv[r][k];
+    }
+    ccf3_conv(a, q, raw);
+    // LayerNorm 2 backward, then d(conv output) = dt * scale with the dscale / dbias partials; d becomes dc
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float mu = 0.f, rs = 1.f;
+      if (ln) { mu = p.mean2[(size_t)b * 16 + r]; rs = p.rstd2[(size_t)b * 16 + r]; }
+      float xh[2], gg[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { xh[k] = act ? (raw[r][k] * q.cs[k] - mu) * rs : 0.f; gg[k] = d[r][k] * q.g2[k]; }
+      float c1 = 0.f, c2 = 0.f;
+      if (ln) { c1 = wave_sum(gg[0] * xh[0] + gg[1] * xh[1]) * invC; c2 = wave_sum(gg[0] + gg[1]) * invC; }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float dt = d[r][k];
+        if (ln) { rg2[k] += d[r][k] * xh[k]; rb2[k] += d[r][k]; dt = act ? rs * (gg[k] - c2 - xh[k] * c1) : 0.f; }
+        if (hs) { rcs[k] += dt * raw[r][k]; dt *= q.cs[k]; }
+        rcb[k] += dt;
+        d[r][k] = dt;
+      }
+    }
+    // convolution backward: tap partials, d(LN1 output) into raw
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float dc = d[y * 4 + x][k];
+          float da = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int yy = y + dy - 1, xx = x + dx - 1;           // forward tap read by output (y, x)
+              if (yy >= 0 && yy < 4 && xx >= 0 && xx < 4) rw[k][dy * 3 + dx] += dc * a[yy * 4 + xx][k];
+              const int yo = y - dy + 1, xo = x - dx + 1;           // outputs that read input (y, x) through tap (dy, dx)
+              if (yo >= 0 && yo < 4 && xo >= 0 && xo < 4) da += q.wt[k][dy * 3 + dx] * d[yo * 4 + xo][k];
+            }
+          raw[y * 4 + x][k] = da;
+        }
+    // LayerNorm 1 backward and the store
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float mu = 0.f, rs = 1.f;
+      if (ln) { mu = p.mean1[(size_t)b * 16 + r]; rs = p.rstd1[(size_t)b * 16 + r]; }
+      float xh[2], gg[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { xh[k] = act ? (hv[r][k] - mu) * rs : 0.f; gg[k] = raw[r][k] * q.g1[k]; }
+      float c1 = 0.f, c2 = 0.f;
+      if (ln) { c1 = wave_sum(gg[0] * xh[0] + gg[1] * xh[1]) * invC; c2 = wave_sum(gg[0] + gg[1]) * invC; }
+      float dx[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        dx[k] = raw[r][k];
+        if (ln) { rg1[k] += raw[r][k] * xh[k]; rb1[k] += raw[r][k]; dx[k] = rs * (gg[k] - c2 - xh[k] * c1); }
+      }
+      if (act) { v2 o; o[0] = from_f<T>(dx[0]); o[1] = from_f<T>(dx[1]); *reinterpret_cast<v2*>(dh + ((size_t)b * 16 + r) * C + c0) = o; }
+    }
+  }
+  // fold the four waves (same row layout as ccf_bwd2_kernel: g1 | b1 | g2 | b2 | conv bias | conv scale | taps [c][9])
+  if (act) {
+    float* pw_ = sm + (size_t)wave * 15 * C;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = c0 + k;
+      pw_[0 * C + c] = rg1[k]; pw_[1 * C + c] = rb1[k]; pw_[2 * C + c] = rg2[k]; pw_[3 * C + c] = rb2[k];
+      pw_[4 * C + c] = rcb[k]; pw_[5 * C + c] = rcs[k];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) pw_[6 * C + c * 9 + t] = rw[k][t];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 15 * C; i += 256) {
+    const float v = (sm[i] + sm[15 * C + i]) + (sm[2 * 15 * C + i] + sm[3 * 15 * C + i]);
+    const int which = i / C;
+    if (p.parts) { p.parts[(size_t)blockIdx.x * 15 * C + i] = (which < 4 && !ln) ? 0.f : v; continue; }
+    if (which >= 6) { atomic_add_f(p.dw + (i - 6 * C), v); continue; }
+    const int c = i - which * C;
+    if (which < 4) {
+      if (!ln) continue;
+      float* dst = which == 0 ? p.dg1 : which == 1 ? p.db1 : which == 2 ? p.dg2 : p.db2;
+      atomic_add_f(dst + c, v);
+    } else if (which == 4) { if (hb && p.dcbias) atomic_add_f(p.dcbias + c, v); }
+    else { if (hs && p.dcscale) atomic_add_f(p.dcscale + c, v); }
+  }
+}
+
 }  // namespace qv
 
 using namespace qv;
@@ -553,6 +767,15 @@ static int ccf_validate(const qavit_ccf_args* a, bool bwd) {
   return QAVIT_OK;
 }
 
+// the register kernels: 4 x 4 map, an even C <= 128, channel pairs loadable as one 4- / 8-byte vector
+static bool ccf3_ok(const qavit_ccf_args* a, bool bwd) {
+  if (!(a->Hs == 4 && a->Ws == 4 && a->C % 2 == 0 && a->C >= 2 && a->C <= 128 && (a->dtype == QAVIT_F32 || a->dtype == QAVIT_BF16))) return false;
+  const uintptr_t al = a->dtype == QAVIT_F32 ? 7 : 3;
+  uintptr_t bits = reinterpret_cast<uintptr_t>(a->h);
+  bits |= bwd ? (reinterpret_cast<uintptr_t>(a->d_out) | reinterpret_cast<uintptr_t>(a->d_h)) : reinterpret_cast<uintptr_t>(a->out);
+  return (bits & al) == 0;
+}
+
 extern "C" int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream) {
   int rc = ccf_validate(a, false);
   if (rc) return rc;
@@ -560,6 +783,14 @@ extern "C" int qavit_ccf_mid_fwd(const qavit_ccf_args* a, void* stream) {
   if (smem > 160 * 1024) return set_error(QAVIT_EINVAL, "ccf_mid_fwd: image tile too large for LDS");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = a->B < 2048 ? a->B : 2048;
+  static const int reg3 = getenv("QAVIT_CCF_REG") ? atoi(getenv("QAVIT_CCF_REG")) : 1;
+  if (reg3 && ccf3_ok(a, false)) {                         // 4 x 4 maps: a wave per image, registers only
+    int g3 = (a->B + 3) / 4;
+    if (g3 > 2048) g3 = 2048;
+    if (a->dtype == QAVIT_F32) hipLaunchKernelGGL((ccf_fwd3_kernel<float>), dim3(g3), dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL((ccf_fwd3_kernel<bf16>), dim3(g3), dim3(256), 0, st, *a);
+    return check_launch("ccf_mid_fwd(reg)");
+  }
   const int threads = a->Hs * a->Ws >= 64 ? 512 : 256;    // 64-token maps fill one CU per image: 8 waves share the rows
   static const int fwd2 = getenv("QAVIT_CCF_FWD2") ? atoi(getenv("QAVIT_CCF_FWD2")) : 1;
   const size_t vecb = a->dtype == QAVIT_F32 ? 16 : 8;      // the register-partial kernels stage images with 4-element vector loads
@@ -603,6 +834,13 @@ extern "C" int qavit_ccf_mid_bwd(const qavit_ccf_args* a, void* stream) {
   const int grid = qavit_ccf_bwd_parts(a->B);
   if (a->parts && !(a->C <= 256 && a->Hs * a->Ws >= 15 && a->C % 8 == 0 && (reinterpret_cast<uintptr_t>(a->parts) & 15) == 0))
     return set_error(QAVIT_EINVAL, "ccf_mid_bwd: parts needs C <= 256, C % 8 == 0, >= 15 tokens and a 16-byte aligned workspace");
+  static const int reg3 = getenv("QAVIT_CCF_REG") ? atoi(getenv("QAVIT_CCF_REG")) : 1;
+  if (reg3 && ccf3_ok(a, true) && (!a->parts || (reinterpret_cast<uintptr_t>(a->parts) & 15) == 0)) {
+    const size_t sm3 = (size_t)4 * 15 * a->C * sizeof(float);
+    if (a->dtype == QAVIT_F32) hipLaunchKernelGGL((ccf_bwd3_kernel<float>), dim3(grid), dim3(256), sm3, st, *a);
+    else hipLaunchKernelGGL((ccf_bwd3_kernel<bf16>), dim3(grid), dim3(256), sm3, st, *a);
+    return check_launch("ccf_mid_bwd(reg)");
+  }
   const size_t vecb = a->dtype == QAVIT_F32 ? 16 : 8;
   if (a->C <= 256 && a->Hs * a->Ws >= 15 && a->C % 4 == 0 &&
       (reinterpret_cast<uintptr_t>(a->h) | reinterpret_cast<uintptr_t>(a->d_out)) % vecb == 0) {   // register-partial kernel (its wave fold needs 60*C floats of the image buffers; vector image loads)
