@@ -605,6 +605,9 @@ __global__ __launch_bounds__(256) void ccf_fwd3_kernel(qavit_ccf_args p) {
   for (int b = blockIdx.x + (int)gridDim.x * wave; b < p.B; b += (int)gridDim.x * 4) {
     float a[16][2];
     ccf3_load_rows<T>(h + (size_t)b * 16 * C, C, c0, act, a);
+    // No lane-dependent branch inside the row loops: a store under `if (lane == 0)` per row cuts the unrolled loop into sixteen basic blocks and
+    // the rows' wave sums -- independent chains -- then run one after the other.  Row r's statistics are parked in lane r and stored once.
+    float m1 = 0.f, s1 = 0.f, m2 = 0.f, s2 = 0.f;
     if (ln) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256) void ccf_fwd3_kernel(qavit_ccf_args p) {
         const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * invC + p.eps);
         a[r][0] = act ? d0 * rstd * q.g1[0] + q.b1[0] : 0.f;
         a[r][1] = act ? d1 * rstd * q.g1[1] + q.b1[1] : 0.f;
-        if (lane == 0) { p.mean1[(size_t)b * 16 + r] = mean; p.rstd1[(size_t)b * 16 + r] = rstd; }
+        m1 = lane == r ? mean : m1; s1 = lane == r ? rstd : s1;
       }
     }
     float v[16][2];
@@ -626,9 +629,17 @@ __global__ __launch_bounds__(256) void ccf_fwd3_kernel(qavit_ccf_args p) {
         const float d0 = act ? v0 - mean : 0.f, d1 = act ? v1 - mean : 0.f;
         const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) * invC + p.eps);
         v0 = d0 * rstd * q.g2[0] + q.b2[0]; v1 = d1 * rstd * q.g2[1] + q.b2[1];
-        if (lane == 0) { p.mean2[(size_t)b * 16 + r] = mean; p.rstd2[(size_t)b * 16 + r] = rstd; }
+        m2 = lane == r ? mean : m2; s2 = lane == r ? rstd : s2;
       }
-      if (act) { v2 o; o[0] = from_f<T>(v0); o[1] = from_f<T>(v1); *reinterpret_cast<v2*>(out + ((size_t)b * 16 + r) * C + c0) = o; }
+      v[r][0] = v0; v[r][1] = v1;
+    }
+    if (act) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { v2 o; o[0] = from_f<T>(v[r][0]); o[1] = from_f<T>(v[r][1]); *reinterpret_cast<v2*>(out + ((size_t)b * 16 + r) * C + c0) = o; }
+    }
+    if (ln && lane < 16) {
+      p.mean1[(size_t)b * 16 + lane] = m1; p.rstd1[(size_t)b * 16 + lane] = s1;
+      p.mean2[(size_t)b * 16 + lane] = m2; p.rstd2[(size_t)b * 16 + lane] = s2;
     }
   }
 }
@@ -714,13 +725,15 @@ __global__ __launch_bounds__(256) void ccf_bwd3_kernel(qavit_ccf_args p) {
       for (int k = 0; k < 2; ++k) { xh[k] = act ? (hv[r][k] - mu) * rs : 0.f; gg[k] = raw[r][k] * q.g1[k]; }
       float c1 = 0.f, c2 = 0.f;
       if (ln) { c1 = wave_sum(gg[0] * xh[0] + gg[1] * xh[1]) * invC; c2 = wave_sum(gg[0] + gg[1]) * invC; }
-      float dx[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        dx[k] = raw[r][k];
-        if (ln) { rg1[k] += raw[r][k] * xh[k]; rb1[k] += raw[r][k]; dx[k] = rs * (gg[k] - c2 - xh[k] * c1); }
+        const float da = raw[r][k];
+        if (ln) { rg1[k] += da * xh[k]; rb1[k] += da; raw[r][k] = rs * (gg[k] - c2 - xh[k] * c1); }
       }
-      if (act) { v2 o; o[0] = from_f<T>(dx[0]); o[1] = from_f<T>(dx[1]); *reinterpret_cast<v2*>(dh + ((size_t)b * 16 + r) * C + c0) = o; }
+    }
+    if (act) {                                           // one branch for the sixteen stores, none inside the row loop (see ccf_fwd3_kernel)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { v2 o; o[0] = from_f<T>(raw[r][0]); o[1] = from_f<T>(raw[r][1]); *reinterpret_cast<v2*>(dh + ((size_t)b * 16 + r) * C + c0) = o; }
     }
   }
   // fold the four waves (same row layout as ccf_bwd2_kernel: g1 | b1 | g2 | b2 | conv bias | conv scale | taps [c][9])
