@@ -415,6 +415,10 @@ int qavit_gather_pool_fwd(int dtype, const void* x, const int32_t* idx, void* y,
                           int stride, int C, void* stream);
 int qavit_gather_pool_bwd(int dtype, const void* dy, const int32_t* idx, void* dx, int B, int N, int NP,
                           int stride, int C, void* stream);
+/* ... with dx rows ldx elements apart (a column slice of a wider matrix: MSDA's landmark-path dk / dv gradients scattered back to token
+ * rows inside the fan node's [rows, 7C] matrix, functional.FanGroup); vector kernel only (16-byte aligned, C and ldx multiples of 8 / 4). */
+int qavit_gather_pool_bwd_ld(int dtype, const void* dy, const int32_t* idx, void* dx, int ldx, int B, int N, int NP,
+                             int stride, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * CCF-FFN middle (HQAViT_CIFAR100.py:706-708, :670-675): h2 = LN2( scale * dwconv3x3( LN1(h) ) (+bias) )

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void gather_pool_bwd_kernel(const T* dy, const
 // vector is the sum of <= 4 rows instead of a scan of all NP*stride entries per element.  Deterministic (list order =
 // index order).  A token with more than 4 readers makes its workgroup take the scan for every element.
 template <typename T>
-__global__ __launch_bounds__(256) void gather_pool_bwd2_kernel(const T* dy, const int32_t* idx, T* dx, int B, int N, int NP, int stride, int C) {
+__global__ __launch_bounds__(256) void gather_pool_bwd2_kernel(const T* dy, const int32_t* idx, T* dx, int B, int N, int NP, int stride, int C, int ldx) {
   constexpr int VEC = 16 / sizeof(T);
   typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) int ism[];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void gather_pool_bwd2_kernel(const T* dy, cons
     vec_t o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o[j] = from_f<T>(acc[j] * inv);
-    *reinterpret_cast<vec_t*>(dx + ((size_t)b * N + n) * C + cv * VEC) = o;
+    *reinterpret_cast<vec_t*>(dx + ((size_t)b * N + n) * ldx + cv * VEC) = o;
   }
 }
 
@@ -502,7 +502,11 @@ extern "C" int qavit_gather_pool_fwd(int dtype, const void* x, const int32_t* id
 }
 
 extern "C" int qavit_gather_pool_bwd(int dtype, const void* dy, const int32_t* idx, void* dx, int B, int N, int NP, int stride, int C, void* stream) {
-  if (!dy || !idx || !dx || B <= 0 || N <= 0 || NP <= 0 || stride <= 0 || C <= 0) return set_error(QAVIT_EINVAL, "gather_pool_bwd: bad arguments");
+  return qavit_gather_pool_bwd_ld(dtype, dy, idx, dx, C, B, N, NP, stride, C, stream);
+}
+
+extern "C" int qavit_gather_pool_bwd_ld(int dtype, const void* dy, const int32_t* idx, void* dx, int ldx, int B, int N, int NP, int stride, int C, void* stream) {
+  if (!dy || !idx || !dx || B <= 0 || N <= 0 || NP <= 0 || stride <= 0 || C <= 0 || ldx < C) return set_error(QAVIT_EINVAL, "gather_pool_bwd: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int64_t total = (int64_t)B * N * C;
   int grid = (int)((total + 1023) / 1024); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
@@ -511,14 +515,15 @@ extern "C" int qavit_gather_pool_bwd(int dtype, const void* dy, const int32_t* i
     const int vec = dtype == QAVIT_BF16 ? 8 : 4;
     const size_t lds = ((size_t)NP * stride + (size_t)N * 4) * sizeof(int);
     const bool al = !((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15);
-    if (small && al && C % vec == 0 && lds <= 96 * 1024 && (dtype == QAVIT_BF16 || dtype == QAVIT_F32)) {
+    if (small && al && C % vec == 0 && ldx % vec == 0 && lds <= 96 * 1024 && (dtype == QAVIT_BF16 || dtype == QAVIT_F32)) {
       int64_t nv = (int64_t)B * N * (C / vec);
       int g2 = (int)((nv + 1023) / 1024); if (g2 > 512) g2 = 512; if (g2 < 1) g2 = 1;
-      if (dtype == QAVIT_BF16) hipLaunchKernelGGL((gather_pool_bwd2_kernel<bf16>), dim3(g2), dim3(256), lds, st, (const bf16*)dy, idx, (bf16*)dx, B, N, NP, stride, C);
-      else hipLaunchKernelGGL((gather_pool_bwd2_kernel<float>), dim3(g2), dim3(256), lds, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);
+      if (dtype == QAVIT_BF16) hipLaunchKernelGGL((gather_pool_bwd2_kernel<bf16>), dim3(g2), dim3(256), lds, st, (const bf16*)dy, idx, (bf16*)dx, B, N, NP, stride, C, ldx);
+      else hipLaunchKernelGGL((gather_pool_bwd2_kernel<float>), dim3(g2), dim3(256), lds, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C, ldx);
       return check_launch("gather_pool_bwd");
     }
   }
+  if (ldx != C) return set_error(QAVIT_EINVAL, "gather_pool_bwd: a row stride needs the vector kernel (16-byte aligned rows, C and ldx multiples of the vector)");
   if (dtype == QAVIT_F32) {
     if (small) hipLaunchKernelGGL((gather_pool_bwd_kernel<float, uint32_t>), dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);
     else hipLaunchKernelGGL((gather_pool_bwd_kernel<float, int64_t>), dim3(grid), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, B, N, NP, stride, C);

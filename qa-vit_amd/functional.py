@@ -757,6 +757,12 @@ class LayerNormFn(Function):
 
 
 _DX_CAT = os.environ.get("QAVIT_DX_CAT", "1") != "0"
+# MSDA's landmark path inside the fan node's GEMM: dk / dv of the pooled landmarks are scattered back to TOKEN rows (the pooling's backward
+# applied to the 2C-wide dk | dv instead of to their C-wide product with Wkv: pooling and the projection commute) into columns [5C, 7C) of
+# the group's matrix, ON A SIDE STREAM beside the next branch's backward kernel, and the fan GEMM contracts over 7C columns.  The landmark
+# path's own input-gradient GEMM and the scatter behind it (two launches on the block's critical chain) are gone.
+_MSDA_SIDE = os.environ.get("QAVIT_MSDA_SIDE", "1") != "0"
+_MSDA_SIDE_STREAM = os.environ.get("QAVIT_MSDA_SIDE_STREAM", "0") != "0"
 
 
 class FanGroup:
@@ -768,12 +774,32 @@ class FanGroup:
     as its residual addend (dx = dq_c Wq_c + [dq dk dv]_s Wqkv_s + dq_m Wq_m + dx_pool; HQAViT_CIFAR100.py:448, :523, :613 backward).
     Two launches, two [M, C] round trips and two addends of the fan-in sum fewer per block."""
     registry = {}                                           # data_ptr of the fan-out tensor -> weakref(FanGroup)
+    _side = {}                                              # device index -> the stream MSDA's landmark scatter runs on
 
     def __init__(self, M, Cc, dtype, device):
         self.M, self.C, self.dtype, self.device = M, Cc, dtype, device
+        self.ld = 7 * Cc                                    # cross q | SWA q k v | MSDA q | MSDA k v (token rows, _MSDA_SIDE)
         self.buf = None
         self.entries = {}                                   # kind -> weight parameter
         self.resid = None
+        self.kv = False                                     # columns [5C, 7C) hold MSDA's dk | dv scattered back to token rows
+        self.kv_side = None                                 # ... written on this stream: run() waits for it
+
+    def _alloc(self):
+        if self.buf is None:
+            self.buf = torch.empty(self.M, 7 * self.C, dtype=self.dtype, device=self.device)
+        return self.buf
+
+    def kv_ptr(self):
+        return self._alloc().data_ptr() + 5 * self.C * self.buf.element_size()
+
+    @classmethod
+    def side_stream(cls, device):
+        key = torch.device(device).index or 0
+        st = cls._side.get(key)
+        if st is None:
+            st = cls._side[key] = torch.cuda.Stream(device=device)
+        return st
 
     # column offset / width of a branch kind's slice: cross q | SWA q k v | MSDA q
     def slot(self, kind):
@@ -781,9 +807,10 @@ class FanGroup:
         return {2: (0, Cc), 0: (Cc, 3 * Cc), 1: (4 * Cc, Cc)}[kind]
 
     def slice_ptr(self, kind):
-        if self.buf is None:
-            self.buf = torch.empty(self.M, 5 * self.C, dtype=self.dtype, device=self.device)
-        return self.buf.data_ptr() + self.slot(kind)[0] * self.buf.element_size()
+        return self._alloc().data_ptr() + self.slot(kind)[0] * self.buf.element_size()
+
+    def kdim(self):
+        return (7 if self.kv else 5) * self.C
 
     @classmethod
     def create(cls, y, rows, Cc):
@@ -817,15 +844,19 @@ class FanGroup:
         M, Cc = self.M, self.C
         out = torch.empty(M, Cc, dtype=self.dtype, device=self.device)
         order = (2, 0, 1)
-        ld = 5 * Cc
+        ld = self.ld
         esz = self.buf.element_size()
+        if self.kv_side is not None:                        # the landmark scatter ran beside the branch kernels: join it here
+            torch.cuda.current_stream(self.device).wait_stream(self.kv_side)
+            self.kv_side = None
         if self.complete():
             _, Wt = pack_for(self.device).get([self.entries[2], self.entries[0], self.entries[1]], self.dtype)      # [C, C + 3C + 3C]
+            Kc = self.kdim()
             if lnbwd is not None:
                 lnbwd = dict(lnbwd, adds=[self.resid] + list(lnbwd.get("adds") or ()))
-                K.gemm_nt(self.buf, Wt, out, M, Cc, 5 * Cc, ld, Wt.shape[1], Cc, None, R=dres, ldr=Cc, lnbwd=lnbwd)
+                K.gemm_nt(self.buf, Wt, out, M, Cc, Kc, ld, Wt.shape[1], Cc, None, R=dres, ldr=Cc, lnbwd=lnbwd)
             else:
-                K.gemm_nt(self.buf, Wt, out, M, Cc, 5 * Cc, ld, Wt.shape[1], Cc, None, R=self.resid, ldr=Cc)
+                K.gemm_nt(self.buf, Wt, out, M, Cc, Kc, ld, Wt.shape[1], Cc, None, R=self.resid, ldr=Cc)
             return out
         assert lnbwd is None
         first = True                                        # a branch without a gradient this pass: a GEMM per registered slice
@@ -833,6 +864,8 @@ class FanGroup:
             if k not in self.entries:
                 continue
             off, width = self.slot(k)
+            if k == 1 and self.kv:
+                width = 3 * Cc                              # q | k | v of MSDA are adjacent columns, as in its transposed weight pack
             _, Wt = pack_for(self.device).get(self.entries[k], self.dtype)
             R = self.resid if first else out
             K.gemm_nt(self.buf, Wt, out, M, Cc, width, ld, Wt.shape[1], Cc, None, R=R, ldr=Cc, A_ptr=self.buf.data_ptr() + off * esz)
@@ -881,7 +914,7 @@ class LayerNormFanFn(Function):
             if not K.ln_dres_ok(x2, dres, Cc):
                 dres = None
         if grp is not None and grp.complete() and _LN_EPI and (dalias is None or dres is not None) and \
-                len(dys) + (grp.resid is not None) <= 2 and K.gemm_nt_lnbwd_ok(x2, rows, Cc, 5 * Cc, 0, grp.resid, dres, *dys):
+                len(dys) + (grp.resid is not None) <= 2 and K.gemm_nt_lnbwd_ok(x2, rows, Cc, grp.kdim(), 0, grp.resid, dres, *dys):
             # ONE launch for the whole node: the branches' input-gradient GEMM (K = 5C) with this LayerNorm's backward as its epilogue
             # -- the remaining consumers' gradients (the channel-group branch) and MSDA's landmark-path gradient are added to the
             # product on load, the residual path's gradient behind the LayerNorm backward
@@ -1138,7 +1171,7 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
         grp = None
     dq_ptr, dq_ld = None, None
     if grp is not None:
-        dq_ptr, dq_ld = grp.slice_ptr(kind), 5 * Cc
+        dq_ptr, dq_ld = grp.slice_ptr(kind), grp.ld
     if kind == 0:
         qkv = saved[0]
         dq = torch.empty_like(qkv) if grp is None else None
@@ -1232,13 +1265,27 @@ def _branch_backward_fused(ctx, dout, x, x2, wqkv, bqkv, wproj, bproj, E_k, E_v,
             if kind == 1:
                 idx, stride = m["pool_idx"], m["pool_stride"]
                 NP = idx.numel() // stride
-                dpool = _linear_bwd(saved[2], wqkv, bqkv, dkv, Cc, 2 * Cc, need_dx)
-                dxp = torch.empty(M, Cc, dtype=x.dtype, device=x.device)
-                K.gather_pool_bwd(dpool.reshape(B, NP, Cc).contiguous(), idx, dxp, B, T, NP, stride, Cc)
-                grp.resid = dxp
+                if _MSDA_SIDE and dkv.is_contiguous() and dkv.data_ptr() % 16 == 0 and (2 * Cc) % 8 == 0:
+                    _linear_bwd(saved[2], wqkv, bqkv, dkv, Cc, 2 * Cc, False)        # weight / bias gradients only
+                    kvp = grp.kv_ptr()
+                    if _MSDA_SIDE_STREAM:
+                        side, cur = FanGroup.side_stream(x.device), torch.cuda.current_stream(x.device)
+                        side.wait_stream(cur)               # dk | dv of the landmarks exist
+                        dkv.record_stream(side)
+                        with torch.cuda.stream(side):
+                            K.gather_pool_bwd_ld(dkv, idx, kvp, grp.ld, B, T, NP, stride, 2 * Cc)
+                        grp.kv, grp.kv_side = True, side
+                    else:
+                        K.gather_pool_bwd_ld(dkv, idx, kvp, grp.ld, B, T, NP, stride, 2 * Cc)
+                        grp.kv = True
+                else:
+                    dpool = _linear_bwd(saved[2], wqkv, bqkv, dkv, Cc, 2 * Cc, need_dx)
+                    dxp = torch.empty(M, Cc, dtype=x.dtype, device=x.device)
+                    K.gather_pool_bwd(dpool.reshape(B, NP, Cc).contiguous(), idx, dxp, B, T, NP, stride, Cc)
+                    grp.resid = dxp
             wq_buf, _ = grad_sink(wqkv)
             bq_buf, _ = grad_sink(bqkv)
-            K.gemm_tn(grp.buf, x2, wq_buf, M, nq, Cc, 5 * Cc, Cc, Cc, None, A_ptr=dq_ptr, C_ptr=wq_buf.data_ptr(),
+            K.gemm_tn(grp.buf, x2, wq_buf, M, nq, Cc, grp.ld, Cc, Cc, None, A_ptr=dq_ptr, C_ptr=wq_buf.data_ptr(),
                       colsum_ptr=None if bq_buf is None else bq_buf.data_ptr())
             grp.entries[kind] = wqkv
             dx = None

@@ -652,6 +652,11 @@ def gather_pool_bwd(dy, idx, dx, B, N, NP, stride, Cc):
     L.check(L.load().qavit_gather_pool_bwd(dt_code(dy.dtype), dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, N, NP, stride, Cc, stream()), "gather_pool_bwd")
 
 
+def gather_pool_bwd_ld(dy, idx, dx_ptr, ldx, B, N, NP, stride, Cc):
+    """gather_pool_bwd into a column slice: ``dx_ptr`` = address of the slice's first element, rows ``ldx`` elements apart."""
+    L.check(L.load().qavit_gather_pool_bwd_ld(dt_code(dy.dtype), dy.data_ptr(), idx.data_ptr(), dx_ptr, ldx, B, N, NP, stride, Cc, stream()), "gather_pool_bwd_ld")
+
+
 def token_mean_fwd(x, y, B, N, Cc):
     L.check(L.load().qavit_token_mean_fwd(dt_code(x.dtype), x.data_ptr(), y.data_ptr(), B, N, Cc, stream()), "token_mean_fwd")
 

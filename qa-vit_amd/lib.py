@@ -223,6 +223,7 @@ _SIGS = {
     "qavit_upmix_bwd_sa": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, i32, vp, vp]),
     "qavit_gather_pool_fwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "qavit_gather_pool_bwd": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "qavit_gather_pool_bwd_ld": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "qavit_ccf_mid_fwd": (i32, [C.POINTER(CcfArgs), vp]),
     "qavit_ccf_mid_bwd": (i32, [C.POINTER(CcfArgs), vp]),
     "qavit_dwconv_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
